@@ -1,0 +1,83 @@
+"""TEST INFRASTRUCTURE ONLY — import-only shims so the *real* reference modules under
+/root/reference can be imported in the build container (CPU, transformers 5.x, no torchaudio).
+
+Nothing here is shipped or measured.  Only oracle/make_golden.py and the
+`not gpu` cross-check tests use it, and only when /root/reference exists (it does not
+on the GPU box).
+
+Shimmed imports (all import-only; none of the stubbed symbols is ever called on the hot path):
+  * torchaudio(+.transforms,.functional)   <- tortoise/models/arch_util.py:8 (TorchMelSpectrogram only)
+  * rotary_embedding_torch                 <- tortoise/models/transformer.py (unused: use_xformers=True, api.py:232)
+  * transformers.utils.model_parallel_utils <- tortoise/models/autoregressive.py:8 (dead parallelize())
+  * tortoise.utils.typical_sampling         <- autoregressive.py:10 (typical_sampling=False default)
+"""
+import os
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get("TORTOISE_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "tortoise", "models"))
+
+
+_installed = False
+
+
+def install():
+    global _installed
+    if _installed:
+        return
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    import transformers  # noqa: F401  (must be imported before the stubs below)
+
+    def _stub(name, **attrs):
+        if name in sys.modules:
+            return sys.modules[name]
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    ta = _stub("torchaudio")
+    ta.transforms = _stub("torchaudio.transforms")
+    ta.functional = _stub("torchaudio.functional")
+
+    class _DummyRotary:  # never instantiated on the shipped config
+        def __init__(self, *a, **k):
+            raise RuntimeError("stub")
+
+    _stub("rotary_embedding_torch", RotaryEmbedding=_DummyRotary, broadcat=None)
+    _stub("transformers.utils.model_parallel_utils",
+          get_device_map=lambda *a, **k: None, assert_device_map=lambda *a, **k: None)
+
+    class _TypicalStub:
+        def __init__(self, *a, **k):
+            raise RuntimeError("typical sampling is out of scope (default off)")
+
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    _stub("tortoise.utils.typical_sampling", TypicalLogitsWarper=_TypicalStub)
+    _installed = True
+
+
+def import_reference():
+    """Returns a namespace with the reference classes on the hot path."""
+    install()
+    ns = types.SimpleNamespace()
+    from tortoise.models.autoregressive import UnifiedVoice
+    from tortoise.models.diffusion_decoder import DiffusionTts
+    from tortoise.models.clvp import CLVP
+    from tortoise.models.vocoder import UnivNetGenerator
+    from tortoise.utils.diffusion import SpacedDiffusion, space_timesteps, get_named_beta_schedule
+    ns.UnifiedVoice = UnifiedVoice
+    ns.DiffusionTts = DiffusionTts
+    ns.CLVP = CLVP
+    ns.UnivNetGenerator = UnivNetGenerator
+    ns.SpacedDiffusion = SpacedDiffusion
+    ns.space_timesteps = space_timesteps
+    ns.get_named_beta_schedule = get_named_beta_schedule
+    return ns
