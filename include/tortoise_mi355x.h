@@ -1,0 +1,266 @@
+/* tortoise_mi355x.h — C-ABI of the MI355X (gfx950) Tortoise inference engine.
+ *
+ * The reference (neonbjb/tortoise-tts) has no FFI: its hot path is five Python call sites inside
+ * TextToSpeech.tts() (tortoise/api.py).  Each entry-point group below replaces exactly one of those
+ * call sites; the file:line it replaces is cited.  Host code (tortoise_tts_amd/api.py) keeps the
+ * reference's Python signature and calls these through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative code on error; tt_last_error() has the text.
+ *     Nothing throws across the boundary.
+ *   - all tensor arguments are DEVICE pointers unless the name ends in _host; the caller owns them.
+ *     Weight pointers passed to *_create must stay valid until *_destroy (the engine keeps them,
+ *     it does not copy weights).
+ *   - `stream` is a hipStream_t (0 = default stream).  Calls are asynchronous on that stream unless
+ *     stated otherwise; no call allocates device memory after *_create / *_reserve.
+ *   - dtype: TT_BF16 or TT_F16 selects the MFMA operand type (weights + GEMM activations);
+ *     residual streams, norms, softmax and accumulators are always f32.
+ *   - "T" below means that operand type.  Weight matrices are [out_features][in_features]
+ *     (K contiguous); conv kernels are [out][tap][in_padded].  tortoise_tts_amd/pack.py produces
+ *     these from reference-layout state_dicts.
+ */
+#ifndef TORTOISE_MI355X_H
+#define TORTOISE_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TT_BF16 0
+#define TT_F16 1
+
+const char* tt_last_error(void);
+int tt_init(void);     /* once per process, after the HIP device is selected */
+int tt_abi_version(void);
+size_t tt_struct_size(int which);  /* sizeof of boundary struct #which (order of declaration below) */
+
+/* ============================================================================================
+ * Stage 1 — UnifiedVoice / GPT2InferenceModel   (reference: tortoise/models/autoregressive.py)
+ * ============================================================================================ */
+typedef struct tt_gpt_layer {
+  const float* ln1_g; const float* ln1_b;     /* gpt.h.i.ln_1 */
+  const void* w_qkv;  const float* b_qkv;     /* T [3D][D]  (HF Conv1D c_attn transposed) */
+  const void* w_proj; const float* b_proj;    /* T [D][D] */
+  const float* ln2_g; const float* ln2_b;
+  const void* w_fc;   const float* b_fc;      /* T [4D][D] */
+  const void* w_proj2; const float* b_proj2;  /* T [D][4D] */
+} tt_gpt_layer;
+
+typedef struct tt_ar_config {
+  int dtype;
+  int layers, model_dim, heads;
+  int vocab;             /* number_mel_codes (8194) */
+  int start_mel_token, stop_mel_token;
+  int mel_pos_len;       /* rows of mel_pos_embedding */
+  int max_batch;         /* candidates decoded together */
+  int max_prefix;        /* max P+1 (conditioning + text + start token) */
+  int max_new_tokens;    /* per-sequence KV slots */
+  int max_full_rows;     /* rows of the largest teacher-forced pass (k * (1 + T+2 + M+2)) */
+} tt_ar_config;
+
+typedef struct tt_ar_weights {
+  const tt_gpt_layer* layers_host;  /* HOST array of `layers` entries (device pointers inside) */
+  const float* lnf_g; const float* lnf_b;               /* gpt.ln_f */
+  const float* final_norm_g; const float* final_norm_b; /* final_norm */
+  const void* w_mel_head; const float* b_mel_head;      /* T [vocab][D] */
+  const float* mel_emb;   /* f32 [vocab][D]   mel_embedding.weight */
+  const float* mel_pos;   /* f32 [mel_pos_len][D]  mel_pos_embedding.emb.weight */
+} tt_ar_weights;
+
+typedef struct tt_ar tt_ar;
+int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out);
+void tt_ar_destroy(tt_ar* h);
+
+/* Replaces the first GenerationMixin step of UnifiedVoice.inference_speech
+ * (autoregressive.py:538-549 prefix + 134-144 prefill branch, called from api.py:416-424).
+ * prefix_emb f32 [P][D] = [cond latent | text_emb + text_pos].  The start-token row is appended
+ * here.  All candidates share this prefix, so it is evaluated ONCE (M = P+1 rows) and its K/V are
+ * shared by every sequence of the following tt_ar_generate / tt_ar_decode_step calls. */
+int tt_ar_prefill(tt_ar* h, const float* prefix_emb, int P, void* stream);
+
+/* Logits of the newest position: f32 [rows][vocab]; rows = 1 after prefill, B after a decode step. */
+int tt_ar_get_logits(tt_ar* h, float* dst, int rows, void* stream);
+
+typedef struct tt_sampling {
+  float temperature, top_p, repetition_penalty;
+  int top_k;                 /* HF GenerationConfig default 50 (api.py never overrides it) */
+  unsigned long long seed;   /* Philox key when exp_noise == NULL */
+  int row_offset;            /* global index of candidate 0 of this rank */
+  const float* exp_noise;    /* optional f32 [max_new][B][vocab] Exp(1) draws: multinomial == argmax(p/q) */
+} tt_sampling;
+
+/* Replaces `self.inference_model.generate(... do_sample=True ...)` (autoregressive.py:560-563;
+ * loop spec stream_generator.py:916-1000): samples B candidates for up to max_new tokens, stops
+ * early when every row has emitted stop_mel_token.  codes int32 [B][max_new], pre-filled with
+ * stop_mel_token past each row's end (api.py:425-426 padding).  The per-token step is replayed
+ * from a hipGraph.  Synchronises `stream` before returning; *n_steps_host = tokens per row. */
+int tt_ar_generate(tt_ar* h, int B, int max_new, const tt_sampling* s, int* codes, int* n_steps_host, void* stream);
+
+/* Teacher-forced single steps for parity tests: tt_ar_begin resets per-sequence state for B rows
+ * after a prefill; tt_ar_decode_step feeds tokens int32 [B] (KV-cached position rule of
+ * autoregressive.py:145-149: mel position row = index + 1 for index >= 1) and leaves the logits for
+ * tt_ar_get_logits. */
+int tt_ar_begin(tt_ar* h, int B, void* stream);
+int tt_ar_decode_step(tt_ar* h, const int* tokens, void* stream);
+
+/* Replaces UnifiedVoice.forward(..., return_latent=True, clip_inputs=False) (autoregressive.py:454-506,
+ * get_logits 417-431; called from api.py:521-524).  emb f32 [k][n][D] is the concatenated
+ * [cond | text | mel] embedding; out f32 [k][n][D] = final_norm(ln_f(trunk(emb))) for every row
+ * (the host slices the mel rows). */
+int tt_ar_latents(tt_ar* h, const float* emb, int k, int n, float* out, void* stream);
+
+/* ============================================================================================
+ * CLVP scoring   (reference: tortoise/models/clvp.py:99-135, called from api.py:463)
+ * ============================================================================================ */
+typedef struct tt_clvp_layer {   /* one attention + one feed-forward sublayer */
+  const float* attn_norm_g;
+  const void* w_qkv;             /* T [3D][D] = [to_q; to_k; to_v] (no bias) */
+  const void* w_out; const float* b_out;
+  const float* ff_norm_g;
+  const void* w_ff1; const float* b_ff1;   /* T [2*inner][D]  (GEGLU proj) */
+  const void* w_ff2; const float* b_ff2;   /* T [D][inner] */
+} tt_clvp_layer;
+typedef struct tt_clvp_tower {
+  const tt_clvp_layer* layers_host;
+  const float* emb;              /* f32 [tokens][D] */
+  const float* inv_freq;         /* f32 [rot/2] */
+  const float* norm_g; const float* norm_b;  /* final LayerNorm */
+  const void* w_latent;          /* T [latent][D] (no bias) */
+} tt_clvp_tower;
+typedef struct tt_clvp_config {
+  int dtype, dim, latent_dim, depth, heads, ff_inner, rot_dim;
+  int max_rows;                  /* max B * n tokens in one tower call */
+} tt_clvp_config;
+typedef struct tt_clvp tt_clvp;
+int tt_clvp_create(const tt_clvp_config* cfg, const tt_clvp_tower* text, const tt_clvp_tower* speech,
+                   const float* temperature, tt_clvp** out);
+void tt_clvp_destroy(tt_clvp* h);
+/* text int32 [T] (one prompt, evaluated once instead of B times — api.py:463 repeats it),
+ * codes int32 [B][n] -> scores f32 [B]. */
+int tt_clvp_score(tt_clvp* h, const int* text, int T, const int* codes, int B, int n, float* scores, void* stream);
+
+/* ============================================================================================
+ * Stage 2 — DiffusionTts + SpacedDiffusion.p_sample_loop
+ * (reference: tortoise/models/diffusion_decoder.py:232-322, tortoise/utils/diffusion.py:312-621,
+ *  called from api.py:117-130 do_spectrogram_diffusion)
+ * ============================================================================================ */
+typedef struct tt_attn_block {       /* arch_util.AttentionBlock */
+  const float* norm_g; const float* norm_b;
+  const void* w_qkv; const float* b_qkv;    /* T [3C][C], rows reordered to [q|k|v][head][64] */
+  const void* w_proj; const float* b_proj;  /* T [C][C] */
+  const float* relpos;                      /* f32 [heads][129] = bias[bucket(clamp(k-q,-64,64))] * 8, or NULL */
+} tt_attn_block;
+typedef struct tt_res_block {        /* diffusion_decoder.ResBlock */
+  const float* gn1_g; const float* gn1_b;
+  const void* w_in; const float* b_in;      /* T [C][C]      in_layers.2 (1x1) */
+  const float* gn2_g; const float* gn2_b;
+  const void* w_out; const float* b_out;    /* T [C][3][C]   out_layers.3 (k3) */
+} tt_res_block;
+typedef struct tt_diff_config {
+  int dtype, channels, heads, num_layers;   /* 1024, 16, 10 */
+  int in_channels, in_pad;                  /* 100, 128 */
+  int out_channels;                         /* 200 */
+  int latent_channels;                      /* 1024 */
+  int max_seq;                              /* max S */
+  int max_codes;                            /* max M */
+  int max_steps;
+} tt_diff_config;
+typedef struct tt_diff_weights {
+  /* timestep-independent conditioning (diffusion_decoder.py:232-255) */
+  const void* w_latent_conv; const float* b_latent_conv;   /* T [C][3][latent] latent_conditioner.0 */
+  const tt_attn_block* latent_attn_host;                   /* 4 blocks */
+  const float* code_norm_g; const float* code_norm_b;
+  const float* uncond_emb;                                 /* f32 [C] */
+  /* per-step network */
+  const void* w_time1; const float* b_time1;               /* T [C][C] time_embed.0 */
+  const void* w_time2; const float* b_time2;               /* T [C][C] time_embed.2 */
+  const void* w_emb_all; const float* b_emb_all;           /* T [(3+L+3)*2C][C] all ResBlock emb_layers.1 stacked */
+  const tt_res_block* res_host;                            /* 3 integrator + L layers + 3 tail */
+  const tt_attn_block* attn_host;                          /* 3 integrator + L layers */
+  const void* w_inp; const float* b_inp;                   /* T [C][3][in_pad] */
+  const void* w_integ; const float* b_integ;               /* T [C][2C] */
+  const float* out_gn_g; const float* out_gn_b;
+  const void* w_final; const float* b_final;               /* T [out][3][C] */
+} tt_diff_weights;
+typedef struct tt_diff tt_diff;
+int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff** out);
+void tt_diff_destroy(tt_diff* h);
+
+/* DiffusionTts.timestep_independent (diffusion_decoder.py:232-260), latent branch, eval mode.
+ * latents f32 [M][latent]; cond f32 [2C] (scale | shift); interp_idx int32 [S] = nearest-neighbour
+ * source row of F.interpolate.  Keeps the [S][C] conditioning inside the handle. */
+int tt_diff_condition(tt_diff* h, const float* latents, int M, const float* cond, const int* interp_idx, int S, void* stream);
+int tt_diff_get_code_emb(tt_diff* h, float* dst, void* stream);  /* f32 [S][C], tests */
+
+typedef struct tt_diff_step {   /* float32 views of the float64 schedule tables (utils/diffusion.py:1237-1250) */
+  int timestep;                 /* timestep_map[i] fed to the network */
+  float min_log, max_log;       /* posterior_log_variance_clipped[i], log(betas[i]) */
+  float cfk;                    /* conditioning_free_k * (1 - i / N)   (diffusion.py:378-384) */
+  float sqrt_recip, sqrt_recipm1, coef1, coef2;
+  float nonzero;                /* 0 for i == 0 */
+} tt_diff_step;
+
+/* One denoiser evaluation (DiffusionTts.forward, diffusion_decoder.py:262-322), conditioned and
+ * unconditioned rows batched so weights stream once.  x f32 [S][in_channels] token-major;
+ * out f32 [2][S][out_channels] (row 0 conditioned, row 1 conditioning_free).  Tests. */
+int tt_diff_forward(tt_diff* h, const float* x, int timestep, int cond_free, float* out, void* stream);
+
+/* SpacedDiffusion.p_sample_loop (utils/diffusion.py:533-621).  steps_host[n_steps] in the order they
+ * run (i = N-1 ... 0).  x_T f32 [in_channels][S] and step_noise f32 [n_steps][in_channels][S]
+ * use the reference's channels-first layout (step_noise[j] is the draw consumed by the j-th step run;
+ * the entry for i == 0 is ignored).  mel_out f32 [in_channels][S] = denormalize_tacotron_mel(x_0)
+ * (utils/audio.py:59-64).  Each step replays one hipGraph. */
+int tt_diff_sample(tt_diff* h, const float* x_T, const float* step_noise, const tt_diff_step* steps_host, int n_steps,
+                   int cond_free, float* mel_out, void* stream);
+
+/* ============================================================================================
+ * Stage 3 — UnivNetGenerator.inference   (reference: tortoise/models/vocoder.py:300-312, api.py:559)
+ * ============================================================================================ */
+typedef struct tt_voc_block {
+  const float* w_convt; const float* b_convt;        /* f32 [32][32][2*stride] */
+  const void* w_kp_in; const float* b_kp_in;         /* T [64][5][mel_pad] */
+  const void* w_kp_res[6]; const float* b_kp_res[6]; /* T [64][3][64] x (3 blocks x 2 convs) */
+  const void* w_kp_kernel; const float* b_kp_kernel; /* T [24576][3][64] */
+  const void* w_kp_bias; const float* b_kp_bias;     /* T [256][3][64] */
+  const float* w_conv[4]; const float* b_conv[4];    /* f32 [32][32][3], dilations 1,3,9,27 */
+  int stride;
+} tt_voc_block;
+typedef struct tt_voc_config { int dtype, max_frames, mel_channels, mel_pad; } tt_voc_config;
+typedef struct tt_voc_weights {
+  const float* w_pre; const float* b_pre;     /* f32 [32][64][7] */
+  const tt_voc_block* blocks_host;            /* 3 */
+  const float* w_post; const float* b_post;   /* f32 [1][32][7] */
+} tt_voc_weights;
+typedef struct tt_voc tt_voc;
+int tt_voc_create(const tt_voc_config* cfg, const tt_voc_weights* w, tt_voc** out);
+void tt_voc_destroy(tt_voc* h);
+/* mel f32 [mel_channels][S] (channels-first, as the diffusion stage emits it); z f32 [64][S+10];
+ * audio f32 [S*256].  Pads 10 frames of -11.5129 and drops the matching tail (vocoder.py:303-311). */
+int tt_voc_run(tt_voc* h, const float* mel, int S, const float* z, float* audio, void* stream);
+
+/* ============================================================================================
+ * Operator-level entry points (used by tests/ to check single kernels against torch references)
+ * ============================================================================================ */
+int tt_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int taps, int seq_len,
+               int splitk, const float* bias, int act, const float* res, float* out_f32, void* out_t, void* stream);
+int tt_op_layernorm(int dtype, const float* x, int M, int D, const float* g, const float* b, float eps, int rms,
+                    void* out_t, float* out_f32, void* stream);
+int tt_op_groupnorm(int dtype, const float* x, int B, int S, int C, const float* g, const float* b, const float* scale_shift,
+                    int act, void* out_t, float* out_f32, float* workspace, void* stream);
+size_t tt_op_groupnorm_workspace(int B, int S);
+int tt_op_flash_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int heads, int n, int n_pad,
+                          int causal, const float* relpos, void* stream);
+int tt_op_sample(const float* logits, int ldl, int B, int V, unsigned* seen, const tt_sampling* s, int step, int* unfinished,
+                 int stop_token, int* codes, int ldcodes, void* stream);
+int tt_op_conv1d(const float* x, const float* w, const float* bias, float* y, int Cin, int Cout, int T, int k, int dilation,
+                 int reflect, float in_slope, int out_act, float out_slope, void* stream);
+int tt_op_convt1d(const float* x, const float* w, const float* bias, float* y, int C, int Tin, int stride, float in_slope, void* stream);
+int tt_op_lvc(const float* x_in, const float* kernels, int ldk, int koff, const float* bias, int ldb, int boff, float* x, int L,
+              int hop, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

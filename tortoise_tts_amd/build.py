@@ -1,0 +1,90 @@
+"""In-tree build of the gfx950 engine library (hipcc cross-compiles without a GPU).
+
+`python -m tortoise_tts_amd.build` or `__graft_entry__.build()` produces
+tortoise_tts_amd/lib/libtortoise_mi355x.so.  Objects are cached by source hash so an
+unchanged file is not recompiled.  There is exactly one target (gfx950); no other arch, no
+fallback path.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libtortoise_mi355x.so")
+SOURCES = ["common.hip", "gemm.hip", "norm.hip", "attention.hip", "sampling.hip", "misc.hip", "univnet.hip",
+           "gpt2.hip", "clvp.hip", "diffusion.hip", "vocoder.hip", "capi.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-ffp-contract=on"]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X engine cannot be built")
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "tortoise_mi355x.h"))
+    return hs
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = _headers()
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ, src.replace(".hip", ".o"))
+        stamp = op + ".sha"
+        dig = _digest([sp] + headers)
+        objs.append(op)
+        if not force and os.path.exists(op) and os.path.exists(stamp) and open(stamp).read() == dig:
+            continue
+        jobs.append((sp, op, stamp, dig))
+
+    def compile_one(job):
+        sp, op, stamp, dig = job
+        cmd = [hipcc] + FLAGS + ["-c", sp, "-o", op]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (sp, r.stdout, r.stderr))
+        with open(stamp, "w") as f:
+            f.write(dig)
+        return sp
+
+    if jobs:
+        if verbose:
+            print("[build] compiling %d file(s) for gfx950 ..." % len(jobs), file=sys.stderr)
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(compile_one, jobs))
+    if jobs or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("[build] linked %s" % LIB, file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,271 @@
+// Attention kernels for gfx950, head_dim = 64.
+//
+// flash_attention: one wave owns NQ blocks of 16 queries and walks the keys 32 at a time with an
+// online softmax.  Both products run "swapped" so the softmax axis is lane-local:
+//   S^T[key][q] = K[key][:] . Q[q][:]        (MFMA A = K rows, B = Q rows: both 16-B row reads)
+//   O^T[d][q]   = V^T[d][key] . P^T[key][q]  (MFMA A = V^T rows, B = P straight from the S^T registers)
+// A lane therefore holds one query column (l & 15) in every accumulator: running max / sum and
+// the rescale factor are per-lane scalars and the row reductions are two xor-shuffles (16, 32).
+// The S^T -> P^T hand-off needs no LDS: the 32 keys of a tile are fed to the second MFMA in the
+// order the first one left them in registers, and V^T is read with the same permutation.
+// K/V for one (batch, head) is at most a few hundred KB, i.e. L2 resident, so nothing is staged
+// through LDS (the only LDS use is the 129-entry relative-position table of DiffusionTts).
+//
+// decode_attention: one wave per (sequence, head), one new query against [shared prefix | own
+// generated keys].  HBM-bound on the per-sequence cache: keys are stored in 16-byte dim-chunks
+// that are key-major so the lane-per-key dot product issues fully coalesced 1-KiB loads; values are
+// row-major and read 4 rows (512 B) per wave instruction.
+#include "ops.h"
+
+namespace tt {
+
+template <typename T, int NQ>
+__global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
+  typedef typename Vec<T>::x8 x8;
+  typedef typename Vec<T>::x4 x4;
+  __shared__ float rp[132];
+  const int bh = blockIdx.y;
+  const int h = bh % a.heads, b = bh / a.heads;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n = a.n;
+  if (a.relpos) {
+    if (threadIdx.x < 129) rp[threadIdx.x] = a.relpos[h * 129 + threadIdx.x];
+    __syncthreads();
+  }
+  const int qbase = (blockIdx.x * 4 + wave) * 16 * NQ;
+  if (qbase >= n) return;
+  const T* Q = (const T*)a.q + (size_t)bh * n * 64;
+  const T* K = (const T*)a.k + (size_t)bh * n * 64;
+  const T* VT = (const T*)a.vt + (size_t)bh * 64 * a.n_pad;
+
+  x8 qf[NQ][2];
+#pragma unroll
+  for (int iq = 0; iq < NQ; ++iq) {
+    const int qr = min(qbase + iq * 16 + fr, n - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[iq][ks] = *(const x8*)(Q + (size_t)qr * 64 + ks * 32 + fg * 8);
+  }
+  float m_run[NQ], l_run[NQ];
+  f32x4 acc[NQ][4];
+#pragma unroll
+  for (int iq = 0; iq < NQ; ++iq) {
+    m_run[iq] = -1e30f;
+    l_run[iq] = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) acc[iq][blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int q_last = min(qbase + 16 * NQ, n) - 1;
+  const int kend = a.causal ? q_last + 1 : n;
+
+  for (int key0 = 0; key0 < kend; key0 += 32) {
+    x8 kf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int kr = min(key0 + kb * 16 + fr, n - 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) kf[kb][ks] = *(const x8*)(K + (size_t)kr * 64 + ks * 32 + fg * 8);
+    }
+    x8 vf[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      const T* vrow = VT + (size_t)(blk * 16 + fr) * a.n_pad + key0 + fg * 4;
+      const x4 lo = *(const x4*)vrow;
+      const x4 hi = *(const x4*)(vrow + 16);
+      x8 v;
+      v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+      v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+      vf[blk] = v;
+    }
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) {
+      const int qi = qbase + iq * 16 + fr;
+      float s[2][4];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f};
+        st = mfma16(kf[kb][0], qf[iq][0], st);
+        st = mfma16(kf[kb][1], qf[iq][1], st);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + kb * 16 + fg * 4 + r;
+          float v = st[r];
+          if (a.relpos) {
+            int d = key - qi;
+            d = d < -64 ? -64 : (d > 64 ? 64 : d);
+            v += rp[d + 64];
+          }
+          if (key >= n || (a.causal && key > qi)) v = -INFINITY;
+          s[kb][r] = v;
+        }
+      }
+      float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
+                       fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[iq], mx);
+      const float alpha = __expf(m_run[iq] - m_new);
+      float p[2][4];
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[kb][r] = __expf(s[kb][r] - m_new);
+          psum += p[kb][r];
+        }
+      psum += __shfl_xor(psum, 16, 64);
+      psum += __shfl_xor(psum, 32, 64);
+      l_run[iq] = l_run[iq] * alpha + psum;
+      m_run[iq] = m_new;
+      x8 pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pf[r] = (T)p[0][r];
+        pf[4 + r] = (T)p[1][r];
+      }
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        f32x4 o = acc[iq][blk];
+        o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+        acc[iq][blk] = mfma16(vf[blk], pf, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int iq = 0; iq < NQ; ++iq) {
+    const int qi = qbase + iq * 16 + fr;
+    if (qi < n) {
+      const float inv = 1.0f / l_run[iq];
+      T* o = (T*)a.out + ((size_t)b * n + qi) * a.ldo + h * 64 + fg * 4;
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+        *(x4*)(o + blk * 16) = pack4<T>(acc[iq][blk][0] * inv, acc[iq][blk][1] * inv, acc[iq][blk][2] * inv, acc[iq][blk][3] * inv);
+    }
+  }
+}
+
+int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
+  TT_REQUIRE(a.BH > 0 && a.n > 0 && a.heads > 0 && a.BH % a.heads == 0, "flash: bad shape BH=%d n=%d heads=%d", a.BH, a.n, a.heads);
+  TT_REQUIRE(a.n_pad % 32 == 0 && a.n_pad >= ((a.n + 31) / 32) * 32, "flash: n_pad=%d must be a multiple of 32 covering n=%d", a.n_pad, a.n);
+  TT_REQUIRE(a.ldo % 4 == 0, "flash: ldo must be a multiple of 4");
+  // 32 queries per wave once there is enough work to fill the chip; 16 otherwise.
+  const long blocks2 = (long)cdiv(a.n, 128) * a.BH;
+  if (blocks2 >= 512) {
+    dim3 grid(cdiv(a.n, 128), a.BH);
+    if (dtype == DT_BF16) flash_kernel<bf16, 2><<<grid, 256, 0, stream>>>(a);
+    else flash_kernel<f16, 2><<<grid, 256, 0, stream>>>(a);
+  } else {
+    dim3 grid(cdiv(a.n, 64), a.BH);
+    if (dtype == DT_BF16) flash_kernel<bf16, 1><<<grid, 256, 0, stream>>>(a);
+    else flash_kernel<f16, 1><<<grid, 256, 0, stream>>>(a);
+  }
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------- decode
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnArgs a, int ctx_cap) {
+  typedef typename Vec<T>::x8 x8;
+  typedef typename Vec<T>::x4 x4;
+  extern __shared__ __attribute__((aligned(16))) float sc_all[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pair = blockIdx.x * 4 + wave;
+  const bool valid = pair < a.B * a.heads;
+  const int b = valid ? pair / a.heads : 0;
+  const int h = valid ? pair % a.heads : 0;
+  const int tgen = *a.step + 1;       // generated keys 0..*step
+  const int P1 = a.P1;
+  const int ctx = P1 + tgen;
+  float* sc = sc_all + (size_t)wave * ctx_cap;
+
+  float qv[64];
+  {
+    const T* qp = (const T*)a.q + (size_t)b * a.heads * 64 + h * 64;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const x8 t = *(const x8*)(qp + c * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) qv[c * 8 + i] = (float)t[i];
+    }
+  }
+  const T* kp = (const T*)a.kp + (size_t)h * P1 * 64;
+  const T* vp = (const T*)a.vp + (size_t)h * P1 * 64;
+  const size_t bh = (size_t)b * a.heads + h;
+  const T* kc = (const T*)a.kc + bh * 8 * a.tmax * 8;
+  const T* vc = (const T*)a.vc + bh * a.tmax * 64;
+
+  float mx = -1e30f;
+  if (valid) {
+    for (int j = lane; j < P1; j += 64) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const x8 t = *(const x8*)(kp + (size_t)j * 64 + c * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += qv[c * 8 + i] * (float)t[i];
+      }
+      sc[j] = s;
+      mx = fmaxf(mx, s);
+    }
+    for (int t0 = lane; t0 < tgen; t0 += 64) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const x8 t = *(const x8*)(kc + ((size_t)c * a.tmax + t0) * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += qv[c * 8 + i] * (float)t[i];
+      }
+      sc[P1 + t0] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  if (valid) {
+    for (int j = lane; j < ctx; j += 64) {
+      const float e = __expf(sc[j] - mx);
+      sc[j] = e;
+      sum += e;
+    }
+  }
+  sum = wave_sum(sum);
+  __syncthreads();  // every lane's sc[] writes are visible to the whole wave (and block)
+  const int fr = lane & 15, fg = lane >> 4;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+  if (valid) {
+    for (int j = fg; j < ctx; j += 4) {
+      const float p = sc[j];
+      const T* vr = j < P1 ? vp + (size_t)j * 64 : vc + (size_t)(j - P1) * 64;
+      const x4 t = *(const x4*)(vr + fr * 4);
+      o0 += p * (float)t[0];
+      o1 += p * (float)t[1];
+      o2 += p * (float)t[2];
+      o3 += p * (float)t[3];
+    }
+  }
+  o0 += __shfl_xor(o0, 16, 64); o0 += __shfl_xor(o0, 32, 64);
+  o1 += __shfl_xor(o1, 16, 64); o1 += __shfl_xor(o1, 32, 64);
+  o2 += __shfl_xor(o2, 16, 64); o2 += __shfl_xor(o2, 32, 64);
+  o3 += __shfl_xor(o3, 16, 64); o3 += __shfl_xor(o3, 32, 64);
+  if (valid && fg == 0) {
+    const float inv = 1.0f / sum;
+    T* o = (T*)a.out + (size_t)b * a.heads * 64 + h * 64 + fr * 4;
+    *(x4*)o = pack4<T>(o0 * inv, o1 * inv, o2 * inv, o3 * inv);
+  }
+}
+
+int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stream) {
+  TT_REQUIRE(a.B > 0 && a.heads > 0 && a.P1 >= 0 && a.tmax > 0, "decode_attention: bad shape");
+  const int ctx_cap = a.P1 + a.tmax;
+  const size_t smem = (size_t)4 * ctx_cap * sizeof(float);
+  TT_REQUIRE(smem <= 64 * 1024, "decode_attention: context %d too long for the score buffer", ctx_cap);
+  const int blocks = cdiv(a.B * a.heads, 4);
+  if (dtype == DT_BF16) decode_attn_kernel<bf16><<<blocks, 256, smem, stream>>>(a, ctx_cap);
+  else decode_attn_kernel<f16><<<blocks, 256, smem, stream>>>(a, ctx_cap);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace tt

@@ -1,0 +1,133 @@
+// Process-level and operator-level C-ABI entry points (include/tortoise_mi355x.h).
+#include "runtime.h"
+#include "../../include/tortoise_mi355x.h"
+
+using namespace tt;
+
+extern "C" {
+
+const char* tt_last_error(void) { return tt::last_error(); }
+int tt_abi_version(void) { return 1; }
+
+int tt_init(void) {
+  int dev = 0;
+  TT_CHECK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  TT_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+  TT_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "tt_init: device is %s; this engine is built for gfx950 (MI355X) only", prop.gcnArchName);
+  return gemm_init();
+}
+
+int tt_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int taps, int seq_len, int splitk,
+               const float* bias, int act, const float* res, float* out_f32, void* out_t, void* stream) {
+  GemmArgs g = gemm_args(A, lda, W, ldw, M, N, K);
+  g.taps = taps; g.seq_len = seq_len > 0 ? seq_len : M; g.splitk = splitk;
+  g.bias = bias; g.act = act; g.slope = 0.2f; g.res = res; g.ldres = N; g.out_f32 = out_f32; g.ldo32 = N; g.out_t = out_t; g.ldot = N;
+  return gemm_launch(dtype, EPI_STD, g, (hipStream_t)stream);
+}
+
+int tt_op_layernorm(int dtype, const float* x, int M, int D, const float* g, const float* b, float eps, int rms, void* out_t,
+                    float* out_f32, void* stream) {
+  RowNormArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = (float*)x; a.ldx = D; a.M = M; a.D = D; a.mode = rms ? NORM_RMS : NORM_LAYER; a.g1 = g; a.b1 = b; a.eps1 = eps;
+  a.out_t = out_t; a.ldot = D; a.out_f32 = out_f32; a.ldo32 = D;
+  return rownorm_launch(dtype, a, (hipStream_t)stream);
+}
+
+size_t tt_op_groupnorm_workspace(int B, int S) { return groupnorm_partial_floats(B, S) * sizeof(float); }
+
+int tt_op_groupnorm(int dtype, const float* x, int B, int S, int C, const float* g, const float* b, const float* scale_shift, int act,
+                    void* out_t, float* out_f32, float* workspace, void* stream) {
+  GroupNormArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.B = B; a.S = S; a.C = C; a.gamma = g; a.beta = b; a.eps = 1e-5f; a.scale_shift = scale_shift;
+  a.ss_batch_stride = 2 * (size_t)C; a.act = act; a.out_t = out_t; a.ldot = C; a.out_f32 = out_f32; a.ldo32 = C; a.partial = workspace;
+  return groupnorm_launch(dtype, a, (hipStream_t)stream);
+}
+
+int tt_op_flash_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int heads, int n, int n_pad,
+                          int causal, const float* relpos, void* stream) {
+  FlashArgs f;
+  memset(&f, 0, sizeof(f));
+  f.q = q; f.k = k; f.vt = vt; f.out = out; f.ldo = heads * 64; f.BH = B * heads; f.heads = heads; f.n = n; f.n_pad = n_pad;
+  f.causal = causal; f.relpos = relpos;
+  return flash_attention_launch(dtype, f, (hipStream_t)stream);
+}
+
+// One sampling step on caller-provided state (seen bitmask, unfinished flags); `step` indexes codes / exp_noise.
+int tt_op_sample(const float* logits, int ldl, int B, int V, unsigned* seen, const tt_sampling* sp, int step, int* unfinished,
+                 int stop_token, int* codes, int ldcodes, void* stream) {
+  TT_REQUIRE(sp, "tt_op_sample: null sampling parameters");
+  hipStream_t s = (hipStream_t)stream;
+  int* scratch = nullptr;  // state[2] | next_tok[B] | unfinished_count[step+1]
+  const size_t n = 2 + (size_t)B + step + 1;
+  TT_CHECK_HIP(hipMalloc((void**)&scratch, n * sizeof(int)));
+  TT_CHECK_HIP(hipMemsetAsync(scratch, 0, n * sizeof(int), s));
+  const int st[2] = {step, step - 1};
+  TT_CHECK_HIP(hipMemcpyAsync(scratch, st, sizeof(st), hipMemcpyHostToDevice, s));
+  TT_CHECK_HIP(hipStreamSynchronize(s));
+  SampleArgs a;
+  memset(&a, 0, sizeof(a));
+  a.logits = logits; a.ldl = ldl; a.B = B; a.V = V; a.seen = seen;
+  a.rep_penalty = sp->repetition_penalty; a.temperature = sp->temperature; a.top_p = sp->top_p; a.top_k = sp->top_k;
+  a.exp_noise = sp->exp_noise; a.seed = sp->seed; a.row_offset = sp->row_offset;
+  a.state = scratch; a.unfinished = unfinished; a.stop_token = stop_token; a.codes = codes; a.ldcodes = ldcodes;
+  a.next_tok = scratch + 2; a.unfinished_count = scratch + 2 + B;
+  int rc = sample_launch(a, s);
+  hipError_t e = hipStreamSynchronize(s);
+  (void)hipFree(scratch);
+  TT_TRY(rc);
+  TT_CHECK_HIP(e);
+  return 0;
+}
+
+int tt_op_conv1d(const float* x, const float* w, const float* bias, float* y, int Cin, int Cout, int T, int k, int dilation, int reflect,
+                 float in_slope, int out_act, float out_slope, void* stream) {
+  Conv1dArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.Cin = Cin; a.Cout = Cout; a.T = T; a.k = k; a.dilation = dilation; a.reflect = reflect;
+  a.in_slope = in_slope; a.out_act = out_act; a.out_slope = out_slope;
+  return conv1d_direct_launch(a, (hipStream_t)stream);
+}
+
+int tt_op_convt1d(const float* x, const float* w, const float* bias, float* y, int C, int Tin, int stride, float in_slope, void* stream) {
+  ConvT1dArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.C = C; a.Tin = Tin; a.stride = stride; a.in_slope = in_slope;
+  return convt1d_launch(a, (hipStream_t)stream);
+}
+
+int tt_op_lvc(const float* x_in, const float* kernels, int ldk, int koff, const float* bias, int ldb, int boff, float* x, int L, int hop,
+              void* stream) {
+  LvcArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x_in = x_in; a.kernels = kernels; a.ldk = ldk; a.koff = koff; a.bias = bias; a.ldb = ldb; a.boff = boff; a.x = x; a.L = L; a.hop = hop;
+  a.in_slope = -1.f;
+  return lvc_launch(a, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// sizeof() of every struct that crosses the boundary, so host bindings can verify their mirrors
+// without a GPU (tests/test_abi.py).
+extern "C" size_t tt_struct_size(int which) {
+  switch (which) {
+    case 0: return sizeof(tt_gpt_layer);
+    case 1: return sizeof(tt_ar_config);
+    case 2: return sizeof(tt_ar_weights);
+    case 3: return sizeof(tt_sampling);
+    case 4: return sizeof(tt_clvp_layer);
+    case 5: return sizeof(tt_clvp_tower);
+    case 6: return sizeof(tt_clvp_config);
+    case 7: return sizeof(tt_attn_block);
+    case 8: return sizeof(tt_res_block);
+    case 9: return sizeof(tt_diff_config);
+    case 10: return sizeof(tt_diff_weights);
+    case 11: return sizeof(tt_diff_step);
+    case 12: return sizeof(tt_voc_block);
+    case 13: return sizeof(tt_voc_config);
+    case 14: return sizeof(tt_voc_weights);
+  }
+  return 0;
+}

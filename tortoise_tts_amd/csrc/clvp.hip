@@ -1,0 +1,130 @@
+// CLVP candidate scoring (reference: tortoise/models/clvp.py:99-135 over the x-transformers Encoder,
+// tortoise/models/xtransformers.py:731-1013): pre-RMSNorm, bias-free q/k/v, rotary on the first 32
+// dims of q, k and v, softmax(q k^T / 8), GEGLU feed-forward, final LayerNorm, mean pool, latent
+// projection, cosine similarity * exp(temperature).  The text tower runs once per utterance (the
+// reference repeats the prompt B times, api.py:463); the speech tower runs over B x n code rows.
+#include "runtime.h"
+#include "../../include/tortoise_mi355x.h"
+
+using namespace tt;
+
+struct ClvpTower {
+  tt_clvp_tower w;
+  std::vector<tt_clvp_layer> L;
+};
+
+struct tt_clvp {
+  tt_clvp_config cfg;
+  ClvpTower text, speech;
+  const float* temperature;
+  Arena arena;
+  StreamBridge sb;
+  float* x = nullptr; void* h = nullptr; void* u = nullptr; void* gg = nullptr; void* attn = nullptr;
+  void* q = nullptr; void* k = nullptr; void* vt = nullptr;
+  float* enc = nullptr; float* pooled = nullptr; void* pooled_t = nullptr;
+  float* text_latent = nullptr; float* speech_latent = nullptr;
+  int max_batch = 0;
+};
+
+static int clvp_tower_run(tt_clvp* e, const ClvpTower& t, const int* tokens, int B, int n, float* latent_out, hipStream_t s) {
+  const int D = e->cfg.dim, H = e->cfg.heads, inner = e->cfg.ff_inner, dt = e->cfg.dtype;
+  const int M = B * n, n_pad = round_up(n, 32);
+  TT_TRY(gather_rows_launch(t.w.emb, tokens, e->x, M, D, s));
+  for (int l = 0; l < e->cfg.depth; ++l) {
+    const tt_clvp_layer& w = t.L[l];
+    RowNormArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = e->x; a.ldx = D; a.M = M; a.D = D; a.mode = NORM_RMS; a.g1 = w.attn_norm_g; a.eps1 = 1e-8f;
+    a.out_t = e->h; a.ldot = D;
+    TT_TRY(rownorm_launch(dt, a, s));
+    GemmArgs g = gemm_args(e->h, D, w.w_qkv, D, M, 3 * D, D);
+    g.seq_len = n; g.dmodel = D; g.heads = H; g.q = e->q; g.k = e->k; g.vt = e->vt; g.seq_pad = n_pad; g.q_scale = 0.125f;
+    TT_TRY(gemm_launch(dt, EPI_QKV_HEADS, g, s));
+    TT_TRY(rotary_launch(dt, e->q, e->k, e->vt, t.w.inv_freq, B * H, n, n_pad, e->cfg.rot_dim, s));
+    FlashArgs f;
+    memset(&f, 0, sizeof(f));
+    f.q = e->q; f.k = e->k; f.vt = e->vt; f.out = e->attn; f.ldo = D; f.BH = B * H; f.heads = H; f.n = n; f.n_pad = n_pad;
+    TT_TRY(flash_attention_launch(dt, f, s));
+    g = gemm_args(e->attn, D, w.w_out, D, M, D, D);
+    g.bias = w.b_out; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
+    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+    a.g1 = w.ff_norm_g;
+    TT_TRY(rownorm_launch(dt, a, s));
+    g = gemm_args(e->h, D, w.w_ff1, D, M, 2 * inner, D);
+    g.bias = w.b_ff1; g.out_t = e->u; g.ldot = 2 * inner;
+    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+    TT_TRY(geglu_launch(dt, e->u, 2 * inner, e->gg, inner, M, inner, s));
+    g = gemm_args(e->gg, inner, w.w_ff2, inner, M, D, inner);
+    g.bias = w.b_ff2; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
+    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+  }
+  RowNormArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = e->x; a.ldx = D; a.M = M; a.D = D; a.mode = NORM_LAYER; a.g1 = t.w.norm_g; a.b1 = t.w.norm_b; a.eps1 = 1e-5f;
+  a.out_f32 = e->enc; a.ldo32 = D;
+  TT_TRY(rownorm_launch(dt, a, s));
+  TT_TRY(mean_rows_launch(e->enc, e->pooled, B, n, D, s));
+  TT_TRY(cast_pad_launch(dt, e->pooled, D, e->pooled_t, D, B, D, D, s));
+  GemmArgs g = gemm_args(e->pooled_t, D, t.w.w_latent, D, B, e->cfg.latent_dim, D);
+  g.out_f32 = latent_out; g.ldo32 = e->cfg.latent_dim;
+  return gemm_launch(dt, EPI_STD, g, s);
+}
+
+extern "C" {
+
+int tt_clvp_create(const tt_clvp_config* cfg, const tt_clvp_tower* text, const tt_clvp_tower* speech, const float* temperature,
+                   tt_clvp** out) {
+  TT_REQUIRE(cfg && text && speech && temperature && out, "tt_clvp_create: null argument");
+  TT_REQUIRE(cfg->heads * 64 == cfg->dim && cfg->dim % 64 == 0 && cfg->ff_inner % 64 == 0, "tt_clvp_create: unsupported dims");
+  tt_clvp* e = new tt_clvp();
+  e->cfg = *cfg;
+  e->text.w = *text; e->text.L.assign(text->layers_host, text->layers_host + cfg->depth);
+  e->speech.w = *speech; e->speech.L.assign(speech->layers_host, speech->layers_host + cfg->depth);
+  e->temperature = temperature;
+  const size_t rows = (size_t)cfg->max_rows + 64;
+  const int D = cfg->dim;
+  e->max_batch = cfg->max_rows;  // every row could be its own sequence in the worst case
+  int rc = e->sb.init();
+  if (!rc) rc = e->arena.alloc_t(&e->x, rows * D);
+  if (!rc) rc = e->arena.alloc(&e->h, rows * D * 2);
+  if (!rc) rc = e->arena.alloc(&e->u, rows * 2 * cfg->ff_inner * 2);
+  if (!rc) rc = e->arena.alloc(&e->gg, rows * cfg->ff_inner * 2);
+  if (!rc) rc = e->arena.alloc(&e->attn, rows * D * 2);
+  if (!rc) rc = e->arena.alloc(&e->q, rows * D * 2);
+  if (!rc) rc = e->arena.alloc(&e->k, rows * D * 2);
+  // V^T: [B*H][64][n_pad]; n_pad <= n + 31 and B*n <= max_rows, B <= max_rows / 1
+  if (!rc) rc = e->arena.alloc(&e->vt, (size_t)D * (rows + 32 * (size_t)(cfg->max_rows / 8 + 8)) * 2);
+  if (!rc) rc = e->arena.alloc_t(&e->enc, rows * D);
+  if (!rc) rc = e->arena.alloc_t(&e->pooled, rows * D / 8 + D);
+  if (!rc) rc = e->arena.alloc(&e->pooled_t, (rows * D / 8 + D) * 2);
+  if (!rc) rc = e->arena.alloc_t(&e->text_latent, cfg->latent_dim);
+  if (!rc) rc = e->arena.alloc_t(&e->speech_latent, (rows / 8 + 8) * cfg->latent_dim);
+  if (rc) {
+    tt_clvp_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return 0;
+}
+
+void tt_clvp_destroy(tt_clvp* e) {
+  if (!e) return;
+  (void)hipDeviceSynchronize();
+  e->arena.release();
+  e->sb.destroy();
+  delete e;
+}
+
+int tt_clvp_score(tt_clvp* e, const int* text, int T, const int* codes, int B, int n, float* scores, void* stream) {
+  TT_REQUIRE(e && text && codes && scores, "tt_clvp_score: null argument");
+  TT_REQUIRE(T >= 1 && n >= 8 && B >= 1 && (size_t)B * n <= (size_t)e->cfg.max_rows && T <= e->cfg.max_rows,
+             "tt_clvp_score: T=%d B=%d n=%d exceed capacity %d rows (n must be >= 8)", T, B, n, e->cfg.max_rows);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  TT_TRY(clvp_tower_run(e, e->text, text, 1, T, e->text_latent, s));
+  TT_TRY(clvp_tower_run(e, e->speech, codes, B, n, e->speech_latent, s));
+  TT_TRY(clvp_score_launch(e->text_latent, 1, e->speech_latent, e->temperature, scores, B, e->cfg.latent_dim, s));
+  return e->sb.leave(us);
+}
+
+}  // extern "C"

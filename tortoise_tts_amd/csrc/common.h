@@ -1,0 +1,124 @@
+// Shared device/host helpers for the MI355X (gfx950) Tortoise engine.
+// Everything here targets CDNA4 directly: 64-lane waves, v_mfma_f32_16x16x32_{bf16,f16}.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+namespace tt {
+
+typedef __bf16 bf16;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <typename T> struct Vec;
+template <> struct Vec<bf16> {
+  typedef __attribute__((ext_vector_type(8))) __bf16 x8;
+  typedef __attribute__((ext_vector_type(4))) __bf16 x4;
+  typedef __attribute__((ext_vector_type(2))) __bf16 x2;
+};
+template <> struct Vec<f16> {
+  typedef __attribute__((ext_vector_type(8))) _Float16 x8;
+  typedef __attribute__((ext_vector_type(4))) _Float16 x4;
+  typedef __attribute__((ext_vector_type(2))) _Float16 x2;
+};
+
+// D(16x16 f32) += A(16x32) * B(32x16).  Lane l holds A[row = l&15][k = (l>>4)*8 .. +7],
+// B[k = (l>>4)*8 .. +7][col = l&15]; D lane l reg r = D[row = (l>>4)*4 + r][col = l&15].
+__device__ __forceinline__ f32x4 mfma16(Vec<bf16>::x8 a, Vec<bf16>::x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(Vec<f16>::x8 a, Vec<f16>::x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+template <typename T> __device__ __forceinline__ typename Vec<T>::x4 pack4(float a, float b, float c, float d) {
+  typename Vec<T>::x4 r;
+  r[0] = (T)a; r[1] = (T)b; r[2] = (T)c; r[3] = (T)d;
+  return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__device__ __forceinline__ float gelu_tanh(float x) {  // HF "gelu_new"
+  const float k = 0.7978845608028654f;
+  return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+enum Act { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_LRELU = 4 };
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case ACT_GELU_TANH: return gelu_tanh(v);
+    case ACT_GELU_ERF: return gelu_erf(v);
+    case ACT_SILU: return silu(v);
+    case ACT_LRELU: return v > 0.f ? v : v * slope;
+    default: return v;
+  }
+}
+
+// ---------------------------------------------------------------- host side
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define TT_CHECK_HIP(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      tt::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return -2;                                                                        \
+    }                                                                                   \
+  } while (0)
+
+#define TT_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      tt::set_error(__VA_ARGS__);        \
+      return -1;                         \
+    }                                    \
+  } while (0)
+
+#define TT_TRY(expr)          \
+  do {                        \
+    int _r = (expr);          \
+    if (_r != 0) return _r;   \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+enum DType { DT_BF16 = 0, DT_F16 = 1 };
+
+}  // namespace tt

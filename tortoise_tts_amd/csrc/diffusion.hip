@@ -1,0 +1,329 @@
+// Stage 2: DiffusionTts denoiser + SpacedDiffusion.p_sample_loop as an MI355X-native engine
+// (reference: tortoise/models/diffusion_decoder.py:232-322, tortoise/utils/diffusion.py:312-621).
+//
+// Layout: activations are token-major [batch][S][C] so every 1x1 conv is a plain GEMM and every k3
+// conv a 3-tap conv-GEMM (gemm.hip).  The conditioned and the conditioning-free evaluation of a
+// step run as batch rows 0/1 of ONE pass, so each weight matrix streams once per step instead of
+// twice (diffusion.py:341-342 calls the model twice).  Everything that depends only on the
+// timestep (time_embed MLP and all 16 ResBlock emb_layers) is evaluated for the whole schedule
+// in three GEMMs before the loop.  The sampler maths (CFG blend, learned-range variance, x0 clamp,
+// posterior mean, noise) is one fused kernel with no host round trip (the reference does a
+// .item() per step, diffusion.py:380).  Per-step scalars, the scale/shift rows and the noise slice
+// are all indexed by a device-side step counter, so one captured hipGraph replays every step.
+#include "runtime.h"
+#include "../../include/tortoise_mi355x.h"
+
+using namespace tt;
+
+static_assert(sizeof(PSampleStep) == sizeof(tt_diff_step), "PSampleStep must mirror tt_diff_step");
+
+struct tt_diff {
+  tt_diff_config cfg;
+  tt_diff_weights w;
+  std::vector<tt_attn_block> latent_attn, attn;
+  std::vector<tt_res_block> res;
+  int C, H, NR;  // NR = number of ResBlocks (3 + L + 3)
+  Arena arena;
+  StreamBridge sb;
+  int S = 0;
+  int rows_max = 0;
+  float* code_emb = nullptr;   // [2][S][C]: row 0 conditioned, row 1 unconditioned embedding broadcast
+  float* tmp_a = nullptr;      // [rows][C] f32 scratch
+  float* tmp_b = nullptr;
+  float* tmp_c = nullptr;
+  void* act = nullptr;         // [rows][C] T   GN/SiLU output (GEMM operand)
+  void* cat = nullptr;         // [rows][2C] T  [inp_block(x) | integrated code_emb]
+  void* q = nullptr; void* k = nullptr; void* vt = nullptr; void* att = nullptr;
+  float* gn_partial = nullptr;
+  void* lat_t = nullptr;       // [M][latent] T
+  int* ts_dev = nullptr;       // [steps]
+  float* temb_sin = nullptr;   // [steps][C]
+  void* temb_t = nullptr;      // [steps][C] T
+  void* temb_t2 = nullptr;     // [steps][C] T
+  float* temb_mid = nullptr;   // [steps][C]
+  float* ss_all = nullptr;     // [steps][NR][2C]
+  PSampleStep* steps_dev = nullptr;
+  int* slot = nullptr;         // device step counter
+  float* x = nullptr;          // [S][in]
+  void* x_t = nullptr;         // [2][S][in_pad] T
+  float* out = nullptr;        // [2][S][out]
+};
+
+static int run_gn(tt_diff* e, const float* x, int B, int S, const float* g, const float* b, const float* ss, bool ss_slotted,
+                  int act, void* out_t, int ldot, float* out_f32, hipStream_t s) {
+  GroupNormArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.B = B; a.S = S; a.C = e->C; a.gamma = g; a.beta = b; a.eps = 1e-5f;
+  a.scale_shift = ss; a.ss_batch_stride = 0; a.act = act;
+  if (ss && ss_slotted) { a.ss_slot = e->slot; a.ss_slot_stride = (size_t)e->NR * 2 * e->C; }
+  a.out_t = out_t; a.ldot = ldot; a.out_f32 = out_f32; a.ldo32 = e->C;
+  a.partial = e->gn_partial;
+  return groupnorm_launch(e->cfg.dtype, a, s);
+}
+
+// AttentionBlock (arch_util.py:80-123): out = in + proj(attn(qkv(GN(in))))
+static int run_attn_block(tt_diff* e, const tt_attn_block& w, const float* in, int B, int S, float* out_f32, void* out_t, int ldot,
+                          hipStream_t s) {
+  const int C = e->C, H = e->H, dt = e->cfg.dtype, M = B * S, n_pad = round_up(S, 32);
+  TT_TRY(run_gn(e, in, B, S, w.norm_g, w.norm_b, nullptr, false, ACT_NONE, e->act, C, nullptr, s));
+  GemmArgs g = gemm_args(e->act, C, w.w_qkv, C, M, 3 * C, C);
+  g.bias = w.b_qkv; g.seq_len = S; g.dmodel = C; g.heads = H; g.q = e->q; g.k = e->k; g.vt = e->vt; g.seq_pad = n_pad;
+  g.q_scale = 0.125f;  // (q * 64^-1/4) . (k * 64^-1/4)  ==  (q/8) . k   (arch_util.py:64-67)
+  TT_TRY(gemm_launch(dt, EPI_QKV_HEADS, g, s));
+  FlashArgs f;
+  memset(&f, 0, sizeof(f));
+  f.q = e->q; f.k = e->k; f.vt = e->vt; f.out = e->att; f.ldo = C; f.BH = B * H; f.heads = H; f.n = S; f.n_pad = n_pad;
+  f.relpos = w.relpos;
+  TT_TRY(flash_attention_launch(dt, f, s));
+  g = gemm_args(e->att, C, w.w_proj, C, M, C, C);
+  g.bias = w.b_proj; g.res = in; g.ldres = C; g.out_f32 = out_f32; g.ldo32 = C; g.out_t = out_t; g.ldot = ldot;
+  return gemm_launch(dt, EPI_STD, g, s);
+}
+
+// ResBlock (diffusion_decoder.py:60-120, use_scale_shift_norm, efficient_config, kernel 3).
+static int run_res_block(tt_diff* e, const tt_res_block& w, const float* ss, const float* in, int B, int S, float* out_f32,
+                         hipStream_t s) {
+  const int C = e->C, dt = e->cfg.dtype, M = B * S;
+  TT_TRY(run_gn(e, in, B, S, w.gn1_g, w.gn1_b, nullptr, false, ACT_SILU, e->act, C, nullptr, s));
+  GemmArgs g = gemm_args(e->act, C, w.w_in, C, M, C, C);
+  g.bias = w.b_in; g.out_f32 = e->tmp_c; g.ldo32 = C;
+  TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+  TT_TRY(run_gn(e, e->tmp_c, B, S, w.gn2_g, w.gn2_b, ss, true, ACT_SILU, e->act, C, nullptr, s));
+  g = gemm_args(e->act, C, w.w_out, 3 * C, M, C, 3 * C);
+  g.taps = 3; g.seq_len = S; g.bias = w.b_out; g.res = in; g.ldres = C; g.out_f32 = out_f32; g.ldo32 = C;
+  return gemm_launch(dt, EPI_STD, g, s);
+}
+
+// One denoiser evaluation on B batch rows (B = 2: conditioned + unconditioned); the schedule slot is *e->slot.
+static int diff_forward(tt_diff* e, int B, hipStream_t s) {
+  const int C = e->C, S = e->S, dt = e->cfg.dtype, M = B * S, L = e->cfg.num_layers;
+  const float* ss = e->ss_all;  // + *slot * NR*2C inside the GroupNorm kernel
+  // conditioning_timestep_integrator: 3 DiffusionLayers over the [cond | uncond] code embeddings
+  const float* cur = e->code_emb;
+  for (int i = 0; i < 3; ++i) {
+    TT_TRY(run_res_block(e, e->res[i], ss + (size_t)i * 2 * C, cur, B, S, e->tmp_a, s));
+    if (i < 2) {
+      TT_TRY(run_attn_block(e, e->attn[i], e->tmp_a, B, S, e->tmp_b, nullptr, 0, s));
+      cur = e->tmp_b;
+    } else {
+      // the last integrator layer writes straight into the right half of the concat operand
+      TT_TRY(run_attn_block(e, e->attn[i], e->tmp_a, B, S, nullptr, offset_t(e->cat, C), 2 * C, s));
+    }
+  }
+  // inp_block (k3, in_pad -> C) into the left half of the concat operand
+  GemmArgs g = gemm_args(e->x_t, e->cfg.in_pad, e->w.w_inp, 3 * e->cfg.in_pad, M, C, 3 * e->cfg.in_pad);
+  g.taps = 3; g.seq_len = S; g.bias = e->w.b_inp; g.out_t = e->cat; g.ldot = 2 * C;
+  TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+  g = gemm_args(e->cat, 2 * C, e->w.w_integ, 2 * C, M, C, 2 * C);
+  g.bias = e->w.b_integ; g.out_f32 = e->tmp_a; g.ldo32 = C;
+  TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+  float* hcur = e->tmp_a;
+  float* hoth = e->tmp_b;
+  for (int i = 0; i < L; ++i) {
+    TT_TRY(run_res_block(e, e->res[3 + i], ss + (size_t)(3 + i) * 2 * C, hcur, B, S, hoth, s));
+    TT_TRY(run_attn_block(e, e->attn[3 + i], hoth, B, S, hcur, nullptr, 0, s));
+  }
+  for (int i = 0; i < 3; ++i) {
+    TT_TRY(run_res_block(e, e->res[3 + L + i], ss + (size_t)(3 + L + i) * 2 * C, hcur, B, S, hoth, s));
+    float* t = hcur; hcur = hoth; hoth = t;
+  }
+  TT_TRY(run_gn(e, hcur, B, S, e->w.out_gn_g, e->w.out_gn_b, nullptr, false, ACT_SILU, e->act, C, nullptr, s));
+  g = gemm_args(e->act, C, e->w.w_final, 3 * C, M, e->cfg.out_channels, 3 * C);
+  g.taps = 3; g.seq_len = S; g.bias = e->w.b_final; g.out_f32 = e->out; g.ldo32 = e->cfg.out_channels;
+  return gemm_launch(dt, EPI_STD, g, s);
+}
+
+__global__ void timestep_embedding_kernel(const int* ts, float* out, int n, int dim) {
+  // diffusion_decoder.py:21-39: [cos(t * f_j) | sin(t * f_j)], f_j = exp(-ln(10000) * j / half)
+  const int half = dim / 2;
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n * half; f += gridDim.x * blockDim.x) {
+    const int i = f / half, j = f % half;
+    const float freq = expf(-logf(10000.f) * (float)j / (float)half);
+    const float a = (float)ts[i] * freq;
+    out[(size_t)i * dim + j] = cosf(a);
+    out[(size_t)i * dim + half + j] = sinf(a);
+  }
+}
+
+// time_embed MLP + every ResBlock's emb_layers for the n timesteps in e->ts_dev -> ss_all[0..n)
+static int diff_prepare_timesteps(tt_diff* e, int n, hipStream_t s) {
+  const int C = e->C, dt = e->cfg.dtype;
+  timestep_embedding_kernel<<<std::min(cdiv(n * C / 2, 256), 1024), 256, 0, s>>>(e->ts_dev, e->temb_sin, n, C);
+  TT_CHECK_HIP(hipGetLastError());
+  TT_TRY(cast_pad_launch(dt, e->temb_sin, C, e->temb_t, C, n, C, C, s));
+  GemmArgs g = gemm_args(e->temb_t, C, e->w.w_time1, C, n, C, C);
+  g.bias = e->w.b_time1; g.act = ACT_SILU; g.out_t = e->temb_t2; g.ldot = C;
+  TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+  g = gemm_args(e->temb_t2, C, e->w.w_time2, C, n, C, C);
+  g.bias = e->w.b_time2; g.out_f32 = e->temb_mid; g.ldo32 = C;
+  TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+  TT_TRY(silu_cast_launch(dt, e->temb_mid, e->temb_t, n * C, s));
+  const int N = e->NR * 2 * C;
+  g = gemm_args(e->temb_t, C, e->w.w_emb_all, C, n, N, C);
+  g.bias = e->w.b_emb_all; g.out_f32 = e->ss_all; g.ldo32 = N;
+  return gemm_launch(dt, EPI_STD, g, s);
+}
+
+extern "C" {
+
+int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff** out) {
+  TT_REQUIRE(cfg && w && out, "tt_diff_create: null argument");
+  TT_REQUIRE(cfg->heads * 64 == cfg->channels, "tt_diff_create: head_dim must be 64");
+  TT_REQUIRE(cfg->in_pad % 64 == 0 && cfg->in_pad >= cfg->in_channels && cfg->latent_channels % 64 == 0, "tt_diff_create: in_pad/latent must be multiples of 64");
+  TT_REQUIRE(cfg->max_steps >= 1 && cfg->max_seq >= 1 && cfg->max_codes >= 1, "tt_diff_create: bad capacity");
+  tt_diff* e = new tt_diff();
+  e->cfg = *cfg;
+  e->w = *w;
+  e->C = cfg->channels; e->H = cfg->heads; e->NR = 3 + cfg->num_layers + 3;
+  e->latent_attn.assign(w->latent_attn_host, w->latent_attn_host + 4);
+  e->attn.assign(w->attn_host, w->attn_host + 3 + cfg->num_layers);
+  e->res.assign(w->res_host, w->res_host + e->NR);
+  const int C = e->C;
+  e->rows_max = std::max(2 * cfg->max_seq, cfg->max_codes);
+  const size_t rows = (size_t)e->rows_max + 64;
+  int rc = e->sb.init();
+  if (!rc) rc = e->arena.alloc_t(&e->code_emb, (size_t)2 * cfg->max_seq * C);
+  if (!rc) rc = e->arena.alloc_t(&e->tmp_a, rows * C);
+  if (!rc) rc = e->arena.alloc_t(&e->tmp_b, rows * C);
+  if (!rc) rc = e->arena.alloc_t(&e->tmp_c, rows * C);
+  if (!rc) rc = e->arena.alloc(&e->act, rows * C * 2);
+  if (!rc) rc = e->arena.alloc(&e->cat, rows * 2 * C * 2);
+  if (!rc) rc = e->arena.alloc(&e->q, rows * C * 2);
+  if (!rc) rc = e->arena.alloc(&e->k, rows * C * 2);
+  if (!rc) rc = e->arena.alloc(&e->vt, (size_t)C * (rows + 64) * 2);
+  if (!rc) rc = e->arena.alloc(&e->att, rows * C * 2);
+  if (!rc) rc = e->arena.alloc_t(&e->gn_partial, groupnorm_partial_floats(2, e->rows_max) + 64);
+  if (!rc) rc = e->arena.alloc(&e->lat_t, ((size_t)cfg->max_codes + 8) * cfg->latent_channels * 2);
+  if (!rc) rc = e->arena.alloc_t(&e->ts_dev, cfg->max_steps);
+  if (!rc) rc = e->arena.alloc_t(&e->temb_sin, (size_t)cfg->max_steps * C);
+  if (!rc) rc = e->arena.alloc(&e->temb_t, (size_t)cfg->max_steps * C * 2);
+  if (!rc) rc = e->arena.alloc(&e->temb_t2, (size_t)cfg->max_steps * C * 2);
+  if (!rc) rc = e->arena.alloc_t(&e->temb_mid, (size_t)cfg->max_steps * C);
+  if (!rc) rc = e->arena.alloc_t(&e->ss_all, (size_t)cfg->max_steps * e->NR * 2 * C);
+  if (!rc) rc = e->arena.alloc_t(&e->steps_dev, cfg->max_steps);
+  if (!rc) rc = e->arena.alloc_t(&e->slot, 4);
+  if (!rc) rc = e->arena.alloc_t(&e->x, (size_t)cfg->max_seq * cfg->in_channels);
+  if (!rc) rc = e->arena.alloc(&e->x_t, ((size_t)2 * cfg->max_seq + 8) * cfg->in_pad * 2);
+  if (!rc) rc = e->arena.alloc_t(&e->out, (size_t)2 * cfg->max_seq * cfg->out_channels);
+  if (rc) {
+    tt_diff_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return 0;
+}
+
+void tt_diff_destroy(tt_diff* e) {
+  if (!e) return;
+  (void)hipDeviceSynchronize();
+  e->arena.release();
+  e->sb.destroy();
+  delete e;
+}
+
+int tt_diff_condition(tt_diff* e, const float* latents, int M, const float* cond, const int* interp_idx, int S, void* stream) {
+  TT_REQUIRE(e && latents && cond && interp_idx, "tt_diff_condition: null argument");
+  TT_REQUIRE(M >= 1 && M <= e->cfg.max_codes && S >= 1 && S <= e->cfg.max_seq, "tt_diff_condition: M=%d S=%d exceed capacity (%d, %d)", M, S, e->cfg.max_codes, e->cfg.max_seq);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  const int C = e->C, dt = e->cfg.dtype, LC = e->cfg.latent_channels;
+  e->S = S;
+  TT_TRY(cast_pad_launch(dt, latents, LC, e->lat_t, LC, M, LC, LC, s));
+  GemmArgs g = gemm_args(e->lat_t, LC, e->w.w_latent_conv, 3 * LC, M, C, 3 * LC);
+  g.taps = 3; g.seq_len = M; g.bias = e->w.b_latent_conv; g.out_f32 = e->tmp_a; g.ldo32 = C;
+  TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+  float* cur = e->tmp_a;
+  float* oth = e->tmp_b;
+  for (int i = 0; i < 4; ++i) {
+    TT_TRY(run_attn_block(e, e->latent_attn[i], cur, 1, M, oth, nullptr, 0, s));
+    float* t = cur; cur = oth; oth = t;
+  }
+  // code_norm(h) * (1 + cond_scale) + cond_shift   (diffusion_decoder.py:249-250)
+  TT_TRY(run_gn(e, cur, 1, M, e->w.code_norm_g, e->w.code_norm_b, cond, false, ACT_NONE, nullptr, 0, oth, s));
+  TT_TRY(gather_rows_launch(oth, interp_idx, e->code_emb, S, C, s));                 // F.interpolate(nearest)
+  TT_TRY(broadcast_rows_launch(e->w.uncond_emb, e->code_emb + (size_t)S * C, S, C, s));  // unconditioned_embedding.repeat
+  return e->sb.leave(us);
+}
+
+int tt_diff_get_code_emb(tt_diff* e, float* dst, void* stream) {
+  TT_REQUIRE(e && dst && e->S > 0, "tt_diff_get_code_emb: no conditioning");
+  hipStream_t us = (hipStream_t)stream;
+  TT_TRY(e->sb.enter(us));
+  TT_CHECK_HIP(hipMemcpyAsync(dst, e->code_emb, (size_t)e->S * e->C * sizeof(float), hipMemcpyDeviceToDevice, e->sb.own));
+  return e->sb.leave(us);
+}
+
+int tt_diff_forward(tt_diff* e, const float* x, int timestep, int cond_free, float* out, void* stream) {
+  TT_REQUIRE(e && x && out && e->S > 0, "tt_diff_forward: call tt_diff_condition first");
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  const int S = e->S, IC = e->cfg.in_channels, IP = e->cfg.in_pad;
+  TT_CHECK_HIP(hipMemcpyAsync(e->ts_dev, &timestep, sizeof(int), hipMemcpyHostToDevice, s));
+  TT_CHECK_HIP(hipStreamSynchronize(s));  // `timestep` lives on the caller's stack
+  TT_CHECK_HIP(hipMemsetAsync(e->slot, 0, sizeof(int), s));
+  TT_TRY(diff_prepare_timesteps(e, 1, s));
+  TT_TRY(cast_pad_launch(e->cfg.dtype, x, IC, e->x_t, IP, S, IC, IP, s));
+  TT_TRY(cast_pad_launch(e->cfg.dtype, x, IC, offset_t(e->x_t, (size_t)S * IP), IP, S, IC, IP, s));
+  const int B = cond_free ? 2 : 1;
+  TT_TRY(diff_forward(e, B, s));
+  TT_CHECK_HIP(hipMemcpyAsync(out, e->out, (size_t)B * S * e->cfg.out_channels * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return e->sb.leave(us);
+}
+
+int tt_diff_sample(tt_diff* e, const float* x_T, const float* step_noise, const tt_diff_step* steps_host, int n_steps, int cond_free,
+                   float* mel_out, void* stream) {
+  TT_REQUIRE(e && x_T && steps_host && mel_out && e->S > 0, "tt_diff_sample: call tt_diff_condition first");
+  TT_REQUIRE(n_steps >= 1 && n_steps <= e->cfg.max_steps, "tt_diff_sample: %d steps exceed capacity %d", n_steps, e->cfg.max_steps);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  const int S = e->S, IC = e->cfg.in_channels, IP = e->cfg.in_pad, dt = e->cfg.dtype;
+  std::vector<int> ts(n_steps);
+  for (int i = 0; i < n_steps; ++i) ts[i] = steps_host[i].timestep;
+  TT_CHECK_HIP(hipMemcpyAsync(e->ts_dev, ts.data(), n_steps * sizeof(int), hipMemcpyHostToDevice, s));
+  TT_CHECK_HIP(hipMemcpyAsync(e->steps_dev, steps_host, n_steps * sizeof(tt_diff_step), hipMemcpyHostToDevice, s));
+  TT_CHECK_HIP(hipStreamSynchronize(s));  // host staging buffers may go away
+  TT_CHECK_HIP(hipMemsetAsync(e->slot, 0, sizeof(int), s));
+  TT_TRY(diff_prepare_timesteps(e, n_steps, s));
+  TT_TRY(transpose_launch(x_T, e->x, IC, S, s));  // [C][S] -> [S][C]
+  TT_TRY(cast_pad_launch(dt, e->x, IC, e->x_t, IP, S, IC, IP, s));
+  TT_TRY(cast_pad_launch(dt, e->x, IC, offset_t(e->x_t, (size_t)S * IP), IP, S, IC, IP, s));
+  const int B = cond_free ? 2 : 1;
+  PSampleArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.steps = e->steps_dev; pa.slot = e->slot; pa.x = e->x; pa.x_t = e->x_t; pa.cpad = IP; pa.out = e->out;
+  pa.has_uncond = cond_free ? 1 : 0; pa.noise = step_noise; pa.S = S; pa.C = IC;
+  pa.mel_out = mel_out;
+  pa.mel_scale = 2.3143386840820312f - (-11.512925148010254f);
+  pa.mel_shift = -11.512925148010254f;
+
+  auto one_step = [&]() -> int {
+    TT_TRY(diff_forward(e, B, s));
+    TT_TRY(psample_launch(dt, pa, s));
+    return slot_advance_launch(e->slot, s);
+  };
+  int rc = 0;
+  if (graphs_enabled() && n_steps > 2) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    TT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    rc = one_step();
+    hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (!rc && ce != hipSuccess) { set_error("tt_diff_sample: capture failed: %s", hipGetErrorString(ce)); rc = -2; }
+    if (!rc) {
+      ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (ce != hipSuccess) { set_error("tt_diff_sample: instantiate failed: %s", hipGetErrorString(ce)); rc = -2; }
+    }
+    for (int i = 0; i < n_steps && !rc; ++i) {
+      ce = hipGraphLaunch(exec, s);
+      if (ce != hipSuccess) { set_error("tt_diff_sample: hipGraphLaunch: %s", hipGetErrorString(ce)); rc = -2; }
+    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+  } else {
+    for (int i = 0; i < n_steps && !rc; ++i) rc = one_step();
+  }
+  TT_TRY(rc);
+  return e->sb.leave(us);
+}
+
+}  // extern "C"

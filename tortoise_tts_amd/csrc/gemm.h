@@ -1,0 +1,56 @@
+// MFMA GEMM / conv1d-as-GEMM for gfx950.  out[m][n] = epilogue(sum_k A[m][k] * W[n][k]).
+//
+// A is token-major ([rows][channels], K contiguous); W is [N][K] with K contiguous (the layout torch
+// Linear / Conv1d(k=1) already use; HF Conv1D weights are transposed once at pack time).  A conv1d
+// with `taps` taps over sequences of `seq_len` rows is the same GEMM with a virtual
+// K = taps * cin whose k-tile `tap` reads row s + tap - taps/2 (zero outside the sequence), so
+// the k3/k5 convolutions of DiffusionTts / KernelPredictor never materialise an im2col buffer.
+#pragma once
+#include "common.h"
+
+namespace tt {
+
+enum EpiKind { EPI_STD = 0, EPI_QKV_HEADS = 1, EPI_QKV_DECODE = 2 };
+
+struct GemmArgs {
+  // operands
+  const void* A;
+  int lda;  // elements between consecutive A rows
+  const void* W;
+  int ldw;  // elements between consecutive W rows (>= K)
+  int M, N, K;
+  int taps;     // 1 = plain GEMM
+  int seq_len;  // rows per sequence (conv boundary / head-layout epilogues)
+  int cin;      // K / taps
+  int splitk;   // >1: raw partial sums go to out_f32 + z * M * ldo32 (EPI_STD only)
+  // EPI_STD
+  const float* bias;
+  int act;
+  float slope;
+  const float* res;  // f32 residual, added after the activation
+  int ldres;
+  float* out_f32;
+  int ldo32;
+  void* out_t;  // T-typed copy of the result (operand of the next GEMM)
+  int ldot;
+  // EPI_QKV_HEADS: n -> (part = n / dmodel, head = (n % dmodel) / 64, d = n % 64), m -> (b, s)
+  int dmodel, heads;
+  void* q;        // [b*heads + h][seq_len][64]
+  void* k;        // same
+  void* v;        // same, may be null
+  void* vt;       // [b*heads + h][64][seq_pad], may be null
+  int seq_pad;
+  float q_scale;  // multiplies q (softmax scale folded into q)
+  // EPI_QKV_DECODE: m = sequence b; K/V appended at position *step of the per-sequence cache
+  const int* step;  // device int
+  void* qbuf;       // [M][dmodel]
+  void* kc;         // [b][h][8][tmax][8]  (16-byte dim chunks are key-major: coalesced lane-per-key reads)
+  void* vc;         // [b][h][tmax][64]
+  int tmax;
+};
+
+// dtype: DT_BF16 / DT_F16.  Returns 0 or a negative error (message via tt::last_error()).
+int gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t stream);
+int gemm_init();  // sets dynamic-LDS attributes; called once per process
+
+}  // namespace tt

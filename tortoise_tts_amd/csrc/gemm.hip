@@ -1,0 +1,325 @@
+// MFMA GEMM for gfx950 (see gemm.h).  256 threads = 4 waves in a 2x2 grid; each wave owns a
+// (BM/2)x(BN/2) sub-tile built from v_mfma_f32_16x16x32 fragments.  The MFMA is issued "swapped"
+// (W fragment as the A operand, activation fragment as B) so that a lane ends up holding four
+// consecutive output columns n..n+3 of one row m: epilogue stores are 16 B (f32) / 8 B (bf16).
+// Tiles move global -> registers -> LDS (double buffered, one barrier per 64-deep k-step); the
+// register stage is what lets the conv taps shift rows and zero-fill sequence edges for free.
+#include "gemm.h"
+
+namespace tt {
+
+constexpr int BK = 64;
+constexpr int BKP = BK + 8;  // LDS row pitch in elements: 144 B keeps 16-B alignment, staggers banks
+
+template <typename T>
+struct EpiStd {
+  __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4 v, int nvalid, int z) const {
+    if (g.splitk > 1) {
+      float* o = g.out_f32 + (size_t)z * g.M * g.ldo32 + (size_t)m * g.ldo32 + n;
+      if (nvalid == 4 && (g.ldo32 & 3) == 0) {
+        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        for (int i = 0; i < nvalid; ++i) o[i] = v[i];
+      }
+      return;
+    }
+    if (g.bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < nvalid) v[i] += g.bias[n + i];
+    }
+    if (g.act != ACT_NONE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], g.act, g.slope);
+    }
+    if (g.res) {
+      const float* r = g.res + (size_t)m * g.ldres + n;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < nvalid) v[i] += r[i];
+    }
+    if (g.out_f32) {
+      float* o = g.out_f32 + (size_t)m * g.ldo32 + n;
+      if (nvalid == 4 && (g.ldo32 & 3) == 0) {
+        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        for (int i = 0; i < nvalid; ++i) o[i] = v[i];
+      }
+    }
+    if (g.out_t) {
+      T* o = (T*)g.out_t + (size_t)m * g.ldot + n;
+      if (nvalid == 4 && (g.ldot & 3) == 0) {
+        *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
+      } else {
+        for (int i = 0; i < nvalid; ++i) o[i] = (T)v[i];
+      }
+    }
+  }
+};
+
+template <typename T>
+struct EpiQkvHeads {
+  __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4 v, int nvalid, int z) const {
+    // N == 3 * dmodel and dmodel % 64 == 0, so nvalid is always 4 here.
+    if (g.bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += g.bias[n + i];
+    }
+    const int part = n / g.dmodel;
+    const int c = n - part * g.dmodel;
+    const int h = c >> 6, d = c & 63;
+    const int b = m / g.seq_len, s = m - b * g.seq_len;
+    const size_t bh = (size_t)b * g.heads + h;
+    if (part == 0) {
+      T* o = (T*)g.q + (bh * g.seq_len + s) * 64 + d;
+      *(typename Vec<T>::x4*)o = pack4<T>(v[0] * g.q_scale, v[1] * g.q_scale, v[2] * g.q_scale, v[3] * g.q_scale);
+    } else if (part == 1) {
+      T* o = (T*)g.k + (bh * g.seq_len + s) * 64 + d;
+      *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
+    } else {
+      if (g.v) {
+        T* o = (T*)g.v + (bh * g.seq_len + s) * 64 + d;
+        *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
+      }
+      if (g.vt) {
+        T* o = (T*)g.vt + (bh * 64 + d) * g.seq_pad + s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[(size_t)i * g.seq_pad] = (T)v[i];
+      }
+    }
+  }
+};
+
+template <typename T>
+struct EpiQkvDecode {
+  __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4 v, int nvalid, int z) const {
+    if (g.bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += g.bias[n + i];
+    }
+    const int part = n / g.dmodel;
+    const int c = n - part * g.dmodel;
+    const int h = c >> 6, d = c & 63;
+    const int t = *g.step;
+    const size_t bh = (size_t)m * g.heads + h;
+    if (part == 0) {
+      T* o = (T*)g.qbuf + (size_t)m * g.dmodel + c;
+      *(typename Vec<T>::x4*)o = pack4<T>(v[0] * g.q_scale, v[1] * g.q_scale, v[2] * g.q_scale, v[3] * g.q_scale);
+    } else if (part == 1) {
+      T* o = (T*)g.kc + ((bh * 8 + (d >> 3)) * g.tmax + t) * 8 + (d & 7);
+      *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
+    } else {
+      T* o = (T*)g.vc + (bh * g.tmax + t) * 64 + d;
+      *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+  }
+};
+
+template <typename T, int BM, int BN, typename Epi>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  typedef typename Vec<T>::x8 x8;
+  constexpr int TM = BM / 2, TN = BN / 2;  // wave tile
+  constexpr int FM = TM / 16, FN = TN / 16;
+  constexpr int PA = BM / 32, PW = BN / 32;  // 32 rows of 128 B per 256-thread pass
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* As = (T*)smem_raw;                 // [2][BM][BKP]
+  T* Ws = As + 2 * BM * BKP;            // [2][BN][BKP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int z = blockIdx.z;
+  const int nk_total = g.K / BK;
+  const int kt_begin = (int)((long long)nk_total * z / g.splitk);
+  const int kt_end = (int)((long long)nk_total * (z + 1) / g.splitk);
+
+  const int lrow = tid >> 3;       // 0..31
+  const int lcol = (tid & 7) * 8;  // element offset inside the 64-wide k-tile
+  const T* A = (const T*)g.A;
+  const T* W = (const T*)g.W;
+
+  // per-pass source rows (conv taps shift them per k-tile)
+  int a_b[PA], a_s[PA];
+  bool a_ok[PA];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int m = m0 + lrow + 32 * p;
+    a_ok[p] = m < g.M;
+    if (g.taps > 1) {
+      a_b[p] = m / g.seq_len;
+      a_s[p] = m - a_b[p] * g.seq_len;
+    } else {
+      a_b[p] = 0;
+      a_s[p] = m;
+    }
+  }
+
+  x8 ra[PA], rw[PW];
+  const x8 zero8 = {};
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+    int tap = 0, kin = k0;
+    if (g.taps > 1) {
+      tap = k0 / g.cin;
+      kin = k0 - tap * g.cin;
+    }
+    const int shift = tap - (g.taps >> 1);
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      bool ok = a_ok[p];
+      size_t row;
+      if (g.taps > 1) {
+        const int s2 = a_s[p] + shift;
+        ok = ok && s2 >= 0 && s2 < g.seq_len;
+        row = (size_t)a_b[p] * g.seq_len + s2;
+      } else {
+        row = (size_t)a_s[p];
+      }
+      ra[p] = ok ? *(const x8*)(A + row * g.lda + kin + lcol) : zero8;
+    }
+#pragma unroll
+    for (int p = 0; p < PW; ++p) {
+      const int n = n0 + lrow + 32 * p;
+      rw[p] = n < g.N ? *(const x8*)(W + (size_t)n * g.ldw + k0 + lcol) : zero8;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    T* as = As + buf * BM * BKP;
+    T* ws = Ws + buf * BN * BKP;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) *(x8*)(as + (lrow + 32 * p) * BKP + lcol) = ra[p];
+#pragma unroll
+    for (int p = 0; p < PW; ++p) *(x8*)(ws + (lrow + 32 * p) * BKP + lcol) = rw[p];
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  if (kt_begin < kt_end) {
+    load_tile(kt_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = kt + 1 < kt_end;
+    if (more) load_tile(kt + 1);
+    const T* as = As + cur * BM * BKP + (wm * TM + fr) * BKP + fg * 8;
+    const T* ws = Ws + cur * BN * BKP + (wn * TN + fr) * BKP + fg * 8;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      x8 fa[FM], fw[FN];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) fa[j] = *(const x8*)(as + j * 16 * BKP + ks * 32);
+#pragma unroll
+      for (int i = 0; i < FN; ++i) fw[i] = *(const x8*)(ws + i * 16 * BKP + ks * 32);
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  Epi epi;
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int n = n0 + wn * TN + i * 16 + fg * 4;
+    if (n >= g.N) continue;
+    const int nvalid = g.N - n >= 4 ? 4 : g.N - n;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = m0 + wm * TM + j * 16 + fr;
+      if (m < g.M) epi(g, m, n, acc[i][j], nvalid, z);
+    }
+  }
+}
+
+template <int BM, int BN>
+constexpr int smem_bytes() {
+  return 2 * (BM + BN) * BKP * 2;
+}
+
+template <typename T, int BM, int BN, typename Epi>
+static int launch_one(const GemmArgs& a, hipStream_t stream) {
+  dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), a.splitk);
+  constexpr int smem = smem_bytes<BM, BN>();
+  gemm_kernel<T, BM, BN, Epi><<<grid, dim3(256), smem, stream>>>(a);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T, typename Epi>
+static int launch_tiles(const GemmArgs& a, hipStream_t stream) {
+  // Tile choice: the chip has 256 CUs.  Prefer the largest tile that still yields >= ~200 blocks.
+  const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk;
+  const long b12864 = (long)cdiv(a.M, 128) * cdiv(a.N, 64) * a.splitk;
+  if (a.M > 64 && b128 >= 200) return launch_one<T, 128, 128, Epi>(a, stream);
+  if (a.M > 64 && b12864 >= 160) return launch_one<T, 128, 64, Epi>(a, stream);
+  return launch_one<T, 64, 64, Epi>(a, stream);
+}
+
+template <typename T>
+static int launch_epi(int epi, const GemmArgs& a, hipStream_t stream) {
+  switch (epi) {
+    case EPI_STD: return launch_tiles<T, EpiStd<T>>(a, stream);
+    case EPI_QKV_HEADS: return launch_tiles<T, EpiQkvHeads<T>>(a, stream);
+    case EPI_QKV_DECODE: return launch_tiles<T, EpiQkvDecode<T>>(a, stream);
+  }
+  set_error("gemm: unknown epilogue %d", epi);
+  return -1;
+}
+
+int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
+  GemmArgs a = a0;
+  if (a.taps < 1) a.taps = 1;
+  if (a.splitk < 1) a.splitk = 1;
+  a.cin = a.K / a.taps;
+  TT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+  TT_REQUIRE(a.K % BK == 0 && a.cin % BK == 0, "gemm: K=%d (taps=%d) must be a multiple of %d per tap", a.K, a.taps, BK);
+  TT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda=%d / ldw=%d must be multiples of 8 elements", a.lda, a.ldw);
+  TT_REQUIRE(a.splitk == 1 || (epi == EPI_STD && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
+  TT_REQUIRE(a.splitk <= a.K / BK, "gemm: splitk=%d exceeds the %d k-tiles", a.splitk, a.K / BK);
+  if (epi != EPI_STD) {
+    TT_REQUIRE(a.dmodel % 64 == 0 && a.N == 3 * a.dmodel && a.heads * 64 == a.dmodel, "gemm: qkv epilogue needs N == 3*dmodel, head_dim 64");
+  }
+  if (a.taps > 1 || epi == EPI_QKV_HEADS) TT_REQUIRE(a.seq_len > 0 && a.M % a.seq_len == 0, "gemm: M=%d is not a whole number of sequences of %d", a.M, a.seq_len);
+  if (dtype == DT_BF16) return launch_epi<bf16>(epi, a, stream);
+  if (dtype == DT_F16) return launch_epi<f16>(epi, a, stream);
+  set_error("gemm: unknown dtype %d", dtype);
+  return -1;
+}
+
+template <typename T, int BM, int BN, typename Epi>
+static int set_attr_one() {
+  const void* fn = (const void*)gemm_kernel<T, BM, BN, Epi>;
+  TT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN>()));
+  return 0;
+}
+template <typename T, typename Epi>
+static int set_attr() {
+  TT_TRY((set_attr_one<T, 128, 128, Epi>()));
+  TT_TRY((set_attr_one<T, 128, 64, Epi>()));
+  TT_TRY((set_attr_one<T, 64, 64, Epi>()));
+  return 0;
+}
+
+int gemm_init() {
+  TT_TRY((set_attr<bf16, EpiStd<bf16>>()));
+  TT_TRY((set_attr<bf16, EpiQkvHeads<bf16>>()));
+  TT_TRY((set_attr<bf16, EpiQkvDecode<bf16>>()));
+  TT_TRY((set_attr<f16, EpiStd<f16>>()));
+  TT_TRY((set_attr<f16, EpiQkvHeads<f16>>()));
+  TT_TRY((set_attr<f16, EpiQkvDecode<f16>>()));
+  return 0;
+}
+
+}  // namespace tt

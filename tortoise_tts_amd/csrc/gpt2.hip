@@ -1,0 +1,369 @@
+// Stage 1: UnifiedVoice's GPT-2 trunk (30 x 1024 x 16 heads) as an MI355X-native engine.
+//   * prefill:   every candidate of an utterance shares the same [cond | text | start] prefix, so it is
+//                evaluated once (M = P+1 rows) and its K/V are shared by all sequences
+//                (the reference recomputes it B times: autoregressive.py:134-144 + repeat_interleave).
+//   * decode:    KV-cached step for B sequences; K/V appended by the QKV GEMM epilogue; projections
+//                use split-K slabs that the following LayerNorm kernel folds into the residual stream
+//                (deterministic, no atomics); sampling on device; whole step replayed from one hipGraph.
+//   * latents:   teacher-forced full pass for the CLVP winners (autoregressive.py:454-506).
+#include "runtime.h"
+#include "../../include/tortoise_mi355x.h"
+
+using namespace tt;
+
+struct tt_ar {
+  tt_ar_config cfg;
+  tt_ar_weights w;
+  std::vector<tt_gpt_layer> L;
+  int D, H, V;
+  Arena arena;
+  StreamBridge sb;
+  // shared prefix cache [layers][H][P1][64] (row-major) and per-sequence cache
+  void* kp = nullptr; void* vp = nullptr;
+  void* kc = nullptr; void* vc = nullptr;
+  size_t prefix_layer_elems = 0, gen_layer_elems = 0;
+  int tmax = 0;
+  // activations
+  float* x = nullptr;      // [rows][D] residual stream
+  void* h = nullptr;       // [rows][D]  T
+  void* ff = nullptr;      // [rows][4D] T
+  void* attn = nullptr;    // [rows][D]  T
+  void* q = nullptr;       // full pass: [BH][n][64]; decode: [B][D]
+  void* kfull = nullptr;   // full pass scratch keys
+  void* vt = nullptr;      // full pass V^T [BH][64][n_pad]
+  float* slabs = nullptr;  // split-K partials [MAX_SPLIT][max_batch][D]
+  float* logits = nullptr; // [max_batch][V]
+  int* state = nullptr; unsigned* seen = nullptr; int* unfinished = nullptr; int* unfinished_count = nullptr;
+  int* next_tok = nullptr;
+  int* count_host = nullptr;  // pinned
+  int max_rows = 0;
+  int P1 = 0;      // current prefix length (incl. start token)
+  int B = 0;       // current batch
+  int logits_rows = 0;
+};
+
+static const int MAX_SPLIT = 8;
+
+static int ar_rownorm(tt_ar* e, float* x, int M, const float* g1, const float* b1, const float* g2, const float* b2,
+                      const float* add_bias, int nslab, int slab_rows, hipStream_t s) {
+  RowNormArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.ldx = e->D; a.M = M; a.D = e->D;
+  a.add_bias = add_bias;
+  a.add_slabs = nslab ? e->slabs : nullptr;
+  a.nslab = nslab; a.slab_stride = (size_t)slab_rows * e->D; a.ldslab = e->D;
+  a.write_x = (add_bias || nslab) ? 1 : 0;
+  a.mode = NORM_LAYER;
+  a.g1 = g1; a.b1 = b1; a.eps1 = 1e-5f;
+  a.g2 = g2; a.b2 = b2; a.eps2 = 1e-5f;
+  a.out_t = e->h; a.ldot = e->D;
+  return rownorm_launch(e->cfg.dtype, a, s);
+}
+
+// GPT2Model.forward over full sequences (causal), in place on e->x [B*n][D].
+static int gpt_trunk_full(tt_ar* e, int B, int n, bool to_prefix, hipStream_t s) {
+  const int D = e->D, H = e->H, M = B * n, dt = e->cfg.dtype;
+  const int n_pad = round_up(n, 32);
+  for (int l = 0; l < e->cfg.layers; ++l) {
+    const tt_gpt_layer& w = e->L[l];
+    TT_TRY(ar_rownorm(e, e->x, M, w.ln1_g, w.ln1_b, nullptr, nullptr, nullptr, 0, 0, s));
+    GemmArgs g = gemm_args(e->h, D, w.w_qkv, D, M, 3 * D, D);
+    g.bias = w.b_qkv; g.seq_len = n; g.dmodel = D; g.heads = H;
+    g.q = e->q;
+    g.k = to_prefix ? offset_t(e->kp, (size_t)l * e->prefix_layer_elems) : e->kfull;
+    g.v = to_prefix ? offset_t(e->vp, (size_t)l * e->prefix_layer_elems) : nullptr;
+    g.vt = e->vt; g.seq_pad = n_pad; g.q_scale = 0.125f;
+    TT_TRY(gemm_launch(dt, EPI_QKV_HEADS, g, s));
+    FlashArgs f;
+    memset(&f, 0, sizeof(f));
+    f.q = e->q; f.k = g.k; f.vt = e->vt; f.out = e->attn; f.ldo = D;
+    f.BH = B * H; f.heads = H; f.n = n; f.n_pad = n_pad; f.causal = 1;
+    TT_TRY(flash_attention_launch(dt, f, s));
+    g = gemm_args(e->attn, D, w.w_proj, D, M, D, D);
+    g.bias = w.b_proj; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
+    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+    TT_TRY(ar_rownorm(e, e->x, M, w.ln2_g, w.ln2_b, nullptr, nullptr, nullptr, 0, 0, s));
+    g = gemm_args(e->h, D, w.w_fc, D, M, 4 * D, D);
+    g.bias = w.b_fc; g.act = ACT_GELU_TANH; g.out_t = e->ff; g.ldot = 4 * D;
+    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+    g = gemm_args(e->ff, 4 * D, w.w_proj2, 4 * D, M, D, 4 * D);
+    g.bias = w.b_proj2; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
+    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+  }
+  return 0;
+}
+
+static int pick_split(int B, int N, int K) {
+  const int tiles = cdiv(B, 64) * cdiv(N, 64);
+  int sk = 512 / (tiles > 0 ? tiles : 1);
+  const int nk = K / 64;
+  if (sk > MAX_SPLIT) sk = MAX_SPLIT;
+  if (sk > nk) sk = nk;
+  if (sk < 1) sk = 1;
+  return sk;
+}
+
+// lm_head = Sequential(final_norm, mel_head) applied to ln_f(x) (autoregressive.py:42, 174)
+static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, hipStream_t s) {
+  TT_TRY(ar_rownorm(e, x, M, e->w.lnf_g, e->w.lnf_b, e->w.final_norm_g, e->w.final_norm_b, add_bias, nslab, e->B, s));
+  GemmArgs g = gemm_args(e->h, e->D, e->w.w_mel_head, e->D, M, e->V, e->D);
+  g.bias = e->w.b_mel_head; g.out_f32 = e->logits; g.ldo32 = e->V;
+  TT_TRY(gemm_launch(e->cfg.dtype, EPI_STD, g, s));
+  e->logits_rows = M;
+  return 0;
+}
+
+// One KV-cached decode step for e->B sequences; the fed tokens are in e->next_tok.
+static int decode_step_enqueue(tt_ar* e, hipStream_t s) {
+  const int D = e->D, H = e->H, B = e->B, dt = e->cfg.dtype;
+  TT_TRY(ar_embed_launch(e->next_tok, e->state, e->w.mel_emb, e->w.mel_pos, e->x, B, D, s));
+  const float* pend_bias = nullptr;
+  int pend_slabs = 0;
+  for (int l = 0; l < e->cfg.layers; ++l) {
+    const tt_gpt_layer& w = e->L[l];
+    TT_TRY(ar_rownorm(e, e->x, B, w.ln1_g, w.ln1_b, nullptr, nullptr, pend_bias, pend_slabs, B, s));
+    GemmArgs g = gemm_args(e->h, D, w.w_qkv, D, B, 3 * D, D);
+    g.bias = w.b_qkv; g.dmodel = D; g.heads = H; g.q_scale = 0.125f;
+    g.step = e->state + 1; g.qbuf = e->q;
+    g.kc = offset_t(e->kc, (size_t)l * e->gen_layer_elems);
+    g.vc = offset_t(e->vc, (size_t)l * e->gen_layer_elems);
+    g.tmax = e->tmax;
+    TT_TRY(gemm_launch(dt, EPI_QKV_DECODE, g, s));
+    DecodeAttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = e->q;
+    a.kp = offset_t(e->kp, (size_t)l * e->prefix_layer_elems);
+    a.vp = offset_t(e->vp, (size_t)l * e->prefix_layer_elems);
+    a.P1 = e->P1; a.kc = g.kc; a.vc = g.vc; a.tmax = e->tmax; a.step = e->state + 1;
+    a.out = e->attn; a.B = B; a.heads = H;
+    TT_TRY(decode_attention_launch(dt, a, s));
+    int sk = pick_split(B, D, D);
+    g = gemm_args(e->attn, D, w.w_proj, D, B, D, D);
+    g.splitk = sk; g.out_f32 = e->slabs; g.ldo32 = D;
+    if (sk == 1) { g.bias = nullptr; }
+    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+    TT_TRY(ar_rownorm(e, e->x, B, w.ln2_g, w.ln2_b, nullptr, nullptr, w.b_proj, sk, B, s));
+    g = gemm_args(e->h, D, w.w_fc, D, B, 4 * D, D);
+    g.bias = w.b_fc; g.act = ACT_GELU_TANH; g.out_t = e->ff; g.ldot = 4 * D;
+    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+    sk = pick_split(B, D, 4 * D);
+    g = gemm_args(e->ff, 4 * D, w.w_proj2, 4 * D, B, D, 4 * D);
+    g.splitk = sk; g.out_f32 = e->slabs; g.ldo32 = D;
+    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+    pend_bias = w.b_proj2;
+    pend_slabs = sk;
+  }
+  return ar_head(e, e->x, B, pend_bias, pend_slabs, s);
+}
+
+extern "C" {
+
+int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
+  TT_REQUIRE(cfg && w && out, "tt_ar_create: null argument");
+  TT_REQUIRE(cfg->heads * 64 == cfg->model_dim, "tt_ar_create: head_dim must be 64 (model_dim=%d heads=%d)", cfg->model_dim, cfg->heads);
+  TT_REQUIRE(cfg->model_dim % 64 == 0 && cfg->model_dim <= 4096, "tt_ar_create: unsupported model_dim %d", cfg->model_dim);
+  TT_REQUIRE(cfg->max_batch > 0 && cfg->max_prefix > 1 && cfg->max_new_tokens > 0, "tt_ar_create: bad capacity");
+  TT_REQUIRE(cfg->vocab <= 10240, "tt_ar_create: vocab %d exceeds the sampler's 10240 limit", cfg->vocab);
+  tt_ar* e = new tt_ar();
+  e->cfg = *cfg;
+  e->w = *w;
+  e->L.assign(w->layers_host, w->layers_host + cfg->layers);
+  e->D = cfg->model_dim; e->H = cfg->heads; e->V = cfg->vocab;
+  e->tmax = cfg->max_new_tokens;
+  const int D = e->D, H = e->H;
+  int rc = e->sb.init();
+  e->max_rows = std::max(std::max(cfg->max_prefix, cfg->max_full_rows), cfg->max_batch);
+  const size_t rows = (size_t)e->max_rows + 64;
+  e->prefix_layer_elems = (size_t)H * cfg->max_prefix * 64;
+  e->gen_layer_elems = (size_t)cfg->max_batch * H * e->tmax * 64;
+  const int npad_max = round_up(e->max_rows, 32) + 32;
+  if (!rc) rc = e->arena.alloc(&e->kp, (e->prefix_layer_elems * cfg->layers + 4096) * 2);
+  if (!rc) rc = e->arena.alloc(&e->vp, (e->prefix_layer_elems * cfg->layers + 4096) * 2);
+  if (!rc) rc = e->arena.alloc(&e->kc, (e->gen_layer_elems * cfg->layers + 4096) * 2);
+  if (!rc) rc = e->arena.alloc(&e->vc, (e->gen_layer_elems * cfg->layers + 4096) * 2);
+  if (!rc) rc = e->arena.alloc_t(&e->x, rows * D);
+  if (!rc) rc = e->arena.alloc(&e->h, rows * D * 2);
+  if (!rc) rc = e->arena.alloc(&e->ff, rows * 4 * D * 2);
+  if (!rc) rc = e->arena.alloc(&e->attn, rows * D * 2);
+  if (!rc) rc = e->arena.alloc(&e->q, rows * D * 2);
+  if (!rc) rc = e->arena.alloc(&e->kfull, rows * D * 2);
+  // V^T scratch: per (batch, head) 64 rows of n_pad keys; total keys <= max_rows (+ padding per sequence)
+  if (!rc) rc = e->arena.alloc(&e->vt, ((size_t)H * 64 * ((size_t)npad_max + 32 * (size_t)cfg->max_batch)) * 2);
+  if (!rc) rc = e->arena.alloc_t(&e->slabs, (size_t)MAX_SPLIT * cfg->max_batch * D);
+  if (!rc) rc = e->arena.alloc_t(&e->logits, (size_t)cfg->max_batch * e->V);
+  if (!rc) rc = e->arena.alloc_t(&e->state, 4);
+  if (!rc) rc = e->arena.alloc_t(&e->seen, (size_t)cfg->max_batch * ((e->V + 31) / 32));
+  if (!rc) rc = e->arena.alloc_t(&e->unfinished, cfg->max_batch);
+  if (!rc) rc = e->arena.alloc_t(&e->unfinished_count, e->tmax + 8);
+  if (!rc) rc = e->arena.alloc_t(&e->next_tok, cfg->max_batch);
+  if (!rc && hipHostMalloc((void**)&e->count_host, (e->tmax + 8) * sizeof(int)) != hipSuccess) {
+    set_error("tt_ar_create: hipHostMalloc failed");
+    rc = -2;
+  }
+  if (rc) {
+    tt_ar_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return 0;
+}
+
+void tt_ar_destroy(tt_ar* e) {
+  if (!e) return;
+  (void)hipDeviceSynchronize();
+  if (e->count_host) (void)hipHostFree(e->count_host);
+  e->arena.release();
+  e->sb.destroy();
+  delete e;
+}
+
+int tt_ar_prefill(tt_ar* e, const float* prefix_emb, int P, void* stream) {
+  TT_REQUIRE(e && prefix_emb, "tt_ar_prefill: null argument");
+  TT_REQUIRE(P >= 1 && P + 1 <= e->cfg.max_prefix, "tt_ar_prefill: prefix of %d rows exceeds capacity %d", P + 1, e->cfg.max_prefix);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  const int D = e->D;
+  e->P1 = P + 1;
+  e->prefix_layer_elems = (size_t)e->H * e->P1 * 64;  // dense per-layer stride for this prefix length
+  TT_CHECK_HIP(hipMemcpyAsync(e->x, prefix_emb, (size_t)P * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // start-token row: mel_embedding[start] + mel_pos_embedding[0]  (autoregressive.py:137-141)
+  {
+    RowNormArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = e->x + (size_t)P * D; a.ldx = D; a.M = 1; a.D = D;
+    a.x_in = e->w.mel_emb + (size_t)e->cfg.start_mel_token * D; a.ldxin = D;
+    a.add_bias = e->w.mel_pos;  // row 0
+    a.write_x = 1; a.mode = NORM_NONE;
+    TT_TRY(rownorm_launch(e->cfg.dtype, a, s));
+  }
+  TT_TRY(gpt_trunk_full(e, 1, e->P1, true, s));
+  const int B_saved = e->B;
+  e->B = 1;
+  int rc = ar_head(e, e->x + (size_t)P * D, 1, nullptr, 0, s);
+  e->B = B_saved;
+  TT_TRY(rc);
+  return e->sb.leave(us);
+}
+
+int tt_ar_get_logits(tt_ar* e, float* dst, int rows, void* stream) {
+  TT_REQUIRE(e && dst && rows >= 1 && rows <= e->logits_rows, "tt_ar_get_logits: %d rows requested, %d available", rows, e ? e->logits_rows : 0);
+  hipStream_t us = (hipStream_t)stream;
+  TT_TRY(e->sb.enter(us));
+  TT_CHECK_HIP(hipMemcpyAsync(dst, e->logits, (size_t)rows * e->V * sizeof(float), hipMemcpyDeviceToDevice, e->sb.own));
+  return e->sb.leave(us);
+}
+
+int tt_ar_begin(tt_ar* e, int B, void* stream) {
+  TT_REQUIRE(e && B >= 1 && B <= e->cfg.max_batch, "tt_ar_begin: batch %d exceeds capacity", B);
+  TT_REQUIRE(e->P1 > 0, "tt_ar_begin: call tt_ar_prefill first");
+  hipStream_t us = (hipStream_t)stream;
+  TT_TRY(e->sb.enter(us));
+  e->B = B;
+  TT_TRY(ar_begin_launch(e->state, e->seen, e->unfinished, e->unfinished_count, B, e->V, e->tmax + 8, e->cfg.start_mel_token, e->sb.own));
+  return e->sb.leave(us);
+}
+
+int tt_ar_decode_step(tt_ar* e, const int* tokens, void* stream) {
+  TT_REQUIRE(e && tokens && e->B > 0, "tt_ar_decode_step: call tt_ar_begin first");
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  TT_CHECK_HIP(hipMemcpyAsync(e->next_tok, tokens, (size_t)e->B * sizeof(int), hipMemcpyDeviceToDevice, s));
+  TT_TRY(ar_state_advance_launch(e->state, s));  // state[1] = slot of the token being fed
+  TT_TRY(decode_step_enqueue(e, s));
+  return e->sb.leave(us);
+}
+
+int tt_ar_generate(tt_ar* e, int B, int max_new, const tt_sampling* sp, int* codes, int* n_steps_host, void* stream) {
+  TT_REQUIRE(e && sp && codes, "tt_ar_generate: null argument");
+  TT_REQUIRE(B >= 1 && B <= e->cfg.max_batch, "tt_ar_generate: batch %d exceeds capacity %d", B, e->cfg.max_batch);
+  TT_REQUIRE(max_new >= 1 && max_new <= e->tmax, "tt_ar_generate: max_new %d exceeds capacity %d", max_new, e->tmax);
+  TT_REQUIRE(max_new + 1 < e->cfg.mel_pos_len, "tt_ar_generate: max_new %d exceeds the mel position table", max_new);
+  TT_REQUIRE(e->P1 > 0, "tt_ar_generate: call tt_ar_prefill first");
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  e->B = B;
+  TT_TRY(ar_begin_launch(e->state, e->seen, e->unfinished, e->unfinished_count, B, e->V, e->tmax + 8, e->cfg.start_mel_token, s));
+  TT_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)codes, e->cfg.stop_mel_token, (size_t)B * max_new, s));
+  SampleArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.B = B; sa.V = e->V; sa.seen = e->seen;
+  sa.rep_penalty = sp->repetition_penalty; sa.temperature = sp->temperature; sa.top_p = sp->top_p; sa.top_k = sp->top_k;
+  sa.exp_noise = sp->exp_noise; sa.seed = sp->seed; sa.row_offset = sp->row_offset;
+  sa.state = e->state; sa.unfinished = e->unfinished; sa.stop_token = e->cfg.stop_mel_token;
+  sa.codes = codes; sa.ldcodes = max_new; sa.next_tok = e->next_tok; sa.unfinished_count = e->unfinished_count;
+  // token 0: every row samples from the shared prefill logits
+  sa.logits = e->logits; sa.ldl = 0;
+  TT_REQUIRE(e->logits_rows >= 1, "tt_ar_generate: no prefill logits");
+  TT_TRY(sample_launch(sa, s));
+  TT_TRY(ar_state_advance_launch(e->state, s));
+  sa.ldl = e->V;
+
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  const bool use_graph = graphs_enabled() && max_new > 2;
+  int rc = 0;
+  if (use_graph) {
+    TT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    rc = decode_step_enqueue(e, s);
+    if (!rc) rc = sample_launch(sa, s);
+    if (!rc) rc = ar_state_advance_launch(e->state, s);
+    hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (rc) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    TT_CHECK_HIP(ce);
+    TT_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  }
+  int steps_done = 1;
+  bool finished = false;
+  int first_zero = -1;
+  for (int step = 1; step < max_new && !finished; ++step) {
+    if (use_graph) {
+      hipError_t le = hipGraphLaunch(exec, s);
+      if (le != hipSuccess) { set_error("hipGraphLaunch: %s", hipGetErrorString(le)); rc = -2; break; }
+    } else {
+      rc = decode_step_enqueue(e, s);
+      if (!rc) rc = sample_launch(sa, s);
+      if (!rc) rc = ar_state_advance_launch(e->state, s);
+      if (rc) break;
+    }
+    steps_done = step + 1;
+    if ((step & 7) == 7 || step == max_new - 1) {
+      hipError_t ce = hipMemcpyAsync(e->count_host, e->unfinished_count, (size_t)steps_done * sizeof(int), hipMemcpyDeviceToHost, s);
+      if (ce == hipSuccess) ce = hipStreamSynchronize(s);
+      if (ce != hipSuccess) { set_error("tt_ar_generate: %s", hipGetErrorString(ce)); rc = -2; break; }
+      for (int i = 0; i < steps_done; ++i)
+        if (e->count_host[i] == 0) { first_zero = i; finished = true; break; }
+    }
+  }
+  if (max_new == 1 && !rc) {
+    hipError_t ce = hipStreamSynchronize(s);
+    if (ce != hipSuccess) { set_error("tt_ar_generate: %s", hipGetErrorString(ce)); rc = -2; }
+  }
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (graph) (void)hipGraphDestroy(graph);
+  TT_TRY(rc);
+  if (n_steps_host) *n_steps_host = first_zero >= 0 ? first_zero + 1 : steps_done;
+  return e->sb.leave(us);
+}
+
+int tt_ar_latents(tt_ar* e, const float* emb, int k, int n, float* out, void* stream) {
+  TT_REQUIRE(e && emb && out && k >= 1 && n >= 1, "tt_ar_latents: bad arguments");
+  TT_REQUIRE(k * n <= e->max_rows && k <= e->cfg.max_batch, "tt_ar_latents: %d x %d rows exceed capacity %d", k, n, e->max_rows);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  const int D = e->D, M = k * n;
+  TT_CHECK_HIP(hipMemcpyAsync(e->x, emb, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+  TT_TRY(gpt_trunk_full(e, k, n, false, s));
+  RowNormArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = e->x; a.ldx = D; a.M = M; a.D = D; a.mode = NORM_LAYER;
+  a.g1 = e->w.lnf_g; a.b1 = e->w.lnf_b; a.eps1 = 1e-5f;
+  a.g2 = e->w.final_norm_g; a.b2 = e->w.final_norm_b; a.eps2 = 1e-5f;
+  a.out_f32 = out; a.ldo32 = D;
+  TT_TRY(rownorm_launch(e->cfg.dtype, a, s));
+  return e->sb.leave(us);
+}
+
+}  // extern "C"

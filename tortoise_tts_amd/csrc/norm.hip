@@ -1,0 +1,242 @@
+// Row norms (LayerNorm / x-transformers RMSNorm) fused with the residual-stream update, and
+// token-major GroupNorm (stats + apply) for DiffusionTts.  All statistics are fp32 (GroupNorm's
+// cross-chunk combine is fp64); normalised activations are emitted directly in the GEMM operand
+// type so no separate cast pass exists anywhere in the engine.
+#include "ops.h"
+
+namespace tt {
+
+// ------------------------------------------------------------------------------- row norm
+// One 256-thread block per row, D <= 4096, D % 4 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x;
+  constexpr int J = 4;
+  float4 v[J];
+  float* xr = a.x + (size_t)row * a.ldx;
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int c = (tid + 256 * j) * 4;
+    if (c < a.D) {
+      float4 t = a.x_in ? *(const float4*)(a.x_in + (size_t)row * a.ldxin + c) : *(const float4*)(xr + c);
+      if (a.add_bias) {
+        const float4 b = *(const float4*)(a.add_bias + c);
+        t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+      }
+      for (int s = 0; s < a.nslab; ++s) {
+        const float4 p = *(const float4*)(a.add_slabs + (size_t)s * a.slab_stride + (size_t)row * a.ldslab + c);
+        t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+      }
+      if (a.write_x) *(float4*)(xr + c) = t;
+      v[j] = t;
+      sum += t.x + t.y + t.z + t.w;
+    } else {
+      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (a.mode == NORM_NONE) return;
+
+  auto emit = [&](const float4* y) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int c = (tid + 256 * j) * 4;
+      if (c < a.D) {
+        if (a.out_t) *(typename Vec<T>::x4*)((T*)a.out_t + (size_t)row * a.ldot + c) = pack4<T>(y[j].x, y[j].y, y[j].z, y[j].w);
+        if (a.out_f32) *(float4*)(a.out_f32 + (size_t)row * a.ldo32 + c) = y[j];
+      }
+    }
+  };
+
+  float4 y[J];
+  if (a.mode == NORM_RMS) {
+    // x-transformers RMSNorm: x / max(||x|| * D^-0.5, eps) * g
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) sq += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+    sq = block_sum_256(sq, red);
+    const float nrm = sqrtf(sq) * rsqrtf((float)a.D);
+    const float inv = 1.0f / fmaxf(nrm, a.eps1);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int c = (tid + 256 * j) * 4;
+      if (c < a.D) {
+        const float4 g = *(const float4*)(a.g1 + c);
+        y[j] = make_float4(v[j].x * inv * g.x, v[j].y * inv * g.y, v[j].z * inv * g.z, v[j].w * inv * g.w);
+      }
+    }
+    emit(y);
+    return;
+  }
+
+  // LayerNorm (two-pass variance in registers), optionally followed by a second LayerNorm.
+  const float* gs[2] = {a.g1, a.g2};
+  const float* bs[2] = {a.b1, a.b2};
+  const float epss[2] = {a.eps1, a.eps2};
+  const int nln = a.g2 ? 2 : 1;
+  for (int l = 0; l < nln; ++l) {
+    if (l > 0) {
+      sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int c = (tid + 256 * j) * 4;
+        if (c < a.D) sum += v[j].x + v[j].y + v[j].z + v[j].w;
+      }
+    }
+    const float mean = block_sum_256(sum, red) / (float)a.D;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int c = (tid + 256 * j) * 4;
+      if (c < a.D) {
+        const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+        sq += dx * dx + dy * dy + dz * dz + dw * dw;
+      }
+    }
+    const float var = block_sum_256(sq, red) / (float)a.D;
+    const float rstd = rsqrtf(var + epss[l]);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int c = (tid + 256 * j) * 4;
+      if (c < a.D) {
+        const float4 g = *(const float4*)(gs[l] + c);
+        const float4 b = *(const float4*)(bs[l] + c);
+        v[j] = make_float4((v[j].x - mean) * rstd * g.x + b.x, (v[j].y - mean) * rstd * g.y + b.y,
+                           (v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w);
+      }
+    }
+  }
+  emit(v);
+}
+
+int rownorm_launch(int dtype, const RowNormArgs& a, hipStream_t stream) {
+  TT_REQUIRE(a.M > 0 && a.D > 0 && a.D % 4 == 0 && a.D <= 4096, "rownorm: bad shape M=%d D=%d", a.M, a.D);
+  TT_REQUIRE(a.ldx % 4 == 0, "rownorm: ldx must be a multiple of 4");
+  if (dtype == DT_BF16) rownorm_kernel<bf16><<<a.M, 256, 0, stream>>>(a);
+  else rownorm_kernel<f16><<<a.M, 256, 0, stream>>>(a);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------- group norm
+// x: [B][S][C] f32 token-major, 32 groups of cpg = C/32 channels (cpg % 4 == 0), C/4 a power of
+// two <= 256 or C == 1024*k.  Stage 1 writes per-(batch, row-chunk, group) (sum, sumsq).
+constexpr int GN_ROWS = 16;
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int S, int C, float* __restrict__ partial) {
+  __shared__ float ls[256][2];
+  const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
+  const int tid = threadIdx.x;
+  const int c4n = C >> 2;                       // float4 columns per row
+  const int CL = c4n < 256 ? c4n : 256;         // column lanes
+  const int RL = 256 / CL;                      // row lanes
+  const int cl = tid % CL, rl = tid / CL;
+  const int cpg4 = (C / 32) >> 2;               // float4 columns per group
+  const int r0 = chunk * GN_ROWS;
+  const int r1 = min(S, r0 + GN_ROWS);
+  // With C > 1024 a thread owns several columns in different groups: handle one column set per pass.
+  for (int cb = 0; cb < c4n; cb += 256) {
+    float s = 0.f, q = 0.f;
+    const int c4 = cb + cl;
+    if (c4 < c4n) {
+      for (int r = r0 + rl; r < r1; r += RL) {
+        const float4 t = *(const float4*)(x + ((size_t)b * S + r) * C + c4 * 4);
+        s += t.x + t.y + t.z + t.w;
+        q += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+      }
+    }
+    __syncthreads();
+    ls[tid][0] = s;
+    ls[tid][1] = q;
+    __syncthreads();
+    // groups covered by this pass: columns [cb, cb+CL) -> groups (cb/cpg4) .. ; one thread per group
+    const int ngrp = CL / cpg4;
+    if (tid < ngrp) {
+      float ts = 0.f, tq = 0.f;
+      for (int r = 0; r < RL; ++r)
+        for (int c = 0; c < cpg4; ++c) {
+          ts += ls[r * CL + tid * cpg4 + c][0];
+          tq += ls[r * CL + tid * cpg4 + c][1];
+        }
+      const int g = cb / cpg4 + tid;
+      float* p = partial + (((size_t)b * nchunk + chunk) * 32 + g) * 2;
+      p[0] = ts;
+      p[1] = tq;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchunk) {
+  __shared__ float mean_s[32], rstd_s[32];
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int C = a.C, S = a.S;
+  if (tid < 32) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nchunk; ++i) {
+      const float* p = a.partial + (((size_t)b * nchunk + i) * 32 + tid) * 2;
+      s += (double)p[0];
+      q += (double)p[1];
+    }
+    const double n = (double)S * (double)(C / 32);
+    const double m = s / n;
+    double var = q / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)m;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+  const int c4n = C >> 2;
+  const int cpg = C / 32;
+  const int r0 = chunk * GN_ROWS;
+  const int r1 = min(S, r0 + GN_ROWS);
+  const int total = (r1 - r0) * c4n;
+  for (int f = tid; f < total; f += 256) {
+    const int r = r0 + f / c4n;
+    const int c = (f % c4n) * 4;
+    const int g = c / cpg;
+    const size_t off = ((size_t)b * S + r);
+    const float4 t = *(const float4*)(a.x + off * C + c);
+    const float4 gm = *(const float4*)(a.gamma + c);
+    const float4 bt = *(const float4*)(a.beta + c);
+    const float mu = mean_s[g], rs = rstd_s[g];
+    float y[4] = {(t.x - mu) * rs * gm.x + bt.x, (t.y - mu) * rs * gm.y + bt.y, (t.z - mu) * rs * gm.z + bt.z,
+                  (t.w - mu) * rs * gm.w + bt.w};
+    if (a.scale_shift) {
+      const float* ss = a.scale_shift + (size_t)b * a.ss_batch_stride + (a.ss_slot ? (size_t)(*a.ss_slot) * a.ss_slot_stride : 0);
+      const float4 sc = *(const float4*)(ss + c);
+      const float4 sh = *(const float4*)(ss + C + c);
+      y[0] = y[0] * (1.f + sc.x) + sh.x;
+      y[1] = y[1] * (1.f + sc.y) + sh.y;
+      y[2] = y[2] * (1.f + sc.z) + sh.z;
+      y[3] = y[3] * (1.f + sc.w) + sh.w;
+    }
+    if (a.act != ACT_NONE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = apply_act(y[i], a.act, 0.f);
+    }
+    if (a.out_t) *(typename Vec<T>::x4*)((T*)a.out_t + off * a.ldot + c) = pack4<T>(y[0], y[1], y[2], y[3]);
+    if (a.out_f32) *(float4*)(a.out_f32 + off * a.ldo32 + c) = make_float4(y[0], y[1], y[2], y[3]);
+  }
+}
+
+int groupnorm_launch(int dtype, const GroupNormArgs& a, hipStream_t stream) {
+  const int c4n = a.C / 4;
+  TT_REQUIRE(a.C % 128 == 0 && ((c4n <= 256 && (c4n & (c4n - 1)) == 0) || c4n % 256 == 0), "groupnorm: unsupported C=%d", a.C);
+  TT_REQUIRE(a.B > 0 && a.S > 0 && a.partial != nullptr, "groupnorm: bad arguments");
+  const int nchunk = cdiv(a.S, GN_ROWS);
+  dim3 grid(nchunk, a.B);
+  gn_stats_kernel<<<grid, 256, 0, stream>>>(a.x, a.S, a.C, a.partial);
+  TT_CHECK_HIP(hipGetLastError());
+  if (dtype == DT_BF16) gn_apply_kernel<bf16><<<grid, 256, 0, stream>>>(a, nchunk);
+  else gn_apply_kernel<f16><<<grid, 256, 0, stream>>>(a, nchunk);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+size_t groupnorm_partial_floats(int B, int S) { return (size_t)B * cdiv(S, GN_ROWS) * 32 * 2; }
+
+}  // namespace tt

@@ -1,0 +1,190 @@
+// Kernel launchers shared by the stage runners (gpt2 / clvp / diffusion / univnet) and by the
+// operator-level C-ABI entry points the parity tests call.  All pointers are device pointers.
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+namespace tt {
+
+// ------------------------------------------------------------------------------ row norms
+enum NormMode { NORM_NONE = 0, NORM_LAYER = 1, NORM_RMS = 2 };
+struct RowNormArgs {
+  float* x;            // [M][ldx] f32 residual stream (read unless x_in; written when write_x)
+  int ldx;
+  const float* x_in;   // optional separate source rows
+  int ldxin;
+  int M, D;
+  const float* add_bias;   // [D], added before the norm (bias of the preceding split-K GEMM)
+  const float* add_slabs;  // [nslab][M][ldslab] partial sums of the preceding split-K GEMM
+  int nslab;
+  size_t slab_stride;
+  int ldslab;
+  int write_x;         // store the updated row back to x
+  int mode;            // NormMode
+  const float* g1;
+  const float* b1;
+  float eps1;
+  const float* g2;     // optional second LayerNorm applied to the first one's output
+  const float* b2;
+  float eps2;
+  void* out_t;         // normalised row in the GEMM operand type
+  int ldot;
+  float* out_f32;      // optional f32 copy of the normalised row
+  int ldo32;
+};
+int rownorm_launch(int dtype, const RowNormArgs& a, hipStream_t stream);
+
+// ------------------------------------------------------------------------------ group norm
+struct GroupNormArgs {
+  const float* x;  // [B][S][C]
+  int B, S, C;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  const float* scale_shift;  // optional [B?][2C]: y = y * (1 + scale) + shift
+  size_t ss_batch_stride;    // 0 when every batch row shares one timestep embedding
+  const int* ss_slot;        // optional device int: scale_shift += *ss_slot * ss_slot_stride (hipGraph replay)
+  size_t ss_slot_stride;
+  int act;
+  void* out_t;
+  int ldot;
+  float* out_f32;
+  int ldo32;
+  float* partial;  // workspace, groupnorm_partial_floats(B, S) floats
+};
+int groupnorm_launch(int dtype, const GroupNormArgs& a, hipStream_t stream);
+size_t groupnorm_partial_floats(int B, int S);
+
+// ------------------------------------------------------------------------------ attention
+struct FlashArgs {
+  const void* q;   // [BH][n][64], pre-scaled by 1/sqrt(64)
+  const void* k;   // [BH][n][64]
+  const void* vt;  // [BH][64][n_pad]
+  void* out;       // [B][n][ldo] with head h at columns h*64..
+  int ldo;
+  int BH, heads, n, n_pad;
+  int causal;
+  const float* relpos;  // optional [heads][129] additive bias indexed by clamp(key - query, -64, 64) + 64
+};
+int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream);
+
+struct DecodeAttnArgs {
+  const void* q;    // [B][heads*64], pre-scaled
+  const void* kp;   // shared prefix keys   [heads][P1][64]
+  const void* vp;   // shared prefix values [heads][P1][64]
+  int P1;
+  const void* kc;   // per-sequence keys   [B][heads][8][tmax][8]
+  const void* vc;   // per-sequence values [B][heads][tmax][64]
+  int tmax;
+  const int* step;  // device int: slot of the newest generated key (keys 0..*step are valid)
+  void* out;        // [B][heads*64]
+  int B, heads;
+};
+int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stream);
+
+// ------------------------------------------------------------------------------ AR sampling
+struct SampleArgs {
+  const float* logits;  // [B][ldl]; ldl == 0 broadcasts one row (the shared-prefix prefill logits)
+  int ldl;
+  int B, V;
+  unsigned* seen;       // [B][(V+31)/32] bitmask of ids already in input_ids (repetition penalty)
+  float rep_penalty, temperature, top_p;
+  int top_k;
+  const float* exp_noise;  // optional [max_steps][B][V] Exp(1) draws (parity runs); else Philox
+  unsigned long long seed;
+  int row_offset;          // global candidate index of row 0 (sharding-invariant Philox streams)
+  const int* state;        // device: state[0] = tokens sampled so far
+  int* unfinished;         // [B]
+  int stop_token;
+  int* codes;              // [B][ldcodes]
+  int ldcodes;
+  int* next_tok;           // [B]
+  int* unfinished_count;   // [max_steps]: number of unfinished rows after each sampling step
+};
+int sample_launch(const SampleArgs& a, hipStream_t stream);
+int ar_state_advance_launch(int* state, hipStream_t stream);
+int ar_begin_launch(int* state, unsigned* seen, int* unfinished, int* unfinished_count, int B, int V, int max_steps,
+                    int start_token, hipStream_t stream);
+
+// x[b][:] = tok_emb[tok[b]][:] + pos_emb[state[1] + 2][:]   (kv_cache=True position rule)
+int ar_embed_launch(const int* tok, const int* state, const float* tok_emb, const float* pos_emb, float* x, int B, int D,
+                    hipStream_t stream);
+
+// ------------------------------------------------------------------------------ small fused ops
+// out[m][j] = in[m][j] * gelu_erf(in[m][inner + j])
+int geglu_launch(int dtype, const void* in, int ldin, void* out, int ldout, int M, int inner, hipStream_t stream);
+// x-transformers rotary on the first rot dims (rot = 32) of q, k ([BH][n][64]) and vt ([BH][64][n_pad])
+int rotary_launch(int dtype, void* q, void* k, void* vt, const float* inv_freq, int BH, int n, int n_pad, int rot,
+                  hipStream_t stream);
+// dst[r][:] = src[idx[r]][:]   (f32 rows of C floats)
+int gather_rows_launch(const float* src, const int* idx, float* dst, int rows, int C, hipStream_t stream);
+// dst[b][:] = mean over n rows of src[b][n][:]
+int mean_rows_launch(const float* src, float* dst, int B, int n, int C, hipStream_t stream);
+// CLVP tail: out[b] = <normalize(t[b or 0]), normalize(s[b])> * exp(temperature)
+int clvp_score_launch(const float* t, int t_rows, const float* s, const float* temperature, float* out, int B, int D,
+                      hipStream_t stream);
+// f32 -> T with optional column zero-padding: dst[r][0..cpad) = src[r][0..c) | 0
+int cast_pad_launch(int dtype, const float* src, int lds, void* dst, int ldd, int rows, int c, int cpad, hipStream_t stream);
+// broadcast a [C] vector over rows
+int broadcast_rows_launch(const float* vec, float* dst, int rows, int C, hipStream_t stream);
+// f32 transpose: dst[c][r] = src[r][c]
+int transpose_launch(const float* src, float* dst, int rows, int cols, hipStream_t stream);
+// [rows][C] f32 -> SiLU -> T
+int silu_cast_launch(int dtype, const float* src, void* dst, int n, hipStream_t stream);
+
+// Diffusion p_sample epilogue (utils/diffusion.py:312-418, 487-531), token-major model output.
+struct PSampleStep {    // same layout as tt_diff_step (include/tortoise_mi355x.h)
+  int timestep;
+  float min_log, max_log, cfk, sqrt_recip, sqrt_recipm1, coef1, coef2, nonzero;
+};
+struct PSampleArgs {
+  const PSampleStep* steps;  // device array; entry *slot is used
+  const int* slot;           // device int (advanced by diff_slot_advance_launch)
+  float* x;             // [S][C] f32 state, updated in place
+  void* x_t;            // [2][S][cpad] operand copy for the next step's inp_block (both batch rows)
+  int cpad;
+  const float* out;     // [2][S][2C] model output rows: batch 0 = conditioned, batch 1 = unconditioned
+  int has_uncond;
+  const float* noise;   // [n_steps][C][S] channels-first draws (reference layout); entry *slot is used
+  int S, C;
+  float* mel_out;       // optional [C][S] channels-first denormalised mel written on the last step
+  float mel_scale, mel_shift;
+};
+int psample_launch(int dtype, const PSampleArgs& a, hipStream_t stream);
+int slot_advance_launch(int* slot, hipStream_t stream);
+
+// ------------------------------------------------------------------------------ UnivNet (fp32 VALU)
+struct Conv1dArgs {
+  const float* x;  // [Cin][T]
+  const float* w;  // [Cout][Cin][k]
+  const float* bias;
+  float* y;        // [Cout][T]
+  int Cin, Cout, T, k, dilation;
+  int reflect;     // reflect padding (k/2 * dilation each side) instead of zeros
+  float in_slope;  // LeakyReLU applied to the input when >= 0 (negative: none)
+  int out_act;     // ACT_NONE / ACT_LRELU / 5 = tanh
+  float out_slope;
+};
+int conv1d_direct_launch(const Conv1dArgs& a, hipStream_t stream);
+struct ConvT1dArgs {
+  const float* x;  // [C][Tin]
+  const float* w;  // [Cin][Cout][2*stride]
+  const float* bias;
+  float* y;        // [C][Tin*stride]
+  int C, Tin, stride;
+  float in_slope;
+};
+int convt1d_launch(const ConvT1dArgs& a, hipStream_t stream);
+struct LvcArgs {
+  const float* x_in;    // [32][T] conv output (LeakyReLU applied here)
+  const float* kernels; // [L][ldk] row l holds layer j's [32][64][3] block at column koff
+  int ldk, koff;
+  const float* bias;    // [L][ldb], layer j's [64] block at column boff
+  int ldb, boff;
+  float* x;             // [32][T] residual stream: x += sigmoid(o[:32]) * tanh(o[32:])
+  int L, hop;
+  float in_slope;
+};
+int lvc_launch(const LvcArgs& a, hipStream_t stream);
+
+}  // namespace tt

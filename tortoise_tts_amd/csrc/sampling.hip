@@ -1,0 +1,280 @@
+// On-device restatement of the HF transformers==4.31 sampling step that Tortoise's
+// UnifiedVoice.inference_speech drives (reference: tortoise/models/autoregressive.py:535-563,
+// loop skeleton tortoise/models/stream_generator.py:916-1000):
+//   RepetitionPenalty(all input ids) -> /temperature -> top-k (ties kept) -> top-p (ascending
+//   cumulative prob <= 1 - top_p removed, at least one kept) -> softmax -> multinomial
+//   -> finished rows emit the stop token.
+// One 256-thread block per candidate row, no host synchronisation: the step index lives in device
+// memory so the whole decode step (this kernel included) replays from one hipGraph.
+// multinomial(p, 1) is realised as argmax(p / q), q ~ Exp(1): q is either an injected tensor
+// (parity runs share the oracle's draws) or Philox4x32-10 keyed by (seed; global row, step, token),
+// which makes the sampled codes independent of how candidates are sharded over GPUs.
+#include "ops.h"
+
+namespace tt {
+
+constexpr int SURV_CAP = 512;
+
+__device__ __forceinline__ unsigned f2key(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                               unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    const unsigned n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned sel_prefix, sel_remaining;
+  __shared__ int nsurv;
+  __shared__ float sv[SURV_CAP];
+  __shared__ int si[SURV_CAP];
+  __shared__ float sorted_v[SURV_CAP];
+  __shared__ int sorted_i[SURV_CAP];
+  __shared__ int kept;
+  __shared__ float kept_total;
+  __shared__ float red_v[4];
+  __shared__ int red_i[4];
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int V = a.V;
+  const int step = a.state[0];
+  const float* lg = a.logits + (size_t)b * a.ldl;
+  unsigned* seen = a.seen + (size_t)b * ((V + 31) / 32);
+  constexpr int PER = 40;  // supports V <= 10240
+  float val[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int t = tid + 256 * j;
+    float s = -INFINITY;
+    if (t < V) {
+      s = lg[t];
+      if (a.rep_penalty != 1.0f && ((seen[t >> 5] >> (t & 31)) & 1u)) s = s < 0.f ? s * a.rep_penalty : s / a.rep_penalty;
+      if (a.temperature != 1.0f) s = s / a.temperature;
+    }
+    val[j] = s;
+  }
+
+  // ---- top-k threshold: radix-select the k-th largest key (4 passes of 8 bits)
+  const int k = a.top_k < V ? a.top_k : V;
+  if (tid == 0) {
+    sel_prefix = 0u;
+    sel_remaining = (unsigned)k;
+    nsurv = 0;
+  }
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    hist[tid] = 0u;
+    __syncthreads();
+    const unsigned prefix = sel_prefix;
+    const unsigned mask_hi = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int t = tid + 256 * j;
+      if (t < V) {
+        const unsigned key = f2key(val[j]);
+        if ((key & mask_hi) == (prefix & mask_hi)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned rem = sel_remaining;
+      int d = 255;
+      for (; d > 0; --d) {
+        const unsigned c = hist[d];
+        if (c >= rem) break;
+        rem -= c;
+      }
+      sel_prefix = prefix | ((unsigned)d << shift);
+      sel_remaining = rem;
+    }
+    __syncthreads();
+  }
+  const unsigned kth = sel_prefix;  // key of the k-th largest score; everything >= kth survives (ties kept)
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int t = tid + 256 * j;
+    if (t < V && f2key(val[j]) >= kth) {
+      const int slot = atomicAdd(&nsurv, 1);
+      if (slot < SURV_CAP) {
+        sv[slot] = val[j];
+        si[slot] = t;
+      }
+    }
+  }
+  __syncthreads();
+  const int n = nsurv < SURV_CAP ? nsurv : SURV_CAP;
+  // ---- rank sort: descending score, ascending index on ties (deterministic irrespective of slot order)
+  for (int i = tid; i < n; i += 256) {
+    const float v = sv[i];
+    const int id = si[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const float w = sv[j];
+      rank += (w > v) || (w == v && si[j] < id);
+    }
+    sorted_v[rank] = v;
+    sorted_i[rank] = id;
+  }
+  __syncthreads();
+  // ---- top-p on the survivors (everything else already has probability 0)
+  if (tid == 0) {
+    const float m = sorted_v[0];
+    float total = 0.f;
+    for (int i = 0; i < n; ++i) total += __expf(sorted_v[i] - m);
+    int keep = n;
+    if (a.top_p < 1.0f) {
+      float tail = 0.f;
+      keep = 1;
+      const float thr = 1.0f - a.top_p;
+      // ascending cumulative probability of element r == sum of probabilities of elements r..n-1
+      for (int r = n - 1; r >= 1; --r) {
+        tail += __expf(sorted_v[r] - m) / total;
+        if (tail > thr) {
+          keep = r + 1;
+          break;
+        }
+      }
+    }
+    float kt = 0.f;
+    for (int i = 0; i < keep; ++i) kt += __expf(sorted_v[i] - m);
+    kept = keep;
+    kept_total = kt;
+  }
+  __syncthreads();
+  // ---- multinomial == argmax(p / q)
+  const int keep = kept;
+  const float m = sorted_v[0];
+  float best = -1.f;
+  int best_i = 0x7fffffff;
+  for (int i = tid; i < keep; i += 256) {
+    const int id = sorted_i[i];
+    const float p = __expf(sorted_v[i] - m) / kept_total;
+    float q;
+    if (a.exp_noise) {
+      q = a.exp_noise[((size_t)step * a.B + b) * V + id];
+    } else {
+      unsigned r[4];
+      philox4x32_10((unsigned)id, (unsigned)step, (unsigned)(a.row_offset + b), 0u, (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
+      const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+      q = -__logf(u);
+    }
+    const float sc = p / q;
+    if (sc > best || (sc == best && id < best_i)) {
+      best = sc;
+      best_i = id;
+    }
+  }
+  // block argmax (value desc, index asc)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(best_i, o, 64);
+    if (ov > best || (ov == best && oi < best_i)) {
+      best = ov;
+      best_i = oi;
+    }
+  }
+  if ((tid & 63) == 0) {
+    red_v[tid >> 6] = best;
+    red_i[tid >> 6] = best_i;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (red_v[w] > best || (red_v[w] == best && red_i[w] < best_i)) {
+        best = red_v[w];
+        best_i = red_i[w];
+      }
+    const int unf = a.unfinished[b];
+    int tok = unf ? best_i : a.stop_token;
+    const int still = unf && tok != a.stop_token;
+    a.unfinished[b] = still;
+    a.codes[(size_t)b * a.ldcodes + step] = tok;
+    a.next_tok[b] = tok;
+    atomicOr(&seen[tok >> 5], 1u << (tok & 31));
+    if (still) atomicAdd(&a.unfinished_count[step], 1);
+  }
+}
+
+int sample_launch(const SampleArgs& a, hipStream_t stream) {
+  TT_REQUIRE(a.B > 0 && a.V > 0 && a.V <= 10240, "sample: V=%d unsupported (<= 10240)", a.V);
+  TT_REQUIRE(a.top_k > 0 && a.top_k <= 256, "sample: top_k=%d unsupported (1..256; HF default 50)", a.top_k);
+  TT_REQUIRE(a.temperature > 0.f && a.top_p > 0.f && a.rep_penalty > 0.f, "sample: bad sampling parameters");
+  sample_kernel<<<a.B, 256, 0, stream>>>(a);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void ar_advance_kernel(int* state) {
+  if (threadIdx.x == 0) {
+    state[0] += 1;         // tokens sampled so far
+    state[1] = state[0] - 1;  // slot / index of the newest token (the one the next decode step feeds)
+  }
+}
+int ar_state_advance_launch(int* state, hipStream_t stream) {
+  ar_advance_kernel<<<1, 64, 0, stream>>>(state);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void ar_begin_kernel(int* state, unsigned* seen, int* unfinished, int* unfinished_count, int B, int V, int max_steps,
+                                int start_token) {
+  const int words = (V + 31) / 32;
+  const int total = B * words;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int w = i % words;
+    unsigned v = 0u;
+    // fake_inputs = [1] * P + [start_mel_token] (autoregressive.py:546-548): ids 1 and start are "seen"
+    if (w == 0) v |= 1u << 1;
+    if (w == (start_token >> 5)) v |= 1u << (start_token & 31);
+    seen[i] = v;
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) unfinished[i] = 1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < max_steps; i += gridDim.x * blockDim.x) unfinished_count[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    state[0] = 0;
+    state[1] = -1;
+  }
+}
+int ar_begin_launch(int* state, unsigned* seen, int* unfinished, int* unfinished_count, int B, int V, int max_steps,
+                    int start_token, hipStream_t stream) {
+  ar_begin_kernel<<<64, 256, 0, stream>>>(state, seen, unfinished, unfinished_count, B, V, max_steps, start_token);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void ar_embed_kernel(const int* tok, const int* state, const float* tok_emb, const float* pos_emb,
+                                                       float* x, int D) {
+  const int b = blockIdx.x;
+  const int t = tok[b];
+  const int pos = state[1] + 2;
+  for (int c = threadIdx.x * 4; c < D; c += 1024) {
+    const float4 e = *(const float4*)(tok_emb + (size_t)t * D + c);
+    const float4 p = *(const float4*)(pos_emb + (size_t)pos * D + c);
+    *(float4*)(x + (size_t)b * D + c) = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+  }
+}
+int ar_embed_launch(const int* tok, const int* state, const float* tok_emb, const float* pos_emb, float* x, int B, int D,
+                    hipStream_t stream) {
+  TT_REQUIRE(D % 4 == 0, "ar_embed: D must be a multiple of 4");
+  ar_embed_kernel<<<B, 256, 0, stream>>>(tok, state, tok_emb, pos_emb, x, D);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace tt
