@@ -1,0 +1,214 @@
+"""TEST INFRASTRUCTURE ONLY — generates tests/golden/*.npz from the REFERENCE's own nn.Modules.
+
+Run in the build container (needs /root/reference):   python -m oracle.make_golden
+The reference holds no numeric golden vectors, so these fixtures are outputs of the
+reference's classes (UnifiedVoice / GPT2InferenceModel, CLVP, DiffusionTts + SpacedDiffusion,
+UnivNetGenerator, api.fix_autoregressive_output) executed here on CPU in fp32 with the seeded
+synthetic weights of tortoise_tts_amd.weights (regenerated bit-identically from (manifest, seed) on
+any machine with the same torch build, so only inputs and outputs are stored).  The GPU box has no
+/root/reference; tests there compare the oracle and the HIP engine against these files.
+"""
+import ast
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_shims
+from tortoise_tts_amd import weights as W
+from tortoise_tts_amd.config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+# shared case definitions (tests import these so inputs are rebuilt identically)
+AR_CFG = dict(layers=2, model_dim=128, heads=2)
+AR_SEED, AR_B, AR_T = 11, 3, 9
+AR_TOKENS = [[5, 77, 8000], [1, 2, 3], [4000, 4001, 9]]
+LAT_SEED, LAT_K, LAT_N, LAT_T = 12, 2, 24, 7
+CLVP_CFG = dict(dim=128, dim_latent=128, depth=2, heads=2)
+CLVP_SEED, CLVP_B, CLVP_T, CLVP_N = 13, 3, 13, 40
+DIFF_CFG = dict(model_channels=128, num_layers=2, in_latent_channels=128, num_heads=2)
+DIFF_SEED, DIFF_M, DIFF_STEPS, DIFF_TS = 14, 12, 5, 2999
+VOC_SEED, VOC_S = 15, 6
+
+
+def ar_inputs(cfg):
+    g = torch.Generator().manual_seed(0)
+    cond = torch.randn(1, cfg.model_dim, generator=g)
+    text = F.pad(torch.randint(1, 255, (1, AR_T), generator=g).int(), (0, 1))
+    return cond, text
+
+
+def latent_inputs(cfg):
+    g = torch.Generator().manual_seed(1)
+    cond = torch.randn(1, cfg.model_dim, generator=g)
+    text = F.pad(torch.randint(1, 255, (1, LAT_T), generator=g).int(), (0, 1))
+    codes = torch.randint(0, 8192, (LAT_K, LAT_N), generator=g)
+    return cond, text, codes
+
+
+def clvp_inputs():
+    g = torch.Generator().manual_seed(2)
+    text = torch.randint(0, 256, (1, CLVP_T), generator=g)
+    codes = torch.randint(0, 8192, (CLVP_B, CLVP_N), generator=g)
+    return text, codes
+
+
+def diff_inputs(cfg):
+    g = torch.Generator().manual_seed(3)
+    S = DIFF_M * 4 * 24000 // 22050
+    latents = torch.randn(1, DIFF_M, cfg.in_latent_channels, generator=g)
+    cond = torch.randn(1, 2 * cfg.model_channels, generator=g)
+    x = torch.randn(1, 100, S, generator=g)
+    step_noise = torch.randn(DIFF_STEPS, 1, 100, S, generator=g)
+    return S, latents, cond, x, step_noise
+
+
+def voc_inputs():
+    g = torch.Generator().manual_seed(4)
+    mel = torch.randn(1, 100, VOC_S, generator=g) * 2 - 5
+    z = torch.randn(1, 64, VOC_S + 10, generator=g)
+    return mel, z
+
+
+def build_ref_ar(ref, cfg, sd):
+    m = ref.UnifiedVoice(max_mel_tokens=cfg.max_mel_tokens, max_text_tokens=cfg.max_text_tokens,
+                         max_conditioning_inputs=cfg.max_conditioning_inputs, layers=cfg.layers, model_dim=cfg.model_dim,
+                         heads=cfg.heads, number_text_tokens=cfg.number_text_tokens, start_text_token=cfg.start_text_token,
+                         checkpointing=False, train_solo_embeddings=False).eval()
+    m.load_state_dict(sd, strict=True)
+    m.post_init_gpt2_config(kv_cache=True)
+    return m
+
+
+@torch.no_grad()
+def golden_ar(ref):
+    cfg = ARConfig(**AR_CFG)
+    sd = W.synthetic_state_dict(W.ar_manifest(cfg), seed=AR_SEED)
+    m = build_ref_ar(ref, cfg, sd)
+    cond, text = ar_inputs(cfg)
+    t = F.pad(text, (0, 1), value=m.stop_text_token)
+    t, _ = m.build_aligned_inputs_and_targets(t, m.start_text_token, m.stop_text_token)
+    emb = torch.cat([cond.unsqueeze(1), m.text_embedding(t) + m.text_pos_embedding(t)], dim=1)
+    m.inference_model.store_mel_emb(emb)
+    P = emb.shape[1]
+    ids = torch.full((AR_B, P + 1), 1, dtype=torch.long)
+    ids[:, -1] = m.start_mel_token
+    out = m.inference_model(input_ids=ids, attention_mask=torch.ones_like(ids), use_cache=True, return_dict=True)
+    logits = [out.logits[:, -1]]
+    past = out.past_key_values
+    for tk in AR_TOKENS:
+        tk = torch.tensor(tk)
+        ids = torch.cat([ids, tk[:, None]], dim=1)
+        out = m.inference_model(input_ids=tk[:, None], past_key_values=past, attention_mask=torch.ones_like(ids),
+                                use_cache=True, return_dict=True)
+        past = out.past_key_values
+        logits.append(out.logits[:, -1])
+    # latent re-pass
+    cfg2 = ARConfig(**AR_CFG)
+    sd2 = W.synthetic_state_dict(W.ar_manifest(cfg2), seed=LAT_SEED)
+    m2 = build_ref_ar(ref, cfg2, sd2)
+    cond2, text2, codes2 = latent_inputs(cfg2)
+    lat = m2(cond2.repeat(LAT_K, 1), text2.repeat(LAT_K, 1), torch.tensor([text2.shape[-1]]), codes2.clone(),
+             torch.tensor([LAT_N * m2.mel_length_compression]), return_latent=True, clip_inputs=False)
+    np.savez_compressed(os.path.join(OUT, "ar.npz"), prefix_emb=emb.numpy(), logits=torch.stack(logits).numpy(),
+                        latents=lat.numpy())
+
+
+@torch.no_grad()
+def golden_clvp(ref):
+    cfg = CLVPConfig(**CLVP_CFG)
+    sd = W.synthetic_state_dict(W.clvp_manifest(cfg), seed=CLVP_SEED)
+    m = ref.CLVP(dim_text=cfg.dim, dim_speech=cfg.dim, dim_latent=cfg.dim_latent, num_text_tokens=256,
+                 text_enc_depth=cfg.depth, text_seq_len=350, text_heads=cfg.heads, num_speech_tokens=8192,
+                 speech_enc_depth=cfg.depth, speech_heads=cfg.heads, speech_seq_len=430, use_xformers=True).eval()
+    m.load_state_dict(sd, strict=True)
+    text, codes = clvp_inputs()
+    scores = m(text.repeat(CLVP_B, 1), codes, return_loss=False)
+    np.savez_compressed(os.path.join(OUT, "clvp.npz"), scores=scores.numpy())
+
+
+@torch.no_grad()
+def golden_diffusion(ref):
+    cfg = DiffusionConfig(**DIFF_CFG)
+    sd = W.synthetic_state_dict(W.diffusion_manifest(cfg), seed=DIFF_SEED)
+    m = ref.DiffusionTts(model_channels=cfg.model_channels, num_layers=cfg.num_layers, in_channels=cfg.in_channels,
+                         out_channels=cfg.out_channels, in_latent_channels=cfg.in_latent_channels, in_tokens=cfg.in_tokens,
+                         dropout=0, use_fp16=False, num_heads=cfg.num_heads, layer_drop=0, unconditioned_percentage=0).eval()
+    m.load_state_dict(sd, strict=True)
+    S, latents, cond, x, step_noise = diff_inputs(cfg)
+    code_emb = m.timestep_independent(latents, cond, S, False)
+    ts = torch.tensor([DIFF_TS])
+    eps_c = m(x, ts, precomputed_aligned_embeddings=code_emb, conditioning_free=False)
+    eps_u = m(x, ts, precomputed_aligned_embeddings=code_emb, conditioning_free=True)
+    N = DIFF_STEPS
+    diffuser = ref.SpacedDiffusion(use_timesteps=ref.space_timesteps(4000, [N]), model_mean_type='epsilon',
+                                   model_var_type='learned_range', loss_type='mse',
+                                   betas=ref.get_named_beta_schedule('linear', 4000), conditioning_free=True,
+                                   conditioning_free_k=2.0)
+    import tortoise.utils.diffusion as rd
+    order = list(reversed(range(N)))
+    calls = {"n": 0}
+    orig = rd.th.randn_like
+
+    def fake_randn_like(t):
+        i = order[calls["n"]]
+        calls["n"] += 1
+        return step_noise[i]
+    rd.th.randn_like = fake_randn_like
+    try:
+        x0 = diffuser.p_sample_loop(m, (1, 100, S), noise=x.clone(), model_kwargs={'precomputed_aligned_embeddings': code_emb},
+                                    progress=False)
+    finally:
+        rd.th.randn_like = orig
+    np.savez_compressed(os.path.join(OUT, "diffusion.npz"), code_emb=code_emb.numpy(), eps_cond=eps_c.numpy(),
+                        eps_uncond=eps_u.numpy(), x0=x0.numpy(), timestep_map=np.array(diffuser.timestep_map))
+
+
+@torch.no_grad()
+def golden_vocoder(ref):
+    cfg = VocoderConfig()
+    raw = W.synthetic_state_dict(W.vocoder_manifest(cfg), seed=VOC_SEED)
+    m = ref.UnivNetGenerator()
+    m.load_state_dict(raw, strict=True)
+    m.eval(inference=True)
+    mel, z = voc_inputs()
+    wav = m.inference(mel, z)
+    np.savez_compressed(os.path.join(OUT, "vocoder.npz"), wav=wav.numpy())
+
+
+def golden_integer():
+    src = open(os.path.join(ref_shims.REFERENCE_ROOT, "tortoise", "api.py")).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "fix_autoregressive_output"][0]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "api_excerpt", "exec"), ns)
+    rng = np.random.default_rng(0)
+    ins, outs = [], []
+    for trial in range(40):
+        n = 32
+        codes = rng.integers(0, 8192, n)
+        if trial % 3:
+            codes[int(rng.integers(0, n)):] = 8193
+        if trial % 7 == 0:
+            codes[int(rng.integers(0, n))] = 8193
+        ins.append(codes.copy())
+        outs.append(ns["fix_autoregressive_output"](torch.tensor(codes).clone(), 8193, complain=False).numpy())
+    np.savez_compressed(os.path.join(OUT, "integer.npz"), codes_in=np.stack(ins), codes_out=np.stack(outs))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = ref_shims.import_reference()
+    golden_ar(ref)
+    golden_clvp(ref)
+    golden_diffusion(ref)
+    golden_vocoder(ref)
+    golden_integer()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

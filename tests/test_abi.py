@@ -1,0 +1,51 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds/loads, exports every symbol that
+include/tortoise_mi355x.h declares, the ctypes mirrors have the library's struct sizes, and a call
+without a GPU fails loudly through tt_last_error (never silently falls back)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from tortoise_tts_amd import engine as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(E.LIB_PATH):
+        from tortoise_tts_amd.build import build
+        build(verbose=False)
+    return E.load_library()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "tortoise_mi355x.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    assert set(names) == set(E._PROTOS), set(names) ^ set(E._PROTOS)
+
+
+def test_struct_mirrors_match(lib):
+    for i, st in enumerate(E.BOUNDARY_STRUCTS):
+        assert C.sizeof(st) == lib.tt_struct_size(i), st.__name__
+    assert lib.tt_abi_version() == 1
+
+
+def test_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    rc = lib.tt_init()
+    assert rc != 0
+    assert b"hip" in lib.tt_last_error().lower() or b"device" in lib.tt_last_error().lower()
+    with pytest.raises(E.EngineError):
+        E.check(rc)

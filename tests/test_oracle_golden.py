@@ -1,0 +1,85 @@
+"""Pins oracle/tortoise_oracle.py against the committed golden vectors (tests/golden/*.npz), which are
+outputs of the reference's own nn.Modules (oracle/make_golden.py).  Runs anywhere (no reference tree,
+no GPU needed)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import make_golden as G
+from oracle import tortoise_oracle as O
+from tortoise_tts_amd import weights as W
+from tortoise_tts_amd.config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def close(a, b, atol, rtol=1e-4):
+    a = torch.as_tensor(np.asarray(a))
+    b = torch.as_tensor(np.asarray(b))
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.allclose(a, b, atol=atol, rtol=rtol), float((a - b).abs().max())
+
+
+@torch.no_grad()
+def test_ar_logits_and_latents():
+    g = gold("ar.npz")
+    cfg = ARConfig(**G.AR_CFG)
+    sd = W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.AR_SEED)
+    cond, text = G.ar_inputs(cfg)
+    prefix = O.ar_prefix(sd, cfg, cond, text)
+    close(prefix, g["prefix_emb"], 1e-6)
+    lg, kv = O.ar_prefill(sd, cfg, prefix, G.AR_B)
+    close(lg, g["logits"][0], 2e-4)
+    for s, tk in enumerate(G.AR_TOKENS):
+        lg, kv = O.ar_step(sd, cfg, torch.tensor(tk), s + 1, kv)
+        close(lg, g["logits"][s + 1], 2e-4)
+    sd2 = W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.LAT_SEED)
+    cond2, text2, codes2 = G.latent_inputs(cfg)
+    lat = O.ar_latents(sd2, cfg, cond2.repeat(G.LAT_K, 1), text2.repeat(G.LAT_K, 1), codes2)
+    close(lat, g["latents"], 2e-4)
+
+
+@torch.no_grad()
+def test_clvp_scores():
+    cfg = CLVPConfig(**G.CLVP_CFG)
+    sd = W.synthetic_state_dict(W.clvp_manifest(cfg), seed=G.CLVP_SEED)
+    text, codes = G.clvp_inputs()
+    close(O.clvp_score(sd, cfg, text.repeat(G.CLVP_B, 1), codes), gold("clvp.npz")["scores"], 1e-4)
+
+
+@torch.no_grad()
+def test_diffusion_network_and_sampler():
+    g = gold("diffusion.npz")
+    cfg = DiffusionConfig(**G.DIFF_CFG)
+    sd = W.synthetic_state_dict(W.diffusion_manifest(cfg), seed=G.DIFF_SEED)
+    S, latents, cond, x, step_noise = G.diff_inputs(cfg)
+    emb = O.diffusion_timestep_independent(sd, cfg, latents, cond, S)
+    close(emb, g["code_emb"], 1e-4)
+    ts = torch.tensor([G.DIFF_TS])
+    close(O.diffusion_forward(sd, cfg, x, ts, emb, False), g["eps_cond"], 2e-4)
+    close(O.diffusion_forward(sd, cfg, x, ts, emb, True), g["eps_uncond"], 2e-4)
+    sched = O.Schedule(G.DIFF_STEPS, 4000, True, 2.0)
+    assert list(sched.timestep_map) == list(g["timestep_map"])
+    close(O.p_sample_loop(sd, cfg, sched, emb, x.clone(), step_noise), g["x0"], 5e-4, 1e-3)
+
+
+@torch.no_grad()
+def test_univnet_waveform():
+    cfg = VocoderConfig()
+    sd = W.fold_weight_norm(W.synthetic_state_dict(W.vocoder_manifest(cfg), seed=G.VOC_SEED))
+    mel, z = G.voc_inputs()
+    wav = O.univnet_inference(sd, cfg, mel, z)
+    close(wav, gold("vocoder.npz")["wav"], 1e-4)
+    assert wav.shape == (1, 1, G.VOC_S * 256)  # the reference's own shape check (vocoder.py:318-324)
+
+
+def test_fix_autoregressive_output_bit_exact():
+    g = gold("integer.npz")
+    for cin, cout in zip(g["codes_in"], g["codes_out"]):
+        assert np.array_equal(O.fix_autoregressive_output(cin, 8193), cout)

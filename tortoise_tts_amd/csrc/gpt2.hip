@@ -40,6 +40,7 @@ struct tt_ar {
   int P1 = 0;      // current prefix length (incl. start token)
   int B = 0;       // current batch
   int logits_rows = 0;
+  bool logits_from_prefill = false;
 };
 
 static const int MAX_SPLIT = 8;
@@ -93,8 +94,12 @@ static int gpt_trunk_full(tt_ar* e, int B, int n, bool to_prefix, hipStream_t s)
   return 0;
 }
 
+// Split-K factor of the decode projections.  Deliberately independent of the batch size: the k-order
+// of every output element is then the same for any B, so a candidate's logits (and therefore its
+// sampled codes) do not depend on how the candidates are sharded across GPUs.
 static int pick_split(int B, int N, int K) {
-  const int tiles = cdiv(B, 64) * cdiv(N, 64);
+  (void)B;
+  const int tiles = cdiv(N, 64);
   int sk = 512 / (tiles > 0 ? tiles : 1);
   const int nk = K / 64;
   if (sk > MAX_SPLIT) sk = MAX_SPLIT;
@@ -242,6 +247,7 @@ int tt_ar_prefill(tt_ar* e, const float* prefix_emb, int P, void* stream) {
   int rc = ar_head(e, e->x + (size_t)P * D, 1, nullptr, 0, s);
   e->B = B_saved;
   TT_TRY(rc);
+  e->logits_from_prefill = true;
   return e->sb.leave(us);
 }
 
@@ -269,6 +275,7 @@ int tt_ar_decode_step(tt_ar* e, const int* tokens, void* stream) {
   TT_TRY(e->sb.enter(us));
   TT_CHECK_HIP(hipMemcpyAsync(e->next_tok, tokens, (size_t)e->B * sizeof(int), hipMemcpyDeviceToDevice, s));
   TT_TRY(ar_state_advance_launch(e->state, s));  // state[1] = slot of the token being fed
+  e->logits_from_prefill = false;
   TT_TRY(decode_step_enqueue(e, s));
   return e->sb.leave(us);
 }
@@ -293,7 +300,8 @@ int tt_ar_generate(tt_ar* e, int B, int max_new, const tt_sampling* sp, int* cod
   sa.codes = codes; sa.ldcodes = max_new; sa.next_tok = e->next_tok; sa.unfinished_count = e->unfinished_count;
   // token 0: every row samples from the shared prefill logits
   sa.logits = e->logits; sa.ldl = 0;
-  TT_REQUIRE(e->logits_rows >= 1, "tt_ar_generate: no prefill logits");
+  TT_REQUIRE(e->logits_from_prefill, "tt_ar_generate: the logits buffer does not hold prefill logits; call tt_ar_prefill first");
+  e->logits_from_prefill = false;
   TT_TRY(sample_launch(sa, s));
   TT_TRY(ar_state_advance_launch(e->state, s));
   sa.ldl = e->V;

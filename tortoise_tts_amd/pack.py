@@ -1,0 +1,274 @@
+"""Reference-layout state_dicts -> device-resident engine weights.
+
+Input: the state_dicts the reference loads at tortoise/api.py:221-237 (autoregressive.pth,
+clvp2.pth, diffusion_decoder.pth, vocoder.pth['model_g']), fp32 on CPU.  Output: contiguous device
+tensors in the layouts include/tortoise_mi355x.h documents (GEMM weights [out][in] in the MFMA
+operand type, conv kernels [out][tap][in_padded], norms / biases / embeddings f32) plus the ctypes
+structs that point at them.  Every tensor is kept alive by the returned holder object.
+"""
+import math
+import ctypes as C
+
+import torch
+
+from . import engine as E
+from .config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
+
+
+def torch_dtype(dtype):
+    return torch.bfloat16 if dtype == E.TT_BF16 else torch.float16
+
+
+class Holder:
+    """Keeps packed tensors + ctypes arrays alive and offers short helpers."""
+
+    def __init__(self, device, dtype):
+        self.device = device
+        self.dtype = dtype
+        self.tdtype = torch_dtype(dtype)
+        self.keep = []
+
+    def f32(self, t):
+        t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self.keep.append(t)
+        return t
+
+    def op(self, t):
+        """GEMM operand: [out][in...] flattened to 2-D, operand dtype."""
+        t = t.detach().to(device=self.device, dtype=torch.float32)
+        t = t.reshape(t.shape[0], -1).to(self.tdtype).contiguous()
+        self.keep.append(t)
+        return t
+
+    def conv(self, w, in_pad=None):
+        """Conv1d weight [out][in][k] -> [out][k][in_pad] operand."""
+        w = w.detach().to(device=self.device, dtype=torch.float32)
+        out_c, in_c, k = w.shape
+        in_pad = in_pad or in_c
+        p = torch.zeros(out_c, k, in_pad, device=self.device, dtype=torch.float32)
+        p[:, :, :in_c] = w.permute(0, 2, 1)
+        return self.op(p)
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+# ----------------------------------------------------------------------------------------- AR
+def pack_ar(sd, cfg: ARConfig, device, dtype):
+    h = Holder(device, dtype)
+    layers = (E.GptLayer * cfg.layers)()
+    for i in range(cfg.layers):
+        p = f"gpt.h.{i}"
+        L = layers[i]
+        L.ln1_g = _p(h.f32(sd[f"{p}.ln_1.weight"]))
+        L.ln1_b = _p(h.f32(sd[f"{p}.ln_1.bias"]))
+        L.w_qkv = _p(h.op(sd[f"{p}.attn.c_attn.weight"].t()))      # HF Conv1D stores [in, out]
+        L.b_qkv = _p(h.f32(sd[f"{p}.attn.c_attn.bias"]))
+        L.w_proj = _p(h.op(sd[f"{p}.attn.c_proj.weight"].t()))
+        L.b_proj = _p(h.f32(sd[f"{p}.attn.c_proj.bias"]))
+        L.ln2_g = _p(h.f32(sd[f"{p}.ln_2.weight"]))
+        L.ln2_b = _p(h.f32(sd[f"{p}.ln_2.bias"]))
+        L.w_fc = _p(h.op(sd[f"{p}.mlp.c_fc.weight"].t()))
+        L.b_fc = _p(h.f32(sd[f"{p}.mlp.c_fc.bias"]))
+        L.w_proj2 = _p(h.op(sd[f"{p}.mlp.c_proj.weight"].t()))
+        L.b_proj2 = _p(h.f32(sd[f"{p}.mlp.c_proj.bias"]))
+    w = E.ArWeights()
+    w.layers_host = layers
+    w.lnf_g = _p(h.f32(sd["gpt.ln_f.weight"]))
+    w.lnf_b = _p(h.f32(sd["gpt.ln_f.bias"]))
+    w.final_norm_g = _p(h.f32(sd["final_norm.weight"]))
+    w.final_norm_b = _p(h.f32(sd["final_norm.bias"]))
+    w.w_mel_head = _p(h.op(sd["mel_head.weight"]))
+    w.b_mel_head = _p(h.f32(sd["mel_head.bias"]))
+    h.mel_emb = h.f32(sd["mel_embedding.weight"])
+    h.mel_pos = h.f32(sd["mel_pos_embedding.emb.weight"])
+    h.text_emb = h.f32(sd["text_embedding.weight"])
+    h.text_pos = h.f32(sd["text_pos_embedding.emb.weight"])
+    w.mel_emb = _p(h.mel_emb)
+    w.mel_pos = _p(h.mel_pos)
+    h.layers = layers
+    h.weights = w
+    return h
+
+
+# ----------------------------------------------------------------------------------------- CLVP
+def _pack_clvp_tower(h, sd, cfg: CLVPConfig, tower, emb_key, latent_key):
+    base = f"{tower}.transformer"
+    layers = (E.ClvpLayer * cfg.depth)()
+    for li in range(cfg.depth):
+        pa = f"{base}.attn_layers.layers.{2 * li}"
+        pf = f"{base}.attn_layers.layers.{2 * li + 1}"
+        L = layers[li]
+        L.attn_norm_g = _p(h.f32(sd[f"{pa}.0.0.g"]))
+        L.w_qkv = _p(h.op(torch.cat([sd[f"{pa}.1.wrap.to_q.weight"], sd[f"{pa}.1.wrap.to_k.weight"],
+                                     sd[f"{pa}.1.wrap.to_v.weight"]], dim=0)))
+        L.w_out = _p(h.op(sd[f"{pa}.1.wrap.to_out.weight"]))
+        L.b_out = _p(h.f32(sd[f"{pa}.1.wrap.to_out.bias"]))
+        L.ff_norm_g = _p(h.f32(sd[f"{pf}.0.0.g"]))
+        L.w_ff1 = _p(h.op(sd[f"{pf}.1.wrap.net.0.proj.weight"]))
+        L.b_ff1 = _p(h.f32(sd[f"{pf}.1.wrap.net.0.proj.bias"]))
+        L.w_ff2 = _p(h.op(sd[f"{pf}.1.wrap.net.3.weight"]))
+        L.b_ff2 = _p(h.f32(sd[f"{pf}.1.wrap.net.3.bias"]))
+    t = E.ClvpTower()
+    t.layers_host = layers
+    t.emb = _p(h.f32(sd[emb_key]))
+    t.inv_freq = _p(h.f32(sd[f"{base}.attn_layers.rotary_pos_emb.inv_freq"]))
+    t.norm_g = _p(h.f32(sd[f"{base}.norm.weight"]))
+    t.norm_b = _p(h.f32(sd[f"{base}.norm.bias"]))
+    t.w_latent = _p(h.op(sd[latent_key]))
+    h.keep.append(layers)
+    return t
+
+
+def pack_clvp(sd, cfg: CLVPConfig, device, dtype):
+    h = Holder(device, dtype)
+    h.text = _pack_clvp_tower(h, sd, cfg, "text_transformer", "text_emb.weight", "to_text_latent.weight")
+    h.speech = _pack_clvp_tower(h, sd, cfg, "speech_transformer", "speech_emb.weight", "to_speech_latent.weight")
+    h.temperature = h.f32(sd["temperature"].reshape(1))
+    return h
+
+
+# ----------------------------------------------------------------------------------------- diffusion
+def _rel_pos_bucket(rel, num_buckets=32, max_distance=64):
+    # RelativePositionBias._relative_position_bucket, causal=False (xtransformers.py:155-175); rel = k - q
+    nb = num_buckets // 2
+    n = -rel
+    ret = (n < 0).long() * nb
+    n = n.abs()
+    max_exact = nb // 2
+    is_small = n < max_exact
+    large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    return ret + torch.where(is_small, n, large)
+
+
+def relpos_table(weight, scale=8.0):
+    """[heads][129]: additive attention bias for clamp(k - q, -64, 64) (the bucket function saturates
+    well before |k - q| = 64, so the clamp is exact).  weight: [32 buckets][heads]."""
+    d = torch.arange(-64, 65)
+    bucket = _rel_pos_bucket(d)
+    return (weight.detach().float().cpu()[bucket] * scale).t().contiguous()  # [heads][129]
+
+
+def _qkv_head_major_perm(C, heads):
+    """Reference AttentionBlock qkv channels are [head][q|k|v][64] (arch_util.py:63); the engine wants
+    [q|k|v][head][64].  Returns idx with new[n] = old[idx[n]]."""
+    ch = C // heads
+    idx = torch.empty(3 * C, dtype=torch.long)
+    for part in range(3):
+        for hd in range(heads):
+            dst = part * C + hd * ch
+            src = hd * 3 * ch + part * ch
+            idx[dst:dst + ch] = torch.arange(src, src + ch)
+    return idx
+
+
+def _pack_attn(h, sd, prefix, C, heads):
+    a = E.AttnBlock()
+    perm = _qkv_head_major_perm(C, heads)
+    a.norm_g = _p(h.f32(sd[f"{prefix}.norm.weight"]))
+    a.norm_b = _p(h.f32(sd[f"{prefix}.norm.bias"]))
+    a.w_qkv = _p(h.op(sd[f"{prefix}.qkv.weight"][perm]))
+    a.b_qkv = _p(h.f32(sd[f"{prefix}.qkv.bias"][perm]))
+    a.w_proj = _p(h.op(sd[f"{prefix}.proj_out.weight"]))
+    a.b_proj = _p(h.f32(sd[f"{prefix}.proj_out.bias"]))
+    key = f"{prefix}.relative_pos_embeddings.relative_attention_bias.weight"
+    a.relpos = _p(h.f32(relpos_table(sd[key], (C // heads) ** 0.5))) if key in sd else None
+    return a
+
+
+def _pack_res(h, sd, prefix):
+    r = E.ResBlock()
+    r.gn1_g = _p(h.f32(sd[f"{prefix}.in_layers.0.weight"]))
+    r.gn1_b = _p(h.f32(sd[f"{prefix}.in_layers.0.bias"]))
+    r.w_in = _p(h.op(sd[f"{prefix}.in_layers.2.weight"]))
+    r.b_in = _p(h.f32(sd[f"{prefix}.in_layers.2.bias"]))
+    r.gn2_g = _p(h.f32(sd[f"{prefix}.out_layers.0.weight"]))
+    r.gn2_b = _p(h.f32(sd[f"{prefix}.out_layers.0.bias"]))
+    r.w_out = _p(h.conv(sd[f"{prefix}.out_layers.3.weight"]))
+    r.b_out = _p(h.f32(sd[f"{prefix}.out_layers.3.bias"]))
+    return r
+
+
+def pack_diffusion(sd, cfg: DiffusionConfig, device, dtype, in_pad=128):
+    h = Holder(device, dtype)
+    C, H, L = cfg.model_channels, cfg.num_heads, cfg.num_layers
+    NR = 3 + L + 3
+    res = (E.ResBlock * NR)()
+    attn = (E.AttnBlock * (3 + L))()
+    lat = (E.AttnBlock * 4)()
+    res_prefixes = [f"conditioning_timestep_integrator.{i}.resblk" for i in range(3)] + \
+                   [f"layers.{i}.resblk" for i in range(L)] + [f"layers.{i}" for i in range(L, L + 3)]
+    attn_prefixes = [f"conditioning_timestep_integrator.{i}.attn" for i in range(3)] + [f"layers.{i}.attn" for i in range(L)]
+    for i, p in enumerate(res_prefixes):
+        res[i] = _pack_res(h, sd, p)
+    for i, p in enumerate(attn_prefixes):
+        attn[i] = _pack_attn(h, sd, p, C, H)
+    for i in range(4):
+        lat[i] = _pack_attn(h, sd, f"latent_conditioner.{i + 1}", C, H)
+    w = E.DiffWeights()
+    w.w_latent_conv = _p(h.conv(sd["latent_conditioner.0.weight"]))
+    w.b_latent_conv = _p(h.f32(sd["latent_conditioner.0.bias"]))
+    w.latent_attn_host = lat
+    w.code_norm_g = _p(h.f32(sd["code_norm.weight"]))
+    w.code_norm_b = _p(h.f32(sd["code_norm.bias"]))
+    w.uncond_emb = _p(h.f32(sd["unconditioned_embedding"].reshape(-1)))
+    w.w_time1 = _p(h.op(sd["time_embed.0.weight"]))
+    w.b_time1 = _p(h.f32(sd["time_embed.0.bias"]))
+    w.w_time2 = _p(h.op(sd["time_embed.2.weight"]))
+    w.b_time2 = _p(h.f32(sd["time_embed.2.bias"]))
+    w.w_emb_all = _p(h.op(torch.cat([sd[f"{p}.emb_layers.1.weight"] for p in res_prefixes], dim=0)))
+    w.b_emb_all = _p(h.f32(torch.cat([sd[f"{p}.emb_layers.1.bias"] for p in res_prefixes], dim=0)))
+    w.res_host = res
+    w.attn_host = attn
+    w.w_inp = _p(h.conv(sd["inp_block.weight"], in_pad))
+    w.b_inp = _p(h.f32(sd["inp_block.bias"]))
+    w.w_integ = _p(h.op(sd["integrating_conv.weight"]))
+    w.b_integ = _p(h.f32(sd["integrating_conv.bias"]))
+    w.out_gn_g = _p(h.f32(sd["out.0.weight"]))
+    w.out_gn_b = _p(h.f32(sd["out.0.bias"]))
+    w.w_final = _p(h.conv(sd["out.2.weight"]))
+    w.b_final = _p(h.f32(sd["out.2.bias"]))
+    h.keep += [res, attn, lat]
+    h.weights = w
+    h.in_pad = in_pad
+    return h
+
+
+# ----------------------------------------------------------------------------------------- vocoder
+def pack_vocoder(sd_folded, cfg: VocoderConfig, device, dtype, mel_pad=128):
+    """sd_folded: UnivNet state_dict with weight-norm already folded (weights.fold_weight_norm)."""
+    h = Holder(device, dtype)
+    sd = sd_folded
+    blocks = (E.VocBlock * len(cfg.strides))()
+    for bi, stride in enumerate(cfg.strides):
+        p = f"res_stack.{bi}"
+        kp = f"{p}.kernel_predictor"
+        b = blocks[bi]
+        b.stride = stride
+        b.w_convt = _p(h.f32(sd[f"{p}.convt_pre.1.weight"]))
+        b.b_convt = _p(h.f32(sd[f"{p}.convt_pre.1.bias"]))
+        b.w_kp_in = _p(h.conv(sd[f"{kp}.input_conv.0.weight"], mel_pad))
+        b.b_kp_in = _p(h.f32(sd[f"{kp}.input_conv.0.bias"]))
+        for r in range(3):
+            for c, idx in enumerate((1, 3)):
+                b.w_kp_res[2 * r + c] = _p(h.conv(sd[f"{kp}.residual_convs.{r}.{idx}.weight"]))
+                b.b_kp_res[2 * r + c] = _p(h.f32(sd[f"{kp}.residual_convs.{r}.{idx}.bias"]))
+        b.w_kp_kernel = _p(h.conv(sd[f"{kp}.kernel_conv.weight"]))
+        b.b_kp_kernel = _p(h.f32(sd[f"{kp}.kernel_conv.bias"]))
+        b.w_kp_bias = _p(h.conv(sd[f"{kp}.bias_conv.weight"]))
+        b.b_kp_bias = _p(h.f32(sd[f"{kp}.bias_conv.bias"]))
+        for j in range(len(cfg.dilations)):
+            b.w_conv[j] = _p(h.f32(sd[f"{p}.conv_blocks.{j}.1.weight"]))
+            b.b_conv[j] = _p(h.f32(sd[f"{p}.conv_blocks.{j}.1.bias"]))
+    w = E.VocWeights()
+    w.w_pre = _p(h.f32(sd["conv_pre.weight"]))
+    w.b_pre = _p(h.f32(sd["conv_pre.bias"]))
+    w.blocks_host = blocks
+    w.w_post = _p(h.f32(sd["conv_post.1.weight"]))
+    w.b_post = _p(h.f32(sd["conv_post.1.bias"]))
+    h.keep.append(blocks)
+    h.weights = w
+    h.mel_pad = mel_pad
+    return h

@@ -1,0 +1,280 @@
+"""Host-side stage objects: one per C-ABI handle.  They own the packed weights, translate between
+the reference's tensor conventions (channels-first, int64 ids) and the engine's, and keep every
+call on the caller's current torch stream.  No model arithmetic happens here beyond embedding
+gathers for the once-per-utterance prefix (plumbing).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import engine as E
+from . import pack
+from .config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
+from .schedule import Schedule
+
+
+def _i32(t, device):
+    return t.to(device=device, dtype=torch.int32).contiguous()
+
+
+class ArStage:
+    """UnifiedVoice hot path: prefill + sampling loop + latent re-pass (autoregressive.py:454-563)."""
+
+    def __init__(self, sd, cfg: ARConfig = ARConfig(), device="cuda", dtype=E.TT_BF16, max_batch=256, max_text=402,
+                 max_new_tokens=500, max_latent_candidates=4):
+        self.lib = E.init()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.w = pack.pack_ar(sd, cfg, self.device, dtype)
+        c = E.ArConfig()
+        c.dtype = dtype
+        c.layers, c.model_dim, c.heads = cfg.layers, cfg.model_dim, cfg.heads
+        c.vocab = cfg.number_mel_codes
+        c.start_mel_token, c.stop_mel_token = cfg.start_mel_token, cfg.stop_mel_token
+        c.mel_pos_len = cfg.mel_pos_len
+        c.max_batch = max_batch
+        c.max_prefix = 1 + max_text + 2 + 1
+        c.max_new_tokens = max_new_tokens + 2
+        c.max_full_rows = max_latent_candidates * (1 + max_text + 2 + max_new_tokens + 2)
+        self.max_latent_candidates = max_latent_candidates
+        self.ccfg = c
+        self.h = E.vp()
+        E.check(self.lib.tt_ar_create(C.byref(c), C.byref(self.w.weights), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib.tt_ar_destroy(self.h)
+            self.h = E.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- prefix (autoregressive.py:538-544)
+    def prefix_embedding(self, cond_latent, text_tokens):
+        cfg = self.cfg
+        t = F.pad(text_tokens.to(self.device).long(), (0, 1), value=cfg.stop_text_token)
+        t = F.pad(t, (1, 0), value=cfg.start_text_token)
+        n = t.shape[1]
+        text_emb = self.w.text_emb[t] + self.w.text_pos[:n][None]
+        return torch.cat([cond_latent.to(self.device).float()[:, None, :], text_emb], dim=1)  # [1, P, D]
+
+    def prefill(self, cond_latent, text_tokens):
+        emb = self.prefix_embedding(cond_latent[:1], text_tokens[:1])[0].contiguous()
+        self.P = emb.shape[0]
+        E.check(self.lib.tt_ar_prefill(self.h, E.ptr(emb), self.P, E.stream_ptr()))
+
+    def logits(self, rows):
+        out = torch.empty(rows, self.cfg.number_mel_codes, device=self.device, dtype=torch.float32)
+        E.check(self.lib.tt_ar_get_logits(self.h, E.ptr(out), rows, E.stream_ptr()))
+        return out
+
+    def begin(self, B):
+        E.check(self.lib.tt_ar_begin(self.h, B, E.stream_ptr()))
+
+    def decode_step(self, tokens):
+        t = _i32(tokens, self.device)
+        E.check(self.lib.tt_ar_decode_step(self.h, E.ptr(t), E.stream_ptr()))
+
+    def generate(self, B, max_new, temperature=0.8, top_p=0.8, repetition_penalty=2.0, top_k=50, seed=0, row_offset=0,
+                 exp_noise=None):
+        """Returns (codes int64 [B, n_steps], n_steps).  exp_noise: optional f32 [max_new, B, V] Exp(1) draws."""
+        s = E.Sampling()
+        s.temperature, s.top_p, s.repetition_penalty, s.top_k = temperature, top_p, repetition_penalty, top_k
+        s.seed, s.row_offset = seed, row_offset
+        if exp_noise is not None:
+            exp_noise = exp_noise.to(device=self.device, dtype=torch.float32).contiguous()
+            assert exp_noise.shape == (max_new, B, self.cfg.number_mel_codes)
+        s.exp_noise = E.ptr(exp_noise)
+        codes = torch.empty(B, max_new, device=self.device, dtype=torch.int32)
+        n = C.c_int(0)
+        E.check(self.lib.tt_ar_generate(self.h, B, max_new, C.byref(s), E.ptr(codes), C.byref(n), E.stream_ptr()))
+        return codes[:, :n.value].long(), n.value
+
+    # -- latent re-pass (autoregressive.py:454-506 as api.py:521-524 calls it)
+    def latents(self, cond_latent, text_tokens, codes):
+        cfg = self.cfg
+        k, n = codes.shape
+        t = F.pad(text_tokens.to(self.device).long(), (0, 1), value=cfg.stop_text_token)
+        t = F.pad(t, (1, 0), value=cfg.start_text_token)
+        text_emb = self.w.text_emb[t] + self.w.text_pos[: t.shape[1]][None]
+        m = F.pad(codes.to(self.device).long(), (0, 1), value=cfg.stop_mel_token)
+        m = F.pad(m, (1, 0), value=cfg.start_mel_token)
+        mel_emb = self.w.mel_emb[m] + self.w.mel_pos[: m.shape[1]][None]
+        if text_emb.shape[0] == 1 and k > 1:
+            text_emb = text_emb.expand(k, -1, -1)
+        cond = cond_latent.to(self.device).float()
+        if cond.shape[0] == 1 and k > 1:
+            cond = cond.expand(k, -1)
+        emb = torch.cat([cond[:, None, :], text_emb, mel_emb], dim=1).contiguous()
+        outs = []
+        for i in range(0, k, self.max_latent_candidates):
+            e = emb[i:i + self.max_latent_candidates].contiguous()
+            out = torch.empty_like(e)
+            E.check(self.lib.tt_ar_latents(self.h, E.ptr(e), e.shape[0], e.shape[1], E.ptr(out), E.stream_ptr()))
+            outs.append(out)
+        out = torch.cat(outs, dim=0)
+        # enc = hidden[:, 1:]; mel part = last m.shape[1] rows; drop the final two (autoregressive.py:425-431, 503)
+        return out[:, -m.shape[1]:][:, :-2]
+
+
+class ClvpStage:
+    """CLVP.forward(return_loss=False) (clvp.py:99-135)."""
+
+    def __init__(self, sd, cfg: CLVPConfig = CLVPConfig(), device="cuda", dtype=E.TT_BF16, max_rows=256 * 500):
+        self.lib = E.init()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.w = pack.pack_clvp(sd, cfg, self.device, dtype)
+        c = E.ClvpConfig()
+        c.dtype, c.dim, c.latent_dim, c.depth, c.heads = dtype, cfg.dim, cfg.dim_latent, cfg.depth, cfg.heads
+        c.ff_inner, c.rot_dim, c.max_rows = cfg.dim * cfg.ff_mult, cfg.rotary_dim, max_rows
+        self.max_rows = max_rows
+        self.h = E.vp()
+        E.check(self.lib.tt_clvp_create(C.byref(c), C.byref(self.w.text), C.byref(self.w.speech), E.ptr(self.w.temperature),
+                                        C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib.tt_clvp_destroy(self.h)
+            self.h = E.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def score(self, text_tokens, codes):
+        """text_tokens int [1 or B, T] (rows identical), codes int [B, n] -> f32 [B]."""
+        text = _i32(text_tokens[0], self.device)
+        B, n = codes.shape
+        outs = []
+        per = max(1, self.max_rows // n)
+        for i in range(0, B, per):
+            c = _i32(codes[i:i + per], self.device)
+            out = torch.empty(c.shape[0], device=self.device, dtype=torch.float32)
+            E.check(self.lib.tt_clvp_score(self.h, E.ptr(text), text.shape[0], E.ptr(c), c.shape[0], n, E.ptr(out), E.stream_ptr()))
+            outs.append(out)
+        return torch.cat(outs)
+
+
+def nearest_interp_index(m, s):
+    """Source row of F.interpolate(mode='nearest') for each of s outputs given m inputs
+    (ATen nearest_neighbor_compute_source_index: floor(dst * float(m / s)), clamped)."""
+    scale = np.float32(m) / np.float32(s)
+    idx = np.floor(np.arange(s, dtype=np.float32) * scale).astype(np.int64)
+    return np.minimum(idx, m - 1).astype(np.int32)
+
+
+class DiffusionStage:
+    """DiffusionTts + SpacedDiffusion.p_sample_loop (api.py:117-130)."""
+
+    def __init__(self, sd, cfg: DiffusionConfig = DiffusionConfig(), device="cuda", dtype=E.TT_BF16, max_seq=2304, max_codes=512,
+                 max_steps=512):
+        self.lib = E.init()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.w = pack.pack_diffusion(sd, cfg, self.device, dtype)
+        c = E.DiffConfig()
+        c.dtype, c.channels, c.heads, c.num_layers = dtype, cfg.model_channels, cfg.num_heads, cfg.num_layers
+        c.in_channels, c.in_pad, c.out_channels = cfg.in_channels, self.w.in_pad, cfg.out_channels
+        c.latent_channels, c.max_seq, c.max_codes, c.max_steps = cfg.in_latent_channels, max_seq, max_codes, max_steps
+        self.h = E.vp()
+        E.check(self.lib.tt_diff_create(C.byref(c), C.byref(self.w.weights), C.byref(self.h)))
+        self.S = 0
+
+    def close(self):
+        if self.h:
+            self.lib.tt_diff_destroy(self.h)
+            self.h = E.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def condition(self, latents, cond_latent, S):
+        """latents f32 [1, M, latent]; cond_latent f32 [1, 2C] (diffusion_decoder.py:232-260)."""
+        lat = latents[0].to(self.device).float().contiguous()
+        cond = cond_latent[0].to(self.device).float().contiguous()
+        idx = torch.from_numpy(nearest_interp_index(lat.shape[0], S)).to(self.device)
+        E.check(self.lib.tt_diff_condition(self.h, E.ptr(lat), lat.shape[0], E.ptr(cond), E.ptr(idx), S, E.stream_ptr()))
+        self.S = S
+
+    def code_emb(self):
+        out = torch.empty(self.S, self.cfg.model_channels, device=self.device, dtype=torch.float32)
+        E.check(self.lib.tt_diff_get_code_emb(self.h, E.ptr(out), E.stream_ptr()))
+        return out.t()[None]  # [1, C, S] like the reference
+
+    def forward(self, x, timestep, cond_free=True):
+        """x f32 [1, 100, S] -> raw model outputs [B, 200, S] (B = 2 with cond_free: row 0 cond, row 1 uncond)."""
+        xt = x[0].to(self.device).float().t().contiguous()
+        B = 2 if cond_free else 1
+        out = torch.empty(B, self.S, self.cfg.out_channels, device=self.device, dtype=torch.float32)
+        E.check(self.lib.tt_diff_forward(self.h, E.ptr(xt), int(timestep), int(cond_free), E.ptr(out), E.stream_ptr()))
+        return out.permute(0, 2, 1)
+
+    def sample(self, sched: Schedule, x_T, step_noise):
+        """x_T f32 [1, 100, S]; step_noise f32 [N, 1, 100, S] with step_noise[i] the draw of spaced index i
+        (same convention as the oracle).  Returns the denormalised mel [1, 100, S]."""
+        N = sched.num_timesteps
+        steps = (E.DiffStep * N)()
+        order = list(reversed(range(N)))
+        for j, i in enumerate(order):
+            st = steps[j]
+            st.timestep = int(sched.timestep_map[i])
+            st.min_log = sched.f32(sched.post_logvar_clipped, i)
+            st.max_log = sched.f32(sched.log_betas, i)
+            st.cfk = float(np.float32(sched.cond_free_k * (1 - i / N)))
+            st.sqrt_recip = sched.f32(sched.sqrt_recip_ac, i)
+            st.sqrt_recipm1 = sched.f32(sched.sqrt_recipm1_ac, i)
+            st.coef1 = sched.f32(sched.coef1, i)
+            st.coef2 = sched.f32(sched.coef2, i)
+            st.nonzero = 0.0 if i == 0 else 1.0
+        x = x_T[0].to(self.device).float().contiguous()
+        noise = step_noise.to(self.device).float()[order, 0].contiguous()  # run order
+        mel = torch.empty(self.cfg.in_channels, self.S, device=self.device, dtype=torch.float32)
+        E.check(self.lib.tt_diff_sample(self.h, E.ptr(x), E.ptr(noise), steps, N, int(sched.cond_free), E.ptr(mel), E.stream_ptr()))
+        return mel[None]
+
+
+class VocoderStage:
+    """UnivNetGenerator.inference (vocoder.py:300-312)."""
+
+    def __init__(self, sd_folded, cfg: VocoderConfig = VocoderConfig(), device="cuda", dtype=E.TT_BF16, max_frames=2304):
+        self.lib = E.init()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.w = pack.pack_vocoder(sd_folded, cfg, self.device, dtype)
+        c = E.VocConfig()
+        c.dtype, c.max_frames, c.mel_channels, c.mel_pad = dtype, max_frames, cfg.n_mel_channels, self.w.mel_pad
+        self.h = E.vp()
+        E.check(self.lib.tt_voc_create(C.byref(c), C.byref(self.w.weights), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib.tt_voc_destroy(self.h)
+            self.h = E.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def inference(self, mel, z):
+        """mel f32 [1, 100, S]; z f32 [1, 64, S+10] -> audio [1, 1, S*256]."""
+        m = mel[0].to(self.device).float().contiguous()
+        S = m.shape[1]
+        zz = z[0].to(self.device).float().contiguous()
+        assert zz.shape == (self.cfg.noise_dim, S + 10)
+        audio = torch.empty(S * self.cfg.hop_length, device=self.device, dtype=torch.float32)
+        E.check(self.lib.tt_voc_run(self.h, E.ptr(m), S, E.ptr(zz), E.ptr(audio), E.stream_ptr()))
+        return audio.clamp(-1, 1)[None, None]
