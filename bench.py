@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""Headline benchmark: real-time factor (audio-seconds / wall-second) and end-to-end latency of
+`TextToSpeech.tts_with_preset(..., preset='standard')` on N MI355X GPUs (BASELINE.json metric).
+
+A "step" is one complete utterance: 256 autoregressive candidates (sharded N/gpus per rank) x M mel
+tokens -> CLVP ranking (one all_gather) -> latent re-pass -> 200 diffusion iterations (cond_free) ->
+UnivNet.  No checkpoints exist offline, so the four networks are built at the reference's
+hyper-parameters (tortoise/api.py:217-236) with seeded synthetic weights; the stop token is
+suppressed and the decode length fixed at M (default 200 -> 9.28 s of 24 kHz audio) exactly as
+SURVEY.md §8(d) prescribes, because random weights never emit a meaningful end-of-speech.
+
+One JSON line on rank 0.  Extra legs inside the same command (rank 0, N == 1):
+  roofline      one additional un-captured step with every kernel launch bracketed by HIP events on its
+                launch stream; reports the dominant kernel class against the gfx950 roofline
+  cpu_baseline  the CPU oracle (reference algorithm, fp32) timed on the host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16
+
+
+def synthetic_weights(seed=1234):
+    from tortoise_tts_amd import weights as W
+    from tortoise_tts_amd.config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
+    ar_cfg = ARConfig()
+    sds = {
+        "autoregressive": W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(ar_cfg), seed), ar_cfg),
+        "clvp": W.synthetic_state_dict(W.clvp_manifest(CLVPConfig()), seed + 1),
+        "diffusion": W.synthetic_state_dict(W.diffusion_manifest(DiffusionConfig()), seed + 2),
+        "vocoder": W.fold_weight_norm(W.synthetic_state_dict(W.vocoder_manifest(VocoderConfig()), seed + 3)),
+    }
+    return sds
+
+
+def synthetic_prompt(seed=0, text_tokens=54):
+    g = torch.Generator().manual_seed(seed)
+    text = torch.randint(1, 255, (text_tokens,), generator=g)  # do_tts.py default sentence -> 54 BPE ids
+    auto = torch.randn(1, 1024, generator=g) * 0.5             # stands in for voices/cond_latent_example/pat.pth
+    diff = torch.randn(1, 2048, generator=g) * 0.5
+    return text, (auto, diff)
+
+
+def cpu_baseline(sds, text, latents, preset_kw, M, cores):
+    """Reference algorithm (oracle/, fp32) on the host cores, bounded sample, linear extrapolation."""
+    from oracle import tortoise_oracle as O
+    from tortoise_tts_amd.config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
+    import torch.nn.functional as F
+    torch.set_num_threads(cores)
+    ar_cfg, clvp_cfg, d_cfg, v_cfg = ARConfig(), CLVPConfig(), DiffusionConfig(), VocoderConfig()
+    auto, diffc = latents
+    tt = F.pad(text.int()[None], (0, 1))
+    N, iters = preset_kw["num_autoregressive_samples"], preset_kw["diffusion_iterations"]
+    Bc, nsteps = 16, 6  # reference default AR batch on a >=14 GB device (api.py:156-157)
+    with torch.no_grad():
+        sd = sds["autoregressive"]
+        t0 = time.perf_counter()
+        prefix = O.ar_prefix(sd, ar_cfg, auto, tt)
+        lg, kv = O.ar_prefill(sd, ar_cfg, prefix, Bc)
+        t_pf = time.perf_counter() - t0
+        tok = torch.zeros(Bc, dtype=torch.long)
+        t0 = time.perf_counter()
+        for s in range(nsteps):
+            lg, kv = O.ar_step(sd, ar_cfg, tok, s + 1, kv)
+            O.warp_logits(lg, torch.zeros(Bc, 60, dtype=torch.long))
+        t_step = (time.perf_counter() - t0) / nsteps
+        ar_total = (N / Bc) * (t_pf + (M - 1) * t_step)
+        codes = torch.randint(0, 8192, (1, M))
+        t0 = time.perf_counter()
+        O.clvp_score(sds["clvp"], clvp_cfg, tt.long(), codes)
+        clvp_total = (time.perf_counter() - t0) * N
+        t0 = time.perf_counter()
+        lat = O.ar_latents(sd, ar_cfg, auto, tt, codes)
+        lat_total = time.perf_counter() - t0
+        S = M * 4 * 24000 // 22050
+        dsd = sds["diffusion"]
+        t0 = time.perf_counter()
+        emb = O.diffusion_timestep_independent(dsd, d_cfg, lat, diffc, S)
+        t_ti = time.perf_counter() - t0
+        x = torch.randn(1, 100, S)
+        ts = torch.tensor([2000])
+        t0 = time.perf_counter()
+        O.diffusion_forward(dsd, d_cfg, x, ts, emb, False)
+        O.diffusion_forward(dsd, d_cfg, x, ts, emb, True)
+        t_pair = time.perf_counter() - t0
+        diff_total = t_ti + iters * (t_pair if preset_kw.get("cond_free", True) else t_pair / 2)
+        t0 = time.perf_counter()
+        O.univnet_inference(sds["vocoder"], v_cfg, torch.randn(1, 100, S), torch.randn(1, 64, S + 10))
+        voc_total = time.perf_counter() - t0
+    total = ar_total + clvp_total + lat_total + diff_total + voc_total
+    audio_s = S * 256 / 24000.0
+    return {"value": audio_s / total, "unit": "audio-s/wall-s", "cores": cores, "kind": "port",
+            "latency_s_extrapolated": total,
+            "sample": (f"oracle fp32: AR prefill + {nsteps} cached steps at B={Bc} ({t_pf:.2f}s + {t_step:.3f}s/step), CLVP 1 of {N} "
+                       f"candidates, 1 latent pass, timestep_independent + 1 cond/uncond denoiser pair of {iters} ({t_pair:.2f}s), "
+                       f"full UnivNet ({voc_total:.2f}s); stages extrapolated linearly to the full utterance"),
+            "stages_s": {"ar": ar_total, "clvp": clvp_total, "latents": lat_total, "diffusion": diff_total, "vocoder": voc_total}}
+
+
+def roofline_leg(tts, run_step):
+    """One extra step with graphs off and per-launch HIP events (tt_prof_*): dominant kernel class."""
+    import ctypes as C
+    from tortoise_tts_amd import engine as E
+    lib = E.load_library()
+    os.environ["TT_NO_GRAPH"] = "1"
+    lib.tt_prof_enable(1)
+    try:
+        run_step()
+        torch.cuda.synchronize()
+    finally:
+        lib.tt_prof_enable(0)
+        os.environ.pop("TT_NO_GRAPH", None)
+    rows = []
+    buf = (C.c_double * 4)()
+    for i in range(lib.tt_prof_classes()):
+        lib.tt_prof_read(i, buf)
+        if buf[0] > 0:
+            rows.append({"kernel": lib.tt_prof_class_name(i).decode(), "launches": int(buf[0]), "total_ms": buf[1],
+                         "avg_us": 1e3 * buf[1] / buf[0], "flops": buf[2], "bytes": buf[3]})
+    rows.sort(key=lambda r: -r["total_ms"])
+    if not rows:
+        return None, []
+    d = rows[0]
+    sec = d["total_ms"] / 1e3
+    intensity = d["flops"] / max(d["bytes"], 1.0)
+    ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if intensity >= ridge:
+        ach = d["flops"] / sec / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS}
+    else:
+        ach = d["bytes"] / sec / 1e9
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    roof.update({"traffic": None, "kernel": d["kernel"], "launches": d["launches"], "avg_launch_us": d["avg_us"],
+                 "algorithmic_flops_per_launch": d["flops"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                 "arithmetic_intensity": intensity, "share_of_kernel_time": d["total_ms"] / sum(r["total_ms"] for r in rows)})
+    return roof, rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--preset", default="standard")
+    ap.add_argument("--mel-tokens", type=int, default=200, help="fixed decode length M (SURVEY.md §8d: 200 and 500)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from tortoise_tts_amd import dist as tdist
+    rank, world, local = tdist.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    from tortoise_tts_amd.api import TextToSpeech
+    from tortoise_tts_amd.config import PRESETS, BASE_SETTINGS
+
+    preset_kw = dict(BASE_SETTINGS)
+    preset_kw.update(PRESETS[args.preset])
+    N = preset_kw["num_autoregressive_samples"]
+    M = args.mel_tokens
+    t_build = time.perf_counter()
+    sds = synthetic_weights()
+    text, latents = synthetic_prompt()
+    tts = TextToSpeech(state_dicts=sds, dtype=args.dtype, max_candidates=N // world, max_mel_tokens=max(M, 32))
+    t_build = time.perf_counter() - t_build
+
+    def run_step(i=0):
+        return tts.tts_with_preset(text, preset=args.preset, conditioning_latents=latents, max_mel_tokens=M,
+                                   use_deterministic_seed=1000 + i, k=1, verbose=False)
+
+    wav = None
+    for i in range(args.warmup):
+        wav = run_step(i)
+    tdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stage_acc = {}
+    for i in range(args.steps):
+        wav = run_step(100 + i)
+        for k_, v in tts.timings.items():
+            stage_acc[k_] = stage_acc.get(k_, 0.0) + v
+    tdist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    audio_s = float(wav.shape[-1]) / 24000.0
+    assert torch.isfinite(wav).all() and wav.abs().max() <= 1.0
+
+    roof, breakdown, cpu = None, [], None
+    if not args.no_roofline:
+        roof, breakdown = roofline_leg(tts, lambda: run_step(999))  # every rank runs it (the step contains a collective)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cores = min(os.cpu_count() or 1, 64)
+        cpu = cpu_baseline(sds, text, latents, preset_kw, M, cores)
+
+    if rank == 0:
+        out = {
+            "metric": "rtf_standard_preset", "value": audio_s * args.steps / dt, "unit": "audio-s/wall-s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "latency_s": dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"tts_with_preset('{args.preset}'): {N} AR candidates x {M} mel tokens (EOS suppressed, fixed length), "
+                                   f"CLVP top-1, {preset_kw['diffusion_iterations']} diffusion iterations cond_free={preset_kw.get('cond_free', True)}, "
+                                   f"UnivNet; 55 text tokens; {audio_s:.2f} s of 24 kHz audio per step",
+                       "weights": "seeded synthetic at the reference hyper-parameters (no checkpoints offline)",
+                       "parallelism": f"candidates sharded {N // world}/GPU, 1 all_gather, winner rendered on rank 0"},
+            "stages_s_per_step": {k_: v / args.steps for k_, v in stage_acc.items()},
+            "audio_seconds_per_step": audio_s, "engine_build_s": t_build,
+            "roofline": roof, "cpu_baseline": cpu,
+            "kernel_breakdown_ms": [{"kernel": r["kernel"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),
+                                     "avg_us": round(r["avg_us"], 2)} for r in breakdown],
+        }
+        print(json.dumps(out))
+    tdist.barrier()
+
+
+if __name__ == "__main__":
+    main()

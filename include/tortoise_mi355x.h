@@ -241,6 +241,16 @@ void tt_voc_destroy(tt_voc* h);
 int tt_voc_run(tt_voc* h, const float* mel, int S, const float* z, float* audio, void* stream);
 
 /* ============================================================================================
+ * Per-kernel-class timing for bench.py's roofline leg: while enabled every launch is bracketed by HIP
+ * events on its own stream (run with TT_NO_GRAPH=1; never enabled on the product path).
+ * tt_prof_read: out[4] = {launches, total_ms, algorithmic_flops, algorithmic_bytes}; synchronises.
+ * ============================================================================================ */
+int tt_prof_enable(int on);
+int tt_prof_classes(void);
+const char* tt_prof_class_name(int id);
+int tt_prof_read(int id, double* out);
+
+/* ============================================================================================
  * Operator-level entry points (used by tests/ to check single kernels against torch references)
  * ============================================================================================ */
 int tt_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int taps, int seq_len,

@@ -1,0 +1,64 @@
+"""World-size-2 `gloo` test of the candidate-sharding exchange (tortoise_tts_amd/dist.py): each rank holds
+N/R (score, codes) rows; after the single all_gather every rank must select the same top-k as one
+process holding all N rows, with ties resolved to the lowest global index."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tortoise_tts_amd import dist as tdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, N, M, k, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    tdist.init_from_env()
+    assert tdist.world() == (rank, world)
+    g = torch.Generator().manual_seed(0)
+    scores = torch.randn(N, generator=g)
+    scores[5] = scores[11]  # a tie across the shard boundary region
+    scores[N - 1] = scores[0] = scores.max() + 1  # tie for first place between rank 0 and the last rank
+    codes = torch.randint(0, 8192, (N, M), generator=g, dtype=torch.int32)
+    lo, hi = tdist.shard_range(N, rank, world)
+    s_all, c_all = tdist.gather_candidates(scores[lo:hi].clone(), codes[lo:hi].clone())
+    assert torch.equal(s_all, scores) and torch.equal(c_all, codes)
+    best = tdist.topk_lowest_index(s_all, k)
+    np.save(os.path.join(out_dir, f"best_{rank}.npy"), best.numpy())
+    np.save(os.path.join(out_dir, f"codes_{rank}.npy"), c_all[best].numpy())
+    tdist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_topk_matches_single_process(tmp_path):
+    N, M, k, world = 16, 20, 3, 2
+    mp.spawn(_worker, args=(world, _free_port(), N, M, k, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(0)
+    scores = torch.randn(N, generator=g)
+    scores[5] = scores[11]
+    scores[N - 1] = scores[0] = scores.max() + 1
+    want = tdist.topk_lowest_index(scores, k).numpy()
+    assert want[0] == 0 and want[1] == N - 1  # equal scores -> lowest global index first
+    b0, b1 = np.load(tmp_path / "best_0.npy"), np.load(tmp_path / "best_1.npy")
+    assert np.array_equal(b0, want) and np.array_equal(b1, want)
+    assert np.array_equal(np.load(tmp_path / "codes_0.npy"), np.load(tmp_path / "codes_1.npy"))
+
+
+def test_shard_range_and_topk_rules():
+    assert tdist.shard_range(256, 3, 8) == (96, 128)
+    try:
+        tdist.shard_range(10, 0, 4)
+        raise AssertionError("uneven shard accepted")
+    except ValueError:
+        pass
+    s = torch.tensor([1.0, 3.0, 3.0, 2.0])
+    assert tdist.topk_lowest_index(s, 2).tolist() == [1, 2]

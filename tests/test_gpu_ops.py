@@ -51,7 +51,8 @@ def test_gemm_conv_taps(lib, name, dt, tdt, tol, taps):
     bias = torch.randn(Cout, generator=g)
     wp = w.permute(0, 2, 1).reshape(Cout, taps * Cin).contiguous()  # [out][tap][in]
     out = torch.zeros(B * S, Cout, device="cuda")
-    E.check(lib.tt_op_gemm(dt, E.ptr(dev(x)), Cin, E.ptr(dev(wp)), taps * Cin, B * S, Cout, taps * Cin, taps, S, 1, E.ptr(dev(bias)),
+    xd, wd, bd = dev(x), dev(wp), dev(bias)  # keep the device copies alive across the asynchronous launch
+    E.check(lib.tt_op_gemm(dt, E.ptr(xd), Cin, E.ptr(wd), taps * Cin, B * S, Cout, taps * Cin, taps, S, 1, E.ptr(bd),
                            E.ACT_NONE, None, E.ptr(out), None, None))
     torch.cuda.synchronize()
     ref = F.conv1d(x.float().permute(0, 2, 1), w.float(), bias, padding=taps // 2).permute(0, 2, 1).reshape(B * S, Cout)
@@ -156,14 +157,16 @@ def test_sampler_matches_oracle(lib):
     for b in range(B):
         for t in ids[b].tolist():
             seen_np[b, t >> 5] |= np.uint32(1 << (t & 31))
-    seen = dev(torch.from_numpy(seen_np.view(np.int32)))
+    seen0 = dev(torch.from_numpy(seen_np.view(np.int32)))
+    seen = seen0.clone()  # the kernel marks the sampled token as seen
     s = E.Sampling()
     s.temperature, s.top_p, s.repetition_penalty, s.top_k, s.seed, s.row_offset = 0.8, 0.8, 2.0, 50, 0, 0
     qd = dev(q)
     s.exp_noise = E.ptr(qd)
     unfinished = dev(torch.ones(B, dtype=torch.int32))
     codes = torch.zeros(B, 4, device="cuda", dtype=torch.int32)
-    E.check(lib.tt_op_sample(E.ptr(dev(logits)), V, B, V, E.ptr(seen), C.byref(s), 0, E.ptr(unfinished), 8193, E.ptr(codes), 4, None))
+    logits_d = dev(logits)
+    E.check(lib.tt_op_sample(E.ptr(logits_d), V, B, V, E.ptr(seen), C.byref(s), 0, E.ptr(unfinished), 8193, E.ptr(codes), 4, None))
     got = codes[:, 0].cpu().long()
     print("[parity] sampler tokens", got.tolist(), want.tolist())
     assert torch.equal(got, want)
@@ -174,8 +177,8 @@ def test_sampler_matches_oracle(lib):
     c2 = torch.zeros(B, 4, device="cuda", dtype=torch.int32)
     for c in (c1, c2):
         un = dev(torch.ones(B, dtype=torch.int32))
-        sn = seen.clone()
-        E.check(lib.tt_op_sample(E.ptr(dev(logits)), V, B, V, E.ptr(sn), C.byref(s), 0, E.ptr(un), 8193, E.ptr(c), 4, None))
+        sn = seen0.clone()
+        E.check(lib.tt_op_sample(E.ptr(logits_d), V, B, V, E.ptr(sn), C.byref(s), 0, E.ptr(un), 8193, E.ptr(c), 4, None))
     assert torch.equal(c1, c2)
     allowed = torch.isfinite(scores)
     for b in range(B):

@@ -1,0 +1,115 @@
+"""CPU tests of the host-side logic that surrounds the HIP path: integer post-processing (bit-exact),
+schedule tables, interpolation indices, weight re-layouts, the oracle's HF-sampling restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tortoise_oracle as O
+from tortoise_tts_amd import pack
+from tortoise_tts_amd.schedule import Schedule, space_timesteps
+from tortoise_tts_amd.stages import nearest_interp_index
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _api_helpers():
+    # api.py imports the engine binding (ctypes only) -- importable without a GPU
+    from tortoise_tts_amd import api
+    return api
+
+
+def test_fix_autoregressive_output_matches_reference_golden():
+    api = _api_helpers()
+    g = np.load(os.path.join(GOLD, "integer.npz"))
+    got = api.fix_autoregressive_output(torch.from_numpy(g["codes_in"]), 8193)
+    assert np.array_equal(got.numpy(), g["codes_out"])
+    # edge cases: no stop token (unchanged), stop in the last three slots, all stop
+    rows = torch.tensor([[5, 6, 7, 8, 9, 10], [5, 6, 7, 8, 8193, 10], [8193] * 6, [1, 2, 3, 4, 5, 8193]])
+    want = np.stack([O.fix_autoregressive_output(r.numpy(), 8193) for r in rows])
+    assert np.array_equal(api.fix_autoregressive_output(rows, 8193).numpy(), want)
+
+
+def test_calm_trim_matches_oracle():
+    api = _api_helpers()
+    rng = np.random.default_rng(1)
+    for trial in range(200):
+        n = int(rng.integers(1, 60))
+        row = rng.integers(80, 86, n)
+        if trial % 2:
+            s = int(rng.integers(0, n))
+            row[s:s + int(rng.integers(1, 14))] = 83
+        assert api.calm_trim_length(torch.from_numpy(row)) == O.calm_trim_length(row), row
+
+
+@pytest.mark.parametrize("steps", [5, 30, 80, 200, 400])
+def test_schedule_matches_oracle(steps):
+    a, b = Schedule(steps), O.Schedule(steps)
+    assert list(a.timestep_map) == list(b.timestep_map)
+    for name in ("betas", "sqrt_recip_ac", "sqrt_recipm1_ac", "post_logvar_clipped", "log_betas", "coef1", "coef2"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert sorted(space_timesteps(4000, [5])) == [0, 1000, 2000, 2999, 3999]  # SURVEY.md §8a-9 [probed]
+
+
+@pytest.mark.parametrize("m,s", [(12, 52), (200, 870), (500, 2176), (37, 161)])
+def test_nearest_interp_index(m, s):
+    src = torch.arange(m, dtype=torch.float32)[None, None]
+    want = F.interpolate(src, size=s, mode="nearest")[0, 0].long().numpy()
+    assert np.array_equal(nearest_interp_index(m, s), want)
+
+
+def test_relpos_table_matches_oracle_bias():
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(32, 4, generator=g)
+    tab = pack.relpos_table(w, 8.0)  # [heads][129]
+    n = 200
+    bias = O.rel_pos_bias(w, n, 8.0)  # [heads][n][n], index [q][k]
+    pos = torch.arange(n)
+    d = (pos[None, :] - pos[:, None]).clamp(-64, 64) + 64
+    assert torch.equal(tab[:, d], bias)
+
+
+def test_qkv_permutation():
+    C, H = 128, 2
+    perm = pack._qkv_head_major_perm(C, H)
+    assert sorted(perm.tolist()) == list(range(3 * C))
+    old = torch.arange(3 * C)
+    new = old[perm]
+    # new layout [part][head][64]  <- old layout [head][part][64]
+    assert new.reshape(3, H, 64)[1, 1, 5] == old.reshape(H, 3, 64)[1, 1, 5]
+    assert new.reshape(3, H, 64)[2, 0, 63] == old.reshape(H, 3, 64)[0, 2, 63]
+
+
+def test_sampling_restatement_against_installed_transformers():
+    """The reference pins transformers==4.31 (not installable offline); the installed release still ships the
+    same four logits processors, which is the strongest available pin for oracle.warp_logits."""
+    tf = pytest.importorskip("transformers")
+    try:
+        from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+                                                            TopKLogitsWarper, TopPLogitsWarper)
+    except Exception:
+        pytest.skip("logits processors not importable")
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(5, 8194, generator=g) * 4
+    ids = torch.randint(0, 8194, (5, 30), generator=g)
+    want = RepetitionPenaltyLogitsProcessor(2.0)(ids, logits.clone())
+    want = TemperatureLogitsWarper(0.8)(ids, want)
+    want = TopKLogitsWarper(50)(ids, want)
+    want = TopPLogitsWarper(0.8)(ids, want)
+    got = O.warp_logits(logits, ids, 2.0, 0.8, 50, 0.8)
+    assert torch.equal(torch.isfinite(got), torch.isfinite(want))
+    m = torch.isfinite(want)
+    assert torch.allclose(got[m], want[m], atol=1e-6)
+
+
+def test_multinomial_equals_argmax_exponential():
+    """torch.multinomial(p, 1) on CPU == argmax(p / q), q ~ Exp(1) from the same generator state."""
+    for seed in range(10):
+        p = torch.softmax(torch.randn(4, 8194, generator=torch.Generator().manual_seed(100 + seed)) * 3, -1)
+        g1 = torch.Generator().manual_seed(seed)
+        g2 = torch.Generator().manual_seed(seed)
+        want = torch.multinomial(p, 1, generator=g1)[:, 0]
+        q = torch.empty_like(p).exponential_(1, generator=g2)
+        assert torch.equal(O.multinomial_from_exponential(p, q), want)

@@ -150,6 +150,8 @@ int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.n_pad % 32 == 0 && a.n_pad >= ((a.n + 31) / 32) * 32, "flash: n_pad=%d must be a multiple of 32 covering n=%d", a.n_pad, a.n);
   TT_REQUIRE(a.ldo % 4 == 0, "flash: ldo must be a multiple of 4");
   // 32 queries per wave once there is enough work to fill the chip; 16 otherwise.
+  // QK^T + PV: 4 * n * n * 64 flops per (batch, head) (halved when causal); Q, K, V read + O written once
+  ProfScope ps(PROF_FLASH, stream, 4.0 * a.BH * (double)a.n * a.n * 64 * (a.causal ? 0.5 : 1.0), 4.0 * a.BH * (double)a.n * 64 * 2.0);
   const long blocks2 = (long)cdiv(a.n, 128) * a.BH;
   if (blocks2 >= 512) {
     dim3 grid(cdiv(a.n, 128), a.BH);
@@ -262,6 +264,9 @@ int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stre
   const size_t smem = (size_t)4 * ctx_cap * sizeof(float);
   TT_REQUIRE(smem <= 64 * 1024, "decode_attention: context %d too long for the score buffer", ctx_cap);
   const int blocks = cdiv(a.B * a.heads, 4);
+  // algorithmic bytes: every sequence reads its own generated K and V rows once (host_tgen keys) + the shared prefix once
+  ProfScope ps(PROF_DECODE_ATTN, stream, 4.0 * a.B * a.heads * 64.0 * (a.P1 + a.host_tgen),
+               ((double)a.B * a.host_tgen + a.P1) * a.heads * 64 * 2 * 2.0 + 2.0 * a.B * a.heads * 64 * 2.0);
   if (dtype == DT_BF16) decode_attn_kernel<bf16><<<blocks, 256, smem, stream>>>(a, ctx_cap);
   else decode_attn_kernel<f16><<<blocks, 256, smem, stream>>>(a, ctx_cap);
   TT_CHECK_HIP(hipGetLastError());

@@ -122,3 +122,29 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 enum DType { DT_BF16 = 0, DT_F16 = 1 };
 
 }  // namespace tt
+
+// ---------------------------------------------------------------- per-kernel-class timing (bench.py roofline leg)
+// When enabled (tt_prof_enable), every launcher brackets its kernel with HIP events recorded on the
+// launch stream and accumulates the algorithmic flops / bytes of the launch.  Not used on the product
+// path (graphs stay enabled there); bench.py runs one extra un-captured step with it.
+namespace tt {
+enum ProfId {
+  PROF_GEMM_64x64_STD = 0, PROF_GEMM_64x64_QKV, PROF_GEMM_64x64_QKVDEC,
+  PROF_GEMM_128x64_STD, PROF_GEMM_128x64_QKV, PROF_GEMM_128x64_QKVDEC,
+  PROF_GEMM_128x128_STD, PROF_GEMM_128x128_QKV, PROF_GEMM_128x128_QKVDEC,
+  PROF_FLASH, PROF_DECODE_ATTN, PROF_ROWNORM, PROF_GROUPNORM, PROF_SAMPLE, PROF_GLUE, PROF_CONV1D, PROF_CONVT, PROF_LVC,
+  PROF_COUNT
+};
+extern bool g_prof_on;
+void prof_record(int id, hipStream_t s, bool begin, double flops, double bytes);
+struct ProfScope {
+  int id; hipStream_t s; bool on;
+  ProfScope(int id_, hipStream_t s_, double flops, double bytes) : id(id_), s(s_), on(g_prof_on) {
+    if (on) prof_record(id, s, true, flops, bytes);
+  }
+  ~ProfScope() {
+    if (on) prof_record(id, s, false, 0, 0);
+  }
+};
+const char* prof_name(int id);
+}  // namespace tt

@@ -13,6 +13,7 @@ constexpr int BKP = BK + 8;  // LDS row pitch in elements: 144 B keeps 16-B alig
 
 template <typename T>
 struct EpiStd {
+  static constexpr int kId = 0;
   __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4 v, int nvalid, int z) const {
     if (g.splitk > 1) {
       float* o = g.out_f32 + (size_t)z * g.M * g.ldo32 + (size_t)m * g.ldo32 + n;
@@ -59,6 +60,7 @@ struct EpiStd {
 
 template <typename T>
 struct EpiQkvHeads {
+  static constexpr int kId = 1;
   __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4 v, int nvalid, int z) const {
     // N == 3 * dmodel and dmodel % 64 == 0, so nvalid is always 4 here.
     if (g.bias) {
@@ -92,6 +94,7 @@ struct EpiQkvHeads {
 
 template <typename T>
 struct EpiQkvDecode {
+  static constexpr int kId = 2;
   __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4 v, int nvalid, int z) const {
     if (g.bias) {
 #pragma unroll
@@ -252,6 +255,11 @@ template <typename T, int BM, int BN, typename Epi>
 static int launch_one(const GemmArgs& a, hipStream_t stream) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), a.splitk);
   constexpr int smem = smem_bytes<BM, BN>();
+  constexpr int tile_id = BM == 64 ? 0 : (BN == 64 ? 1 : 2);
+  // algorithmic work of this launch: 2*M*N*K flops; operands read once + result written once
+  const double out_bytes = (double)a.M * a.N * ((a.out_f32 || Epi::kId != 0 ? 4.0 : 0.0) * (Epi::kId == 0 ? 1.0 : 0.0) + (a.out_t || Epi::kId != 0 ? 2.0 : 0.0));
+  ProfScope ps(tile_id * 3 + Epi::kId, stream, 2.0 * a.M * a.N * a.K,
+               ((double)a.N * a.K + (double)a.M * a.cin) * 2.0 + out_bytes * (a.splitk > 1 ? a.splitk : 1) + (a.res ? 4.0 * a.M * a.N : 0.0));
   gemm_kernel<T, BM, BN, Epi><<<grid, dim3(256), smem, stream>>>(a);
   TT_CHECK_HIP(hipGetLastError());
   return 0;

@@ -41,6 +41,7 @@ struct tt_ar {
   int B = 0;       // current batch
   int logits_rows = 0;
   bool logits_from_prefill = false;
+  int host_slot = -1;  // host mirror of state[1]; only feeds the profiler's byte estimates
 };
 
 static const int MAX_SPLIT = 8;
@@ -140,7 +141,7 @@ static int decode_step_enqueue(tt_ar* e, hipStream_t s) {
     a.kp = offset_t(e->kp, (size_t)l * e->prefix_layer_elems);
     a.vp = offset_t(e->vp, (size_t)l * e->prefix_layer_elems);
     a.P1 = e->P1; a.kc = g.kc; a.vc = g.vc; a.tmax = e->tmax; a.step = e->state + 1;
-    a.out = e->attn; a.B = B; a.heads = H;
+    a.out = e->attn; a.B = B; a.heads = H; a.host_tgen = e->host_slot + 1;
     TT_TRY(decode_attention_launch(dt, a, s));
     int sk = pick_split(B, D, D);
     g = gemm_args(e->attn, D, w.w_proj, D, B, D, D);
@@ -265,6 +266,7 @@ int tt_ar_begin(tt_ar* e, int B, void* stream) {
   hipStream_t us = (hipStream_t)stream;
   TT_TRY(e->sb.enter(us));
   e->B = B;
+  e->host_slot = -1;
   TT_TRY(ar_begin_launch(e->state, e->seen, e->unfinished, e->unfinished_count, B, e->V, e->tmax + 8, e->cfg.start_mel_token, e->sb.own));
   return e->sb.leave(us);
 }
@@ -275,6 +277,7 @@ int tt_ar_decode_step(tt_ar* e, const int* tokens, void* stream) {
   TT_TRY(e->sb.enter(us));
   TT_CHECK_HIP(hipMemcpyAsync(e->next_tok, tokens, (size_t)e->B * sizeof(int), hipMemcpyDeviceToDevice, s));
   TT_TRY(ar_state_advance_launch(e->state, s));  // state[1] = slot of the token being fed
+  e->host_slot += 1;
   e->logits_from_prefill = false;
   TT_TRY(decode_step_enqueue(e, s));
   return e->sb.leave(us);
@@ -331,6 +334,7 @@ int tt_ar_generate(tt_ar* e, int B, int max_new, const tt_sampling* sp, int* cod
       hipError_t le = hipGraphLaunch(exec, s);
       if (le != hipSuccess) { set_error("hipGraphLaunch: %s", hipGetErrorString(le)); rc = -2; break; }
     } else {
+      e->host_slot = step - 1;
       rc = decode_step_enqueue(e, s);
       if (!rc) rc = sample_launch(sa, s);
       if (!rc) rc = ar_state_advance_launch(e->state, s);

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
 int rownorm_launch(int dtype, const RowNormArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.M > 0 && a.D > 0 && a.D % 4 == 0 && a.D <= 4096, "rownorm: bad shape M=%d D=%d", a.M, a.D);
   TT_REQUIRE(a.ldx % 4 == 0, "rownorm: ldx must be a multiple of 4");
+  ProfScope ps(PROF_ROWNORM, stream, 0.0, (double)a.M * a.D * (4.0 * (1 + a.nslab + (a.write_x ? 1 : 0)) + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)));
   if (dtype == DT_BF16) rownorm_kernel<bf16><<<a.M, 256, 0, stream>>>(a);
   else rownorm_kernel<f16><<<a.M, 256, 0, stream>>>(a);
   TT_CHECK_HIP(hipGetLastError());
@@ -229,6 +230,7 @@ int groupnorm_launch(int dtype, const GroupNormArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.B > 0 && a.S > 0 && a.partial != nullptr, "groupnorm: bad arguments");
   const int nchunk = cdiv(a.S, GN_ROWS);
   dim3 grid(nchunk, a.B);
+  ProfScope ps(PROF_GROUPNORM, stream, 0.0, (double)a.B * a.S * a.C * (8.0 + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)));
   gn_stats_kernel<<<grid, 256, 0, stream>>>(a.x, a.S, a.C, a.partial);
   TT_CHECK_HIP(hipGetLastError());
   if (dtype == DT_BF16) gn_apply_kernel<bf16><<<grid, 256, 0, stream>>>(a, nchunk);

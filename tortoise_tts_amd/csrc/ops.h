@@ -77,6 +77,7 @@ struct DecodeAttnArgs {
   const void* vc;   // per-sequence values [B][heads][tmax][64]
   int tmax;
   const int* step;  // device int: slot of the newest generated key (keys 0..*step are valid)
+  int host_tgen;    // host-side copy of *step + 1 for profiling estimates only (0 when unknown)
   void* out;        // [B][heads*64]
   int B, heads;
 };

@@ -215,6 +215,7 @@ int sample_launch(const SampleArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.B > 0 && a.V > 0 && a.V <= 10240, "sample: V=%d unsupported (<= 10240)", a.V);
   TT_REQUIRE(a.top_k > 0 && a.top_k <= 256, "sample: top_k=%d unsupported (1..256; HF default 50)", a.top_k);
   TT_REQUIRE(a.temperature > 0.f && a.top_p > 0.f && a.rep_penalty > 0.f, "sample: bad sampling parameters");
+  ProfScope ps(PROF_SAMPLE, stream, 0.0, (double)a.B * a.V * 4.0);
   sample_kernel<<<a.B, 256, 0, stream>>>(a);
   TT_CHECK_HIP(hipGetLastError());
   return 0;

@@ -53,6 +53,7 @@ int conv1d_direct_launch(const Conv1dArgs& a, hipStream_t stream) {
   const size_t smem = (size_t)a.Cin * a.k * a.Cout * sizeof(float);
   TT_REQUIRE(smem <= 60 * 1024, "conv1d_direct: weights do not fit LDS");
   const int blocks = cdiv(a.T, 256);
+  ProfScope ps(PROF_CONV1D, stream, 2.0 * a.Cin * a.Cout * a.k * (double)a.T, 4.0 * (a.Cin + a.Cout) * (double)a.T);
   if (a.Cout == 32) conv1d_direct_kernel<32><<<blocks, 256, smem, stream>>>(a);
   else conv1d_direct_kernel<1><<<blocks, 256, smem, stream>>>(a);
   TT_CHECK_HIP(hipGetLastError());
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void convt1d_kernel(ConvT1dArgs a) {
 int convt1d_launch(const ConvT1dArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.C == 32 && a.stride % 2 == 0, "convt1d: C=%d stride=%d unsupported (C == 32, even stride)", a.C, a.stride);
   dim3 grid(cdiv(a.Tin + 1, 256), a.stride);
+  ProfScope ps(PROF_CONVT, stream, 2.0 * a.C * a.C * 2.0 * a.Tin * a.stride, 4.0 * a.C * (double)a.Tin * (1 + a.stride));
   convt1d_kernel<<<grid, 256, 0, stream>>>(a);
   TT_CHECK_HIP(hipGetLastError());
   return 0;
@@ -149,6 +151,8 @@ __global__ __launch_bounds__(256) void lvc_kernel(LvcArgs a) {
 }
 int lvc_launch(const LvcArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.ldk % 4 == 0 && a.koff % 4 == 0, "lvc: kernel rows must be 16-byte aligned");
+  // algorithmic bytes: the predicted kernels (L x 6144 f32) are read once, x_in read + x updated
+  ProfScope ps(PROF_LVC, stream, 2.0 * 96 * 64 * (double)a.L * a.hop, 4.0 * (6144.0 + 64) * a.L + 4.0 * 96 * (double)a.L * a.hop);
   switch (a.hop) {
     case 8: lvc_kernel<8><<<a.L, 256, 0, stream>>>(a); break;
     case 64: lvc_kernel<64><<<a.L, 256, 0, stream>>>(a); break;

@@ -122,6 +122,10 @@ _PROTOS = {
     "tt_voc_create": (_i, [C.POINTER(VocConfig), C.POINTER(VocWeights), C.POINTER(vp)]),
     "tt_voc_destroy": (None, [vp]),
     "tt_voc_run": (_i, [vp, vp, _i, vp, vp, vp]),
+    "tt_prof_enable": (_i, [_i]),
+    "tt_prof_classes": (_i, []),
+    "tt_prof_class_name": (C.c_char_p, [_i]),
+    "tt_prof_read": (_i, [_i, C.POINTER(C.c_double)]),
     "tt_op_gemm": (_i, [_i, vp, _i, vp, _i, _i, _i, _i, _i, _i, _i, vp, _i, vp, vp, vp, vp]),
     "tt_op_layernorm": (_i, [_i, vp, _i, _i, vp, vp, _f, _i, vp, vp, vp]),
     "tt_op_groupnorm": (_i, [_i, vp, _i, _i, _i, vp, vp, vp, _i, vp, vp, vp, vp]),
@@ -145,6 +149,9 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise EngineError("MI355X engine library not built: %s is missing. Run `python -m tortoise_tts_amd.build` "
                           "(hipcc, gfx950). There is no fallback path." % LIB_PATH)
+    # torch must be loaded first: the engine shares device pointers and streams with PyTorch-ROCm, so
+    # both have to bind to the ONE HIP runtime that torch ships (libamdhip64.so.7, resolved by SONAME).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)
