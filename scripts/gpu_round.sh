@@ -18,7 +18,8 @@ for ph in $PHASES; do
     gpu)    timeout 2400 python -m pytest tests -x -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest-gpu rc=$?" | tee -a $OUT/summary.txt ;;
     smoke)  timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/summary.txt ;;
     bench)  timeout 1500 python bench.py ${BENCH_ARGS:-} > $OUT/bench.log 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.txt; tail -2 $OUT/bench.log ;;
-    prof)   (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o prof -- python $OLDPWD/bench.py ${PROF_ARGS:---steps 1 --warmup 1 --no-cpu-baseline} > $OLDPWD/$OUT/prof.log 2>&1); echo "prof rc=$?" | tee -a $OUT/summary.txt ;;
+    prof)   rm -rf $OUT/prof; (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o prof -- python $OLDPWD/bench.py ${PROF_ARGS:---steps 1 --warmup 1 --no-cpu-baseline} > $OLDPWD/$OUT/prof.log 2>&1); echo "prof rc=$?" | tee -a $OUT/summary.txt
+            find $OUT/prof -type f -size +8M -delete; find $OUT/prof -type f | head -20; tail -3 $OUT/prof.log ;;
   esac
 done
 grep -h "\[parity\]" $OUT/*.log 2>/dev/null | tail -150 > $OUT/parity.txt
