@@ -58,15 +58,15 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
   const int q_last = min(qbase + 16 * NQ, n) - 1;
   const int kend = a.causal ? q_last + 1 : n;
 
-  for (int key0 = 0; key0 < kend; key0 += 32) {
-    x8 kf[2][2];
+  // K / V^T fragments of tile t+1 are fetched into a second register set while tile t is processed:
+  // a wave's loop body is shorter than an L2 round trip, so without this every tile pays the latency.
+  auto load_kv = [&](x8 (&kf)[2][2], x8 (&vf)[4], int key0) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int kr = min(key0 + kb * 16 + fr, n - 1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) kf[kb][ks] = *(const x8*)(K + (size_t)kr * 64 + ks * 32 + fg * 8);
     }
-    x8 vf[4];
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
       const T* vrow = VT + (size_t)(blk * 16 + fr) * a.n_pad + key0 + fg * 4;
@@ -77,6 +77,11 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
       v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
       vf[blk] = v;
     }
+  };
+  x8 kfA[2][2], vfA[4], kfB[2][2], vfB[4];
+  load_kv(kfA, vfA, 0);
+
+  auto process = [&](const x8 (&kf)[2][2], const x8 (&vf)[4], int key0) {
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) {
       const int qi = qbase + iq * 16 + fr;
@@ -131,6 +136,13 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
         acc[iq][blk] = mfma16(vf[blk], pf, o);
       }
     }
+  };
+  for (int key0 = 0; key0 < kend; key0 += 64) {
+    if (key0 + 32 < kend) load_kv(kfB, vfB, key0 + 32);
+    process(kfA, vfA, key0);
+    if (key0 + 32 >= kend) break;
+    if (key0 + 64 < kend) load_kv(kfA, vfA, key0 + 64);
+    process(kfB, vfB, key0 + 32);
   }
 #pragma unroll
   for (int iq = 0; iq < NQ; ++iq) {
@@ -237,14 +249,25 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnArgs a, int 
   const int fr = lane & 15, fg = lane >> 4;
   float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
   if (valid) {
-    for (int j = fg; j < ctx; j += 4) {
-      const float p = sc[j];
-      const T* vr = j < P1 ? vp + (size_t)j * 64 : vc + (size_t)(j - P1) * 64;
-      const x4 t = *(const x4*)(vr + fr * 4);
-      o0 += p * (float)t[0];
-      o1 += p * (float)t[1];
-      o2 += p * (float)t[2];
-      o3 += p * (float)t[3];
+    // 8 independent row loads per lane group in flight: the loop is HBM-latency bound otherwise
+    for (int j0 = fg; j0 < ctx; j0 += 32) {
+      x4 t[8];
+      float p[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + 4 * u;
+        const int jc = j < ctx ? j : ctx - 1;
+        const T* vr = jc < P1 ? vp + (size_t)jc * 64 : vc + (size_t)(jc - P1) * 64;
+        t[u] = *(const x4*)(vr + fr * 4);
+        p[u] = j < ctx ? sc[j] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        o0 += p[u] * (float)t[u][0];
+        o1 += p[u] * (float)t[u][1];
+        o2 += p[u] * (float)t[u][2];
+        o3 += p[u] * (float)t[u][3];
+      }
     }
   }
   o0 += __shfl_xor(o0, 16, 64); o0 += __shfl_xor(o0, 32, 64);

@@ -158,10 +158,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
   }
 
-  x8 ra[PA], rw[PW];
+  // Two register tile sets: loads run TWO k-tiles ahead of the MFMAs (one tile being written to LDS,
+  // one still in flight), because at these shapes a block's k-step is shorter than the L2/HBM latency.
+  x8 ra0[PA], rw0[PW], ra1[PA], rw1[PW];
   const x8 zero8 = {};
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](x8 (&ra)[PA], x8 (&rw)[PW], int kt) {
     const int k0 = kt * BK;
     int tap = 0, kin = k0;
     if (g.taps > 1) {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       rw[p] = n < g.N ? *(const x8*)(W + (size_t)n * g.ldw + k0 + lcol) : zero8;
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](const x8 (&ra)[PA], const x8 (&rw)[PW], int buf) {
     T* as = As + buf * BM * BKP;
     T* ws = Ws + buf * BN * BKP;
 #pragma unroll
@@ -204,17 +206,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = lane >> 4;
-  if (kt_begin < kt_end) {
-    load_tile(kt_begin);
-    store_tile(0);
-  }
-  __syncthreads();
-  int cur = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const bool more = kt + 1 < kt_end;
-    if (more) load_tile(kt + 1);
-    const T* as = As + cur * BM * BKP + (wm * TM + fr) * BKP + fg * 8;
-    const T* ws = Ws + cur * BN * BKP + (wn * TN + fr) * BKP + fg * 8;
+  auto compute = [&](int buf) {
+    const T* as = As + buf * BM * BKP + (wm * TM + fr) * BKP + fg * 8;
+    const T* ws = Ws + buf * BN * BKP + (wn * TN + fr) * BKP + fg * 8;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       x8 fa[FM], fw[FN];
@@ -227,9 +221,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
     }
-    if (more) store_tile(cur ^ 1);
+  };
+
+  const int nt = kt_end - kt_begin;
+  if (nt > 0) load_tile(ra0, rw0, kt_begin);
+  if (nt > 1) load_tile(ra1, rw1, kt_begin + 1);
+  if (nt > 0) store_tile(ra0, rw0, 0);
+  __syncthreads();
+  for (int i = 0; i < nt; i += 2) {
+    // tile i is in LDS buffer 0, tile i+1 in flight in set 1, set 0 is free
+    if (i + 2 < nt) load_tile(ra0, rw0, kt_begin + i + 2);
+    compute(0);
+    if (i + 1 < nt) store_tile(ra1, rw1, 1);
     __syncthreads();
-    cur ^= 1;
+    if (i + 1 >= nt) break;
+    // tile i+1 is in LDS buffer 1, tile i+2 in flight in set 0, set 1 is free
+    if (i + 3 < nt) load_tile(ra1, rw1, kt_begin + i + 3);
+    compute(1);
+    if (i + 2 < nt) store_tile(ra0, rw0, 0);
+    __syncthreads();
   }
 
   Epi epi;

@@ -125,8 +125,10 @@ int rownorm_launch(int dtype, const RowNormArgs& a, hipStream_t stream) {
 // x: [B][S][C] f32 token-major, 32 groups of cpg = C/32 channels (cpg % 4 == 0), C/4 a power of
 // two <= 256 or C == 1024*k.  Stage 1 writes per-(batch, row-chunk, group) (sum, sumsq).
 constexpr int GN_ROWS = 16;
+constexpr int GN_MAX_CHUNKS = 64;  // the apply kernel's finalize prologue reduces <= 8 partials per thread
+static inline int gn_rows_per_chunk(int S) { return std::max(GN_ROWS, cdiv(S, GN_MAX_CHUNKS)); }
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int S, int C, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int S, int C, float* __restrict__ partial, int rows_per_chunk) {
   __shared__ float ls[256][2];
   const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
   const int tid = threadIdx.x;
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   const int RL = 256 / CL;                      // row lanes
   const int cl = tid % CL, rl = tid / CL;
   const int cpg4 = (C / 32) >> 2;               // float4 columns per group
-  const int r0 = chunk * GN_ROWS;
-  const int r1 = min(S, r0 + GN_ROWS);
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = min(S, r0 + rows_per_chunk);
   // With C > 1024 a thread owns several columns in different groups: handle one column set per pass.
   for (int cb = 0; cb < c4n; cb += 256) {
     float s = 0.f, q = 0.f;
@@ -170,17 +172,31 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchunk) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchunk, int rows_per_chunk, int rows_per_block) {
   __shared__ float mean_s[32], rstd_s[32];
+  __shared__ double part_s[8][32], part_q[8][32];
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x;
   const int C = a.C, S = a.S;
-  if (tid < 32) {
+  {
+    // finalize: 8 threads per group each reduce every 8th chunk partial (independent loads), then combine in fp64
+    const int g = tid & 31, part = tid >> 5;
     double s = 0.0, q = 0.0;
-    for (int i = 0; i < nchunk; ++i) {
-      const float* p = a.partial + (((size_t)b * nchunk + i) * 32 + tid) * 2;
+    for (int i = part; i < nchunk; i += 8) {
+      const float* p = a.partial + (((size_t)b * nchunk + i) * 32 + g) * 2;
       s += (double)p[0];
       q += (double)p[1];
+    }
+    part_s[part][g] = s;
+    part_q[part][g] = q;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      s += part_s[p][tid];
+      q += part_q[p][tid];
     }
     const double n = (double)S * (double)(C / 32);
     const double m = s / n;
@@ -192,8 +208,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchu
   __syncthreads();
   const int c4n = C >> 2;
   const int cpg = C / 32;
-  const int r0 = chunk * GN_ROWS;
-  const int r1 = min(S, r0 + GN_ROWS);
+  const int r0 = chunk * rows_per_block;
+  const int r1 = min(S, r0 + rows_per_block);
   const int total = (r1 - r0) * c4n;
   for (int f = tid; f < total; f += 256) {
     const int r = r0 + f / c4n;
@@ -228,17 +244,20 @@ int groupnorm_launch(int dtype, const GroupNormArgs& a, hipStream_t stream) {
   const int c4n = a.C / 4;
   TT_REQUIRE(a.C % 128 == 0 && ((c4n <= 256 && (c4n & (c4n - 1)) == 0) || c4n % 256 == 0), "groupnorm: unsupported C=%d", a.C);
   TT_REQUIRE(a.B > 0 && a.S > 0 && a.partial != nullptr, "groupnorm: bad arguments");
-  const int nchunk = cdiv(a.S, GN_ROWS);
+  const int rpc = gn_rows_per_chunk(a.S);
+  const int nchunk = cdiv(a.S, rpc);
   dim3 grid(nchunk, a.B);
   ProfScope ps(PROF_GROUPNORM, stream, 0.0, (double)a.B * a.S * a.C * (8.0 + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)));
-  gn_stats_kernel<<<grid, 256, 0, stream>>>(a.x, a.S, a.C, a.partial);
+  gn_stats_kernel<<<grid, 256, 0, stream>>>(a.x, a.S, a.C, a.partial, rpc);
   TT_CHECK_HIP(hipGetLastError());
-  if (dtype == DT_BF16) gn_apply_kernel<bf16><<<grid, 256, 0, stream>>>(a, nchunk);
-  else gn_apply_kernel<f16><<<grid, 256, 0, stream>>>(a, nchunk);
+  const int rpb = 8;  // apply is pure streaming: many small blocks
+  dim3 grid2(cdiv(a.S, rpb), a.B);
+  if (dtype == DT_BF16) gn_apply_kernel<bf16><<<grid2, 256, 0, stream>>>(a, nchunk, rpc, rpb);
+  else gn_apply_kernel<f16><<<grid2, 256, 0, stream>>>(a, nchunk, rpc, rpb);
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-size_t groupnorm_partial_floats(int B, int S) { return (size_t)B * cdiv(S, GN_ROWS) * 32 * 2; }
+size_t groupnorm_partial_floats(int B, int S) { return (size_t)B * cdiv(S, gn_rows_per_chunk(S)) * 32 * 2; }
 
 }  // namespace tt
