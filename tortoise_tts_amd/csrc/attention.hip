@@ -137,11 +137,12 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
       }
     }
   };
+  const int klast = ((kend - 1) / 32) * 32;  // prefetches are unconditional (clamped): straight-line body, counted waits
   for (int key0 = 0; key0 < kend; key0 += 64) {
-    if (key0 + 32 < kend) load_kv(kfB, vfB, key0 + 32);
+    load_kv(kfB, vfB, min(key0 + 32, klast));
     process(kfA, vfA, key0);
     if (key0 + 32 >= kend) break;
-    if (key0 + 64 < kend) load_kv(kfA, vfA, key0 + 64);
+    load_kv(kfA, vfA, min(key0 + 64, klast));
     process(kfB, vfB, key0 + 32);
   }
 #pragma unroll

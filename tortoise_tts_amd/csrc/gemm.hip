@@ -118,7 +118,7 @@ struct EpiQkvDecode {
   }
 };
 
-template <typename T, int BM, int BN, typename Epi>
+template <typename T, int BM, int BN, typename Epi, bool CONV>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   typedef typename Vec<T>::x8 x8;
   constexpr int TM = BM / 2, TN = BN / 2;  // wave tile
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   for (int p = 0; p < PA; ++p) {
     const int m = m0 + lrow + 32 * p;
     a_ok[p] = m < g.M;
-    if (g.taps > 1) {
+    if (CONV) {
       a_b[p] = m / g.seq_len;
       a_s[p] = m - a_b[p] * g.seq_len;
     } else {
@@ -163,10 +163,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   x8 ra0[PA], rw0[PW], ra1[PA], rw1[PW];
   const x8 zero8 = {};
 
+  // Loads are unconditional (out-of-range rows read row 0 / the last W row and are zeroed by a select):
+  // branch-free issue is what lets the compiler keep counted s_waitcnt vmcnt(N) instead of draining to 0.
   auto load_tile = [&](x8 (&ra)[PA], x8 (&rw)[PW], int kt) {
     const int k0 = kt * BK;
     int tap = 0, kin = k0;
-    if (g.taps > 1) {
+    if (CONV) {
       tap = k0 / g.cin;
       kin = k0 - tap * g.cin;
     }
@@ -175,19 +177,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int p = 0; p < PA; ++p) {
       bool ok = a_ok[p];
       size_t row;
-      if (g.taps > 1) {
+      if (CONV) {
         const int s2 = a_s[p] + shift;
         ok = ok && s2 >= 0 && s2 < g.seq_len;
         row = (size_t)a_b[p] * g.seq_len + s2;
       } else {
         row = (size_t)a_s[p];
       }
-      ra[p] = ok ? *(const x8*)(A + row * g.lda + kin + lcol) : zero8;
+      const x8 v = *(const x8*)(A + (ok ? row : 0) * g.lda + kin + lcol);
+      ra[p] = ok ? v : zero8;
     }
 #pragma unroll
     for (int p = 0; p < PW; ++p) {
       const int n = n0 + lrow + 32 * p;
-      rw[p] = n < g.N ? *(const x8*)(W + (size_t)n * g.ldw + k0 + lcol) : zero8;
+      const x8 v = *(const x8*)(W + (size_t)(n < g.N ? n : g.N - 1) * g.ldw + k0 + lcol);
+      rw[p] = n < g.N ? v : zero8;
     }
   };
   auto store_tile = [&](const x8 (&ra)[PA], const x8 (&rw)[PW], int buf) {
@@ -223,22 +227,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
   };
 
-  const int nt = kt_end - kt_begin;
-  if (nt > 0) load_tile(ra0, rw0, kt_begin);
-  if (nt > 1) load_tile(ra1, rw1, kt_begin + 1);
-  if (nt > 0) store_tile(ra0, rw0, 0);
+  const int nt = kt_end - kt_begin;  // >= 1 (the launcher guarantees splitk <= k-tiles)
+  const int last = kt_end - 1;
+  // Every iteration issues its prefetch unconditionally (clamped to the last tile; a redundant reload of
+  // the final tile is harmless) so the body stays straight-line and the waits stay counted.
+  load_tile(ra0, rw0, kt_begin);
+  load_tile(ra1, rw1, min(kt_begin + 1, last));
+  store_tile(ra0, rw0, 0);
   __syncthreads();
   for (int i = 0; i < nt; i += 2) {
     // tile i is in LDS buffer 0, tile i+1 in flight in set 1, set 0 is free
-    if (i + 2 < nt) load_tile(ra0, rw0, kt_begin + i + 2);
+    load_tile(ra0, rw0, min(kt_begin + i + 2, last));
     compute(0);
-    if (i + 1 < nt) store_tile(ra1, rw1, 1);
+    store_tile(ra1, rw1, 1);
     __syncthreads();
     if (i + 1 >= nt) break;
     // tile i+1 is in LDS buffer 1, tile i+2 in flight in set 0, set 1 is free
-    if (i + 3 < nt) load_tile(ra1, rw1, kt_begin + i + 3);
+    load_tile(ra1, rw1, min(kt_begin + i + 3, last));
     compute(1);
-    if (i + 2 < nt) store_tile(ra0, rw0, 0);
+    store_tile(ra0, rw0, 0);
     __syncthreads();
   }
 
@@ -270,7 +277,12 @@ static int launch_one(const GemmArgs& a, hipStream_t stream) {
   const double out_bytes = (double)a.M * a.N * ((a.out_f32 || Epi::kId != 0 ? 4.0 : 0.0) * (Epi::kId == 0 ? 1.0 : 0.0) + (a.out_t || Epi::kId != 0 ? 2.0 : 0.0));
   ProfScope ps(tile_id * 3 + Epi::kId, stream, 2.0 * a.M * a.N * a.K,
                ((double)a.N * a.K + (double)a.M * a.cin) * 2.0 + out_bytes * (a.splitk > 1 ? a.splitk : 1) + (a.res ? 4.0 * a.M * a.N : 0.0));
-  gemm_kernel<T, BM, BN, Epi><<<grid, dim3(256), smem, stream>>>(a);
+  if constexpr (Epi::kId == 0) {
+    if (a.taps > 1) gemm_kernel<T, BM, BN, Epi, true><<<grid, dim3(256), smem, stream>>>(a);
+    else gemm_kernel<T, BM, BN, Epi, false><<<grid, dim3(256), smem, stream>>>(a);
+  } else {
+    gemm_kernel<T, BM, BN, Epi, false><<<grid, dim3(256), smem, stream>>>(a);
+  }
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -307,6 +319,7 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   TT_REQUIRE(a.splitk == 1 || (epi == EPI_STD && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
   TT_REQUIRE(a.splitk <= a.K / BK, "gemm: splitk=%d exceeds the %d k-tiles", a.splitk, a.K / BK);
   if (epi != EPI_STD) {
+    TT_REQUIRE(a.taps == 1, "gemm: conv taps are only supported with the standard epilogue");
     TT_REQUIRE(a.dmodel % 64 == 0 && a.N == 3 * a.dmodel && a.heads * 64 == a.dmodel, "gemm: qkv epilogue needs N == 3*dmodel, head_dim 64");
   }
   if (a.taps > 1 || epi == EPI_QKV_HEADS) TT_REQUIRE(a.seq_len > 0 && a.M % a.seq_len == 0, "gemm: M=%d is not a whole number of sequences of %d", a.M, a.seq_len);
@@ -318,8 +331,12 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
 
 template <typename T, int BM, int BN, typename Epi>
 static int set_attr_one() {
-  const void* fn = (const void*)gemm_kernel<T, BM, BN, Epi>;
+  const void* fn = (const void*)gemm_kernel<T, BM, BN, Epi, false>;
   TT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN>()));
+  if constexpr (Epi::kId == 0) {
+    const void* fc = (const void*)gemm_kernel<T, BM, BN, Epi, true>;
+    TT_CHECK_HIP(hipFuncSetAttribute(fc, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN>()));
+  }
   return 0;
 }
 template <typename T, typename Epi>
