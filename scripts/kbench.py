@@ -58,6 +58,10 @@ def main():
         gemm_case("clvp ff1 256x200", 51200, 3072, 768)
         gemm_case("clvp out 256x200", 51200, 768, 768)
         gemm_case("square 4096", 4096, 4096, 4096)
+    if "tiles" in which:
+        for M, N, K, taps, seq in ((1740, 1024, 1024, 1, 0), (1740, 1024, 3072, 3, 870), (1740, 3072, 1024, 1, 0), (256, 4096, 1024, 1, 0),
+                                   (256, 1024, 4096, 1, 0), (4096, 4096, 4096, 1, 0)):
+            gemm_case(f"tile={os.environ.get('TT_GEMM_TILE', 'auto')}", M, N, K, taps=taps, seq=seq)
     if "gn" in which:
         for (B, S, C_) in ((2, 870, 1024), (2, 2176, 1024)):
             x = torch.randn(B, S, C_, device="cuda")

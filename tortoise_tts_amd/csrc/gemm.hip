@@ -8,8 +8,9 @@
 
 namespace tt {
 
-constexpr int BK = 64;
-constexpr int BKP = BK + 8;  // LDS row pitch in elements: 144 B keeps 16-B alignment, staggers banks
+// BK (k-depth of one LDS stage) is a template parameter: 64 for the MFMA-bound shapes, 256 for the decode
+// shapes (M <= 256), where a block's k-loop is a chain of memory round trips and fewer, fatter stages win.
+// LDS row pitch = BK + 8 elements (keeps 16-B alignment, staggers banks).
 
 template <typename T>
 struct EpiStd {
@@ -118,12 +119,15 @@ struct EpiQkvDecode {
   }
 };
 
-template <typename T, int BM, int BN, typename Epi, bool CONV>
+template <typename T, int BM, int BN, int BK, typename Epi, bool CONV>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   typedef typename Vec<T>::x8 x8;
+  constexpr int BKP = BK + 8;
   constexpr int TM = BM / 2, TN = BN / 2;  // wave tile
   constexpr int FM = TM / 16, FN = TN / 16;
-  constexpr int PA = BM / 32, PW = BN / 32;  // 32 rows of 128 B per 256-thread pass
+  constexpr int TPR = BK / 8;        // threads per tile row (16 B each)
+  constexpr int RPP = 256 / TPR;     // rows per 256-thread pass
+  constexpr int PA = BM / RPP, PW = BN / RPP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* As = (T*)smem_raw;                 // [2][BM][BKP]
   T* Ws = As + 2 * BM * BKP;            // [2][BN][BKP]
@@ -131,14 +135,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order: hardware dispatches workgroup i to XCD i % 8, each with a private 4 MiB L2.
+  // Remap so every XCD owns a contiguous run of tiles (m fastest): its blocks then share W panels and
+  // re-use A rows out of ITS L2 instead of all eight L2s each streaming every panel.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int nwg = gridDim.x * gridDim.y;
+    const int id = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = id & 7, loc = id >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    bx = nid % gridDim.x;
+    by = nid / gridDim.x;
+  }
+  const int m0 = bx * BM, n0 = by * BN;
   const int z = blockIdx.z;
   const int nk_total = g.K / BK;
   const int kt_begin = (int)((long long)nk_total * z / g.splitk);
   const int kt_end = (int)((long long)nk_total * (z + 1) / g.splitk);
 
-  const int lrow = tid >> 3;       // 0..31
-  const int lcol = (tid & 7) * 8;  // element offset inside the 64-wide k-tile
+  const int lrow = tid / TPR;
+  const int lcol = (tid % TPR) * 8;  // element offset inside the k-tile
   const T* A = (const T*)g.A;
   const T* W = (const T*)g.W;
 
@@ -147,7 +164,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   bool a_ok[PA];
 #pragma unroll
   for (int p = 0; p < PA; ++p) {
-    const int m = m0 + lrow + 32 * p;
+    const int m = m0 + lrow + RPP * p;
     a_ok[p] = m < g.M;
     if (CONV) {
       a_b[p] = m / g.seq_len;
@@ -189,7 +206,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 #pragma unroll
     for (int p = 0; p < PW; ++p) {
-      const int n = n0 + lrow + 32 * p;
+      const int n = n0 + lrow + RPP * p;
       const x8 v = *(const x8*)(W + (size_t)(n < g.N ? n : g.N - 1) * g.ldw + k0 + lcol);
       rw[p] = n < g.N ? v : zero8;
     }
@@ -198,9 +215,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     T* as = As + buf * BM * BKP;
     T* ws = Ws + buf * BN * BKP;
 #pragma unroll
-    for (int p = 0; p < PA; ++p) *(x8*)(as + (lrow + 32 * p) * BKP + lcol) = ra[p];
+    for (int p = 0; p < PA; ++p) *(x8*)(as + (lrow + RPP * p) * BKP + lcol) = ra[p];
 #pragma unroll
-    for (int p = 0; p < PW; ++p) *(x8*)(ws + (lrow + 32 * p) * BKP + lcol) = rw[p];
+    for (int p = 0; p < PW; ++p) *(x8*)(ws + (lrow + RPP * p) * BKP + lcol) = rw[p];
   };
 
   f32x4 acc[FN][FM];
@@ -263,38 +280,62 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 constexpr int smem_bytes() {
-  return 2 * (BM + BN) * BKP * 2;
+  return 2 * (BM + BN) * (BK + 8) * 2;
 }
 
-template <typename T, int BM, int BN, typename Epi>
-static int launch_one(const GemmArgs& a, hipStream_t stream) {
+// tile configurations: id -> (BM, BN, BK)
+//   0: 64x64x64   1: 128x64x64   2: 128x128x64   3: 64x64x256 (decode: few fat k-stages)
+template <typename T, int BM, int BN, int BK, typename Epi>
+static int launch_one(const GemmArgs& a, hipStream_t stream, int tile_id) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), a.splitk);
-  constexpr int smem = smem_bytes<BM, BN>();
-  constexpr int tile_id = BM == 64 ? 0 : (BN == 64 ? 1 : 2);
+  constexpr int smem = smem_bytes<BM, BN, BK>();
   // algorithmic work of this launch: 2*M*N*K flops; operands read once + result written once
   const double out_bytes = (double)a.M * a.N * ((a.out_f32 || Epi::kId != 0 ? 4.0 : 0.0) * (Epi::kId == 0 ? 1.0 : 0.0) + (a.out_t || Epi::kId != 0 ? 2.0 : 0.0));
-  ProfScope ps(tile_id * 3 + Epi::kId, stream, 2.0 * a.M * a.N * a.K,
+  ProfScope ps((tile_id == 3 ? 0 : tile_id) * 3 + Epi::kId, stream, 2.0 * a.M * a.N * a.K,
                ((double)a.N * a.K + (double)a.M * a.cin) * 2.0 + out_bytes * (a.splitk > 1 ? a.splitk : 1) + (a.res ? 4.0 * a.M * a.N : 0.0));
   if constexpr (Epi::kId == 0) {
-    if (a.taps > 1) gemm_kernel<T, BM, BN, Epi, true><<<grid, dim3(256), smem, stream>>>(a);
-    else gemm_kernel<T, BM, BN, Epi, false><<<grid, dim3(256), smem, stream>>>(a);
+    if (a.taps > 1) gemm_kernel<T, BM, BN, BK, Epi, true><<<grid, dim3(256), smem, stream>>>(a);
+    else gemm_kernel<T, BM, BN, BK, Epi, false><<<grid, dim3(256), smem, stream>>>(a);
   } else {
-    gemm_kernel<T, BM, BN, Epi, false><<<grid, dim3(256), smem, stream>>>(a);
+    gemm_kernel<T, BM, BN, BK, Epi, false><<<grid, dim3(256), smem, stream>>>(a);
   }
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
+static int forced_tile() {
+  static int v = -2;
+  if (v == -2) {
+    const char* e = getenv("TT_GEMM_TILE");  // experiments only (scripts/kbench.py)
+    v = e ? atoi(e) : -1;
+  }
+  return v;
+}
+
 template <typename T, typename Epi>
 static int launch_tiles(const GemmArgs& a, hipStream_t stream) {
-  // Tile choice: the chip has 256 CUs.  Prefer the largest tile that still yields >= ~200 blocks.
-  const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk;
-  const long b12864 = (long)cdiv(a.M, 128) * cdiv(a.N, 64) * a.splitk;
-  if (a.M > 64 && b128 >= 200) return launch_one<T, 128, 128, Epi>(a, stream);
-  if (a.M > 64 && b12864 >= 160) return launch_one<T, 128, 64, Epi>(a, stream);
-  return launch_one<T, 64, 64, Epi>(a, stream);
+  int tile = forced_tile();
+  const int nk64 = a.K / 64;
+  if (tile < 0) {
+    // The chip has 256 CUs.  Small M (decode / per-utterance vectors): the k-loop is latency bound -> 256-deep
+    // stages when K allows.  Otherwise the largest tile that still yields enough blocks to fill the chip.
+    const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk;
+    const long b12864 = (long)cdiv(a.M, 128) * cdiv(a.N, 64) * a.splitk;
+    if (a.M <= 256 && a.cin % 256 == 0 && (a.K / 256) >= a.splitk) tile = 3;
+    else if (a.M > 64 && b128 >= 200) tile = 2;
+    else if (a.M > 64 && b12864 >= 160) tile = 1;
+    else tile = 0;
+  }
+  if (tile == 3 && (a.cin % 256 != 0 || (a.K / 256) < a.splitk)) tile = 0;
+  (void)nk64;
+  switch (tile) {
+    case 3: return launch_one<T, 64, 64, 256, Epi>(a, stream, 3);
+    case 2: return launch_one<T, 128, 128, 64, Epi>(a, stream, 2);
+    case 1: return launch_one<T, 128, 64, 64, Epi>(a, stream, 1);
+    default: return launch_one<T, 64, 64, 64, Epi>(a, stream, 0);
+  }
 }
 
 template <typename T>
@@ -314,10 +355,10 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   if (a.splitk < 1) a.splitk = 1;
   a.cin = a.K / a.taps;
   TT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
-  TT_REQUIRE(a.K % BK == 0 && a.cin % BK == 0, "gemm: K=%d (taps=%d) must be a multiple of %d per tap", a.K, a.taps, BK);
+  TT_REQUIRE(a.K % 64 == 0 && a.cin % 64 == 0, "gemm: K=%d (taps=%d) must be a multiple of 64 per tap", a.K, a.taps);
   TT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda=%d / ldw=%d must be multiples of 8 elements", a.lda, a.ldw);
   TT_REQUIRE(a.splitk == 1 || (epi == EPI_STD && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
-  TT_REQUIRE(a.splitk <= a.K / BK, "gemm: splitk=%d exceeds the %d k-tiles", a.splitk, a.K / BK);
+  TT_REQUIRE(a.splitk <= a.K / 64, "gemm: splitk=%d exceeds the %d k-tiles", a.splitk, a.K / 64);
   if (epi != EPI_STD) {
     TT_REQUIRE(a.taps == 1, "gemm: conv taps are only supported with the standard epilogue");
     TT_REQUIRE(a.dmodel % 64 == 0 && a.N == 3 * a.dmodel && a.heads * 64 == a.dmodel, "gemm: qkv epilogue needs N == 3*dmodel, head_dim 64");
@@ -329,21 +370,22 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   return -1;
 }
 
-template <typename T, int BM, int BN, typename Epi>
+template <typename T, int BM, int BN, int BK, typename Epi>
 static int set_attr_one() {
-  const void* fn = (const void*)gemm_kernel<T, BM, BN, Epi, false>;
-  TT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN>()));
+  const void* fn = (const void*)gemm_kernel<T, BM, BN, BK, Epi, false>;
+  TT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN, BK>()));
   if constexpr (Epi::kId == 0) {
-    const void* fc = (const void*)gemm_kernel<T, BM, BN, Epi, true>;
-    TT_CHECK_HIP(hipFuncSetAttribute(fc, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN>()));
+    const void* fc = (const void*)gemm_kernel<T, BM, BN, BK, Epi, true>;
+    TT_CHECK_HIP(hipFuncSetAttribute(fc, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN, BK>()));
   }
   return 0;
 }
 template <typename T, typename Epi>
 static int set_attr() {
-  TT_TRY((set_attr_one<T, 128, 128, Epi>()));
-  TT_TRY((set_attr_one<T, 128, 64, Epi>()));
-  TT_TRY((set_attr_one<T, 64, 64, Epi>()));
+  TT_TRY((set_attr_one<T, 128, 128, 64, Epi>()));
+  TT_TRY((set_attr_one<T, 128, 64, 64, Epi>()));
+  TT_TRY((set_attr_one<T, 64, 64, 64, Epi>()));
+  TT_TRY((set_attr_one<T, 64, 64, 256, Epi>()));
   return 0;
 }
 

@@ -100,9 +100,11 @@ static int gpt_trunk_full(tt_ar* e, int B, int n, bool to_prefix, hipStream_t s)
 // sampled codes) do not depend on how the candidates are sharded across GPUs.
 static int pick_split(int B, int N, int K) {
   (void)B;
-  const int tiles = cdiv(N, 64);
-  int sk = 512 / (tiles > 0 ? tiles : 1);
-  const int nk = K / 64;
+  // decode GEMMs run 64x64 tiles with 256-deep k-stages: aim for ~256 blocks at the full candidate batch
+  // (4 row tiles) and at least one whole stage per split.
+  const int tiles = 4 * cdiv(N, 64);
+  int sk = 256 / (tiles > 0 ? tiles : 1);
+  const int nk = K / 256;
   if (sk > MAX_SPLIT) sk = MAX_SPLIT;
   if (sk > nk) sk = nk;
   if (sk < 1) sk = 1;
