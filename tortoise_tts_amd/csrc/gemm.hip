@@ -178,11 +178,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // Two register tile sets: loads run TWO k-tiles ahead of the MFMAs (one tile being written to LDS,
   // one still in flight), because at these shapes a block's k-step is shorter than the L2/HBM latency.
   x8 ra0[PA], rw0[PW], ra1[PA], rw1[PW];
+  unsigned zm0 = 0u, zm1 = 0u;  // CONV only: bit p set = A row p of that set is conv padding (must read as zero)
   const x8 zero8 = {};
 
-  // Loads are unconditional (out-of-range rows read row 0 / the last W row and are zeroed by a select):
-  // branch-free issue is what lets the compiler keep counted s_waitcnt vmcnt(N) instead of draining to 0.
-  auto load_tile = [&](x8 (&ra)[PA], x8 (&rw)[PW], int kt) {
+  // Loads are unconditional and their results are NOT touched until store_tile: rows beyond M / N are
+  // clamped to a valid address and simply produce output rows / columns that the epilogue never stores,
+  // so no select is needed (a select right after the load would force an immediate vmcnt wait and
+  // destroy the prefetch distance).  Only conv padding needs real zeros; that select happens at store time.
+  auto load_tile = [&](x8 (&ra)[PA], x8 (&rw)[PW], unsigned& zm, int kt) {
     const int k0 = kt * BK;
     int tap = 0, kin = k0;
     if (CONV) {
@@ -190,32 +193,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       kin = k0 - tap * g.cin;
     }
     const int shift = tap - (g.taps >> 1);
+    unsigned z = 0u;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      bool ok = a_ok[p];
       size_t row;
       if (CONV) {
         const int s2 = a_s[p] + shift;
-        ok = ok && s2 >= 0 && s2 < g.seq_len;
-        row = (size_t)a_b[p] * g.seq_len + s2;
+        const bool ok = a_ok[p] && s2 >= 0 && s2 < g.seq_len;
+        if (!ok) z |= 1u << p;
+        row = ok ? (size_t)a_b[p] * g.seq_len + s2 : 0;
       } else {
-        row = (size_t)a_s[p];
+        row = a_ok[p] ? (size_t)a_s[p] : 0;
       }
-      const x8 v = *(const x8*)(A + (ok ? row : 0) * g.lda + kin + lcol);
-      ra[p] = ok ? v : zero8;
+      ra[p] = *(const x8*)(A + row * g.lda + kin + lcol);
     }
+    zm = z;
 #pragma unroll
     for (int p = 0; p < PW; ++p) {
       const int n = n0 + lrow + RPP * p;
-      const x8 v = *(const x8*)(W + (size_t)(n < g.N ? n : g.N - 1) * g.ldw + k0 + lcol);
-      rw[p] = n < g.N ? v : zero8;
+      rw[p] = *(const x8*)(W + (size_t)(n < g.N ? n : g.N - 1) * g.ldw + k0 + lcol);
     }
   };
-  auto store_tile = [&](const x8 (&ra)[PA], const x8 (&rw)[PW], int buf) {
+  auto store_tile = [&](const x8 (&ra)[PA], const x8 (&rw)[PW], unsigned zm, int buf) {
     T* as = As + buf * BM * BKP;
     T* ws = Ws + buf * BN * BKP;
 #pragma unroll
-    for (int p = 0; p < PA; ++p) *(x8*)(as + (lrow + RPP * p) * BKP + lcol) = ra[p];
+    for (int p = 0; p < PA; ++p) *(x8*)(as + (lrow + RPP * p) * BKP + lcol) = (CONV && ((zm >> p) & 1u)) ? zero8 : ra[p];
 #pragma unroll
     for (int p = 0; p < PW; ++p) *(x8*)(ws + (lrow + RPP * p) * BKP + lcol) = rw[p];
   };
@@ -248,21 +251,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int last = kt_end - 1;
   // Every iteration issues its prefetch unconditionally (clamped to the last tile; a redundant reload of
   // the final tile is harmless) so the body stays straight-line and the waits stay counted.
-  load_tile(ra0, rw0, kt_begin);
-  load_tile(ra1, rw1, min(kt_begin + 1, last));
-  store_tile(ra0, rw0, 0);
+  load_tile(ra0, rw0, zm0, kt_begin);
+  load_tile(ra1, rw1, zm1, min(kt_begin + 1, last));
+  store_tile(ra0, rw0, zm0, 0);
   __syncthreads();
   for (int i = 0; i < nt; i += 2) {
     // tile i is in LDS buffer 0, tile i+1 in flight in set 1, set 0 is free
-    load_tile(ra0, rw0, min(kt_begin + i + 2, last));
+    load_tile(ra0, rw0, zm0, min(kt_begin + i + 2, last));
     compute(0);
-    store_tile(ra1, rw1, 1);
+    store_tile(ra1, rw1, zm1, 1);
     __syncthreads();
     if (i + 1 >= nt) break;
     // tile i+1 is in LDS buffer 1, tile i+2 in flight in set 0, set 1 is free
-    load_tile(ra1, rw1, min(kt_begin + i + 3, last));
+    load_tile(ra1, rw1, zm1, min(kt_begin + i + 3, last));
     compute(1);
-    store_tile(ra0, rw0, 0);
+    store_tile(ra0, rw0, zm0, 0);
     __syncthreads();
   }
 
