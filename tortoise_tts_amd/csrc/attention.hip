@@ -19,7 +19,11 @@
 
 namespace tt {
 
-template <typename T, int NQ>
+// SPLIT = false: each wave owns its own NQ x 16 queries and walks all keys.
+// SPLIT = true : the 4 waves of a block share ONE block of queries and take every 4th key tile each; partial
+//                (max, sum, O) states are merged through LDS.  4x the resident waves for the same work, which is
+//                what hides the per-tile dependency chain (MFMA -> softmax -> MFMA) when batch*heads is small.
+template <typename T, int NQ, bool SPLIT>
 __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
   typedef typename Vec<T>::x8 x8;
   typedef typename Vec<T>::x4 x4;
@@ -33,7 +37,7 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
     if (threadIdx.x < 129) rp[threadIdx.x] = a.relpos[h * 129 + threadIdx.x];
     __syncthreads();
   }
-  const int qbase = (blockIdx.x * 4 + wave) * 16 * NQ;
+  const int qbase = (SPLIT ? blockIdx.x : blockIdx.x * 4 + wave) * 16 * NQ;
   if (qbase >= n) return;
   const T* Q = (const T*)a.q + (size_t)bh * n * 64;
   const T* K = (const T*)a.k + (size_t)bh * n * 64;
@@ -79,7 +83,6 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
     }
   };
   x8 kfA[2][2], vfA[4], kfB[2][2], vfB[4];
-  load_kv(kfA, vfA, 0);
 
   auto process = [&](const x8 (&kf)[2][2], const x8 (&vf)[4], int key0) {
 #pragma unroll
@@ -137,13 +140,59 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
       }
     }
   };
-  const int klast = ((kend - 1) / 32) * 32;  // prefetches are unconditional (clamped): straight-line body, counted waits
-  for (int key0 = 0; key0 < kend; key0 += 64) {
-    load_kv(kfB, vfB, min(key0 + 32, klast));
-    process(kfA, vfA, key0);
-    if (key0 + 32 >= kend) break;
-    load_kv(kfA, vfA, min(key0 + 64, klast));
-    process(kfB, vfB, key0 + 32);
+  // prefetches are unconditional (clamped to the last tile): straight-line body, counted waits
+  const int ntile = (kend + 31) / 32;
+  constexpr int TSTEP = SPLIT ? 4 : 1;
+  int t = SPLIT ? wave : 0;
+  if (t < ntile) {
+    load_kv(kfA, vfA, 32 * t);
+    while (true) {
+      load_kv(kfB, vfB, 32 * min(t + TSTEP, ntile - 1));
+      process(kfA, vfA, 32 * t);
+      t += TSTEP;
+      if (t >= ntile) break;
+      load_kv(kfA, vfA, 32 * min(t + TSTEP, ntile - 1));
+      process(kfB, vfB, 32 * t);
+      t += TSTEP;
+      if (t >= ntile) break;
+    }
+  }
+  if (SPLIT) {
+    static_assert(!SPLIT || NQ == 1, "key-split mode merges one query block per workgroup");
+    __shared__ float mbuf[4][16], lbuf[4][16];
+    __shared__ float obuf[4][64][17];
+    if (fg == 0) {
+      mbuf[wave][fr] = m_run[0];
+      lbuf[wave][fr] = l_run[0];
+    }
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) obuf[wave][lane][blk * 4 + r] = acc[0][blk][r];
+    __syncthreads();
+    if (wave != 0) return;
+    float mw[4], M = -1e30f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      mw[w] = mbuf[w][fr];
+      M = fmaxf(M, mw[w]);
+    }
+    float L = 0.f;
+    float o[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = __expf(mw[w] - M);
+      L += f * lbuf[w][fr];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] += f * obuf[w][lane][j];
+    }
+    l_run[0] = L;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[0][blk][r] = o[blk * 4 + r];
   }
 #pragma unroll
   for (int iq = 0; iq < NQ; ++iq) {
@@ -165,15 +214,16 @@ int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
   // 32 queries per wave once there is enough work to fill the chip; 16 otherwise.
   // QK^T + PV: 4 * n * n * 64 flops per (batch, head) (halved when causal); Q, K, V read + O written once
   ProfScope ps(PROF_FLASH, stream, 4.0 * a.BH * (double)a.n * a.n * 64 * (a.causal ? 0.5 : 1.0), 4.0 * a.BH * (double)a.n * 64 * 2.0);
-  const long blocks2 = (long)cdiv(a.n, 128) * a.BH;
-  if (blocks2 >= 512) {
+  const long waves_own = (long)cdiv(a.n, 16) * a.BH;  // waves if every wave owned 16 queries
+  if (waves_own >= 16384) {
+    // plenty of parallelism (CLVP: batch*heads in the thousands): 32 queries per wave, no key split
     dim3 grid(cdiv(a.n, 128), a.BH);
-    if (dtype == DT_BF16) flash_kernel<bf16, 2><<<grid, 256, 0, stream>>>(a);
-    else flash_kernel<f16, 2><<<grid, 256, 0, stream>>>(a);
+    if (dtype == DT_BF16) flash_kernel<bf16, 2, false><<<grid, 256, 0, stream>>>(a);
+    else flash_kernel<f16, 2, false><<<grid, 256, 0, stream>>>(a);
   } else {
-    dim3 grid(cdiv(a.n, 64), a.BH);
-    if (dtype == DT_BF16) flash_kernel<bf16, 1><<<grid, 256, 0, stream>>>(a);
-    else flash_kernel<f16, 1><<<grid, 256, 0, stream>>>(a);
+    dim3 grid(cdiv(a.n, 16), a.BH);
+    if (dtype == DT_BF16) flash_kernel<bf16, 1, true><<<grid, 256, 0, stream>>>(a);
+    else flash_kernel<f16, 1, true><<<grid, 256, 0, stream>>>(a);
   }
   TT_CHECK_HIP(hipGetLastError());
   return 0;

@@ -111,12 +111,111 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
   emit(v);
 }
 
+// Wave-per-row variant for D <= 1024: no block barriers, reductions are register shuffles only, four rows per
+// 256-thread block.  Same arithmetic order per row as the block variant is NOT required (tests compare to torch).
+template <typename T>
+__global__ __launch_bounds__(256) void rownorm_wave_kernel(RowNormArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.M) return;
+  constexpr int J = 4;
+  float4 v[J];
+  float* xr = a.x + (size_t)row * a.ldx;
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    if (c < a.D) {
+      float4 t = a.x_in ? *(const float4*)(a.x_in + (size_t)row * a.ldxin + c) : *(const float4*)(xr + c);
+      if (a.add_bias) {
+        const float4 b = *(const float4*)(a.add_bias + c);
+        t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+      }
+      for (int s = 0; s < a.nslab; ++s) {
+        const float4 p = *(const float4*)(a.add_slabs + (size_t)s * a.slab_stride + (size_t)row * a.ldslab + c);
+        t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+      }
+      if (a.write_x) *(float4*)(xr + c) = t;
+      v[j] = t;
+      sum += t.x + t.y + t.z + t.w;
+    } else {
+      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (a.mode == NORM_NONE) return;
+  if (a.mode == NORM_RMS) {
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) sq += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+    sq = wave_sum(sq);
+    const float nrm = sqrtf(sq) * rsqrtf((float)a.D);
+    const float inv = 1.0f / fmaxf(nrm, a.eps1);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      if (c < a.D) {
+        const float4 g = *(const float4*)(a.g1 + c);
+        v[j] = make_float4(v[j].x * inv * g.x, v[j].y * inv * g.y, v[j].z * inv * g.z, v[j].w * inv * g.w);
+      }
+    }
+  } else {
+    const float* gs[2] = {a.g1, a.g2};
+    const float* bs[2] = {a.b1, a.b2};
+    const float epss[2] = {a.eps1, a.eps2};
+    const int nln = a.g2 ? 2 : 1;
+    for (int l = 0; l < nln; ++l) {
+      if (l > 0) {
+        sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int c = (lane + 64 * j) * 4;
+          if (c < a.D) sum += v[j].x + v[j].y + v[j].z + v[j].w;
+        }
+      }
+      const float mean = wave_sum(sum) / (float)a.D;
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < a.D) {
+          const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+          sq += dx * dx + dy * dy + dz * dz + dw * dw;
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(sq) / (float)a.D + epss[l]);
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < a.D) {
+          const float4 g = *(const float4*)(gs[l] + c);
+          const float4 b = *(const float4*)(bs[l] + c);
+          v[j] = make_float4((v[j].x - mean) * rstd * g.x + b.x, (v[j].y - mean) * rstd * g.y + b.y,
+                             (v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    if (c < a.D) {
+      if (a.out_t) *(typename Vec<T>::x4*)((T*)a.out_t + (size_t)row * a.ldot + c) = pack4<T>(v[j].x, v[j].y, v[j].z, v[j].w);
+      if (a.out_f32) *(float4*)(a.out_f32 + (size_t)row * a.ldo32 + c) = v[j];
+    }
+  }
+}
+
 int rownorm_launch(int dtype, const RowNormArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.M > 0 && a.D > 0 && a.D % 4 == 0 && a.D <= 4096, "rownorm: bad shape M=%d D=%d", a.M, a.D);
   TT_REQUIRE(a.ldx % 4 == 0, "rownorm: ldx must be a multiple of 4");
   ProfScope ps(PROF_ROWNORM, stream, 0.0, (double)a.M * a.D * (4.0 * (1 + a.nslab + (a.write_x ? 1 : 0)) + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)));
-  if (dtype == DT_BF16) rownorm_kernel<bf16><<<a.M, 256, 0, stream>>>(a);
-  else rownorm_kernel<f16><<<a.M, 256, 0, stream>>>(a);
+  if (a.D <= 1024) {
+    if (dtype == DT_BF16) rownorm_wave_kernel<bf16><<<cdiv(a.M, 4), 256, 0, stream>>>(a);
+    else rownorm_wave_kernel<f16><<<cdiv(a.M, 4), 256, 0, stream>>>(a);
+  } else {
+    if (dtype == DT_BF16) rownorm_kernel<bf16><<<a.M, 256, 0, stream>>>(a);
+    else rownorm_kernel<f16><<<a.M, 256, 0, stream>>>(a);
+  }
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
