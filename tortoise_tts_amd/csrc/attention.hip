@@ -158,41 +158,47 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
     }
   }
   if (SPLIT) {
-    static_assert(!SPLIT || NQ == 1, "key-split mode merges one query block per workgroup");
+    // merge the four waves' partial (max, sum, O) states, one query block at a time, into wave 0
     __shared__ float mbuf[4][16], lbuf[4][16];
     __shared__ float obuf[4][64][17];
-    if (fg == 0) {
-      mbuf[wave][fr] = m_run[0];
-      lbuf[wave][fr] = l_run[0];
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) {
+      if (iq > 0) __syncthreads();  // wave 0 finished reading the previous query block
+      if (fg == 0) {
+        mbuf[wave][fr] = m_run[iq];
+        lbuf[wave][fr] = l_run[iq];
+      }
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) obuf[wave][lane][blk * 4 + r] = acc[iq][blk][r];
+      __syncthreads();
+      if (wave == 0) {
+        float mw[4], M = -1e30f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          mw[w] = mbuf[w][fr];
+          M = fmaxf(M, mw[w]);
+        }
+        float L = 0.f;
+        float o[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[j] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float f = __expf(mw[w] - M);
+          L += f * lbuf[w][fr];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) o[j] += f * obuf[w][lane][j];
+        }
+        l_run[iq] = L;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[iq][blk][r] = o[blk * 4 + r];
+      }
     }
-#pragma unroll
-    for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) obuf[wave][lane][blk * 4 + r] = acc[0][blk][r];
-    __syncthreads();
     if (wave != 0) return;
-    float mw[4], M = -1e30f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      mw[w] = mbuf[w][fr];
-      M = fmaxf(M, mw[w]);
-    }
-    float L = 0.f;
-    float o[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) o[j] = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float f = __expf(mw[w] - M);
-      L += f * lbuf[w][fr];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) o[j] += f * obuf[w][lane][j];
-    }
-    l_run[0] = L;
-#pragma unroll
-    for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[0][blk][r] = o[blk * 4 + r];
   }
 #pragma unroll
   for (int iq = 0; iq < NQ; ++iq) {
@@ -214,12 +220,18 @@ int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
   // 32 queries per wave once there is enough work to fill the chip; 16 otherwise.
   // QK^T + PV: 4 * n * n * 64 flops per (batch, head) (halved when causal); Q, K, V read + O written once
   ProfScope ps(PROF_FLASH, stream, 4.0 * a.BH * (double)a.n * a.n * 64 * (a.causal ? 0.5 : 1.0), 4.0 * a.BH * (double)a.n * 64 * 2.0);
-  const long waves_own = (long)cdiv(a.n, 16) * a.BH;  // waves if every wave owned 16 queries
-  if (waves_own >= 16384) {
-    // plenty of parallelism (CLVP: batch*heads in the thousands): 32 queries per wave, no key split
+  // Every K / V^T tile a wave loads is used by NQ*16 of its queries, so L2->CU traffic per flop falls as 1/NQ
+  // (with NQ = 1 the kernel sits on the L2 bandwidth, ~80 TFLOP/s).  Few (batch, head) pairs: 64 queries per
+  // wave and the keys split over the block's 4 waves; many pairs: 32 queries per wave, no split.
+  const long waves_own = (long)cdiv(a.n, 32) * a.BH;
+  if (waves_own >= 8192) {
     dim3 grid(cdiv(a.n, 128), a.BH);
     if (dtype == DT_BF16) flash_kernel<bf16, 2, false><<<grid, 256, 0, stream>>>(a);
     else flash_kernel<f16, 2, false><<<grid, 256, 0, stream>>>(a);
+  } else if (a.n > 128) {
+    dim3 grid(cdiv(a.n, 64), a.BH);
+    if (dtype == DT_BF16) flash_kernel<bf16, 4, true><<<grid, 256, 0, stream>>>(a);
+    else flash_kernel<f16, 4, true><<<grid, 256, 0, stream>>>(a);
   } else {
     dim3 grid(cdiv(a.n, 16), a.BH);
     if (dtype == DT_BF16) flash_kernel<bf16, 1, true><<<grid, 256, 0, stream>>>(a);
