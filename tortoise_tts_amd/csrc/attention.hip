@@ -275,27 +275,34 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnArgs a, int 
 
   float mx = -1e30f;
   if (valid) {
-    for (int j = lane; j < P1; j += 64) {
-      float s = 0.f;
+    // Lane-per-key dot products, TWO key slots (16 x 16-byte loads) in flight per lane per iteration:
+    // slot s < P1 is a shared-prefix key (row-major), otherwise this sequence's key s - P1 (chunk-major).
+    for (int s0 = lane; s0 < ctx; s0 += 128) {
+      x8 kk[2][8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const x8 t = *(const x8*)(kp + (size_t)j * 64 + c * 8);
+      for (int u = 0; u < 2; ++u) {
+        const int sl = min(s0 + 64 * u, ctx - 1);
+        if (sl < P1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += qv[c * 8 + i] * (float)t[i];
+          for (int c = 0; c < 8; ++c) kk[u][c] = *(const x8*)(kp + (size_t)sl * 64 + c * 8);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) kk[u][c] = *(const x8*)(kc + ((size_t)c * a.tmax + (sl - P1)) * 8);
+        }
       }
-      sc[j] = s;
-      mx = fmaxf(mx, s);
-    }
-    for (int t0 = lane; t0 < tgen; t0 += 64) {
-      float s = 0.f;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const x8 t = *(const x8*)(kc + ((size_t)c * a.tmax + t0) * 8);
+      for (int u = 0; u < 2; ++u) {
+        const int sl = s0 + 64 * u;
+        float sv = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += qv[c * 8 + i] * (float)t[i];
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sv += qv[c * 8 + i] * (float)kk[u][c][i];
+        if (sl < ctx) {
+          sc[sl] = sv;
+          mx = fmaxf(mx, sv);
+        }
       }
-      sc[P1 + t0] = s;
-      mx = fmaxf(mx, s);
     }
   }
   mx = wave_max(mx);

@@ -209,7 +209,8 @@ int rownorm_launch(int dtype, const RowNormArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.M > 0 && a.D > 0 && a.D % 4 == 0 && a.D <= 4096, "rownorm: bad shape M=%d D=%d", a.M, a.D);
   TT_REQUIRE(a.ldx % 4 == 0, "rownorm: ldx must be a multiple of 4");
   ProfScope ps(PROF_ROWNORM, stream, 0.0, (double)a.M * a.D * (4.0 * (1 + a.nslab + (a.write_x ? 1 : 0)) + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)));
-  if (a.D <= 1024) {
+  // few rows (decode): one block per row keeps 4x more loads in flight; many rows: wave per row, no barriers
+  if (a.D <= 1024 && a.M >= 1024) {
     if (dtype == DT_BF16) rownorm_wave_kernel<bf16><<<cdiv(a.M, 4), 256, 0, stream>>>(a);
     else rownorm_wave_kernel<f16><<<cdiv(a.M, 4), 256, 0, stream>>>(a);
   } else {
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     float s = 0.f, q = 0.f;
     const int c4 = cb + cl;
     if (c4 < c4n) {
+#pragma unroll 8
       for (int r = r0 + rl; r < r1; r += RL) {
         const float4 t = *(const float4*)(x + ((size_t)b * S + r) * C + c4 * 4);
         s += t.x + t.y + t.z + t.w;
@@ -281,10 +283,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchu
     // finalize: 8 threads per group each reduce every 8th chunk partial (independent loads), then combine in fp64
     const int g = tid & 31, part = tid >> 5;
     double s = 0.0, q = 0.0;
-    for (int i = part; i < nchunk; i += 8) {
-      const float* p = a.partial + (((size_t)b * nchunk + i) * 32 + g) * 2;
-      s += (double)p[0];
-      q += (double)p[1];
+    float2 pv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // nchunk <= 64: at most 8 independent loads per thread
+      const int i = part + 8 * k;
+      pv[k] = i < nchunk ? *(const float2*)(a.partial + (((size_t)b * nchunk + i) * 32 + g) * 2) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s += (double)pv[k].x;
+      q += (double)pv[k].y;
     }
     part_s[part][g] = s;
     part_q[part][g] = q;
@@ -339,6 +347,89 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchu
   }
 }
 
+// C == 1024 fast path: thread t owns channels 4t..4t+3 (group t/8) of GN_APPLY_ROWS consecutive rows.  The x rows
+// are requested BEFORE the statistics are finalised, so the streaming loads overlap the (latency-bound) prologue.
+constexpr int GN_APPLY_ROWS = 8;
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, int nchunk) {
+  __shared__ float mean_s[32], rstd_s[32];
+  __shared__ double part_s[8][32], part_q[8][32];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int S = a.S;
+  constexpr int C = 1024;
+  const int r0 = blockIdx.x * GN_APPLY_ROWS;
+  const int c = tid * 4;
+  float4 xr[GN_APPLY_ROWS];
+#pragma unroll
+  for (int i = 0; i < GN_APPLY_ROWS; ++i) {
+    const int r = min(r0 + i, S - 1);
+    xr[i] = *(const float4*)(a.x + ((size_t)b * S + r) * C + c);
+  }
+  const float4 gm = *(const float4*)(a.gamma + c);
+  const float4 bt = *(const float4*)(a.beta + c);
+  float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+  if (a.scale_shift) {
+    const float* ss = a.scale_shift + (size_t)b * a.ss_batch_stride + (a.ss_slot ? (size_t)(*a.ss_slot) * a.ss_slot_stride : 0);
+    sc = *(const float4*)(ss + c);
+    sh = *(const float4*)(ss + C + c);
+  }
+  {
+    const int g = tid & 31, part = tid >> 5;
+    double s = 0.0, q = 0.0;
+    float2 pv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = part + 8 * k;
+      pv[k] = i < nchunk ? *(const float2*)(a.partial + (((size_t)b * nchunk + i) * 32 + g) * 2) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s += (double)pv[k].x;
+      q += (double)pv[k].y;
+    }
+    part_s[part][g] = s;
+    part_q[part][g] = q;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      s += part_s[p][tid];
+      q += part_q[p][tid];
+    }
+    const double n = (double)S * 32.0;
+    const double m = s / n;
+    double var = q / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)m;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+  const float mu = mean_s[tid >> 3], rs = rstd_s[tid >> 3];
+#pragma unroll
+  for (int i = 0; i < GN_APPLY_ROWS; ++i) {
+    const int r = r0 + i;
+    if (r >= S) break;
+    const float4 t = xr[i];
+    float y[4] = {(t.x - mu) * rs * gm.x + bt.x, (t.y - mu) * rs * gm.y + bt.y, (t.z - mu) * rs * gm.z + bt.z,
+                  (t.w - mu) * rs * gm.w + bt.w};
+    if (a.scale_shift) {
+      y[0] = y[0] * (1.f + sc.x) + sh.x;
+      y[1] = y[1] * (1.f + sc.y) + sh.y;
+      y[2] = y[2] * (1.f + sc.z) + sh.z;
+      y[3] = y[3] * (1.f + sc.w) + sh.w;
+    }
+    if (a.act != ACT_NONE) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = apply_act(y[k], a.act, 0.f);
+    }
+    const size_t off = (size_t)b * S + r;
+    if (a.out_t) *(typename Vec<T>::x4*)((T*)a.out_t + off * a.ldot + c) = pack4<T>(y[0], y[1], y[2], y[3]);
+    if (a.out_f32) *(float4*)(a.out_f32 + off * a.ldo32 + c) = make_float4(y[0], y[1], y[2], y[3]);
+  }
+}
+
 int groupnorm_launch(int dtype, const GroupNormArgs& a, hipStream_t stream) {
   const int c4n = a.C / 4;
   TT_REQUIRE(a.C % 128 == 0 && ((c4n <= 256 && (c4n & (c4n - 1)) == 0) || c4n % 256 == 0), "groupnorm: unsupported C=%d", a.C);
@@ -349,10 +440,15 @@ int groupnorm_launch(int dtype, const GroupNormArgs& a, hipStream_t stream) {
   ProfScope ps(PROF_GROUPNORM, stream, 0.0, (double)a.B * a.S * a.C * (8.0 + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)));
   gn_stats_kernel<<<grid, 256, 0, stream>>>(a.x, a.S, a.C, a.partial, rpc);
   TT_CHECK_HIP(hipGetLastError());
-  const int rpb = 8;  // apply is pure streaming: many small blocks
+  const int rpb = GN_APPLY_ROWS;  // apply is pure streaming: many small blocks
   dim3 grid2(cdiv(a.S, rpb), a.B);
-  if (dtype == DT_BF16) gn_apply_kernel<bf16><<<grid2, 256, 0, stream>>>(a, nchunk, rpc, rpb);
-  else gn_apply_kernel<f16><<<grid2, 256, 0, stream>>>(a, nchunk, rpc, rpb);
+  if (a.C == 1024) {
+    if (dtype == DT_BF16) gn_apply_c1024_kernel<bf16><<<grid2, 256, 0, stream>>>(a, nchunk);
+    else gn_apply_c1024_kernel<f16><<<grid2, 256, 0, stream>>>(a, nchunk);
+  } else {
+    if (dtype == DT_BF16) gn_apply_kernel<bf16><<<grid2, 256, 0, stream>>>(a, nchunk, rpc, rpb);
+    else gn_apply_kernel<f16><<<grid2, 256, 0, stream>>>(a, nchunk, rpc, rpb);
+  }
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
