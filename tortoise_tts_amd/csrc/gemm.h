@@ -23,6 +23,7 @@ struct GemmArgs {
   int seq_len;  // rows per sequence (conv boundary / head-layout epilogues)
   int cin;      // K / taps
   int splitk;   // >1: raw partial sums go to out_f32 + z * M * ldo32 (EPI_STD only)
+  int xcd_mode; // set by gemm_launch: workgroup -> tile order w.r.t. the 8 XCD L2s (0 none, 1 row-fastest runs, 2 col-fastest, 3 2-D)
   // EPI_STD
   const float* bias;
   int act;

@@ -119,14 +119,16 @@ struct EpiQkvDecode {
   }
 };
 
-template <typename T, int BM, int BN, int BK, typename Epi, bool CONV>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+template <typename T, int BM, int BN, int BK, int NW, typename Epi, bool CONV>
+__global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs g) {
   typedef typename Vec<T>::x8 x8;
   constexpr int BKP = BK + 8;
-  constexpr int TM = BM / 2, TN = BN / 2;  // wave tile
+  constexpr int NT = NW * 64;               // threads per workgroup
+  constexpr int WGN = NW / 2;               // wave grid: 2 (rows) x WGN (columns)
+  constexpr int TM = BM / 2, TN = BN / WGN;  // wave tile
   constexpr int FM = TM / 16, FN = TN / 16;
   constexpr int TPR = BK / 8;        // threads per tile row (16 B each)
-  constexpr int RPP = 256 / TPR;     // rows per 256-thread pass
+  constexpr int RPP = NT / TPR;      // rows per workgroup-wide pass
   constexpr int PA = BM / RPP, PW = BN / RPP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* As = (T*)smem_raw;                 // [2][BM][BKP]
@@ -139,14 +141,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // Remap so every XCD owns a contiguous run of tiles (m fastest): its blocks then share W panels and
   // re-use A rows out of ITS L2 instead of all eight L2s each streaming every panel.
   int bx = blockIdx.x, by = blockIdx.y;
-  {
-    const int nwg = gridDim.x * gridDim.y;
-    const int id = blockIdx.x + gridDim.x * blockIdx.y;
+  if (g.xcd_mode != 0) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int nwg = gx * gy;
+    const int id = blockIdx.x + gx * blockIdx.y;
     const int xcd = id & 7, loc = id >> 3;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    bx = nid % gridDim.x;
-    by = nid / gridDim.x;
+    if (g.xcd_mode == 3 && (gx & 1) == 0 && (gy & 3) == 0) {
+      // 2-D ownership: XCD (xm, xn) owns half of the row tiles and a quarter of the column tiles
+      const int hx = gx >> 1, qy = gy >> 2;
+      const int xm = xcd & 1, xn = xcd >> 1;
+      bx = xm * hx + loc % hx;
+      by = xn * qy + loc / hx;
+    } else {
+      const int q = nwg >> 3, r = nwg & 7;
+      const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+      if (g.xcd_mode == 2) {  // column tiles fastest: an XCD owns a band of rows and sees every W panel
+        by = nid % gy;
+        bx = nid / gy;
+      } else {                // row tiles fastest: an XCD owns a few W panels and sees every A row
+        bx = nid % gx;
+        by = nid / gx;
+      }
+    }
   }
   const int m0 = bx * BM, n0 = by * BN;
   const int z = blockIdx.z;
@@ -283,6 +299,207 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Direct-to-LDS variant (global_load_lds_dwordx4): tiles go HBM/L2 -> LDS without passing through VGPRs or
+// ds_write instructions (the register-staged kernel spends about as many LDS-issue cycles writing a stage as
+// the MFMAs take to consume it).  A wave instruction fills 1 KiB = 8 rows x 128 B, lane-linear, so rows are
+// unpadded; bank conflicts are removed by an XOR swizzle applied on the SOURCE side: LDS chunk c of row r
+// holds global 16-byte chunk c ^ ((r >> 1) & 7), and fragment reads apply the same involution.
+// Conv padding / out-of-range rows cannot be zero-filled by a select any more: those lanes read a 16-byte
+// zero page instead.  Two LDS stages; the stage for k-tile t+1 is in flight while tile t is multiplied.
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <typename T, int BM, int BN, int NW, int ST, typename Epi, bool CONV>
+__global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(GemmArgs g) {
+  typedef typename Vec<T>::x8 x8;
+  constexpr int BK = 64;
+  constexpr int WGN = NW / 2;
+  constexpr int TM = BM / 2, TN = BN / WGN;
+  constexpr int FM = TM / 16, FN = TN / 16;
+  constexpr int PA = BM / 8 / NW, PW = BN / 8 / NW;  // 1-KiB pieces (8 rows) per wave per stage
+  static_assert(PA >= 1 && PW >= 1, "tile too small for this many waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* As = (T*)smem_raw;             // [ST][BM][64]
+  T* Ws = As + ST * BM * BK;        // [ST][BN][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x;
+    const int nwg = gx * gridDim.y;
+    const int id = blockIdx.x + gx * blockIdx.y;
+    const int xcd = id & 7, loc = id >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    bx = nid % gx;
+    by = nid / gx;
+  }
+  const int m0 = bx * BM, n0 = by * BN;
+  const int z = blockIdx.z;
+  const int nk_total = g.K / BK;
+  const int kt_begin = (int)((long long)nk_total * z / g.splitk);
+  const int kt_end = (int)((long long)nk_total * (z + 1) / g.splitk);
+  const T* A = (const T*)g.A;
+  const T* W = (const T*)g.W;
+  const T* zero = (const T*)g_zero_page;
+
+  // per-piece lane geometry: this lane fills LDS chunk lc of row (piece * 8 + lr) with global chunk lc ^ swz(row)
+  const int lr = lane >> 3, lc = lane & 7;
+  int a_row[PA], a_b[PA], a_s[PA], a_src[PA];
+  bool a_ok[PA];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int row = (wave + NW * p) * 8 + lr;
+    a_row[p] = row;
+    a_src[p] = (lc ^ ((row >> 1) & 7)) * 8;
+    const int m = m0 + row;
+    a_ok[p] = m < g.M;
+    if (CONV) {
+      a_b[p] = m / g.seq_len;
+      a_s[p] = m - a_b[p] * g.seq_len;
+    } else {
+      a_b[p] = 0;
+      a_s[p] = a_ok[p] ? m : 0;  // rows beyond M re-read row 0: their outputs are never stored
+    }
+  }
+  const T* w_ptr[PW];
+#pragma unroll
+  for (int p = 0; p < PW; ++p) {
+    const int row = (wave + NW * p) * 8 + lr;
+    const int n = n0 + row;
+    w_ptr[p] = W + (size_t)(n < g.N ? n : g.N - 1) * g.ldw + (lc ^ ((row >> 1) & 7)) * 8;
+  }
+
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    int tap = 0, kin = k0;
+    if (CONV) {
+      tap = k0 / g.cin;
+      kin = k0 - tap * g.cin;
+    }
+    const int shift = tap - (g.taps >> 1);
+    T* as = As + buf * BM * BK;
+    T* ws = Ws + buf * BN * BK;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const T* src;
+      if (CONV) {
+        const int s2 = a_s[p] + shift;
+        const bool ok = a_ok[p] && s2 >= 0 && s2 < g.seq_len;
+        src = ok ? A + ((size_t)a_b[p] * g.seq_len + s2) * g.lda + kin + a_src[p] : zero;
+      } else {
+        src = A + (size_t)a_s[p] * g.lda + kin + a_src[p];
+      }
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(as + (wave + NW * p) * 8 * BK), 16, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < PW; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_ptr[p] + k0), (lds_void_t*)(ws + (wave + NW * p) * 8 * BK), 16, 0, 0);
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  auto compute = [&](int buf) {
+    const T* as = As + buf * BM * BK;
+    const T* ws = Ws + buf * BN * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      x8 fa[FM], fw[FN];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int r = wm * TM + j * 16 + fr;
+        fa[j] = *(const x8*)(as + r * BK + (((ks * 4 + fg) ^ ((r >> 1) & 7)) * 8));
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int r = wn * TN + i * 16 + fr;
+        fw[i] = *(const x8*)(ws + r * BK + (((ks * 4 + fg) ^ ((r >> 1) & 7)) * 8));
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
+    }
+  };
+
+  if constexpr (ST == 2) {
+    issue(kt_begin, 0);
+    __syncthreads();  // (drains the LDS-DMA: hipcc emits vmcnt(0) before the barrier while a global_load_lds is pending)
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1);
+      compute(cur);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    // ST-stage ring, ST-1 tiles in flight.  One raw barrier per k-step; the wait is a COUNTED vmcnt so the
+    // newer stages stay in flight across the barrier (a __syncthreads() here would drain them: vmcnt(0)).
+    // Every iteration issues exactly G loads (tile index clamped; a redundant reload targets the ring slot
+    // that was consumed last iteration and is never read again), which keeps the count uniform in the tail.
+    constexpr int G = PA + PW;
+    const int last = kt_end - 1;
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s) issue(min(kt_begin + s, last), s);
+    int slot = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * G) : "memory");
+      __builtin_amdgcn_s_barrier();
+      int nslot = slot + ST - 1;
+      if (nslot >= ST) nslot -= ST;
+      issue(min(kt + ST - 1, last), nslot);
+      compute(slot);
+      slot = slot + 1 == ST ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+
+  Epi epi;
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int n = n0 + wn * TN + i * 16 + fg * 4;
+    if (n >= g.N) continue;
+    const int nvalid = g.N - n >= 4 ? 4 : g.N - n;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = m0 + wm * TM + j * 16 + fr;
+      if (m < g.M) epi(g, m, n, acc[i][j], nvalid, z);
+    }
+  }
+}
+
+template <int BM, int BN, int ST>
+constexpr int smem_bytes_glds() {
+  return ST * (BM + BN) * 64 * 2;
+}
+
+template <typename T, int BM, int BN, int NW, int ST, typename Epi>
+static int launch_glds(const GemmArgs& a, hipStream_t stream, int prof_tile) {
+  dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), a.splitk);
+  constexpr int smem = smem_bytes_glds<BM, BN, ST>();
+  const double out_bytes = (double)a.M * a.N * ((a.out_f32 || Epi::kId != 0 ? 4.0 : 0.0) * (Epi::kId == 0 ? 1.0 : 0.0) + (a.out_t || Epi::kId != 0 ? 2.0 : 0.0));
+  ProfScope ps(prof_tile * 3 + Epi::kId, stream, 2.0 * a.M * a.N * a.K,
+               ((double)a.N * a.K + (double)a.M * a.cin) * 2.0 + out_bytes * (a.splitk > 1 ? a.splitk : 1) + (a.res ? 4.0 * a.M * a.N : 0.0));
+  if constexpr (Epi::kId == 0) {
+    if (a.taps > 1) gemm_glds_kernel<T, BM, BN, NW, ST, Epi, true><<<grid, dim3(NW * 64), smem, stream>>>(a);
+    else gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false><<<grid, dim3(NW * 64), smem, stream>>>(a);
+  } else {
+    gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false><<<grid, dim3(NW * 64), smem, stream>>>(a);
+  }
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int BM, int BN, int BK>
 constexpr int smem_bytes() {
   return 2 * (BM + BN) * (BK + 8) * 2;
@@ -290,19 +507,22 @@ constexpr int smem_bytes() {
 
 // tile configurations: id -> (BM, BN, BK)
 //   0: 64x64x64   1: 128x64x64   2: 128x128x64   3: 64x64x256 (decode: few fat k-stages)
-template <typename T, int BM, int BN, int BK, typename Epi>
+//   4: 128x128x64 with 8 waves   5: 128x64x64 with 8 waves   (two waves per SIMD overlap LDS and MFMA phases)
+//   6: 128x128 / 7: 128x64 (8 waves), 8: 64x64 (4 waves): direct-to-LDS (global_load_lds) staging
+template <typename T, int BM, int BN, int BK, int NW, typename Epi>
 static int launch_one(const GemmArgs& a, hipStream_t stream, int tile_id) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), a.splitk);
   constexpr int smem = smem_bytes<BM, BN, BK>();
   // algorithmic work of this launch: 2*M*N*K flops; operands read once + result written once
   const double out_bytes = (double)a.M * a.N * ((a.out_f32 || Epi::kId != 0 ? 4.0 : 0.0) * (Epi::kId == 0 ? 1.0 : 0.0) + (a.out_t || Epi::kId != 0 ? 2.0 : 0.0));
-  ProfScope ps((tile_id == 3 ? 0 : tile_id) * 3 + Epi::kId, stream, 2.0 * a.M * a.N * a.K,
+  const int prof_tile = tile_id == 3 ? 0 : (tile_id == 4 ? 2 : (tile_id == 5 ? 1 : tile_id));
+  ProfScope ps(prof_tile * 3 + Epi::kId, stream, 2.0 * a.M * a.N * a.K,
                ((double)a.N * a.K + (double)a.M * a.cin) * 2.0 + out_bytes * (a.splitk > 1 ? a.splitk : 1) + (a.res ? 4.0 * a.M * a.N : 0.0));
   if constexpr (Epi::kId == 0) {
-    if (a.taps > 1) gemm_kernel<T, BM, BN, BK, Epi, true><<<grid, dim3(256), smem, stream>>>(a);
-    else gemm_kernel<T, BM, BN, BK, Epi, false><<<grid, dim3(256), smem, stream>>>(a);
+    if (a.taps > 1) gemm_kernel<T, BM, BN, BK, NW, Epi, true><<<grid, dim3(NW * 64), smem, stream>>>(a);
+    else gemm_kernel<T, BM, BN, BK, NW, Epi, false><<<grid, dim3(NW * 64), smem, stream>>>(a);
   } else {
-    gemm_kernel<T, BM, BN, BK, Epi, false><<<grid, dim3(256), smem, stream>>>(a);
+    gemm_kernel<T, BM, BN, BK, NW, Epi, false><<<grid, dim3(NW * 64), smem, stream>>>(a);
   }
   TT_CHECK_HIP(hipGetLastError());
   return 0;
@@ -322,22 +542,29 @@ static int launch_tiles(const GemmArgs& a, hipStream_t stream) {
   int tile = forced_tile();
   const int nk64 = a.K / 64;
   if (tile < 0) {
-    // The chip has 256 CUs.  Small M (decode / per-utterance vectors): the k-loop is latency bound -> 256-deep
-    // stages when K allows.  Otherwise the largest tile that still yields enough blocks to fill the chip.
+    // Direct-to-LDS kernels by default (measured on MI355X, scripts/kbench.py):
+    //   >= 256 tiles of 128x128 : 128x128, 8 waves, 2 stages (highest flop per L2 byte; 2 blocks per CU)
+    //   fewer, M > 64           : 128x64, 8 waves, 4-stage ring (more blocks, 3 tiles in flight)
+    //   decode / small M        : 64x64, 4 waves, 4-stage ring (weights stream from HBM: depth hides latency)
     const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk;
-    const long b12864 = (long)cdiv(a.M, 128) * cdiv(a.N, 64) * a.splitk;
-    if (a.M <= 256 && a.cin % 256 == 0 && (a.K / 256) >= a.splitk) tile = 3;
-    else if (a.M > 64 && b128 >= 200) tile = 2;
-    else if (a.M > 64 && b12864 >= 160) tile = 1;
-    else tile = 0;
+    if (a.M > 256 && b128 >= 256) tile = 6;
+    else if (a.M > 256) tile = 10;
+    else tile = 11;
   }
-  if (tile == 3 && (a.cin % 256 != 0 || (a.K / 256) < a.splitk)) tile = 0;
   (void)nk64;
   switch (tile) {
-    case 3: return launch_one<T, 64, 64, 256, Epi>(a, stream, 3);
-    case 2: return launch_one<T, 128, 128, 64, Epi>(a, stream, 2);
-    case 1: return launch_one<T, 128, 64, 64, Epi>(a, stream, 1);
-    default: return launch_one<T, 64, 64, 64, Epi>(a, stream, 0);
+    case 11: return launch_glds<T, 64, 64, 4, 4, Epi>(a, stream, 0);
+    case 10: return launch_glds<T, 128, 64, 8, 4, Epi>(a, stream, 1);
+    case 9: return launch_glds<T, 128, 128, 8, 3, Epi>(a, stream, 2);
+    case 8: return launch_glds<T, 64, 64, 4, 2, Epi>(a, stream, 0);
+    case 7: return launch_glds<T, 128, 64, 8, 2, Epi>(a, stream, 1);
+    case 6: return launch_glds<T, 128, 128, 8, 2, Epi>(a, stream, 2);
+    case 5: return launch_one<T, 128, 64, 64, 8, Epi>(a, stream, 5);
+    case 4: return launch_one<T, 128, 128, 64, 8, Epi>(a, stream, 4);
+    case 3: return launch_one<T, 64, 64, 256, 4, Epi>(a, stream, 3);
+    case 2: return launch_one<T, 128, 128, 64, 4, Epi>(a, stream, 2);
+    case 1: return launch_one<T, 128, 64, 64, 4, Epi>(a, stream, 1);
+    default: return launch_one<T, 64, 64, 64, 4, Epi>(a, stream, 0);
   }
 }
 
@@ -356,6 +583,11 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   GemmArgs a = a0;
   if (a.taps < 1) a.taps = 1;
   if (a.splitk < 1) a.splitk = 1;
+  {
+    static int xm = -2;
+    if (xm == -2) { const char* e = getenv("TT_GEMM_XCD"); xm = e ? atoi(e) : -1; }
+    a.xcd_mode = xm >= 0 ? xm : 1;
+  }
   a.cin = a.K / a.taps;
   TT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   TT_REQUIRE(a.K % 64 == 0 && a.cin % 64 == 0, "gemm: K=%d (taps=%d) must be a multiple of 64 per tap", a.K, a.taps);
@@ -373,22 +605,40 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   return -1;
 }
 
-template <typename T, int BM, int BN, int BK, typename Epi>
+template <typename T, int BM, int BN, int BK, int NW, typename Epi>
 static int set_attr_one() {
-  const void* fn = (const void*)gemm_kernel<T, BM, BN, BK, Epi, false>;
+  const void* fn = (const void*)gemm_kernel<T, BM, BN, BK, NW, Epi, false>;
   TT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN, BK>()));
   if constexpr (Epi::kId == 0) {
-    const void* fc = (const void*)gemm_kernel<T, BM, BN, BK, Epi, true>;
+    const void* fc = (const void*)gemm_kernel<T, BM, BN, BK, NW, Epi, true>;
     TT_CHECK_HIP(hipFuncSetAttribute(fc, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN, BK>()));
+  }
+  return 0;
+}
+template <typename T, int BM, int BN, int NW, int ST, typename Epi>
+static int set_attr_glds() {
+  const void* fn = (const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false>;
+  TT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes_glds<BM, BN, ST>()));
+  if constexpr (Epi::kId == 0) {
+    const void* fc = (const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, true>;
+    TT_CHECK_HIP(hipFuncSetAttribute(fc, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes_glds<BM, BN, ST>()));
   }
   return 0;
 }
 template <typename T, typename Epi>
 static int set_attr() {
-  TT_TRY((set_attr_one<T, 128, 128, 64, Epi>()));
-  TT_TRY((set_attr_one<T, 128, 64, 64, Epi>()));
-  TT_TRY((set_attr_one<T, 64, 64, 64, Epi>()));
-  TT_TRY((set_attr_one<T, 64, 64, 256, Epi>()));
+  TT_TRY((set_attr_glds<T, 128, 128, 8, 2, Epi>()));
+  TT_TRY((set_attr_glds<T, 128, 64, 8, 2, Epi>()));
+  TT_TRY((set_attr_glds<T, 64, 64, 4, 2, Epi>()));
+  TT_TRY((set_attr_glds<T, 128, 128, 8, 3, Epi>()));
+  TT_TRY((set_attr_glds<T, 128, 64, 8, 4, Epi>()));
+  TT_TRY((set_attr_glds<T, 64, 64, 4, 4, Epi>()));
+  TT_TRY((set_attr_one<T, 128, 128, 64, 4, Epi>()));
+  TT_TRY((set_attr_one<T, 128, 64, 64, 4, Epi>()));
+  TT_TRY((set_attr_one<T, 64, 64, 64, 4, Epi>()));
+  TT_TRY((set_attr_one<T, 64, 64, 256, 4, Epi>()));
+  TT_TRY((set_attr_one<T, 128, 128, 64, 8, Epi>()));
+  TT_TRY((set_attr_one<T, 128, 64, 64, 8, Epi>()));
   return 0;
 }
 
