@@ -175,3 +175,33 @@ def test_univnet(name, dt, tdt, tol):
     report(f"UnivNet waveform {name} vs oracle", wav, want, tol * 2)
     report(f"UnivNet waveform {name} vs reference golden", wav, torch.from_numpy(gold("vocoder.npz")["wav"]), tol * 3)
     st.close()
+
+
+@torch.no_grad()
+def test_diffusion_full_width_short_sequence():
+    """1024 channels / 16 heads (the reference width) with 2 layers and a short sequence: exercises the kernels the
+    128-channel configuration cannot reach (GroupNorm statistics fused into the GEMM epilogue, 128-row tiles,
+    the C == 1024 GroupNorm fast path) against the CPU oracle."""
+    cfg = DiffusionConfig(model_channels=1024, num_layers=2, in_latent_channels=1024, num_heads=16)
+    tdt, dt, tol = torch.bfloat16, E.TT_BF16, 2.5e-2
+    sd = quantize_sd(W.synthetic_state_dict(W.diffusion_manifest(cfg), seed=21), tdt)
+    g = torch.Generator().manual_seed(5)
+    M = 40
+    S = M * 4 * 24000 // 22050
+    latents = torch.randn(1, M, 1024, generator=g)
+    cond = torch.randn(1, 2048, generator=g)
+    x = torch.randn(1, 100, S, generator=g)
+    st = stages.DiffusionStage(sd, cfg, dtype=dt, max_seq=256, max_codes=64, max_steps=16)
+    st.condition(latents, cond, S)
+    emb = O.diffusion_timestep_independent(sd, cfg, latents, cond, S)
+    report("full-width timestep_independent vs oracle", st.code_emb(), emb, tol)
+    ts = torch.tensor([1234])
+    out = st.forward(x, 1234, cond_free=True)
+    report("full-width forward cond vs oracle", out[0], O.diffusion_forward(sd, cfg, x, ts, emb, False)[0], tol)
+    report("full-width forward uncond vs oracle", out[1], O.diffusion_forward(sd, cfg, x, ts, emb, True)[0], tol)
+    N = 4
+    step_noise = torch.randn(N, 1, 100, S, generator=g)
+    mel = st.sample(Schedule(N, 4000, True, 2.0), x, step_noise)
+    want = O.denormalize_tacotron_mel(O.p_sample_loop(sd, cfg, O.Schedule(N, 4000, True, 2.0), emb, x.clone(), step_noise))
+    report("full-width p_sample_loop mel vs oracle", mel, want, tol * 2)
+    st.close()

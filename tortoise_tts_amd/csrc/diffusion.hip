@@ -35,6 +35,10 @@ struct tt_diff {
   void* cat = nullptr;         // [rows][2C] T  [inp_block(x) | integrated code_emb]
   void* q = nullptr; void* k = nullptr; void* vt = nullptr; void* att = nullptr;
   float* gn_partial = nullptr;
+  float* gn_gemm_part = nullptr;   // statistics emitted by GEMM epilogues: [row_tile][2][C/16][2]
+  const float* stats_ptr = nullptr; // tensor those statistics describe (the last such GEMM's f32 output)
+  int stats_rows = 0;              // its row-tile height
+  int stats_seq = 0;
   void* lat_t = nullptr;       // [M][latent] T
   int* ts_dev = nullptr;       // [steps]
   float* temb_sin = nullptr;   // [steps][C]
@@ -58,7 +62,29 @@ static int run_gn(tt_diff* e, const float* x, int B, int S, const float* g, cons
   if (ss && ss_slotted) { a.ss_slot = e->slot; a.ss_slot_stride = (size_t)e->NR * 2 * e->C; }
   a.out_t = out_t; a.ldot = ldot; a.out_f32 = out_f32; a.ldo32 = e->C;
   a.partial = e->gn_partial;
+  if (x == e->stats_ptr && e->stats_seq == S && S >= e->stats_rows) {
+    a.gemm_part = e->gn_gemm_part;
+    a.part_rows = e->stats_rows;
+  }
   return groupnorm_launch(e->cfg.dtype, a, s);
+}
+
+// EPI_STD GEMM whose f32 output will be group-normalised next: let its epilogue emit the statistics.
+static int gemm_with_stats(tt_diff* e, GemmArgs& g, int S, hipStream_t s) {
+  const bool fused = (e->C / 32) % 16 == 0 && g.out_f32 != nullptr && g.N == e->C && g.splitk <= 1;
+  if (fused) {
+    g.gn_part = e->gn_gemm_part;
+    g.gn_seq = S;
+  }
+  TT_TRY(gemm_launch(e->cfg.dtype, EPI_STD, g, s));
+  if (fused) {
+    e->stats_ptr = g.out_f32;
+    e->stats_rows = gemm_stat_rows(g);
+    e->stats_seq = S;
+  } else if (g.out_f32 == e->stats_ptr) {
+    e->stats_ptr = nullptr;  // tensor overwritten without fresh statistics
+  }
+  return 0;
 }
 
 // AttentionBlock (arch_util.py:80-123): out = in + proj(attn(qkv(GN(in))))
@@ -77,7 +103,7 @@ static int run_attn_block(tt_diff* e, const tt_attn_block& w, const float* in, i
   TT_TRY(flash_attention_launch(dt, f, s));
   g = gemm_args(e->att, C, w.w_proj, C, M, C, C);
   g.bias = w.b_proj; g.res = in; g.ldres = C; g.out_f32 = out_f32; g.ldo32 = C; g.out_t = out_t; g.ldot = ldot;
-  return gemm_launch(dt, EPI_STD, g, s);
+  return gemm_with_stats(e, g, S, s);
 }
 
 // ResBlock (diffusion_decoder.py:60-120, use_scale_shift_norm, efficient_config, kernel 3).
@@ -87,17 +113,18 @@ static int run_res_block(tt_diff* e, const tt_res_block& w, const float* ss, con
   TT_TRY(run_gn(e, in, B, S, w.gn1_g, w.gn1_b, nullptr, false, ACT_SILU, e->act, C, nullptr, s));
   GemmArgs g = gemm_args(e->act, C, w.w_in, C, M, C, C);
   g.bias = w.b_in; g.out_f32 = e->tmp_c; g.ldo32 = C;
-  TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+  TT_TRY(gemm_with_stats(e, g, S, s));
   TT_TRY(run_gn(e, e->tmp_c, B, S, w.gn2_g, w.gn2_b, ss, true, ACT_SILU, e->act, C, nullptr, s));
   g = gemm_args(e->act, C, w.w_out, 3 * C, M, C, 3 * C);
   g.taps = 3; g.seq_len = S; g.bias = w.b_out; g.res = in; g.ldres = C; g.out_f32 = out_f32; g.ldo32 = C;
-  return gemm_launch(dt, EPI_STD, g, s);
+  return gemm_with_stats(e, g, S, s);
 }
 
 // One denoiser evaluation on B batch rows (B = 2: conditioned + unconditioned); the schedule slot is *e->slot.
 static int diff_forward(tt_diff* e, int B, hipStream_t s) {
   const int C = e->C, S = e->S, dt = e->cfg.dtype, M = B * S, L = e->cfg.num_layers;
   const float* ss = e->ss_all;  // + *slot * NR*2C inside the GroupNorm kernel
+  e->stats_ptr = nullptr;       // no epilogue statistics are valid at the start of a pass
   // conditioning_timestep_integrator: 3 DiffusionLayers over the [cond | uncond] code embeddings
   const float* cur = e->code_emb;
   for (int i = 0; i < 3; ++i) {
@@ -116,7 +143,7 @@ static int diff_forward(tt_diff* e, int B, hipStream_t s) {
   TT_TRY(gemm_launch(dt, EPI_STD, g, s));
   g = gemm_args(e->cat, 2 * C, e->w.w_integ, 2 * C, M, C, 2 * C);
   g.bias = e->w.b_integ; g.out_f32 = e->tmp_a; g.ldo32 = C;
-  TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+  TT_TRY(gemm_with_stats(e, g, S, s));
   float* hcur = e->tmp_a;
   float* hoth = e->tmp_b;
   for (int i = 0; i < L; ++i) {
@@ -193,6 +220,7 @@ int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff*
   if (!rc) rc = e->arena.alloc(&e->vt, (size_t)C * (rows + 64) * 2);
   if (!rc) rc = e->arena.alloc(&e->att, rows * C * 2);
   if (!rc) rc = e->arena.alloc_t(&e->gn_partial, groupnorm_partial_floats(2, e->rows_max) + 64);
+  if (!rc) rc = e->arena.alloc_t(&e->gn_gemm_part, ((size_t)e->rows_max / 32 + 2) * 2 * (C / 16) * 2 + 64);
   if (!rc) rc = e->arena.alloc(&e->lat_t, ((size_t)cfg->max_codes + 8) * cfg->latent_channels * 2);
   if (!rc) rc = e->arena.alloc_t(&e->ts_dev, cfg->max_steps);
   if (!rc) rc = e->arena.alloc_t(&e->temb_sin, (size_t)cfg->max_steps * C);
@@ -228,10 +256,11 @@ int tt_diff_condition(tt_diff* e, const float* latents, int M, const float* cond
   TT_TRY(e->sb.enter(us));
   const int C = e->C, dt = e->cfg.dtype, LC = e->cfg.latent_channels;
   e->S = S;
+  e->stats_ptr = nullptr;
   TT_TRY(cast_pad_launch(dt, latents, LC, e->lat_t, LC, M, LC, LC, s));
   GemmArgs g = gemm_args(e->lat_t, LC, e->w.w_latent_conv, 3 * LC, M, C, 3 * LC);
   g.taps = 3; g.seq_len = M; g.bias = e->w.b_latent_conv; g.out_f32 = e->tmp_a; g.ldo32 = C;
-  TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+  TT_TRY(gemm_with_stats(e, g, M, s));
   float* cur = e->tmp_a;
   float* oth = e->tmp_b;
   for (int i = 0; i < 4; ++i) {

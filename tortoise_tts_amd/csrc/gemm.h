@@ -34,6 +34,9 @@ struct GemmArgs {
   int ldo32;
   void* out_t;  // T-typed copy of the result (operand of the next GEMM)
   int ldot;
+  float* gn_part;  // optional: per-(row tile, 16-column strip) sum / sum-of-squares of the f32 output (see gemm.hip)
+  int gn_seq;      // rows per sequence for those statistics
+  int gn_ncol16;   // set by gemm_launch
   // EPI_QKV_HEADS: n -> (part = n / dmodel, head = (n % dmodel) / 64, d = n % 64), m -> (b, s)
   int dmodel, heads;
   void* q;        // [b*heads + h][seq_len][64]
@@ -53,5 +56,6 @@ struct GemmArgs {
 // dtype: DT_BF16 / DT_F16.  Returns 0 or a negative error (message via tt::last_error()).
 int gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t stream);
 int gemm_init();  // sets dynamic-LDS attributes; called once per process
+int gemm_stat_rows(const GemmArgs& a);  // rows per statistics tile of the kernel gemm_launch would pick for `a`
 
 }  // namespace tt

@@ -15,7 +15,7 @@ namespace tt {
 template <typename T>
 struct EpiStd {
   static constexpr int kId = 0;
-  __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4 v, int nvalid, int z) const {
+  __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4& v, int nvalid, int z) const {
     if (g.splitk > 1) {
       float* o = g.out_f32 + (size_t)z * g.M * g.ldo32 + (size_t)m * g.ldo32 + n;
       if (nvalid == 4 && (g.ldo32 & 3) == 0) {
@@ -62,7 +62,7 @@ struct EpiStd {
 template <typename T>
 struct EpiQkvHeads {
   static constexpr int kId = 1;
-  __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4 v, int nvalid, int z) const {
+  __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4& v, int nvalid, int z) const {
     // N == 3 * dmodel and dmodel % 64 == 0, so nvalid is always 4 here.
     if (g.bias) {
 #pragma unroll
@@ -96,7 +96,7 @@ struct EpiQkvHeads {
 template <typename T>
 struct EpiQkvDecode {
   static constexpr int kId = 2;
-  __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4 v, int nvalid, int z) const {
+  __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4& v, int nvalid, int z) const {
     if (g.bias) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] += g.bias[n + i];
@@ -118,6 +118,65 @@ struct EpiQkvDecode {
     }
   }
 };
+
+// Epilogue shared by both GEMM kernels.  With g.gn_part set (EPI_STD, f32 output feeding a GroupNorm32) every
+// wave also emits (sum, sum of squares) of the values it just produced, per 16-column strip of its TM-row
+// tile: gn_part[row_tile][slot][n / 16][2], slot 1 = rows that belong to the NEXT sequence when the row tile
+// straddles a sequence boundary.  The GroupNorm apply kernel adds these up in a fixed order (deterministic),
+// which removes the separate statistics pass over the tensor.
+template <typename Epi, int FM, int FN, int TM, int TN>
+__device__ __forceinline__ void run_epilogue(const GemmArgs& g, f32x4 (&acc)[FN][FM], int m0w, int n0w, int lane, int z) {
+  const int fr = lane & 15, fg = lane >> 4;
+  Epi epi;
+  const bool stats = Epi::kId == 0 && g.gn_part != nullptr && g.splitk == 1;
+  const int rt = m0w / TM;                              // row-tile index (m0w is a multiple of TM)
+  const int b_first = stats ? m0w / g.gn_seq : 0;
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int n = n0w + i * 16 + fg * 4;
+    const int nvalid = g.N - n >= 4 ? 4 : g.N - n;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = m0w + j * 16 + fr;
+      if (m < g.M && n < g.N) {
+        epi(g, m, n, acc[i][j], nvalid, z);
+        if (stats) {
+          float s = 0.f, q = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nvalid) {
+              s += acc[i][j][r];
+              q += acc[i][j][r] * acc[i][j][r];
+            }
+          if (m / g.gn_seq == b_first) {
+            s0 += s; q0 += q;
+          } else {
+            s1 += s; q1 += q;
+          }
+        }
+      }
+    }
+    if (stats) {
+      const int n16 = (n0w + i * 16) >> 4;
+      if (n0w + i * 16 < g.N) {
+        const bool straddle = (m0w + TM - 1) / g.gn_seq != b_first;  // wave-uniform
+        s0 = wave_sum(s0);
+        q0 = wave_sum(q0);
+        if (straddle) {
+          s1 = wave_sum(s1);
+          q1 = wave_sum(q1);
+        }
+        if (lane == 0) {
+          float* p = g.gn_part + (((size_t)rt * 2 + 0) * g.gn_ncol16 + n16) * 2;
+          p[0] = s0; p[1] = q0;
+          float* p1 = g.gn_part + (((size_t)rt * 2 + 1) * g.gn_ncol16 + n16) * 2;
+          p1[0] = straddle ? s1 : 0.f; p1[1] = straddle ? q1 : 0.f;
+        }
+      }
+    }
+  }
+}
 
 template <typename T, int BM, int BN, int BK, int NW, typename Epi, bool CONV>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs g) {
@@ -285,18 +344,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  Epi epi;
-#pragma unroll
-  for (int i = 0; i < FN; ++i) {
-    const int n = n0 + wn * TN + i * 16 + fg * 4;
-    if (n >= g.N) continue;
-    const int nvalid = g.N - n >= 4 ? 4 : g.N - n;
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = m0 + wm * TM + j * 16 + fr;
-      if (m < g.M) epi(g, m, n, acc[i][j], nvalid, z);
-    }
-  }
+  run_epilogue<Epi, FM, FN, TM, TN>(g, acc, m0 + wm * TM, n0 + wn * TN, lane, z);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -464,18 +512,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 
-  Epi epi;
-#pragma unroll
-  for (int i = 0; i < FN; ++i) {
-    const int n = n0 + wn * TN + i * 16 + fg * 4;
-    if (n >= g.N) continue;
-    const int nvalid = g.N - n >= 4 ? 4 : g.N - n;
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = m0 + wm * TM + j * 16 + fr;
-      if (m < g.M) epi(g, m, n, acc[i][j], nvalid, z);
-    }
-  }
+  run_epilogue<Epi, FM, FN, TM, TN>(g, acc, m0 + wm * TM, n0 + wn * TN, lane, z);
 }
 
 template <int BM, int BN, int ST>
@@ -537,21 +574,33 @@ static int forced_tile() {
   return v;
 }
 
-template <typename T, typename Epi>
-static int launch_tiles(const GemmArgs& a, hipStream_t stream) {
+static int pick_tile(const GemmArgs& a) {
   int tile = forced_tile();
-  const int nk64 = a.K / 64;
   if (tile < 0) {
     // Direct-to-LDS kernels by default (measured on MI355X, scripts/kbench.py):
     //   >= 256 tiles of 128x128 : 128x128, 8 waves, 2 stages (highest flop per L2 byte; 2 blocks per CU)
-    //   fewer, M > 64           : 128x64, 8 waves, 4-stage ring (more blocks, 3 tiles in flight)
+    //   fewer, M > 256          : 128x64, 8 waves, 4-stage ring (more blocks, 3 tiles in flight)
     //   decode / small M        : 64x64, 4 waves, 4-stage ring (weights stream from HBM: depth hides latency)
     const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk;
     if (a.M > 256 && b128 >= 256) tile = 6;
     else if (a.M > 256) tile = 10;
     else tile = 11;
   }
-  (void)nk64;
+  if (tile == 3 && (a.cin % 256 != 0 || (a.K / 256) < a.splitk)) tile = 0;
+  return tile;
+}
+
+// rows per statistics tile (= the wave tile height TM of the kernel that pick_tile selects)
+static int tile_stat_rows(int tile) {
+  switch (tile) {
+    case 0: case 3: case 8: case 11: return 32;
+    default: return 64;
+  }
+}
+
+template <typename T, typename Epi>
+static int launch_tiles(const GemmArgs& a, hipStream_t stream) {
+  const int tile = pick_tile(a);
   switch (tile) {
     case 11: return launch_glds<T, 64, 64, 4, 4, Epi>(a, stream, 0);
     case 10: return launch_glds<T, 128, 64, 8, 4, Epi>(a, stream, 1);
@@ -579,21 +628,36 @@ static int launch_epi(int epi, const GemmArgs& a, hipStream_t stream) {
   return -1;
 }
 
-int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
-  GemmArgs a = a0;
+static void normalise(GemmArgs& a) {
   if (a.taps < 1) a.taps = 1;
   if (a.splitk < 1) a.splitk = 1;
-  {
-    static int xm = -2;
-    if (xm == -2) { const char* e = getenv("TT_GEMM_XCD"); xm = e ? atoi(e) : -1; }
-    a.xcd_mode = xm >= 0 ? xm : 1;
-  }
   a.cin = a.K / a.taps;
+  static int xm = -2;
+  if (xm == -2) {
+    const char* e = getenv("TT_GEMM_XCD");
+    xm = e ? atoi(e) : -1;
+  }
+  a.xcd_mode = xm >= 0 ? xm : 1;
+}
+
+int gemm_stat_rows(const GemmArgs& a0) {
+  GemmArgs a = a0;
+  normalise(a);
+  return tile_stat_rows(pick_tile(a));
+}
+
+int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
+  GemmArgs a = a0;
+  normalise(a);
   TT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   TT_REQUIRE(a.K % 64 == 0 && a.cin % 64 == 0, "gemm: K=%d (taps=%d) must be a multiple of 64 per tap", a.K, a.taps);
   TT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda=%d / ldw=%d must be multiples of 8 elements", a.lda, a.ldw);
   TT_REQUIRE(a.splitk == 1 || (epi == EPI_STD && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
   TT_REQUIRE(a.splitk <= a.K / 64, "gemm: splitk=%d exceeds the %d k-tiles", a.splitk, a.K / 64);
+  if (a.gn_part) {
+    TT_REQUIRE(epi == EPI_STD && a.splitk == 1 && a.out_f32 && a.gn_seq > 0 && a.N % 16 == 0, "gemm: GroupNorm statistics need the standard epilogue, an f32 output, no split-K and N %% 16 == 0");
+    a.gn_ncol16 = a.N / 16;
+  }
   if (epi != EPI_STD) {
     TT_REQUIRE(a.taps == 1, "gemm: conv taps are only supported with the standard epilogue");
     TT_REQUIRE(a.dmodel % 64 == 0 && a.N == 3 * a.dmodel && a.heads * 64 == a.dmodel, "gemm: qkv epilogue needs N == 3*dmodel, head_dim 64");

@@ -272,17 +272,26 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchunk, int rows_per_chunk, int rows_per_block) {
-  __shared__ float mean_s[32], rstd_s[32];
-  __shared__ double part_s[8][32], part_q[8][32];
-  const int chunk = blockIdx.x, b = blockIdx.y;
-  const int tid = threadIdx.x;
-  const int C = a.C, S = a.S;
-  {
-    // finalize: 8 threads per group each reduce every 8th chunk partial (independent loads), then combine in fp64
-    const int g = tid & 31, part = tid >> 5;
-    double s = 0.0, q = 0.0;
+// Per-(batch, group) mean / rstd from partial sums, fp64 combine in a fixed order.  Two sources:
+//   a.gemm_part == nullptr : partial[b][chunk][32][2] from gn_stats_kernel
+//   a.gemm_part != nullptr : [row_tile][slot][C/16][2] written by the producing GEMM's epilogue
+__device__ __forceinline__ void gn_finalize(const GroupNormArgs& a, int b, int tid, int nchunk, float* mean_s, float* rstd_s,
+                                            double (*part_s)[32], double (*part_q)[32]) {
+  const int g = tid & 31, part = tid >> 5;
+  double s = 0.0, q = 0.0;
+  if (a.gemm_part) {
+    const int S = a.S, R = a.part_rows, nc16 = a.C >> 4, spg = (a.C / 32) >> 4;  // 16-column strips per group
+    const int t0 = (b * S) / R, t1 = ((b + 1) * S - 1) / R;
+    const int nitems = (t1 - t0 + 1) * spg;
+#pragma unroll 4
+    for (int e = part; e < nitems; e += 8) {
+      const int t = t0 + e / spg, strip = g * spg + e % spg;
+      const int slot = (t * R) / S == b ? 0 : 1;
+      const float2 v = *(const float2*)(a.gemm_part + (((size_t)t * 2 + slot) * nc16 + strip) * 2);
+      s += (double)v.x;
+      q += (double)v.y;
+    }
+  } else {
     float2 pv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {  // nchunk <= 64: at most 8 independent loads per thread
@@ -294,25 +303,35 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchu
       s += (double)pv[k].x;
       q += (double)pv[k].y;
     }
-    part_s[part][g] = s;
-    part_q[part][g] = q;
   }
+  part_s[part][g] = s;
+  part_q[part][g] = q;
   __syncthreads();
   if (tid < 32) {
-    double s = 0.0, q = 0.0;
+    double ss = 0.0, qq = 0.0;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      s += part_s[p][tid];
-      q += part_q[p][tid];
+      ss += part_s[p][tid];
+      qq += part_q[p][tid];
     }
-    const double n = (double)S * (double)(C / 32);
-    const double m = s / n;
-    double var = q / n - m * m;
+    const double n = (double)a.S * (double)(a.C / 32);
+    const double m = ss / n;
+    double var = qq / n - m * m;
     if (var < 0.0) var = 0.0;
     mean_s[tid] = (float)m;
     rstd_s[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
   }
   __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchunk, int rows_per_chunk, int rows_per_block) {
+  __shared__ float mean_s[32], rstd_s[32];
+  __shared__ double part_s[8][32], part_q[8][32];
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int C = a.C, S = a.S;
+  gn_finalize(a, b, tid, nchunk, mean_s, rstd_s, part_s, part_q);
   const int c4n = C >> 2;
   const int cpg = C / 32;
   const int r0 = chunk * rows_per_block;
@@ -373,39 +392,7 @@ __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, in
     sc = *(const float4*)(ss + c);
     sh = *(const float4*)(ss + C + c);
   }
-  {
-    const int g = tid & 31, part = tid >> 5;
-    double s = 0.0, q = 0.0;
-    float2 pv[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int i = part + 8 * k;
-      pv[k] = i < nchunk ? *(const float2*)(a.partial + (((size_t)b * nchunk + i) * 32 + g) * 2) : make_float2(0.f, 0.f);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      s += (double)pv[k].x;
-      q += (double)pv[k].y;
-    }
-    part_s[part][g] = s;
-    part_q[part][g] = q;
-  }
-  __syncthreads();
-  if (tid < 32) {
-    double s = 0.0, q = 0.0;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      s += part_s[p][tid];
-      q += part_q[p][tid];
-    }
-    const double n = (double)S * 32.0;
-    const double m = s / n;
-    double var = q / n - m * m;
-    if (var < 0.0) var = 0.0;
-    mean_s[tid] = (float)m;
-    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
-  }
-  __syncthreads();
+  gn_finalize(a, b, tid, nchunk, mean_s, rstd_s, part_s, part_q);
   const float mu = mean_s[tid >> 3], rs = rstd_s[tid >> 3];
 #pragma unroll
   for (int i = 0; i < GN_APPLY_ROWS; ++i) {
@@ -437,9 +424,13 @@ int groupnorm_launch(int dtype, const GroupNormArgs& a, hipStream_t stream) {
   const int rpc = gn_rows_per_chunk(a.S);
   const int nchunk = cdiv(a.S, rpc);
   dim3 grid(nchunk, a.B);
-  ProfScope ps(PROF_GROUPNORM, stream, 0.0, (double)a.B * a.S * a.C * (8.0 + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)));
-  gn_stats_kernel<<<grid, 256, 0, stream>>>(a.x, a.S, a.C, a.partial, rpc);
-  TT_CHECK_HIP(hipGetLastError());
+  ProfScope ps(PROF_GROUPNORM, stream, 0.0, (double)a.B * a.S * a.C * ((a.gemm_part ? 4.0 : 8.0) + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)));
+  if (a.gemm_part) {
+    TT_REQUIRE((a.C / 32) % 16 == 0 && a.part_rows > 0 && a.S >= a.part_rows, "groupnorm: fused statistics need >= 16 channels per group and S >= the row tile");
+  } else {
+    gn_stats_kernel<<<grid, 256, 0, stream>>>(a.x, a.S, a.C, a.partial, rpc);
+    TT_CHECK_HIP(hipGetLastError());
+  }
   const int rpb = GN_APPLY_ROWS;  // apply is pure streaming: many small blocks
   dim3 grid2(cdiv(a.S, rpb), a.B);
   if (a.C == 1024) {
