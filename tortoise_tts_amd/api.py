@@ -78,7 +78,8 @@ class TextToSpeech:
 
     def __init__(self, autoregressive_batch_size=None, models_dir=MODELS_DIR, enable_redaction=True, kv_cache=False,
                  use_deepspeed=False, half=False, device=None, tokenizer_vocab_file=None, tokenizer_basic=False, *,
-                 state_dicts=None, dtype="bf16", max_candidates=256, configs=None, max_mel_tokens=500, max_text_tokens=402):
+                 state_dicts=None, dtype="bf16", max_candidates=256, configs=None, max_mel_tokens=500, max_text_tokens=402,
+                 decode_streams=2):
         self.models_dir = models_dir
         if use_deepspeed:
             raise NotImplementedError("use_deepspeed: DeepSpeed kernel injection is a CUDA-only reference option; the MI355X engine "
@@ -111,6 +112,14 @@ class TextToSpeech:
         max_S = max_mel_tokens * 4 * 24000 // 22050 + 8
         self.ar = stages.ArStage(sd("autoregressive"), self.ar_cfg, self.device, self.dtype, max_batch=cap,
                                  max_text=max_text_tokens, max_new_tokens=max_mel_tokens, max_latent_candidates=4)
+        # A decode step is a chain of ~215 short, latency-bound kernels that leaves most of the chip idle.  Two (or
+        # more) independent candidate sub-batches decoded concurrently on their own streams overlap each other's
+        # memory waits; the weights are shared and the second pass over a layer's weights hits the Infinity Cache.
+        # Sampled codes do not change: Philox streams are keyed by the global candidate index.
+        self.decode_streams = max(1, int(decode_streams))
+        self.ar_extra = [stages.ArStage(None, self.ar_cfg, self.device, self.dtype, max_batch=-(-cap // self.decode_streams),
+                                        max_text=max_text_tokens, max_new_tokens=max_mel_tokens, max_latent_candidates=1,
+                                        share_weights_with=self.ar) for _ in range(self.decode_streams - 1)]
         self.clvp = stages.ClvpStage(sd("clvp"), self.clvp_cfg, self.device, self.dtype, max_rows=max(cap, 8) * max_mel_tokens)
         self.diffusion = stages.DiffusionStage(sd("diffusion"), self.diff_cfg, self.device, self.dtype, max_seq=max_S,
                                                max_codes=max_mel_tokens + 8, max_steps=512)
@@ -198,15 +207,45 @@ class TextToSpeech:
         N = int(num_autoregressive_samples)
         lo, hi = tdist.shard_range(N, self.rank, self.world)
         stop = self.ar_cfg.stop_mel_token
-        batches = []
         exp_noise = noise.get("exp_noise")
+        jobs = []  # (first global candidate, count)
         for b0 in range(lo, hi, self.autoregressive_batch_size):
             B = min(self.autoregressive_batch_size, hi - b0)
-            self.ar.prefill(auto_conditioning, text_tokens)
-            en = exp_noise[:, b0:b0 + B] if exp_noise is not None else None
-            codes, n = self.ar.generate(B, max_mel_tokens, temperature=temperature, top_p=top_p, repetition_penalty=repetition_penalty,
-                                        top_k=top_k, seed=seed, row_offset=b0, exp_noise=en)
-            batches.append(F.pad(codes, (0, max_mel_tokens - codes.shape[1]), value=stop))  # api.py:425-426
+            nsub = self.decode_streams if B >= 32 * self.decode_streams else 1
+            per = -(-B // nsub)
+            for j in range(nsub):
+                c0 = b0 + j * per
+                if c0 < b0 + B:
+                    jobs.append((c0, min(per, b0 + B - c0)))
+
+        def decode(stage, c0, B, out, idx, stream):
+            with torch.cuda.stream(stream):
+                stage.prefill(auto_conditioning, text_tokens)
+                en = exp_noise[:, c0 - lo:c0 - lo + B] if exp_noise is not None else None
+                codes, n = stage.generate(B, max_mel_tokens, temperature=temperature, top_p=top_p, repetition_penalty=repetition_penalty,
+                                          top_k=top_k, seed=seed, row_offset=c0, exp_noise=en)
+                out[idx] = F.pad(codes, (0, max_mel_tokens - codes.shape[1]), value=stop)  # api.py:425-426
+
+        batches = [None] * len(jobs)
+        handles = [self.ar] + self.ar_extra
+        cur = torch.cuda.current_stream()
+        for w0 in range(0, len(jobs), len(handles)):
+            wave = jobs[w0:w0 + len(handles)]
+            if len(wave) == 1:
+                decode(handles[0], wave[0][0], wave[0][1], batches, w0, cur)
+                continue
+            import threading
+            streams = [torch.cuda.Stream(device=dev) for _ in wave]
+            for st_ in streams:
+                st_.wait_stream(cur)
+            threads = [threading.Thread(target=decode, args=(handles[i], c0, B, batches, w0 + i, streams[i]))
+                       for i, (c0, B) in enumerate(wave)]
+            for t_ in threads:
+                t_.start()
+            for t_ in threads:
+                t_.join()
+            for st_ in streams:
+                cur.wait_stream(st_)
         samples = torch.cat(batches, dim=0)
         ev[1].record()
 

@@ -23,12 +23,13 @@ class ArStage:
     """UnifiedVoice hot path: prefill + sampling loop + latent re-pass (autoregressive.py:454-563)."""
 
     def __init__(self, sd, cfg: ARConfig = ARConfig(), device="cuda", dtype=E.TT_BF16, max_batch=256, max_text=402,
-                 max_new_tokens=500, max_latent_candidates=4):
+                 max_new_tokens=500, max_latent_candidates=4, share_weights_with=None):
         self.lib = E.init()
         self.cfg = cfg
         self.device = torch.device(device)
         self.dtype = dtype
-        self.w = pack.pack_ar(sd, cfg, self.device, dtype)
+        # several handles (one per concurrent decode stream) can share one packed copy of the weights
+        self.w = share_weights_with.w if share_weights_with is not None else pack.pack_ar(sd, cfg, self.device, dtype)
         c = E.ArConfig()
         c.dtype = dtype
         c.layers, c.model_dim, c.heads = cfg.layers, cfg.model_dim, cfg.heads
