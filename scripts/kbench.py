@@ -62,6 +62,64 @@ def main():
         for M, N, K, taps, seq in ((1740, 1024, 1024, 1, 0), (1740, 1024, 3072, 3, 870), (1740, 3072, 1024, 1, 0), (256, 4096, 1024, 1, 0),
                                    (256, 1024, 4096, 1, 0), (4096, 4096, 4096, 1, 0)):
             gemm_case(f"tile={os.environ.get('TT_GEMM_TILE', 'auto')}", M, N, K, taps=taps, seq=seq)
+    if "cold" in which:
+        # decode GEMMs with HBM-cold weights: cycle through enough distinct weight matrices to defeat the 256 MB Infinity Cache
+        for (name, M, N, K, sk) in (("qkv", 256, 3072, 1024, 1), ("fc", 256, 4096, 1024, 1), ("proj", 256, 1024, 1024, 4),
+                                    ("proj2", 256, 1024, 4096, 4), ("qkv32", 32, 3072, 1024, 1), ("fc32", 32, 4096, 1024, 1)):
+            nW = max(8, int(600e6 // (N * K * 2)))
+            Ws = [(torch.randn(N, K, device="cuda") / math.sqrt(K)).to(T) for _ in range(nW)]
+            A = torch.randn(M, K, device="cuda").to(T)
+            bias = torch.randn(N, device="cuda")
+            out = torch.zeros(max(sk, 1), M, N, device="cuda")
+            it = [0]
+
+            def fn():
+                W = Ws[it[0] % nW]
+                it[0] += 1
+                E.check(lib.tt_op_gemm(DT, E.ptr(A), K, E.ptr(W), K, M, N, K, 1, 0, sk, E.ptr(bias) if sk == 1 else None, 0, None,
+                                       E.ptr(out), None, None))
+            us = timeit(fn, iters=4 * nW, warm=nW)
+            print(f"cold gemm {name:6s} tile={os.environ.get('TT_GEMM_TILE', 'auto'):4s} M={M} N={N} K={K} sk={sk}: {us:8.2f} us  {N * K * 2 / us / 1e3:8.1f} GB/s weights")
+            del Ws
+    if "coldpacked" in which:
+        from tortoise_tts_amd.pack import Holder
+        hold = Holder(torch.device("cuda"), DT)
+        for (name, M, N, K, sk) in (("qkv", 256, 3072, 1024, 1), ("fc", 256, 4096, 1024, 1), ("proj", 256, 1024, 1024, 4),
+                                    ("proj2", 256, 1024, 4096, 4), ("fc32", 32, 4096, 1024, 1)):
+            nW = max(8, int(600e6 // (N * K * 2)))
+            Ws = []
+            for _ in range(nW):
+                hold.keep.clear()
+                Ws.append(hold.op_packed(torch.randn(N, K, device="cuda") / math.sqrt(K)))
+            A = torch.randn(M, K, device="cuda").to(T)
+            out = torch.zeros(max(sk, 1), M, N, device="cuda")
+            it = [0]
+
+            def fn():
+                W = Ws[it[0] % nW]
+                it[0] += 1
+                E.check(lib.tt_op_gemm_packed(DT, E.ptr(A), K, E.ptr(W), M, N, K, sk, None, 0, None, E.ptr(out), None, None))
+            us = timeit(fn, iters=4 * nW, warm=nW)
+            print(f"cold packed gemm {name:6s} M={M} N={N} K={K} sk={sk}: {us:8.2f} us  {N * K * 2 / us / 1e3:8.1f} GB/s weights")
+            del Ws
+    if "kscale" in which:
+        for M in (32, 256):
+            for K in (64, 256, 1024, 4096):
+                N = 4096
+                nW = max(8, int(600e6 // (N * K * 2)))
+                nW = min(nW, 256)
+                Ws = [(torch.randn(N, K, device="cuda") / math.sqrt(K)).to(T) for _ in range(nW)]
+                A = torch.randn(M, K, device="cuda").to(T)
+                out_t = torch.zeros(M, N, device="cuda", dtype=T)
+                it = [0]
+
+                def fn():
+                    W = Ws[it[0] % nW]
+                    it[0] += 1
+                    E.check(lib.tt_op_gemm(DT, E.ptr(A), K, E.ptr(W), K, M, N, K, 1, 0, 1, None, 0, None, None, E.ptr(out_t), None))
+                us = timeit(fn, iters=4 * nW, warm=nW)
+                print(f"kscale M={M} N={N} K={K}: {us:8.2f} us  ({N * K * 2 / 1e6:.1f} MB weights, {N * K * 2 / us / 1e3:8.1f} GB/s)")
+                del Ws
     if "gn" in which:
         for (B, S, C_) in ((2, 870, 1024), (2, 2176, 1024)):
             x = torch.randn(B, S, C_, device="cuda")

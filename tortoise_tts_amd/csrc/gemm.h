@@ -18,6 +18,8 @@ struct GemmArgs {
   int lda;  // elements between consecutive A rows
   const void* W;
   int ldw;  // elements between consecutive W rows (>= K)
+  int w_packed;  // 1: W is tile-packed [ceil(N/64)][K/64][64][64] (rows beyond N are zero); ldw ignored
+  int n_pad;     // set by gemm_launch
   int M, N, K;
   int taps;     // 1 = plain GEMM
   int seq_len;  // rows per sequence (conv boundary / head-layout epilogues)

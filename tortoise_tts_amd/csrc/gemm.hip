@@ -360,7 +360,7 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_page[16] = {0, 0, 0,
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <typename T, int BM, int BN, int NW, int ST, typename Epi, bool CONV>
+template <typename T, int BM, int BN, int NW, int ST, typename Epi, bool CONV, bool QUART = false>
 __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(GemmArgs g) {
   typedef typename Vec<T>::x8 x8;
   constexpr int BK = 64;
@@ -420,8 +420,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(GemmArgs g) {
   for (int p = 0; p < PW; ++p) {
     const int row = (wave + NW * p) * 8 + lr;
     const int n = n0 + row;
-    w_ptr[p] = W + (size_t)(n < g.N ? n : g.N - 1) * g.ldw + (lc ^ ((row >> 1) & 7)) * 8;
+    if (g.w_packed) {
+      // tile-packed weights [N/64][K/64][64][64]: every 64x64 k-tile of a column panel is one contiguous 8 KiB
+      // block and a panel is one contiguous run, so a block streams sequential DRAM pages instead of touching
+      // 64 rows that lie K*2 bytes apart (row-major streaming measured ~2 TB/s, a quarter of HBM peak).
+      const int nc = n < g.n_pad ? n : g.n_pad - 1;
+      w_ptr[p] = W + ((size_t)(nc >> 6) * (g.K >> 6) * 64 + (nc & 63)) * 64 + (lc ^ ((row >> 1) & 7)) * 8;
+    } else {
+      w_ptr[p] = W + (size_t)(n < g.N ? n : g.N - 1) * g.ldw + (lc ^ ((row >> 1) & 7)) * 8;
+    }
   }
+  const int w_tile_stride = g.w_packed ? 64 * 64 : BK;  // elements between consecutive k-tiles of a W row
 
   auto issue = [&](int kt, int buf) {
     const int k0 = kt * BK;
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(GemmArgs g) {
     }
 #pragma unroll
     for (int p = 0; p < PW; ++p)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_ptr[p] + k0), (lds_void_t*)(ws + (wave + NW * p) * 8 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_ptr[p] + (size_t)kt * w_tile_stride), (lds_void_t*)(ws + (wave + NW * p) * 8 * BK), 16, 0, 0);
   };
 
   f32x4 acc[FN][FM];
@@ -496,18 +505,75 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(GemmArgs g) {
     // Every iteration issues exactly G loads (tile index clamped; a redundant reload targets the ring slot
     // that was consumed last iteration and is never read again), which keeps the count uniform in the tail.
     constexpr int G = PA + PW;
-    const int last = kt_end - 1;
+    const int nt = kt_end - kt_begin;
+    if constexpr (!QUART) {
+      const int last = kt_end - 1;
 #pragma unroll
-    for (int s = 0; s < ST - 1; ++s) issue(min(kt_begin + s, last), s);
-    int slot = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * G) : "memory");
-      __builtin_amdgcn_s_barrier();
-      int nslot = slot + ST - 1;
-      if (nslot >= ST) nslot -= ST;
-      issue(min(kt + ST - 1, last), nslot);
-      compute(slot);
-      slot = slot + 1 == ST ? 0 : slot + 1;
+      for (int s = 0; s < ST - 1; ++s) issue(min(kt_begin + s, last), s);
+      int slot = 0;
+      for (int kt = kt_begin; kt < kt_end; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * G) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int nslot = slot + ST - 1;
+        if (nslot >= ST) nslot -= ST;
+        issue(min(kt + ST - 1, last), nslot);
+        compute(slot);
+        slot = slot + 1 == ST ? 0 : slot + 1;
+      }
+    } else {
+      // Decode shapes: a CU streams from HBM at only ~24 GB/s, so the four row-tile blocks that share a W panel
+      // must not all pull it in the same order.  The k-range is cut into four quarters; block bx starts at quarter
+      // bx & 3 and wraps, so at any moment the siblings fetch DIFFERENT quarters from HBM and find the others in L2.
+      // Each quarter is summed into its own accumulator in natural k order and the four are combined in a fixed
+      // order, so the result is bit-identical for every rotation (and for every batch size / sharding).
+      const bool quart = (nt & 3) == 0;
+      const int qlen = quart ? nt >> 2 : nt;
+      const int rot = quart ? (bx & 3) : 0;
+      auto tile_of = [&](int i) {  // i-th tile in this block's visiting order (clamped in the tail)
+        const int ii = i < nt ? i : nt - 1;
+        int t = ii + rot * qlen;
+        if (t >= nt) t -= nt;
+        return kt_begin + t;
+      };
+      f32x4 accq[4][FN][FM];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int j = 0; j < FM; ++j) accq[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < ST - 1; ++s) issue(tile_of(s), s);
+      int slot = 0, in_q = 0, seg = 0;
+      for (int i = 0; i < nt; ++i) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * G) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int nslot = slot + ST - 1;
+        if (nslot >= ST) nslot -= ST;
+        issue(tile_of(i + ST - 1), nslot);
+        compute(slot);
+        slot = slot + 1 == ST ? 0 : slot + 1;
+        if (++in_q == qlen) {  // quarter finished: bank it (block-uniform branch, 4 times per kernel)
+          in_q = 0;
+          const int q = quart ? ((seg + rot) & 3) : 0;
+          ++seg;
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq)
+            if (qq == q) {
+#pragma unroll
+              for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FM; ++b) {
+                  accq[qq][a][b] += acc[a][b];
+                  acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = ((accq[0][a][b] + accq[1][a][b]) + accq[2][a][b]) + accq[3][a][b];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -520,7 +586,7 @@ constexpr int smem_bytes_glds() {
   return ST * (BM + BN) * 64 * 2;
 }
 
-template <typename T, int BM, int BN, int NW, int ST, typename Epi>
+template <typename T, int BM, int BN, int NW, int ST, typename Epi, bool QUART = false>
 static int launch_glds(const GemmArgs& a, hipStream_t stream, int prof_tile) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), a.splitk);
   constexpr int smem = smem_bytes_glds<BM, BN, ST>();
@@ -528,10 +594,10 @@ static int launch_glds(const GemmArgs& a, hipStream_t stream, int prof_tile) {
   ProfScope ps(prof_tile * 3 + Epi::kId, stream, 2.0 * a.M * a.N * a.K,
                ((double)a.N * a.K + (double)a.M * a.cin) * 2.0 + out_bytes * (a.splitk > 1 ? a.splitk : 1) + (a.res ? 4.0 * a.M * a.N : 0.0));
   if constexpr (Epi::kId == 0) {
-    if (a.taps > 1) gemm_glds_kernel<T, BM, BN, NW, ST, Epi, true><<<grid, dim3(NW * 64), smem, stream>>>(a);
-    else gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false><<<grid, dim3(NW * 64), smem, stream>>>(a);
+    if (a.taps > 1) gemm_glds_kernel<T, BM, BN, NW, ST, Epi, true, QUART><<<grid, dim3(NW * 64), smem, stream>>>(a);
+    else gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false, QUART><<<grid, dim3(NW * 64), smem, stream>>>(a);
   } else {
-    gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false><<<grid, dim3(NW * 64), smem, stream>>>(a);
+    gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false, QUART><<<grid, dim3(NW * 64), smem, stream>>>(a);
   }
   TT_CHECK_HIP(hipGetLastError());
   return 0;
@@ -587,13 +653,14 @@ static int pick_tile(const GemmArgs& a) {
     else tile = 11;
   }
   if (tile == 3 && (a.cin % 256 != 0 || (a.K / 256) < a.splitk)) tile = 0;
+  if (a.w_packed && tile < 6) tile = a.M > 256 ? 10 : 11;  // only the direct-to-LDS kernels read tile-packed weights
   return tile;
 }
 
 // rows per statistics tile (= the wave tile height TM of the kernel that pick_tile selects)
 static int tile_stat_rows(int tile) {
   switch (tile) {
-    case 0: case 3: case 8: case 11: return 32;
+    case 0: case 3: case 8: case 11: case 14: return 32;
     default: return 64;
   }
 }
@@ -602,6 +669,7 @@ template <typename T, typename Epi>
 static int launch_tiles(const GemmArgs& a, hipStream_t stream) {
   const int tile = pick_tile(a);
   switch (tile) {
+    case 14: return launch_glds<T, 64, 64, 4, 4, Epi, true>(a, stream, 0);
     case 11: return launch_glds<T, 64, 64, 4, 4, Epi>(a, stream, 0);
     case 10: return launch_glds<T, 128, 64, 8, 4, Epi>(a, stream, 1);
     case 9: return launch_glds<T, 128, 128, 8, 3, Epi>(a, stream, 2);
@@ -654,6 +722,10 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   TT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda=%d / ldw=%d must be multiples of 8 elements", a.lda, a.ldw);
   TT_REQUIRE(a.splitk == 1 || (epi == EPI_STD && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
   TT_REQUIRE(a.splitk <= a.K / 64, "gemm: splitk=%d exceeds the %d k-tiles", a.splitk, a.K / 64);
+  if (a.w_packed) {
+    TT_REQUIRE(a.taps == 1, "gemm: tile-packed weights are not supported for conv taps");
+    a.n_pad = (a.N + 63) / 64 * 64;
+  }
   if (a.gn_part) {
     TT_REQUIRE(epi == EPI_STD && a.splitk == 1 && a.out_f32 && a.gn_seq > 0 && a.N % 16 == 0, "gemm: GroupNorm statistics need the standard epilogue, an f32 output, no split-K and N %% 16 == 0");
     a.gn_ncol16 = a.N / 16;
@@ -679,12 +751,12 @@ static int set_attr_one() {
   }
   return 0;
 }
-template <typename T, int BM, int BN, int NW, int ST, typename Epi>
+template <typename T, int BM, int BN, int NW, int ST, typename Epi, bool QUART = false>
 static int set_attr_glds() {
-  const void* fn = (const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false>;
+  const void* fn = (const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false, QUART>;
   TT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes_glds<BM, BN, ST>()));
   if constexpr (Epi::kId == 0) {
-    const void* fc = (const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, true>;
+    const void* fc = (const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, true, QUART>;
     TT_CHECK_HIP(hipFuncSetAttribute(fc, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes_glds<BM, BN, ST>()));
   }
   return 0;
@@ -697,6 +769,7 @@ static int set_attr() {
   TT_TRY((set_attr_glds<T, 128, 128, 8, 3, Epi>()));
   TT_TRY((set_attr_glds<T, 128, 64, 8, 4, Epi>()));
   TT_TRY((set_attr_glds<T, 64, 64, 4, 4, Epi>()));
+  TT_TRY((set_attr_glds<T, 64, 64, 4, 4, Epi, true>()));
   TT_TRY((set_attr_one<T, 128, 128, 64, 4, Epi>()));
   TT_TRY((set_attr_one<T, 128, 64, 64, 4, Epi>()));
   TT_TRY((set_attr_one<T, 64, 64, 64, 4, Epi>()));

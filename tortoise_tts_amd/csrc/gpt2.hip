@@ -46,6 +46,12 @@ struct tt_ar {
 
 static const int MAX_SPLIT = 8;
 
+static inline GemmArgs ar_gemm(const tt_ar* e, const void* A, int lda, const void* W, int ldw, int M, int N, int K) {
+  GemmArgs g = gemm_args(A, lda, W, ldw, M, N, K);
+  g.w_packed = e->cfg.weights_tile_packed;
+  return g;
+}
+
 static int ar_rownorm(tt_ar* e, float* x, int M, const float* g1, const float* b1, const float* g2, const float* b2,
                       const float* add_bias, int nslab, int slab_rows, hipStream_t s) {
   RowNormArgs a;
@@ -69,7 +75,7 @@ static int gpt_trunk_full(tt_ar* e, int B, int n, bool to_prefix, hipStream_t s)
   for (int l = 0; l < e->cfg.layers; ++l) {
     const tt_gpt_layer& w = e->L[l];
     TT_TRY(ar_rownorm(e, e->x, M, w.ln1_g, w.ln1_b, nullptr, nullptr, nullptr, 0, 0, s));
-    GemmArgs g = gemm_args(e->h, D, w.w_qkv, D, M, 3 * D, D);
+    GemmArgs g = ar_gemm(e, e->h, D, w.w_qkv, D, M, 3 * D, D);
     g.bias = w.b_qkv; g.seq_len = n; g.dmodel = D; g.heads = H;
     g.q = e->q;
     g.k = to_prefix ? offset_t(e->kp, (size_t)l * e->prefix_layer_elems) : e->kfull;
@@ -81,14 +87,14 @@ static int gpt_trunk_full(tt_ar* e, int B, int n, bool to_prefix, hipStream_t s)
     f.q = e->q; f.k = g.k; f.vt = e->vt; f.out = e->attn; f.ldo = D;
     f.BH = B * H; f.heads = H; f.n = n; f.n_pad = n_pad; f.causal = 1;
     TT_TRY(flash_attention_launch(dt, f, s));
-    g = gemm_args(e->attn, D, w.w_proj, D, M, D, D);
+    g = ar_gemm(e, e->attn, D, w.w_proj, D, M, D, D);
     g.bias = w.b_proj; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
     TT_TRY(gemm_launch(dt, EPI_STD, g, s));
     TT_TRY(ar_rownorm(e, e->x, M, w.ln2_g, w.ln2_b, nullptr, nullptr, nullptr, 0, 0, s));
-    g = gemm_args(e->h, D, w.w_fc, D, M, 4 * D, D);
+    g = ar_gemm(e, e->h, D, w.w_fc, D, M, 4 * D, D);
     g.bias = w.b_fc; g.act = ACT_GELU_TANH; g.out_t = e->ff; g.ldot = 4 * D;
     TT_TRY(gemm_launch(dt, EPI_STD, g, s));
-    g = gemm_args(e->ff, 4 * D, w.w_proj2, 4 * D, M, D, 4 * D);
+    g = ar_gemm(e, e->ff, 4 * D, w.w_proj2, 4 * D, M, D, 4 * D);
     g.bias = w.b_proj2; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
     TT_TRY(gemm_launch(dt, EPI_STD, g, s));
   }
@@ -114,7 +120,7 @@ static int pick_split(int B, int N, int K) {
 // lm_head = Sequential(final_norm, mel_head) applied to ln_f(x) (autoregressive.py:42, 174)
 static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, hipStream_t s) {
   TT_TRY(ar_rownorm(e, x, M, e->w.lnf_g, e->w.lnf_b, e->w.final_norm_g, e->w.final_norm_b, add_bias, nslab, e->B, s));
-  GemmArgs g = gemm_args(e->h, e->D, e->w.w_mel_head, e->D, M, e->V, e->D);
+  GemmArgs g = ar_gemm(e, e->h, e->D, e->w.w_mel_head, e->D, M, e->V, e->D);
   g.bias = e->w.b_mel_head; g.out_f32 = e->logits; g.ldo32 = e->V;
   TT_TRY(gemm_launch(e->cfg.dtype, EPI_STD, g, s));
   e->logits_rows = M;
@@ -130,7 +136,7 @@ static int decode_step_enqueue(tt_ar* e, hipStream_t s) {
   for (int l = 0; l < e->cfg.layers; ++l) {
     const tt_gpt_layer& w = e->L[l];
     TT_TRY(ar_rownorm(e, e->x, B, w.ln1_g, w.ln1_b, nullptr, nullptr, pend_bias, pend_slabs, B, s));
-    GemmArgs g = gemm_args(e->h, D, w.w_qkv, D, B, 3 * D, D);
+    GemmArgs g = ar_gemm(e, e->h, D, w.w_qkv, D, B, 3 * D, D);
     g.bias = w.b_qkv; g.dmodel = D; g.heads = H; g.q_scale = 0.125f;
     g.step = e->state + 1; g.qbuf = e->q;
     g.kc = offset_t(e->kc, (size_t)l * e->gen_layer_elems);
@@ -146,16 +152,16 @@ static int decode_step_enqueue(tt_ar* e, hipStream_t s) {
     a.out = e->attn; a.B = B; a.heads = H; a.host_tgen = e->host_slot + 1;
     TT_TRY(decode_attention_launch(dt, a, s));
     int sk = pick_split(B, D, D);
-    g = gemm_args(e->attn, D, w.w_proj, D, B, D, D);
+    g = ar_gemm(e, e->attn, D, w.w_proj, D, B, D, D);
     g.splitk = sk; g.out_f32 = e->slabs; g.ldo32 = D;
     if (sk == 1) { g.bias = nullptr; }
     TT_TRY(gemm_launch(dt, EPI_STD, g, s));
     TT_TRY(ar_rownorm(e, e->x, B, w.ln2_g, w.ln2_b, nullptr, nullptr, w.b_proj, sk, B, s));
-    g = gemm_args(e->h, D, w.w_fc, D, B, 4 * D, D);
+    g = ar_gemm(e, e->h, D, w.w_fc, D, B, 4 * D, D);
     g.bias = w.b_fc; g.act = ACT_GELU_TANH; g.out_t = e->ff; g.ldot = 4 * D;
     TT_TRY(gemm_launch(dt, EPI_STD, g, s));
     sk = pick_split(B, D, 4 * D);
-    g = gemm_args(e->ff, 4 * D, w.w_proj2, 4 * D, B, D, 4 * D);
+    g = ar_gemm(e, e->ff, 4 * D, w.w_proj2, 4 * D, B, D, 4 * D);
     g.splitk = sk; g.out_f32 = e->slabs; g.ldo32 = D;
     TT_TRY(gemm_launch(dt, EPI_STD, g, s));
     pend_bias = w.b_proj2;

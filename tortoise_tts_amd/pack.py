@@ -40,6 +40,20 @@ class Holder:
         self.keep.append(t)
         return t
 
+    def op_packed(self, t):
+        """GEMM operand [out][in] re-laid as [ceil(out/64)][in/64][64][64]: every 64x64 k-tile of a 64-row panel is one
+        contiguous 8 KiB block (sequential DRAM pages for the weight-streaming decode GEMMs).  Pad rows are zero."""
+        t = t.detach().to(device=self.device, dtype=torch.float32)
+        t = t.reshape(t.shape[0], -1)
+        n, k = t.shape
+        assert k % 64 == 0, k
+        npad = (n + 63) // 64 * 64
+        p = torch.zeros(npad, k, device=self.device, dtype=torch.float32)
+        p[:n] = t
+        p = p.reshape(npad // 64, 64, k // 64, 64).permute(0, 2, 1, 3).to(self.tdtype).contiguous()
+        self.keep.append(p)
+        return p
+
     def conv(self, w, in_pad=None):
         """Conv1d weight [out][in][k] -> [out][k][in_pad] operand."""
         w = w.detach().to(device=self.device, dtype=torch.float32)
@@ -55,23 +69,25 @@ def _p(t):
 
 
 # ----------------------------------------------------------------------------------------- AR
-def pack_ar(sd, cfg: ARConfig, device, dtype):
+def pack_ar(sd, cfg: ARConfig, device, dtype, tile_packed=True):
     h = Holder(device, dtype)
+    h.tile_packed = bool(tile_packed)
+    wop = h.op_packed if tile_packed else h.op
     layers = (E.GptLayer * cfg.layers)()
     for i in range(cfg.layers):
         p = f"gpt.h.{i}"
         L = layers[i]
         L.ln1_g = _p(h.f32(sd[f"{p}.ln_1.weight"]))
         L.ln1_b = _p(h.f32(sd[f"{p}.ln_1.bias"]))
-        L.w_qkv = _p(h.op(sd[f"{p}.attn.c_attn.weight"].t()))      # HF Conv1D stores [in, out]
+        L.w_qkv = _p(wop(sd[f"{p}.attn.c_attn.weight"].t()))      # HF Conv1D stores [in, out]
         L.b_qkv = _p(h.f32(sd[f"{p}.attn.c_attn.bias"]))
-        L.w_proj = _p(h.op(sd[f"{p}.attn.c_proj.weight"].t()))
+        L.w_proj = _p(wop(sd[f"{p}.attn.c_proj.weight"].t()))
         L.b_proj = _p(h.f32(sd[f"{p}.attn.c_proj.bias"]))
         L.ln2_g = _p(h.f32(sd[f"{p}.ln_2.weight"]))
         L.ln2_b = _p(h.f32(sd[f"{p}.ln_2.bias"]))
-        L.w_fc = _p(h.op(sd[f"{p}.mlp.c_fc.weight"].t()))
+        L.w_fc = _p(wop(sd[f"{p}.mlp.c_fc.weight"].t()))
         L.b_fc = _p(h.f32(sd[f"{p}.mlp.c_fc.bias"]))
-        L.w_proj2 = _p(h.op(sd[f"{p}.mlp.c_proj.weight"].t()))
+        L.w_proj2 = _p(wop(sd[f"{p}.mlp.c_proj.weight"].t()))
         L.b_proj2 = _p(h.f32(sd[f"{p}.mlp.c_proj.bias"]))
     w = E.ArWeights()
     w.layers_host = layers
@@ -79,7 +95,7 @@ def pack_ar(sd, cfg: ARConfig, device, dtype):
     w.lnf_b = _p(h.f32(sd["gpt.ln_f.bias"]))
     w.final_norm_g = _p(h.f32(sd["final_norm.weight"]))
     w.final_norm_b = _p(h.f32(sd["final_norm.bias"]))
-    w.w_mel_head = _p(h.op(sd["mel_head.weight"]))
+    w.w_mel_head = _p(wop(sd["mel_head.weight"]))
     w.b_mel_head = _p(h.f32(sd["mel_head.bias"]))
     h.mel_emb = h.f32(sd["mel_embedding.weight"])
     h.mel_pos = h.f32(sd["mel_pos_embedding.emb.weight"])

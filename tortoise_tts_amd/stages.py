@@ -40,6 +40,7 @@ class ArStage:
         c.max_prefix = 1 + max_text + 2 + 1
         c.max_new_tokens = max_new_tokens + 2
         c.max_full_rows = max_latent_candidates * (1 + max_text + 2 + max_new_tokens + 2)
+        c.weights_tile_packed = int(getattr(self.w, "tile_packed", False))
         self.max_latent_candidates = max_latent_candidates
         self.ccfg = c
         self.h = E.vp()
