@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--decode-streams", type=int, default=2, help="concurrent AR decode sub-batches per GPU")
+    ap.add_argument("--decode-streams", type=int, default=1, help="concurrent AR decode sub-batches per GPU")
     args = ap.parse_args()
 
     from tortoise_tts_amd import dist as tdist

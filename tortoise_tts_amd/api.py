@@ -79,7 +79,7 @@ class TextToSpeech:
     def __init__(self, autoregressive_batch_size=None, models_dir=MODELS_DIR, enable_redaction=True, kv_cache=False,
                  use_deepspeed=False, half=False, device=None, tokenizer_vocab_file=None, tokenizer_basic=False, *,
                  state_dicts=None, dtype="bf16", max_candidates=256, configs=None, max_mel_tokens=500, max_text_tokens=402,
-                 decode_streams=2):
+                 decode_streams=1):
         self.models_dir = models_dir
         if use_deepspeed:
             raise NotImplementedError("use_deepspeed: DeepSpeed kernel injection is a CUDA-only reference option; the MI355X engine "
@@ -112,10 +112,10 @@ class TextToSpeech:
         max_S = max_mel_tokens * 4 * 24000 // 22050 + 8
         self.ar = stages.ArStage(sd("autoregressive"), self.ar_cfg, self.device, self.dtype, max_batch=cap,
                                  max_text=max_text_tokens, max_new_tokens=max_mel_tokens, max_latent_candidates=4)
-        # A decode step is a chain of ~215 short, latency-bound kernels that leaves most of the chip idle.  Two (or
-        # more) independent candidate sub-batches decoded concurrently on their own streams overlap each other's
-        # memory waits; the weights are shared and the second pass over a layer's weights hits the Infinity Cache.
-        # Sampled codes do not change: Philox streams are keyed by the global candidate index.
+        # Optional: decode several candidate sub-batches concurrently on their own streams (shared weights; sampled
+        # codes do not change because Philox streams are keyed by the global candidate index).  Measured on MI355X:
+        # no gain (1 stream 0.505 s, 2 streams 0.515 s, 4 streams 0.915 s for 256 x 200 tokens) - the decode GEMMs
+        # are weight-streaming bound, so splitting the batch only streams the weights more often.  Default 1.
         self.decode_streams = max(1, int(decode_streams))
         self.ar_extra = [stages.ArStage(None, self.ar_cfg, self.device, self.dtype, max_batch=-(-cap // self.decode_streams),
                                         max_text=max_text_tokens, max_new_tokens=max_mel_tokens, max_latent_candidates=1,
