@@ -84,10 +84,18 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
   };
   x8 kfA[2][2], vfA[4], kfB[2][2], vfB[4];
 
+  // The loop body is VALU-bound (PMC: ~24 VALU instructions per MFMA before this diet), so everything that is
+  // wave-uniform is decided once per tile: tiles whose keys are all >= 64 positions away from every query of the
+  // block take a constant relative-position bias, masks are only evaluated on the last / diagonal tile, the
+  // accumulator rescale is skipped when no row maximum moved, the row sums stay lane-partial until the end, and
+  // exp() is a bare v_exp_f32 (exp2) with log2(e) folded into one FMA.
+  constexpr float LOG2E = 1.4426950408889634f;
   auto process = [&](const x8 (&kf)[2][2], const x8 (&vf)[4], int key0) {
+    const bool tail = key0 + 32 > n;
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) {
-      const int qi = qbase + iq * 16 + fr;
+      const int q0 = qbase + iq * 16;
+      const int qi = q0 + fr;
       float s[2][4];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -95,37 +103,66 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
         st = mfma16(kf[kb][0], qf[iq][0], st);
         st = mfma16(kf[kb][1], qf[iq][1], st);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = key0 + kb * 16 + fg * 4 + r;
-          float v = st[r];
-          if (a.relpos) {
-            int d = key - qi;
-            d = d < -64 ? -64 : (d > 64 ? 64 : d);
-            v += rp[d + 64];
-          }
-          if (key >= n || (a.causal && key > qi)) v = -INFINITY;
-          s[kb][r] = v;
+        for (int r = 0; r < 4; ++r) s[kb][r] = st[r];
+      }
+      if (a.relpos) {
+        if (key0 - (q0 + 15) >= 64) {          // every key is >= 64 after every query: bucket saturated
+          const float bconst = rp[128];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kb][r] += bconst;
+        } else if (q0 - (key0 + 31) >= 64) {   // every key is >= 64 before every query
+          const float bconst = rp[0];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kb][r] += bconst;
+        } else {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              int d = key0 + kb * 16 + fg * 4 + r - qi;
+              d = d < -64 ? -64 : (d > 64 ? 64 : d);
+              s[kb][r] += rp[d + 64];
+            }
         }
+      }
+      if (tail || (a.causal && key0 + 31 > q0)) {  // masks only on the last key tile / the causal diagonal
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = key0 + kb * 16 + fg * 4 + r;
+            if (key >= n || (a.causal && key > qi)) s[kb][r] = -INFINITY;
+          }
       }
       float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
                        fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[iq], mx);
-      const float alpha = __expf(m_run[iq] - m_new);
+      if (__any(m_new > m_run[iq])) {  // some row maximum moved: rescale the running state (exact when skipped)
+        const float alpha = __builtin_amdgcn_exp2f((m_run[iq] - m_new) * LOG2E);
+        l_run[iq] *= alpha;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+          acc[iq][blk][0] *= alpha; acc[iq][blk][1] *= alpha; acc[iq][blk][2] *= alpha; acc[iq][blk][3] *= alpha;
+        }
+        m_run[iq] = m_new;
+      }
+      const float mc = m_new * LOG2E;
       float p[2][4];
       float psum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p[kb][r] = __expf(s[kb][r] - m_new);
+          p[kb][r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, -mc));
           psum += p[kb][r];
         }
-      psum += __shfl_xor(psum, 16, 64);
-      psum += __shfl_xor(psum, 32, 64);
-      l_run[iq] = l_run[iq] * alpha + psum;
-      m_run[iq] = m_new;
+      l_run[iq] += psum;  // lane-partial: reduced over the four key groups once, after the loop
       x8 pf;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -133,11 +170,7 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
         pf[4 + r] = (T)p[1][r];
       }
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) {
-        f32x4 o = acc[iq][blk];
-        o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-        acc[iq][blk] = mfma16(vf[blk], pf, o);
-      }
+      for (int blk = 0; blk < 4; ++blk) acc[iq][blk] = mfma16(vf[blk], pf, acc[iq][blk]);
     }
   };
   // prefetches are unconditional (clamped to the last tile): straight-line body, counted waits
@@ -156,6 +189,11 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
       t += TSTEP;
       if (t >= ntile) break;
     }
+  }
+#pragma unroll
+  for (int iq = 0; iq < NQ; ++iq) {
+    l_run[iq] += __shfl_xor(l_run[iq], 16, 64);
+    l_run[iq] += __shfl_xor(l_run[iq], 32, 64);
   }
   if (SPLIT) {
     // merge the four waves' partial (max, sum, O) states, one query block at a time, into wave 0
