@@ -15,7 +15,18 @@ namespace tt {
 template <typename T>
 struct EpiStd {
   static constexpr int kId = 0;
-  __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4& v, int nvalid, int z) const {
+  // Every epilogue is split in two so that run_epilogue can do ALL arithmetic first and issue ALL stores last:
+  // apply() is register-only; bv / rv are the bias and residual quads for (m, n..n+3) fetched ahead (zeros if absent).
+  __device__ __forceinline__ void apply(const GemmArgs& g, f32x4& v, const float4& bv, const float4& rv) const {
+    if (g.splitk > 1) return;  // raw partial sums; bias / activation / residual belong to the slab consumer
+    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    if (g.act != ACT_NONE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], g.act, g.slope);
+    }
+    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+  }
+  __device__ __forceinline__ void store(const GemmArgs& g, int m, int n, const f32x4& v, int nvalid, int z) const {
     if (g.splitk > 1) {
       float* o = g.out_f32 + (size_t)z * g.M * g.ldo32 + (size_t)m * g.ldo32 + n;
       if (nvalid == 4 && (g.ldo32 & 3) == 0) {
@@ -24,21 +35,6 @@ struct EpiStd {
         for (int i = 0; i < nvalid; ++i) o[i] = v[i];
       }
       return;
-    }
-    if (g.bias) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (i < nvalid) v[i] += g.bias[n + i];
-    }
-    if (g.act != ACT_NONE) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], g.act, g.slope);
-    }
-    if (g.res) {
-      const float* r = g.res + (size_t)m * g.ldres + n;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (i < nvalid) v[i] += r[i];
     }
     if (g.out_f32) {
       float* o = g.out_f32 + (size_t)m * g.ldo32 + n;
@@ -62,12 +58,11 @@ struct EpiStd {
 template <typename T>
 struct EpiQkvHeads {
   static constexpr int kId = 1;
-  __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4& v, int nvalid, int z) const {
+  __device__ __forceinline__ void apply(const GemmArgs& g, f32x4& v, const float4& bv, const float4&) const {
+    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+  }
+  __device__ __forceinline__ void store(const GemmArgs& g, int m, int n, const f32x4& v, int nvalid, int z) const {
     // N == 3 * dmodel and dmodel % 64 == 0, so nvalid is always 4 here.
-    if (g.bias) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += g.bias[n + i];
-    }
     const int part = n / g.dmodel;
     const int c = n - part * g.dmodel;
     const int h = c >> 6, d = c & 63;
@@ -96,11 +91,10 @@ struct EpiQkvHeads {
 template <typename T>
 struct EpiQkvDecode {
   static constexpr int kId = 2;
-  __device__ __forceinline__ void operator()(const GemmArgs& g, int m, int n, f32x4& v, int nvalid, int z) const {
-    if (g.bias) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += g.bias[n + i];
-    }
+  __device__ __forceinline__ void apply(const GemmArgs& g, f32x4& v, const float4& bv, const float4&) const {
+    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+  }
+  __device__ __forceinline__ void store(const GemmArgs& g, int m, int n, const f32x4& v, int nvalid, int z) const {
     const int part = n / g.dmodel;
     const int c = n - part * g.dmodel;
     const int h = c >> 6, d = c & 63;
@@ -124,6 +118,15 @@ struct EpiQkvDecode {
 // tile: gn_part[row_tile][slot][n / 16][2], slot 1 = rows that belong to the NEXT sequence when the row tile
 // straddles a sequence boundary.  The GroupNorm apply kernel adds these up in a fixed order (deterministic),
 // which removes the separate statistics pass over the tensor.
+__device__ __forceinline__ float4 load_upto4(const float* p, int nvalid) {  // ragged / unaligned edge: element loads
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nvalid > 0) r.x = p[0];
+  if (nvalid > 1) r.y = p[1];
+  if (nvalid > 2) r.z = p[2];
+  if (nvalid > 3) r.w = p[3];
+  return r;
+}
+
 template <typename Epi, int FM, int FN, int TM, int TN>
 __device__ __forceinline__ void run_epilogue(const GemmArgs& g, f32x4 (&acc)[FN][FM], int m0w, int n0w, int lane, int z) {
   const int fr = lane & 15, fg = lane >> 4;
@@ -131,47 +134,98 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g, f32x4 (&acc)[FN]
   const bool stats = Epi::kId == 0 && g.gn_part != nullptr && g.splitk == 1;
   const int rt = m0w / TM;                              // row-tile index (m0w is a multiple of TM)
   const int b_first = stats ? m0w / g.gn_seq : 0;
+  // Bias and residual operands are requested as whole quads for a full column strip BEFORE any arithmetic or store:
+  // one memory round trip per strip instead of one per element (a per-element `if (i < nvalid) v += bias[n + i]`
+  // compiles to load / s_waitcnt vmcnt(0) / branch chains).  Out-of-range rows / columns are clamped, never stored.
+  const bool use_bias = g.bias != nullptr && !(Epi::kId == 0 && g.splitk > 1);
+  const bool use_res = Epi::kId == 0 && g.res != nullptr && g.splitk == 1;
+  const bool quads = (g.N & 3) == 0 && g.N >= 4 && (!use_bias || ((size_t)g.bias & 15) == 0) &&
+                     (!use_res || (((size_t)g.res & 15) == 0 && (g.ldres & 3) == 0));
+  // phase 1: every bias / residual quad of the wave tile is requested up front
+  float4 bv[FN], rv[FN][FM];
 #pragma unroll
   for (int i = 0; i < FN; ++i) {
     const int n = n0w + i * 16 + fg * 4;
     const int nvalid = g.N - n >= 4 ? 4 : g.N - n;
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = m0w + j * 16 + fr;
-      if (m < g.M && n < g.N) {
-        epi(g, m, n, acc[i][j], nvalid, z);
-        if (stats) {
-          float s = 0.f, q = 0.f;
+    for (int j = 0; j < FM; ++j) rv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (quads) {
+      const int nc = min(n, g.N - 4);
+      if (use_bias) bv[i] = *(const float4*)(g.bias + nc);
+      if (use_res) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < nvalid) {
-              s += acc[i][j][r];
-              q += acc[i][j][r] * acc[i][j][r];
-            }
-          if (m / g.gn_seq == b_first) {
-            s0 += s; q0 += q;
-          } else {
-            s1 += s; q1 += q;
-          }
+        for (int j = 0; j < FM; ++j) {
+          const int mc = min(m0w + j * 16 + fr, g.M - 1);
+          rv[i][j] = *(const float4*)(g.res + (size_t)mc * g.ldres + nc);
+        }
+      }
+    } else {
+      if (use_bias) bv[i] = load_upto4(g.bias + n, nvalid);
+      if (use_res) {
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const int m = m0w + j * 16 + fr;
+          if (m < g.M) rv[i][j] = load_upto4(g.res + (size_t)m * g.ldres + n, nvalid);
         }
       }
     }
-    if (stats) {
+  }
+  // phase 2: arithmetic and GroupNorm partial statistics, registers only
+  float s0[FN], q0[FN], s1[FN], q1[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int n = n0w + i * 16 + fg * 4;
+    const int nvalid = g.N - n >= 4 ? 4 : g.N - n;
+    s0[i] = q0[i] = s1[i] = q1[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = m0w + j * 16 + fr;
+      epi.apply(g, acc[i][j], bv[i], rv[i][j]);
+      if (stats) {
+        float sv = 0.f, qv = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = (r < nvalid && m < g.M) ? acc[i][j][r] : 0.f;
+          sv += e;
+          qv += e * e;
+        }
+        const bool first = m / g.gn_seq == b_first;
+        s0[i] += first ? sv : 0.f;
+        q0[i] += first ? qv : 0.f;
+        s1[i] += first ? 0.f : sv;
+        q1[i] += first ? 0.f : qv;
+      }
+    }
+  }
+  // phase 3: stores, back to back
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int n = n0w + i * 16 + fg * 4;
+    const int nvalid = g.N - n >= 4 ? 4 : g.N - n;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = m0w + j * 16 + fr;
+      if (m < g.M && n < g.N) epi.store(g, m, n, acc[i][j], nvalid, z);
+    }
+  }
+  if (stats) {
+    const bool straddle = (m0w + TM - 1) / g.gn_seq != b_first;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
       const int n16 = (n0w + i * 16) >> 4;
       if (n0w + i * 16 < g.N) {
-        const bool straddle = (m0w + TM - 1) / g.gn_seq != b_first;  // wave-uniform
-        s0 = wave_sum(s0);
-        q0 = wave_sum(q0);
+        const float a0 = wave_sum(s0[i]), b0 = wave_sum(q0[i]);
+        float a1 = 0.f, b1 = 0.f;
         if (straddle) {
-          s1 = wave_sum(s1);
-          q1 = wave_sum(q1);
+          a1 = wave_sum(s1[i]);
+          b1 = wave_sum(q1[i]);
         }
         if (lane == 0) {
           float* p = g.gn_part + (((size_t)rt * 2 + 0) * g.gn_ncol16 + n16) * 2;
-          p[0] = s0; p[1] = q0;
+          *(float2*)p = make_float2(a0, b0);
           float* p1 = g.gn_part + (((size_t)rt * 2 + 1) * g.gn_ncol16 + n16) * 2;
-          p1[0] = straddle ? s1 : 0.f; p1[1] = straddle ? q1 : 0.f;
+          *(float2*)p1 = make_float2(a1, b1);
         }
       }
     }

@@ -8,7 +8,7 @@ namespace tt {
 
 // ------------------------------------------------------------------------------- row norm
 // One 256-thread block per row, D <= 4096, D % 4 == 0.
-template <typename T>
+template <typename T, int NSLAB>
 __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
   __shared__ float red[4];
   const int row = blockIdx.x;
@@ -26,9 +26,20 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
         const float4 b = *(const float4*)(a.add_bias + c);
         t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
       }
-      for (int s = 0; s < a.nslab; ++s) {
-        const float4 p = *(const float4*)(a.add_slabs + (size_t)s * a.slab_stride + (size_t)row * a.ldslab + c);
-        t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+      if constexpr (NSLAB >= 0) {
+        float4 sl[NSLAB > 0 ? NSLAB : 1];
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s)  // all partial-sum slabs requested at once, summed in slab order
+          sl[s] = *(const float4*)(a.add_slabs + (size_t)s * a.slab_stride + (size_t)row * a.ldslab + c);
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s) {
+          t.x += sl[s].x; t.y += sl[s].y; t.z += sl[s].z; t.w += sl[s].w;
+        }
+      } else {  // odd slab counts: same order, one round trip per slab
+        for (int s = 0; s < a.nslab; ++s) {
+          const float4 p = *(const float4*)(a.add_slabs + (size_t)s * a.slab_stride + (size_t)row * a.ldslab + c);
+          t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+        }
       }
       if (a.write_x) *(float4*)(xr + c) = t;
       v[j] = t;
@@ -109,6 +120,76 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
     }
   }
   emit(v);
+}
+
+// Narrow rows (D <= 1024): one float4 per thread and every operand the row needs - input, bias, split-K slabs, affine
+// parameters - requested before the first use, so the row costs one memory round trip instead of three (input, slabs,
+// affine).  NSLAB / BIAS / RMS are compile-time so no branch sits between the requests.  Same arithmetic order as the
+// generic kernel: bias, slabs in order, two-pass variance.
+template <typename T, int NSLAB, bool BIAS, bool RMS>
+__global__ __launch_bounds__(256) void rownorm_narrow_kernel(RowNormArgs a) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const bool live = tid * 4 < a.D;
+  const int c = min(tid * 4, a.D - 4);  // idle lanes re-read the last quad (no branch), masked below
+  float* xr = a.x + (size_t)row * a.ldx;
+  const float* src = a.x_in ? a.x_in + (size_t)row * a.ldxin : xr;
+  float4 t = *(const float4*)(src + c);
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (BIAS) bv = *(const float4*)(a.add_bias + c);
+  float4 sl[NSLAB > 0 ? NSLAB : 1];
+#pragma unroll
+  for (int s = 0; s < NSLAB; ++s) sl[s] = *(const float4*)(a.add_slabs + (size_t)s * a.slab_stride + (size_t)row * a.ldslab + c);
+  const float4 g = *(const float4*)(a.g1 + c);
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (!RMS) b = *(const float4*)(a.b1 + c);
+  __builtin_amdgcn_sched_barrier(0);
+
+  if constexpr (BIAS) { t.x += bv.x; t.y += bv.y; t.z += bv.z; t.w += bv.w; }
+#pragma unroll
+  for (int s = 0; s < NSLAB; ++s) { t.x += sl[s].x; t.y += sl[s].y; t.z += sl[s].z; t.w += sl[s].w; }
+  if (a.write_x && live) *(float4*)(xr + c) = t;
+  if (!live) t = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  float4 y;
+  if constexpr (RMS) {
+    const float sq = block_sum_256(t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w, red);
+    const float nrm = sqrtf(sq) * rsqrtf((float)a.D);
+    const float inv = 1.0f / fmaxf(nrm, a.eps1);
+    y = make_float4(t.x * inv * g.x, t.y * inv * g.y, t.z * inv * g.z, t.w * inv * g.w);
+  } else {
+    const float mean = block_sum_256(t.x + t.y + t.z + t.w, red) / (float)a.D;
+    const float dx = t.x - mean, dy = t.y - mean, dz = t.z - mean, dw = t.w - mean;
+    const float var = block_sum_256(live ? dx * dx + dy * dy + dz * dz + dw * dw : 0.f, red) / (float)a.D;
+    const float rstd = rsqrtf(var + a.eps1);
+    y = make_float4(dx * rstd * g.x + b.x, dy * rstd * g.y + b.y, dz * rstd * g.z + b.z, dw * rstd * g.w + b.w);
+  }
+  if (live) {
+    if (a.out_t) *(typename Vec<T>::x4*)((T*)a.out_t + (size_t)row * a.ldot + c) = pack4<T>(y.x, y.y, y.z, y.w);
+    if (a.out_f32) *(float4*)(a.out_f32 + (size_t)row * a.ldo32 + c) = y;
+  }
+}
+
+template <typename T, int NSLAB>
+static void rownorm_narrow_dispatch(const RowNormArgs& a, hipStream_t stream) {
+  const bool bias = a.add_bias != nullptr, rms = a.mode == NORM_RMS;
+  if (bias && rms) rownorm_narrow_kernel<T, NSLAB, true, true><<<a.M, 256, 0, stream>>>(a);
+  else if (bias) rownorm_narrow_kernel<T, NSLAB, true, false><<<a.M, 256, 0, stream>>>(a);
+  else if (rms) rownorm_narrow_kernel<T, NSLAB, false, true><<<a.M, 256, 0, stream>>>(a);
+  else rownorm_narrow_kernel<T, NSLAB, false, false><<<a.M, 256, 0, stream>>>(a);
+}
+
+template <typename T>
+static bool rownorm_narrow_launch(const RowNormArgs& a, hipStream_t stream) {
+  if (a.D > 1024 || a.mode == NORM_NONE || a.g2 != nullptr) return false;
+  switch (a.nslab) {
+    case 0: rownorm_narrow_dispatch<T, 0>(a, stream); return true;
+    case 1: rownorm_narrow_dispatch<T, 1>(a, stream); return true;
+    case 2: rownorm_narrow_dispatch<T, 2>(a, stream); return true;
+    case 4: rownorm_narrow_dispatch<T, 4>(a, stream); return true;
+    case 8: rownorm_narrow_dispatch<T, 8>(a, stream); return true;
+    default: return false;
+  }
 }
 
 // Wave-per-row variant for D <= 1024: no block barriers, reductions are register shuffles only, four rows per
@@ -214,8 +295,11 @@ int rownorm_launch(int dtype, const RowNormArgs& a, hipStream_t stream) {
     if (dtype == DT_BF16) rownorm_wave_kernel<bf16><<<cdiv(a.M, 4), 256, 0, stream>>>(a);
     else rownorm_wave_kernel<f16><<<cdiv(a.M, 4), 256, 0, stream>>>(a);
   } else {
-    if (dtype == DT_BF16) rownorm_kernel<bf16><<<a.M, 256, 0, stream>>>(a);
-    else rownorm_kernel<f16><<<a.M, 256, 0, stream>>>(a);
+    const bool narrow = dtype == DT_BF16 ? rownorm_narrow_launch<bf16>(a, stream) : rownorm_narrow_launch<f16>(a, stream);
+    if (!narrow) {
+      if (dtype == DT_BF16) rownorm_kernel<bf16, -1><<<a.M, 256, 0, stream>>>(a);
+      else rownorm_kernel<f16, -1><<<a.M, 256, 0, stream>>>(a);
+    }
   }
   TT_CHECK_HIP(hipGetLastError());
   return 0;
@@ -275,19 +359,47 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 // Per-(batch, group) mean / rstd from partial sums, fp64 combine in a fixed order.  Two sources:
 //   a.gemm_part == nullptr : partial[b][chunk][32][2] from gn_stats_kernel
 //   a.gemm_part != nullptr : [row_tile][slot][C/16][2] written by the producing GEMM's epilogue
+// The first GN_HEAD fused partials of every thread can be requested ahead of the activation rows (gn_partial_head) so the
+// statistics round trip overlaps the row loads; gn_finalize then sums head + remainder in the same fixed order.
+constexpr int GN_HEAD = 8;
+
+__device__ __forceinline__ float2 gn_partial_item(const GroupNormArgs& a, int b, int g, int e, int t0, int nitems, int spg, int nc16) {
+  const int ec = min(e, nitems - 1);  // clamped, unconditional load; out-of-range items are zeroed by the caller
+  const int t = t0 + ec / spg, strip = g * spg + ec % spg;
+  const int slot = (t * a.part_rows) / a.S == b ? 0 : 1;
+  return *(const float2*)(a.gemm_part + (((size_t)t * 2 + slot) * nc16 + strip) * 2);
+}
+
+__device__ __forceinline__ void gn_partial_head(const GroupNormArgs& a, int b, int tid, float2 (&head)[GN_HEAD]) {
+  const int g = tid & 31, part = tid >> 5;
+  const int S = a.S, R = a.part_rows, nc16 = a.C >> 4, spg = (a.C / 32) >> 4;
+  const int t0 = (b * S) / R, t1 = ((b + 1) * S - 1) / R;
+  const int nitems = (t1 - t0 + 1) * spg;
+#pragma unroll
+  for (int k = 0; k < GN_HEAD; ++k) head[k] = gn_partial_item(a, b, g, part + 8 * k, t0, nitems, spg, nc16);
+}
+
 __device__ __forceinline__ void gn_finalize(const GroupNormArgs& a, int b, int tid, int nchunk, float* mean_s, float* rstd_s,
-                                            double (*part_s)[32], double (*part_q)[32]) {
+                                            double (*part_s)[32], double (*part_q)[32], const float2* head = nullptr) {
   const int g = tid & 31, part = tid >> 5;
   double s = 0.0, q = 0.0;
   if (a.gemm_part) {
     const int S = a.S, R = a.part_rows, nc16 = a.C >> 4, spg = (a.C / 32) >> 4;  // 16-column strips per group
     const int t0 = (b * S) / R, t1 = ((b + 1) * S - 1) / R;
     const int nitems = (t1 - t0 + 1) * spg;
+    int e = part;
+    if (head) {
+#pragma unroll
+      for (int k = 0; k < GN_HEAD; ++k, e += 8) {
+        if (e < nitems) {
+          s += (double)head[k].x;
+          q += (double)head[k].y;
+        }
+      }
+    }
 #pragma unroll 4
-    for (int e = part; e < nitems; e += 8) {
-      const int t = t0 + e / spg, strip = g * spg + e % spg;
-      const int slot = (t * R) / S == b ? 0 : 1;
-      const float2 v = *(const float2*)(a.gemm_part + (((size_t)t * 2 + slot) * nc16 + strip) * 2);
+    for (; e < nitems; e += 8) {
+      const float2 v = gn_partial_item(a, b, g, e, t0, nitems, spg, nc16);
       s += (double)v.x;
       q += (double)v.y;
     }
@@ -369,7 +481,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchu
 // C == 1024 fast path: thread t owns channels 4t..4t+3 (group t/8) of GN_APPLY_ROWS consecutive rows.  The x rows
 // are requested BEFORE the statistics are finalised, so the streaming loads overlap the (latency-bound) prologue.
 constexpr int GN_APPLY_ROWS = 8;
-template <typename T>
+template <typename T, bool FUSED, bool SS>
 __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, int nchunk) {
   __shared__ float mean_s[32], rstd_s[32];
   __shared__ double part_s[8][32], part_q[8][32];
@@ -378,6 +490,10 @@ __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, in
   constexpr int C = 1024;
   const int r0 = blockIdx.x * GN_APPLY_ROWS;
   const int c = tid * 4;
+  // request order = need order: step slot (scalar), statistics partials, then the rows and the affine parameters
+  const size_t ss_off = SS && a.ss_slot ? (size_t)(*a.ss_slot) * a.ss_slot_stride : 0;
+  float2 head[GN_HEAD];
+  if constexpr (FUSED) gn_partial_head(a, b, tid, head);  // FUSED <=> a.gemm_part != nullptr (compile time: no branch to sink consumers into)
   float4 xr[GN_APPLY_ROWS];
 #pragma unroll
   for (int i = 0; i < GN_APPLY_ROWS; ++i) {
@@ -387,12 +503,13 @@ __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, in
   const float4 gm = *(const float4*)(a.gamma + c);
   const float4 bt = *(const float4*)(a.beta + c);
   float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
-  if (a.scale_shift) {
-    const float* ss = a.scale_shift + (size_t)b * a.ss_batch_stride + (a.ss_slot ? (size_t)(*a.ss_slot) * a.ss_slot_stride : 0);
+  if constexpr (SS) {  // SS <=> a.scale_shift != nullptr
+    const float* ss = a.scale_shift + (size_t)b * a.ss_batch_stride + ss_off;
     sc = *(const float4*)(ss + c);
     sh = *(const float4*)(ss + C + c);
   }
-  gn_finalize(a, b, tid, nchunk, mean_s, rstd_s, part_s, part_q);
+  __builtin_amdgcn_sched_barrier(0);  // keep every request above in flight before the first consumer waits
+  gn_finalize(a, b, tid, nchunk, mean_s, rstd_s, part_s, part_q, FUSED ? head : nullptr);
   const float mu = mean_s[tid >> 3], rs = rstd_s[tid >> 3];
 #pragma unroll
   for (int i = 0; i < GN_APPLY_ROWS; ++i) {
@@ -401,7 +518,7 @@ __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, in
     const float4 t = xr[i];
     float y[4] = {(t.x - mu) * rs * gm.x + bt.x, (t.y - mu) * rs * gm.y + bt.y, (t.z - mu) * rs * gm.z + bt.z,
                   (t.w - mu) * rs * gm.w + bt.w};
-    if (a.scale_shift) {
+    if constexpr (SS) {
       y[0] = y[0] * (1.f + sc.x) + sh.x;
       y[1] = y[1] * (1.f + sc.y) + sh.y;
       y[2] = y[2] * (1.f + sc.z) + sh.z;
@@ -434,8 +551,17 @@ int groupnorm_launch(int dtype, const GroupNormArgs& a, hipStream_t stream) {
   const int rpb = GN_APPLY_ROWS;  // apply is pure streaming: many small blocks
   dim3 grid2(cdiv(a.S, rpb), a.B);
   if (a.C == 1024) {
-    if (dtype == DT_BF16) gn_apply_c1024_kernel<bf16><<<grid2, 256, 0, stream>>>(a, nchunk);
-    else gn_apply_c1024_kernel<f16><<<grid2, 256, 0, stream>>>(a, nchunk);
+    const int variant = (dtype == DT_BF16 ? 0 : 4) + (a.gemm_part ? 2 : 0) + (a.scale_shift ? 1 : 0);
+    switch (variant) {
+      case 0: gn_apply_c1024_kernel<bf16, false, false><<<grid2, 256, 0, stream>>>(a, nchunk); break;
+      case 1: gn_apply_c1024_kernel<bf16, false, true><<<grid2, 256, 0, stream>>>(a, nchunk); break;
+      case 2: gn_apply_c1024_kernel<bf16, true, false><<<grid2, 256, 0, stream>>>(a, nchunk); break;
+      case 3: gn_apply_c1024_kernel<bf16, true, true><<<grid2, 256, 0, stream>>>(a, nchunk); break;
+      case 4: gn_apply_c1024_kernel<f16, false, false><<<grid2, 256, 0, stream>>>(a, nchunk); break;
+      case 5: gn_apply_c1024_kernel<f16, false, true><<<grid2, 256, 0, stream>>>(a, nchunk); break;
+      case 6: gn_apply_c1024_kernel<f16, true, false><<<grid2, 256, 0, stream>>>(a, nchunk); break;
+      default: gn_apply_c1024_kernel<f16, true, true><<<grid2, 256, 0, stream>>>(a, nchunk); break;
+    }
   } else {
     if (dtype == DT_BF16) gn_apply_kernel<bf16><<<grid2, 256, 0, stream>>>(a, nchunk, rpc, rpb);
     else gn_apply_kernel<f16><<<grid2, 256, 0, stream>>>(a, nchunk, rpc, rpb);
