@@ -142,10 +142,31 @@ def roofline_leg(tts, run_step):
     else:
         ach = d["bytes"] / sec / 1e9
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-    roof.update({"traffic": None, "kernel": d["kernel"], "launches": d["launches"], "avg_launch_us": d["avg_us"],
+    traffic, traffic_src = pmc_traffic(d["kernel"])
+    roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": d["kernel"], "launches": d["launches"], "avg_launch_us": d["avg_us"],
                  "algorithmic_flops_per_launch": d["flops"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                  "arithmetic_intensity": intensity, "share_of_kernel_time": d["total_ms"] / sum(r["total_ms"] for r in rows)})
     return roof, rows
+
+
+def pmc_traffic(kernel_class):
+    """HBM-side bytes per launch of one kernel class from the committed PMC summary (profiles/r01_pmc_bench.json,
+    written by scripts/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes over this same
+    workload, aggregated per kernel).  Counters cannot be read from inside a timed run, so the bench line carries the
+    figure of the last committed PMC pass, corrected as MI355X_MICROARCH.md prescribes for gfx950: both counters are
+    in KiB and FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) reads at 64 bytes, so it is doubled."""
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_bench.json")
+    m = re.match(r"gemm_kernel<(\d+),(\d+),(\w+)>", kernel_class)
+    alias = {"gn_stats_kernel+gn_apply_kernel": "gn_apply_c1024_kernel", "rownorm_kernel": "rownorm_narrow_kernelIDF16bLi4ELb1ELb0EEEvNS_11RowNormArgsE"}
+    key = "gemm<%s,%s,%s>" % m.groups() if m else alias.get(kernel_class, kernel_class)
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+        row = pmc[key]
+        return (2.0 * row["FETCH_SIZE"]["avg"] + row["WRITE_SIZE"]["avg"]) * 1024.0, "profiles/r01_pmc_bench.json[%s]" % key
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def main():

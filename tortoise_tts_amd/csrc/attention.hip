@@ -28,7 +28,18 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
   typedef typename Vec<T>::x8 x8;
   typedef typename Vec<T>::x4 x4;
   __shared__ float rp[132];
-  const int bh = blockIdx.y;
+  // XCD-aware block order: the dispatcher deals workgroups round-robin over the 8 XCDs (private L2 each), which
+  // would spread the query blocks of one (batch, head) over all eight L2s and fetch its K / V eight times
+  // (PMC: FETCH_SIZE 4.4x the algorithmic bytes).  Remap so every XCD owns a contiguous run of (head, query block).
+  int bx = blockIdx.x, bh = blockIdx.y;
+  {
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    const int lin = bh * gx + bx, xcd = lin & 7, slot = lin >> 3;
+    const int per = total >> 3, rem = total & 7;
+    const int lin2 = xcd * per + min(xcd, rem) + slot;
+    bh = lin2 / gx;
+    bx = lin2 - bh * gx;
+  }
   const int h = bh % a.heads, b = bh / a.heads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fg = lane >> 4;
@@ -37,7 +48,7 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
     if (threadIdx.x < 129) rp[threadIdx.x] = a.relpos[h * 129 + threadIdx.x];
     __syncthreads();
   }
-  const int qbase = (SPLIT ? blockIdx.x : blockIdx.x * 4 + wave) * 16 * NQ;
+  const int qbase = (SPLIT ? bx : bx * 4 + wave) * 16 * NQ;
   if (qbase >= n) return;
   const T* Q = (const T*)a.q + (size_t)bh * n * 64;
   const T* K = (const T*)a.k + (size_t)bh * n * 64;
@@ -280,109 +291,154 @@ int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------- decode
+// 8-wide dot product with fp32 accumulation on the packed-pair dot instructions (v_dot2c_f32_bf16 / v_dot2c_f32_f16):
+// the query stays packed (32 VGPRs instead of 64 floats) and a key costs 32 VALU ops instead of 64 converts + 64 FMAs.
+__device__ __forceinline__ float dot8(Vec<bf16>::x8 a, Vec<bf16>::x8 b, float acc) {
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), acc, false);
+  return acc;
+}
+__device__ __forceinline__ float dot8(Vec<f16>::x8 a, Vec<f16>::x8 b, float acc) {
+  acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), acc, false);
+  return acc;
+}
+
+// One wave per (sequence, head); 4 waves per block.  Sized to <= 128 VGPRs so that all B*heads = 4096 waves of the
+// full candidate batch are resident at once (16 waves per CU): with 3 blocks per CU the 1024 blocks ran as a full
+// round plus a quarter-full tail.  The shared prefix and the sequence's own keys are walked as separate, uniform
+// segments: every load is then (wave-uniform base) + (32-bit lane offset) - no 64-bit address pairs held in VGPRs -
+// and unconditional (clamped key index), because a branch between two groups of loads makes the compiler drain the
+// first group before it issues the second.
+constexpr int DEC_VROWS = 8;             // V rows per lane group per register set (two sets in flight)
+constexpr int DEC_VKEYS = 4 * DEC_VROWS;  // keys per wave per PV iteration
+
 template <typename T>
-__global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnArgs a, int ctx_cap) {
+__global__ __launch_bounds__(256, 4) void decode_attn_kernel(DecodeAttnArgs a, int ctx_cap) {  // 4 waves per SIMD => <= 128 VGPRs
   typedef typename Vec<T>::x8 x8;
   typedef typename Vec<T>::x4 x4;
   extern __shared__ __attribute__((aligned(16))) float sc_all[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pair = blockIdx.x * 4 + wave;
-  const bool valid = pair < a.B * a.heads;
-  const int b = valid ? pair / a.heads : 0;
-  const int h = valid ? pair % a.heads : 0;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = min((int)blockIdx.x * 4 + wave, a.B * a.heads - 1);  // surplus waves of the last block repeat its last pair
+  const int b = pair / a.heads;
+  const int h = pair % a.heads;
   const int tgen = *a.step + 1;       // generated keys 0..*step
   const int P1 = a.P1;
   const int ctx = P1 + tgen;
-  float* sc = sc_all + (size_t)wave * ctx_cap;
+  float* sc = sc_all + (size_t)wave * ctx_cap;   // scores: [0, P1) prefix keys, [P1, ctx) own keys
 
-  float qv[64];
-  {
-    const T* qp = (const T*)a.q + (size_t)b * a.heads * 64 + h * 64;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const x8 t = *(const x8*)(qp + c * 8);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) qv[c * 8 + i] = (float)t[i];
-    }
-  }
   const T* kp = (const T*)a.kp + (size_t)h * P1 * 64;
   const T* vp = (const T*)a.vp + (size_t)h * P1 * 64;
   const size_t bh = (size_t)b * a.heads + h;
   const T* kc = (const T*)a.kc + bh * 8 * a.tmax * 8;
   const T* vc = (const T*)a.vc + bh * a.tmax * 64;
+  const int fr = lane & 15, fg = lane >> 4;
 
   float mx = -1e30f;
-  if (valid) {
-    // Lane-per-key dot products, TWO key slots (16 x 16-byte loads) in flight per lane per iteration:
-    // slot s < P1 is a shared-prefix key (row-major), otherwise this sequence's key s - P1 (chunk-major).
-    for (int s0 = lane; s0 < ctx; s0 += 128) {
+  {
+    x8 qk[8];
+    const T* qp = (const T*)a.q + (size_t)b * a.heads * 64 + h * 64;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) qk[c] = *(const x8*)(qp + c * 8);
+    // Lane-per-key dot products, TWO key slots (16 x 16-byte loads) in flight per lane per iteration.  Slot list:
+    // prefix keys in 64-key slots (row-major rows of 64), then own keys in 64-key slots (chunk-major [8][tmax][8]).
+    const int nsp = (P1 + 63) >> 6, nso = (tgen + 63) >> 6;
+#pragma unroll 1
+    for (int sl0 = 0; sl0 < nsp + nso; sl0 += 2) {
       x8 kk[2][8];
+      int key[2];
+      bool live[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int sl = min(s0 + 64 * u, ctx - 1);
-        if (sl < P1) {
+        const int slot = min(sl0 + u, nsp + nso - 1);   // an odd slot count repeats the last slot (cached), result dropped
+        const bool pre = slot < nsp;                    // wave-uniform
+        const int k = (pre ? slot : slot - nsp) * 64 + lane;
+        const int lim = pre ? P1 : tgen;
+        const int kcl = min(k, lim - 1);
+        const char* base = (const char*)(pre ? kp : kc);
+        const unsigned off = (pre ? (unsigned)kcl * 64u : (unsigned)kcl * 8u) * (unsigned)sizeof(T);  // byte offsets, 32-bit
+        const unsigned cs = (pre ? 8u : (unsigned)a.tmax * 8u) * (unsigned)sizeof(T);
 #pragma unroll
-          for (int c = 0; c < 8; ++c) kk[u][c] = *(const x8*)(kp + (size_t)sl * 64 + c * 8);
-        } else {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) kk[u][c] = *(const x8*)(kc + ((size_t)c * a.tmax + (sl - P1)) * 8);
-        }
+        for (int c = 0; c < 8; ++c) kk[u][c] = *(const x8*)(base + (off + c * cs));
+        key[u] = (pre ? 0 : P1) + k;
+        live[u] = k < lim && sl0 + u < nsp + nso;
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int sl = s0 + 64 * u;
         float sv = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-          for (int i = 0; i < 8; ++i) sv += qv[c * 8 + i] * (float)kk[u][c][i];
-        if (sl < ctx) {
-          sc[sl] = sv;
+        for (int c = 0; c < 8; ++c) sv = dot8(qk[c], kk[u][c], sv);
+        if (live[u]) {
+          sc[key[u]] = sv;
           mx = fmaxf(mx, sv);
         }
       }
     }
   }
+
+  // PV: iteration `it` covers DEC_VKEYS keys of one segment; lane group fg takes keys fg + 4u, lane fr 4 of the 64 channels
+  const int nvp = (P1 + DEC_VKEYS - 1) / DEC_VKEYS, nvo = (tgen + DEC_VKEYS - 1) / DEC_VKEYS;
+  const int nit = nvp + nvo;
+  auto load_v = [&](x4 (&t)[DEC_VROWS], int it) {
+    const int itc = min(it, nit - 1);  // past the end: repeat the last iteration's rows (cached), weighted 0
+    const bool pre = itc < nvp;
+    const char* base = (const char*)(pre ? vp : vc);
+    const int k0 = (pre ? itc : itc - nvp) * DEC_VKEYS + fg, lim = pre ? P1 : tgen;
+#pragma unroll
+    for (int u = 0; u < DEC_VROWS; ++u) {
+      const unsigned jc = (unsigned)min(k0 + 4 * u, lim - 1);
+      t[u] = *(const x4*)(base + (jc * 64u + (unsigned)fr * 4u) * (unsigned)sizeof(T));  // uniform base + 32-bit byte offset
+    }
+  };
+  // the first V rows do not depend on the scores: request them before the softmax
+  x4 ta[DEC_VROWS], tb[DEC_VROWS];
+  load_v(ta, 0);
   mx = wave_max(mx);
   float sum = 0.f;
-  if (valid) {
-    for (int j = lane; j < ctx; j += 64) {
-      const float e = __expf(sc[j] - mx);
-      sc[j] = e;
-      sum += e;
-    }
+  for (int j = lane; j < ctx; j += 64) {
+    const float e = __expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
   }
   sum = wave_sum(sum);
   __syncthreads();  // every lane's sc[] writes are visible to the whole wave (and block)
-  const int fr = lane & 15, fg = lane >> 4;
   float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-  if (valid) {
-    // 8 independent row loads per lane group in flight: the loop is HBM-latency bound otherwise
-    for (int j0 = fg; j0 < ctx; j0 += 32) {
-      x4 t[8];
-      float p[8];
+  auto consume = [&](const x4 (&t)[DEC_VROWS], int it) {
+    const bool pre = it < nvp;
+    const int k0 = (pre ? it : it - nvp) * DEC_VKEYS + fg, lim = it < nit ? (pre ? P1 : tgen) : 0;
+    const float* scs = sc + (pre ? 0 : P1);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int j = j0 + 4 * u;
-        const int jc = j < ctx ? j : ctx - 1;
-        const T* vr = jc < P1 ? vp + (size_t)jc * 64 : vc + (size_t)(jc - P1) * 64;
-        t[u] = *(const x4*)(vr + fr * 4);
-        p[u] = j < ctx ? sc[j] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        o0 += p[u] * (float)t[u][0];
-        o1 += p[u] * (float)t[u][1];
-        o2 += p[u] * (float)t[u][2];
-        o3 += p[u] * (float)t[u][3];
-      }
+    for (int u = 0; u < DEC_VROWS; ++u) {
+      const int j = k0 + 4 * u;
+      const float pj = j < lim ? scs[j] : 0.f;
+      o0 += pj * (float)t[u][0];
+      o1 += pj * (float)t[u][1];
+      o2 += pj * (float)t[u][2];
+      o3 += pj * (float)t[u][3];
     }
+  };
+#pragma unroll 1
+  for (int it = 0; it < nit; it += 2) {  // two register sets: the next rows are in flight while these are summed
+    load_v(tb, it + 1);
+    __builtin_amdgcn_sched_barrier(0);  // fences keep exactly two row sets live (an early third set spills)
+    consume(ta, it);
+    __builtin_amdgcn_sched_barrier(0);
+    load_v(ta, it + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(tb, it + 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
   o0 += __shfl_xor(o0, 16, 64); o0 += __shfl_xor(o0, 32, 64);
   o1 += __shfl_xor(o1, 16, 64); o1 += __shfl_xor(o1, 32, 64);
   o2 += __shfl_xor(o2, 16, 64); o2 += __shfl_xor(o2, 32, 64);
   o3 += __shfl_xor(o3, 16, 64); o3 += __shfl_xor(o3, 32, 64);
-  if (valid && fg == 0) {
+  if ((int)blockIdx.x * 4 + wave < a.B * a.heads && fg == 0) {
     const float inv = 1.0f / sum;
     T* o = (T*)a.out + (size_t)b * a.heads * 64 + h * 64 + fr * 4;
     *(x4*)o = pack4<T>(o0 * inv, o1 * inv, o2 * inv, o3 * inv);
