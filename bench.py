@@ -218,10 +218,7 @@ def main():
     tdist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = tdist.max_over_ranks(dt)
     audio_s = float(wav.shape[-1]) / 24000.0
     assert torch.isfinite(wav).all() and wav.abs().max() <= 1.0
 

@@ -19,14 +19,25 @@ def init_from_env(device_index=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # TT_DIST_SHARE_DEVICE=1 is a TEST mode for boxes with fewer GPUs than ranks: ranks share devices and talk over
+    # gloo (RCCL refuses two ranks on one device).  It exercises the whole multi-rank control flow - sharding, the
+    # gather, winner selection, rank-0 rendering, timing reduction - not the xGMI transport.
+    share = os.environ.get("TT_DIST_SHARE_DEVICE") == "1"
     if torch.cuda.is_available():
-        torch.cuda.set_device(local if device_index is None else device_index)
+        if device_index is None:
+            device_index = local % torch.cuda.device_count() if share else local
+        torch.cuda.set_device(device_index)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = "nccl" if torch.cuda.is_available() and not share else "gloo"
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def _host_staged():
+    """gloo moves host memory: device tensors are staged through the CPU (CPU tests and the shared-device test mode)."""
+    return dist.get_backend() == "gloo"
 
 
 def world():
@@ -49,11 +60,14 @@ def gather_candidates(scores_local, codes_local):
     ws = dist.get_world_size()
     scores_local = scores_local.contiguous()
     codes_local = codes_local.to(torch.int32).contiguous()
+    dev = scores_local.device
+    if _host_staged() and dev.type != "cpu":
+        scores_local, codes_local = scores_local.cpu(), codes_local.cpu()
     s_all = torch.empty(ws * scores_local.shape[0], dtype=scores_local.dtype, device=scores_local.device)
     c_all = torch.empty(ws * codes_local.shape[0], codes_local.shape[1], dtype=torch.int32, device=codes_local.device)
     dist.all_gather_into_tensor(s_all, scores_local)
     dist.all_gather_into_tensor(c_all, codes_local)
-    return s_all, c_all
+    return s_all.to(dev), c_all.to(dev)
 
 
 def topk_lowest_index(scores, k):
@@ -66,3 +80,13 @@ def topk_lowest_index(scores, k):
 def barrier():
     if dist.is_initialized():
         dist.barrier()
+
+
+def max_over_ranks(value):
+    """MAX of a host scalar over all ranks (bench.py's timing contract)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    dev = "cpu" if _host_staged() or not torch.cuda.is_available() else "cuda"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
