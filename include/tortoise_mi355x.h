@@ -216,6 +216,21 @@ int tt_diff_forward(tt_diff* h, const float* x, int timestep, int cond_free, flo
 int tt_diff_sample(tt_diff* h, const float* x_T, const float* step_noise, const tt_diff_step* steps_host, int n_steps,
                    int cond_free, float* mel_out, void* stream);
 
+/* Split sampling (the reference evaluates both rows on one device, utils/diffusion.py:340-384): the
+ * conditioned and the conditioning-free denoiser rows of ONE utterance run on two GPUs.  Every participant holds the
+ * full sampler state (x, schedule, noise) and evaluates one row per step; the host exchanges the rows (one all_gather
+ * of f32 [S][out_channels] per step) and every participant applies the identical p_sample update, so the states stay
+ * bit-identical without a second exchange.  Per step: split_forward -> exchange -> split_update.
+ *   begin  : tt_diff_sample's setup for n_steps; row = 0 conditioned, 1 conditioning-free; captures the row's hipGraph
+ *   forward: this participant's model row of the current step -> out_row f32 [S][out_channels]
+ *   update : rows f32 [2][S][out_channels] (row 0 conditioned, row 1 conditioning-free); step_noise as tt_diff_sample;
+ *            mel_out f32 [in_channels][S] is rewritten every step (the last write is x_0 denormalised)
+ *   end    : waits for the handle's stream and frees the graph */
+int tt_diff_split_begin(tt_diff* h, const float* x_T, const tt_diff_step* steps_host, int n_steps, int row, void* stream);
+int tt_diff_split_forward(tt_diff* h, float* out_row, void* stream);
+int tt_diff_split_update(tt_diff* h, const float* rows, const float* step_noise, float* mel_out, void* stream);
+int tt_diff_split_end(tt_diff* h);
+
 /* ============================================================================================
  * Stage 3 — UnivNetGenerator.inference   (reference: tortoise/models/vocoder.py:300-312, api.py:559)
  * ============================================================================================ */

@@ -62,3 +62,40 @@ def test_shard_range_and_topk_rules():
         pass
     s = torch.tensor([1.0, 3.0, 3.0, 2.0])
     assert tdist.topk_lowest_index(s, 2).tolist() == [1, 2]
+
+
+def _split_worker(rank, world, port, out_dir):
+    """The split diffusion tail's host protocol with a stand-in denoiser: rank r < 2 produces row r of every step,
+    the pair exchanges rows, both apply the same update -> identical state on ranks 0 and 1; rank 2 takes no part."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    tdist.init_from_env()
+    tdist._PAIR = None
+    assert tdist.pair_group() is not None  # collective: every rank, including non-members, creates it
+    seed = tdist.broadcast_int(1234 + rank)  # rank 0's value wins
+    assert seed == 1234
+    assert tdist.max_over_ranks(float(rank)) == float(world - 1)
+    if rank < 2:
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(7, 5, generator=g)
+        rows = torch.empty(2, 7, 5)
+        for step in range(4):
+            mine = x * (rank + 1) + step  # "model row" of this participant
+            tdist.exchange_rows(rows, mine)
+            assert torch.equal(rows[rank], mine)
+            x = 0.5 * x + 0.25 * (rows[0] - rows[1])
+        np.save(os.path.join(out_dir, f"x_{rank}.npy"), x.numpy())
+    tdist.barrier()
+    dist.destroy_process_group()
+
+
+def test_split_tail_protocol_keeps_pair_in_lockstep(tmp_path):
+    world = 3
+    mp.spawn(_split_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    x0, x1 = np.load(tmp_path / "x_0.npy"), np.load(tmp_path / "x_1.npy")
+    assert np.array_equal(x0, x1)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(7, 5, generator=g)
+    for step in range(4):
+        x = 0.5 * x + 0.25 * ((x * 1 + step) - (x * 2 + step))
+    assert np.array_equal(x0, x.numpy())
+

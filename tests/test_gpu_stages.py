@@ -205,3 +205,50 @@ def test_diffusion_full_width_short_sequence():
     want = O.denormalize_tacotron_mel(O.p_sample_loop(sd, cfg, O.Schedule(N, 4000, True, 2.0), emb, x.clone(), step_noise))
     report("full-width p_sample_loop mel vs oracle", mel, want, tol * 2)
     st.close()
+
+
+@torch.no_grad()
+def test_diffusion_split_rows_match_batched_sampling():
+    """Split sampling (tt_diff_split_*): two engines stand in for two GPUs, one evaluating the
+    conditioned row and one the conditioning-free row of every step, exchanging rows and applying the same update.
+    Must agree with the batched single-engine p_sample_loop (and therefore the oracle) and keep both participants'
+    states identical.  Full width so the fused-statistics GEMM path is the one exercised."""
+    cfg = DiffusionConfig(model_channels=1024, num_layers=2, in_latent_channels=1024, num_heads=16)
+    tdt, dt, tol = torch.bfloat16, E.TT_BF16, 2.5e-2
+    sd = quantize_sd(W.synthetic_state_dict(W.diffusion_manifest(cfg), seed=21), tdt)
+    g = torch.Generator().manual_seed(6)
+    M = 40
+    S = M * 4 * 24000 // 22050
+    latents = torch.randn(1, M, 1024, generator=g)
+    cond = torch.randn(1, 2048, generator=g)
+    x = torch.randn(1, 100, S, generator=g)
+    N = 5
+    step_noise = torch.randn(N, 1, 100, S, generator=g)
+    sched = Schedule(N, 4000, True, 2.0)
+    parts = [stages.DiffusionStage(sd, cfg, dtype=dt, max_seq=256, max_codes=64, max_steps=16) for _ in range(2)]
+    for st in parts:
+        st.condition(latents, cond, S)
+    whole = parts[0].sample(sched, x, step_noise)
+    for r, st in enumerate(parts):
+        assert st.split_begin(sched, x, step_noise, r) == N
+    rows = torch.empty(2, S, cfg.out_channels, device="cuda")
+    for _ in range(N):
+        for r, st in enumerate(parts):
+            rows[r].copy_(st.split_forward())  # the all_gather of the two-GPU run
+        for st in parts:
+            st.split_update(rows)
+    mels = [st.split_end() for st in parts]
+    assert torch.equal(mels[0], mels[1]), "participants diverged"
+    # The conditioned row is bit-identical to the batched run (statistics-emitting GEMMs keep one tile shape); the conditioning-free row sits at batch index 1 there
+    # and 0 here, so its GroupNorm partial sums are grouped differently (~1e-7), which flips occasional bf16 roundings
+    # of the next GEMM operand; five recursive steps with guidance scale <= 3 amplify that to ~6e-3.  Same bar as the
+    # engine-vs-oracle comparison below.
+    report("split-row p_sample_loop mel vs batched engine", mels[0], whole, tol)
+    emb = O.diffusion_timestep_independent(sd, cfg, latents, cond, S)
+    want = O.denormalize_tacotron_mel(O.p_sample_loop(sd, cfg, O.Schedule(N, 4000, True, 2.0), emb, x.clone(), step_noise))
+    report("split-row p_sample_loop mel vs oracle", mels[0], want, tol * 2)
+    with pytest.raises(E.EngineError):
+        parts[0].split_forward()  # ended: must fail loudly, not reuse a stale graph
+    for st in parts:
+        st.close()
+

@@ -86,6 +86,11 @@ class TextToSpeech:
                                       "always runs its own fused HIP path")
         self.enable_redaction = False  # wav2vec2 redaction is outside the hot path
         self.rank, self.world = tdist.world()
+        # With >= 2 ranks a single winner's diffusion tail is split over ranks 0 and 1 (conditioned / conditioning-free
+        # row each, one exchange per step).  TT_SPLIT_DIFFUSION=0 keeps the whole tail on rank 0.
+        self.split_diffusion = self.world >= 2 and os.environ.get("TT_SPLIT_DIFFUSION", "1") != "0"
+        if self.split_diffusion:
+            tdist.pair_group()  # collective over all ranks: create it once, here, where every rank passes
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
         if device is None or torch.device(device).type != "cuda":
@@ -152,6 +157,7 @@ class TextToSpeech:
     def deterministic_state(self, seed=None):
         """api.py:598-609."""
         seed = int(torch.seed() % (2 ** 31)) if seed is None else int(seed)
+        seed = tdist.broadcast_int(seed)  # every rank must draw the same noise and key the same Philox streams
         torch.manual_seed(seed)
         random.seed(seed)
         return seed
@@ -255,16 +261,22 @@ class TextToSpeech:
         scores_all, codes_all = tdist.gather_candidates(scores, fixed.to(torch.int32))
         best = tdist.topk_lowest_index(scores_all, k)
         best_results = codes_all[best].long()
+        self.last_best_codes = best_results  # the k ranked winners' codes (tests, sharding checks)
         ev[2].record()
 
         # ---- AR latent re-pass for the winners (api.py:516-524)
         best_latents = self.ar.latents(auto_conditioning, text_tokens, best_results)
         ev[3].record()
 
-        # ---- stage 2 + 3 per winner; winners are spread round-robin over the ranks
+        # ---- stage 2 + 3 per winner; winners are spread round-robin over the ranks.  A single winner with
+        # conditioning_free is rendered by ranks 0 and 1 together: rank r evaluates denoiser row r of every step.
+        split = self.split_diffusion and k == 1 and bool(sched.cond_free)
         wavs = {}
         for i in range(k):
-            if i % self.world != self.rank:
+            if split:
+                if self.rank > 1:
+                    continue
+            elif i % self.world != self.rank:
                 continue
             codes_i = best_results[i]
             latents = best_latents[i:i + 1]
@@ -278,7 +290,12 @@ class TextToSpeech:
             step_noise = noise.get("step_noise")
             if step_noise is None:
                 step_noise = torch.randn(sched.num_timesteps, 1, 100, S, device=dev, generator=gen)
-            mel = self.diffusion.sample(sched, x_T, step_noise)
+            if split:
+                mel = self.diffusion.sample_split(sched, x_T, step_noise, self.rank, tdist.exchange_rows)
+                if self.rank != 0:
+                    continue  # rank 1 only lends its GPU to the tail; rank 0 holds the same mel and runs the vocoder
+            else:
+                mel = self.diffusion.sample(sched, x_T, step_noise)
             ev[4].record()
             z = noise.get("z")
             z = torch.randn(1, self.voc_cfg.noise_dim, S + 10, device=dev, generator=gen) if z is None else z.to(dev)

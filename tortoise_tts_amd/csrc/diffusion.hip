@@ -51,6 +51,10 @@ struct tt_diff {
   float* x = nullptr;          // [S][in]
   void* x_t = nullptr;         // [2][S][in_pad] T
   float* out = nullptr;        // [2][S][out]
+  // split sampling: this handle evaluates one denoiser row per step
+  hipGraph_t split_graph = nullptr;
+  hipGraphExec_t split_exec = nullptr;
+  int split_row = -1, split_steps = 0, split_done = 0;
 };
 
 static int run_gn(tt_diff* e, const float* x, int B, int S, const float* g, const float* b, const float* ss, bool ss_slotted,
@@ -121,12 +125,13 @@ static int run_res_block(tt_diff* e, const tt_res_block& w, const float* ss, con
 }
 
 // One denoiser evaluation on B batch rows (B = 2: conditioned + unconditioned); the schedule slot is *e->slot.
-static int diff_forward(tt_diff* e, int B, hipStream_t s) {
+// B batch rows starting at conditioning row `row0` (0 = conditioned embedding, 1 = unconditioned embedding)
+static int diff_forward(tt_diff* e, int B, hipStream_t s, int row0 = 0) {
   const int C = e->C, S = e->S, dt = e->cfg.dtype, M = B * S, L = e->cfg.num_layers;
   const float* ss = e->ss_all;  // + *slot * NR*2C inside the GroupNorm kernel
   e->stats_ptr = nullptr;       // no epilogue statistics are valid at the start of a pass
   // conditioning_timestep_integrator: 3 DiffusionLayers over the [cond | uncond] code embeddings
-  const float* cur = e->code_emb;
+  const float* cur = e->code_emb + (size_t)row0 * S * C;
   for (int i = 0; i < 3; ++i) {
     TT_TRY(run_res_block(e, e->res[i], ss + (size_t)i * 2 * C, cur, B, S, e->tmp_a, s));
     if (i < 2) {
@@ -191,6 +196,15 @@ static int diff_prepare_timesteps(tt_diff* e, int n, hipStream_t s) {
   return gemm_launch(dt, EPI_STD, g, s);
 }
 
+static void split_release(tt_diff* e) {
+  if (e->split_exec) (void)hipGraphExecDestroy(e->split_exec);
+  if (e->split_graph) (void)hipGraphDestroy(e->split_graph);
+  e->split_exec = nullptr;
+  e->split_graph = nullptr;
+  e->split_row = -1;
+  e->split_steps = e->split_done = 0;
+}
+
 extern "C" {
 
 int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff** out) {
@@ -244,6 +258,7 @@ int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff*
 void tt_diff_destroy(tt_diff* e) {
   if (!e) return;
   (void)hipDeviceSynchronize();
+  split_release(e);
   e->arena.release();
   e->sb.destroy();
   delete e;
@@ -353,6 +368,83 @@ int tt_diff_sample(tt_diff* e, const float* x_T, const float* step_noise, const 
   }
   TT_TRY(rc);
   return e->sb.leave(us);
+}
+
+int tt_diff_split_begin(tt_diff* e, const float* x_T, const tt_diff_step* steps_host, int n_steps, int row, void* stream) {
+  TT_REQUIRE(e && x_T && steps_host && e->S > 0, "tt_diff_split_begin: call tt_diff_condition first");
+  TT_REQUIRE(n_steps >= 1 && n_steps <= e->cfg.max_steps, "tt_diff_split_begin: %d steps exceed capacity %d", n_steps, e->cfg.max_steps);
+  TT_REQUIRE(row == 0 || row == 1, "tt_diff_split_begin: row must be 0 (conditioned) or 1 (conditioning-free)");
+  split_release(e);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  const int S = e->S, IC = e->cfg.in_channels, IP = e->cfg.in_pad, dt = e->cfg.dtype;
+  std::vector<int> ts(n_steps);
+  for (int i = 0; i < n_steps; ++i) ts[i] = steps_host[i].timestep;
+  TT_CHECK_HIP(hipMemcpyAsync(e->ts_dev, ts.data(), n_steps * sizeof(int), hipMemcpyHostToDevice, s));
+  TT_CHECK_HIP(hipMemcpyAsync(e->steps_dev, steps_host, n_steps * sizeof(tt_diff_step), hipMemcpyHostToDevice, s));
+  TT_CHECK_HIP(hipStreamSynchronize(s));  // host staging buffers may go away
+  TT_CHECK_HIP(hipMemsetAsync(e->slot, 0, sizeof(int), s));
+  TT_TRY(diff_prepare_timesteps(e, n_steps, s));
+  TT_TRY(transpose_launch(x_T, e->x, IC, S, s));  // [C][S] -> [S][C]
+  TT_TRY(cast_pad_launch(dt, e->x, IC, e->x_t, IP, S, IC, IP, s));
+  TT_TRY(cast_pad_launch(dt, e->x, IC, offset_t(e->x_t, (size_t)S * IP), IP, S, IC, IP, s));
+  int rc = 0;
+  if (graphs_enabled()) {
+    TT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    rc = diff_forward(e, 1, s, row);
+    hipError_t ce = hipStreamEndCapture(s, &e->split_graph);
+    if (!rc && ce != hipSuccess) { set_error("tt_diff_split_begin: capture failed: %s", hipGetErrorString(ce)); rc = -2; }
+    if (!rc) {
+      ce = hipGraphInstantiate(&e->split_exec, e->split_graph, nullptr, nullptr, 0);
+      if (ce != hipSuccess) { set_error("tt_diff_split_begin: instantiate failed: %s", hipGetErrorString(ce)); rc = -2; }
+    }
+    if (rc) split_release(e);
+  }
+  TT_TRY(rc);
+  e->split_row = row;
+  e->split_steps = n_steps;
+  e->split_done = 0;
+  return e->sb.leave(us);
+}
+
+int tt_diff_split_forward(tt_diff* e, float* out_row, void* stream) {
+  TT_REQUIRE(e && out_row && e->split_row >= 0, "tt_diff_split_forward: call tt_diff_split_begin first");
+  TT_REQUIRE(e->split_done < e->split_steps, "tt_diff_split_forward: all %d steps already ran", e->split_steps);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  if (e->split_exec) {
+    hipError_t ce = hipGraphLaunch(e->split_exec, s);
+    if (ce != hipSuccess) { set_error("tt_diff_split_forward: hipGraphLaunch: %s", hipGetErrorString(ce)); return -2; }
+  } else {
+    TT_TRY(diff_forward(e, 1, s, e->split_row));
+  }
+  TT_CHECK_HIP(hipMemcpyAsync(out_row, e->out, (size_t)e->S * e->cfg.out_channels * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return e->sb.leave(us);
+}
+
+int tt_diff_split_update(tt_diff* e, const float* rows, const float* step_noise, float* mel_out, void* stream) {
+  TT_REQUIRE(e && rows && mel_out && e->split_row >= 0, "tt_diff_split_update: call tt_diff_split_begin first");
+  TT_REQUIRE(e->split_done < e->split_steps, "tt_diff_split_update: all %d steps already ran", e->split_steps);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  PSampleArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.steps = e->steps_dev; pa.slot = e->slot; pa.x = e->x; pa.x_t = e->x_t; pa.cpad = e->cfg.in_pad; pa.out = rows;
+  pa.has_uncond = 1; pa.noise = step_noise; pa.S = e->S; pa.C = e->cfg.in_channels;
+  pa.mel_out = mel_out;
+  pa.mel_scale = 2.3143386840820312f - (-11.512925148010254f);
+  pa.mel_shift = -11.512925148010254f;
+  TT_TRY(psample_launch(e->cfg.dtype, pa, s));
+  TT_TRY(slot_advance_launch(e->slot, s));
+  e->split_done += 1;
+  return e->sb.leave(us);
+}
+
+int tt_diff_split_end(tt_diff* e) {
+  TT_REQUIRE(e != nullptr, "tt_diff_split_end: null handle");
+  TT_CHECK_HIP(hipStreamSynchronize(e->sb.own));
+  split_release(e);
+  return 0;
 }
 
 }  // extern "C"

@@ -699,12 +699,15 @@ static int pick_tile(const GemmArgs& a) {
   if (tile < 0) {
     // Direct-to-LDS kernels by default (measured on MI355X, scripts/kbench.py):
     //   >= 256 tiles of 128x128 : 128x128, 8 waves, 2 stages (highest flop per L2 byte; 2 blocks per CU)
-    //   fewer, M > 256          : 128x64, 8 waves, 4-stage ring (more blocks, 3 tiles in flight)
-    //   decode / small M        : 64x64, 4 waves, 4-stage ring (weights stream from HBM: depth hides latency)
+    //   fewer, M > 1024         : 128x64, 8 waves, 4-stage ring (more blocks, 3 tiles in flight)
+    //   decode / M <= 1024      : 64x64, 4 waves, 4-stage ring (weights stream from HBM: depth hides latency)
     const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk;
+    // A GEMM that emits GroupNorm statistics keeps the 128x64 tile for every M > 256: the statistics are grouped per
+    // wave tile, so the same tile at one and at two batch rows keeps the denoiser's conditioned row bit-identical
+    // whether it is evaluated alone (split tail) or batched with the conditioning-free row.
     if (a.M > 256 && b128 >= 256) tile = 6;
-    else if (a.M > 256) tile = 10;
-    else tile = 11;
+    else if (a.M > 1024 || (a.M > 256 && a.gn_part != nullptr)) tile = 10;
+    else tile = 11;  // also one denoiser row (M = S <= 1024, the split diffusion tail): 2x the workgroups of 128x64
   }
   if (tile == 3 && (a.cin % 256 != 0 || (a.K / 256) < a.splitk)) tile = 0;
   if (a.w_packed && tile < 6) tile = a.M > 256 ? 10 : 11;  // only the direct-to-LDS kernels read tile-packed weights

@@ -82,6 +82,39 @@ def barrier():
         dist.barrier()
 
 
+_PAIR = None
+
+
+def pair_group():
+    """Process group {0, 1} for the split diffusion tail (created once; new_group is collective over ALL ranks)."""
+    global _PAIR
+    if _PAIR is None and dist.is_initialized() and dist.get_world_size() >= 2:
+        _PAIR = dist.new_group([0, 1])
+    return _PAIR
+
+
+def exchange_rows(rows, mine):
+    """rows[r] <- participant r's `mine` over the pair group: the per-step exchange of the split diffusion tail
+    (f32 [S][200] per rank, ~0.7 MB at S = 870; xGMI point-to-point between GPU 0 and GPU 1)."""
+    group = pair_group()
+    if _host_staged() and mine.device.type != "cpu":
+        host = torch.empty(rows.shape, dtype=rows.dtype)
+        dist.all_gather_into_tensor(host.view(-1), mine.cpu().view(-1), group=group)
+        rows.copy_(host)
+    else:
+        dist.all_gather_into_tensor(rows.view(-1), mine.contiguous().view(-1), group=group)
+
+
+def broadcast_int(value, src=0):
+    """`value` of rank `src` on every rank (host integer; e.g. the utterance seed)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(value)
+    dev = "cpu" if _host_staged() or not torch.cuda.is_available() else "cuda"
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=src)
+    return int(t.item())
+
+
 def max_over_ranks(value):
     """MAX of a host scalar over all ranks (bench.py's timing contract)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

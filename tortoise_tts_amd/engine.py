@@ -119,6 +119,10 @@ _PROTOS = {
     "tt_diff_get_code_emb": (_i, [vp, vp, vp]),
     "tt_diff_forward": (_i, [vp, vp, _i, _i, vp, vp]),
     "tt_diff_sample": (_i, [vp, vp, vp, C.POINTER(DiffStep), _i, _i, vp, vp]),
+    "tt_diff_split_begin": (_i, [vp, vp, C.POINTER(DiffStep), _i, _i, vp]),
+    "tt_diff_split_forward": (_i, [vp, vp, vp]),
+    "tt_diff_split_update": (_i, [vp, vp, vp, vp, vp]),
+    "tt_diff_split_end": (_i, [vp]),
     "tt_voc_create": (_i, [C.POINTER(VocConfig), C.POINTER(VocWeights), C.POINTER(vp)]),
     "tt_voc_destroy": (None, [vp]),
     "tt_voc_run": (_i, [vp, vp, _i, vp, vp, vp]),

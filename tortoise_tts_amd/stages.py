@@ -223,9 +223,9 @@ class DiffusionStage:
         E.check(self.lib.tt_diff_forward(self.h, E.ptr(xt), int(timestep), int(cond_free), E.ptr(out), E.stream_ptr()))
         return out.permute(0, 2, 1)
 
-    def sample(self, sched: Schedule, x_T, step_noise):
-        """x_T f32 [1, 100, S]; step_noise f32 [N, 1, 100, S] with step_noise[i] the draw of spaced index i
-        (same convention as the oracle).  Returns the denormalised mel [1, 100, S]."""
+    @staticmethod
+    def _run_order_steps(sched: Schedule):
+        """tt_diff_step records in the order the steps run (i = N-1 ... 0) + that order."""
         N = sched.num_timesteps
         steps = (E.DiffStep * N)()
         order = list(reversed(range(N)))
@@ -240,11 +240,58 @@ class DiffusionStage:
             st.coef1 = sched.f32(sched.coef1, i)
             st.coef2 = sched.f32(sched.coef2, i)
             st.nonzero = 0.0 if i == 0 else 1.0
+        return steps, order
+
+    def sample(self, sched: Schedule, x_T, step_noise):
+        """x_T f32 [1, 100, S]; step_noise f32 [N, 1, 100, S] with step_noise[i] the draw of spaced index i
+        (same convention as the oracle).  Returns the denormalised mel [1, 100, S]."""
+        N = sched.num_timesteps
+        steps, order = self._run_order_steps(sched)
         x = x_T[0].to(self.device).float().contiguous()
         noise = step_noise.to(self.device).float()[order, 0].contiguous()  # run order
         mel = torch.empty(self.cfg.in_channels, self.S, device=self.device, dtype=torch.float32)
         E.check(self.lib.tt_diff_sample(self.h, E.ptr(x), E.ptr(noise), steps, N, int(sched.cond_free), E.ptr(mel), E.stream_ptr()))
         return mel[None]
+
+    # ---- split sampling (SURVEY.md §8f-2): this engine evaluates ONE denoiser row per step ---------------------
+    def split_begin(self, sched: Schedule, x_T, step_noise, row):
+        """row 0 = conditioned, 1 = conditioning-free.  Keeps the run-order noise and the output buffers alive."""
+        if not sched.cond_free:
+            raise ValueError("split sampling needs conditioning_free (two rows per step)")
+        steps, order = self._run_order_steps(sched)
+        x = x_T[0].to(self.device).float().contiguous()
+        self._split_noise = step_noise.to(self.device).float()[order, 0].contiguous()
+        self._split_mel = torch.empty(self.cfg.in_channels, self.S, device=self.device, dtype=torch.float32)
+        self._split_row = torch.empty(self.S, self.cfg.out_channels, device=self.device, dtype=torch.float32)
+        E.check(self.lib.tt_diff_split_begin(self.h, E.ptr(x), steps, sched.num_timesteps, int(row), E.stream_ptr()))
+        torch.cuda.current_stream().synchronize()  # `x` and `steps` are consumed
+        return sched.num_timesteps
+
+    def split_forward(self):
+        """This engine's model row of the current step: f32 [S, out_channels] (valid until the next call)."""
+        E.check(self.lib.tt_diff_split_forward(self.h, E.ptr(self._split_row), E.stream_ptr()))
+        return self._split_row
+
+    def split_update(self, rows):
+        """rows f32 [2, S, out_channels]: row 0 conditioned, row 1 conditioning-free (from both participants)."""
+        assert rows.shape == (2, self.S, self.cfg.out_channels) and rows.is_contiguous() and rows.dtype == torch.float32
+        E.check(self.lib.tt_diff_split_update(self.h, E.ptr(rows), E.ptr(self._split_noise), E.ptr(self._split_mel), E.stream_ptr()))
+
+    def split_end(self):
+        E.check(self.lib.tt_diff_split_end(self.h))
+        mel = self._split_mel[None]
+        self._split_noise = self._split_row = self._split_mel = None
+        return mel
+
+    def sample_split(self, sched: Schedule, x_T, step_noise, row, exchange):
+        """p_sample_loop with the two rows on two participants.  `exchange(rows, mine)` fills rows[r] with
+        participant r's `mine` (an all_gather over the pair, tortoise_tts_amd/dist.py)."""
+        n = self.split_begin(sched, x_T, step_noise, row)
+        rows = torch.empty(2, self.S, self.cfg.out_channels, device=self.device, dtype=torch.float32)
+        for _ in range(n):
+            exchange(rows, self.split_forward())
+            self.split_update(rows)
+        return self.split_end()
 
 
 class VocoderStage:
