@@ -239,7 +239,9 @@ def main():
                                    f"CLVP top-1, {preset_kw['diffusion_iterations']} diffusion iterations cond_free={preset_kw.get('cond_free', True)}, "
                                    f"UnivNet; 55 text tokens; {audio_s:.2f} s of 24 kHz audio per step",
                        "weights": "seeded synthetic at the reference hyper-parameters (no checkpoints offline)",
-                       "parallelism": f"candidates sharded {N // world}/GPU ({args.decode_streams} concurrent decode streams per GPU), 1 all_gather, winner rendered on rank 0"},
+                       "parallelism": f"candidates sharded {N // world}/GPU ({args.decode_streams} concurrent decode streams per GPU), 1 all_gather of scores+codes, "
+                                      + ("winner's diffusion tail split over ranks 0/1 (one denoiser row each, 1 exchange per step), vocoder on rank 0"
+                                         if tts.split_diffusion else "winner rendered on rank 0")},
             "stages_s_per_step": {k_: v / args.steps for k_, v in stage_acc.items()},
             "audio_seconds_per_step": audio_s, "engine_build_s": t_build,
             "roofline": roof, "cpu_baseline": cpu,
