@@ -7,12 +7,16 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=$PWD/gpurun_out/pmc_bench
 rm -rf $OUT; mkdir -p $OUT
-for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o p -- \
+# PMC_SETS: ';'-separated counter sets, one rocprofv3 pass each (default: the two HBM-traffic counters); PMC_JSON: output name
+IFS=';' read -ra SETS <<< "${PMC_SETS:-FETCH_SIZE;WRITE_SIZE}"
+i=0
+for set in "${SETS[@]}"; do
+  i=$((i+1)); c=pass$i
+  (cd /tmp && timeout 900 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$c -o p -- \
      env TT_NO_GRAPH=1 python $OLDPWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/$c.log 2>&1)
-  echo "pmc $c rc=$?" | tee -a $OUT/summary.txt
+  echo "pmc [$set] rc=$?" | tee -a $OUT/summary.txt
 done
-OUT=$OUT python - <<'PY'
+OUT=$OUT PMC_JSON=${PMC_JSON:-pmc_bench.json} python - <<'PY'
 import csv, glob, collections, json, os, re
 out = os.environ["OUT"]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
@@ -33,7 +37,7 @@ for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
 res = {}
 for k, cs in agg.items():
     res[k] = {c: {"dispatches": v[0], "sum": v[1], "avg": v[1] / max(v[0], 1)} for c, v in cs.items()}
-json.dump(res, open(out + "/../pmc_bench.json", "w"), indent=1, sort_keys=True)
+json.dump(res, open(out + "/../" + os.environ["PMC_JSON"], "w"), indent=1, sort_keys=True)
 for k in sorted(res):
     print(k, {c: round(v["avg"], 1) for c, v in res[k].items()}, {c: v["dispatches"] for c, v in res[k].items()})
 PY
