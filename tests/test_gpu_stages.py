@@ -112,6 +112,54 @@ def test_ar_generate_injected_noise_and_sharding_invariance():
     st.close()
 
 
+@torch.no_grad()
+def test_ar_generate_stop_token_ragged_rows_and_early_exit():
+    """Stop token NOT suppressed (its logit is raised so rows finish at different steps): the decode loop must follow
+    GenerationMixin.sample's finished-row rule (stream_generator.py:980-996: `tok * unfinished + pad * (1 - unfinished)`,
+    stop when every row is finished) and return exactly the steps the reference would have run, even though the engine
+    polls the unfinished counter only every 8 steps."""
+    cfg = ARConfig(**G.AR_CFG)
+    tdt = torch.float16
+    sd = quantize_sd(W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.AR_SEED), tdt)
+    bias = sd["mel_head.bias"].clone()
+    bias[cfg.stop_mel_token] += 4.0
+    sd["mel_head.bias"] = bias
+    cond, text = G.ar_inputs(cfg)
+    B, steps = 6, 48
+    gen = torch.Generator().manual_seed(3)
+    noise = torch.empty(steps, B, cfg.number_mel_codes).exponential_(1, generator=gen)
+    want = O.ar_sample_loop(sd, cfg, cond, text, B, steps, noise)
+    st = stages.ArStage(sd, cfg, dtype=E.TT_F16, max_batch=8, max_text=40, max_new_tokens=64, max_latent_candidates=2)
+    st.prefill(cond, text)
+    got, n = st.generate(B, steps, exp_noise=noise)
+    got = got.cpu()
+    stop = cfg.stop_mel_token
+
+    def first_stop(row):
+        idx = (row == stop).nonzero()
+        return int(idx[0]) if idx.numel() else len(row)
+    fs_got, fs_want = [first_stop(r) for r in got], [first_stop(r) for r in want]
+    print(f"[parity] AR ragged stops: engine {fs_got} (n={n}) oracle {fs_want} (n={want.shape[1]})")
+    assert got.shape == (B, n) and 1 <= n <= steps
+    for r, f in zip(got, fs_got):
+        assert (r[f:] == stop).all(), "a finished row emitted something other than the stop token"
+    assert min(fs_got) < max(fs_got), "rows did not finish at different steps: the test lost its point"
+    if max(fs_got) < steps:  # every row finished: the loop must have stopped exactly one step after the last finisher
+        assert n == max(fs_got) + 1
+    same = sum(int(a == b) for a, b in zip(fs_got, fs_want))
+    assert same >= B // 2, "stop positions disagree with the oracle on most rows"
+    if fs_got == fs_want:
+        assert n == want.shape[1]
+        assert float((got == want).float().mean()) >= 0.9
+    # integer post-processing on the ragged rows is bit-exact against the oracle's restatement (api.py:87-114, 425-426)
+    from tortoise_tts_amd.api import fix_autoregressive_output
+    import torch.nn.functional as F
+    padded = F.pad(got, (0, steps + 2 - n), value=stop)
+    want_fixed = np.stack([O.fix_autoregressive_output(r.numpy(), stop) for r in padded])
+    assert np.array_equal(fix_autoregressive_output(padded.clone(), stop).numpy(), want_fixed)
+    st.close()
+
+
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
 @torch.no_grad()
 def test_clvp(name, dt, tdt, tol):
