@@ -31,6 +31,7 @@ CLVP_SEED, CLVP_B, CLVP_T, CLVP_N = 13, 3, 13, 40
 DIFF_CFG = dict(model_channels=128, num_layers=2, in_latent_channels=128, num_heads=2)
 DIFF_SEED, DIFF_M, DIFF_STEPS, DIFF_TS = 14, 12, 5, 2999
 VOC_SEED, VOC_S = 15, 6
+COND_SEED, COND_CLIPS, COND_T_AR, COND_T_DIFF = 16, 2, 37, 44
 
 
 def ar_inputs(cfg):
@@ -63,6 +64,12 @@ def diff_inputs(cfg):
     x = torch.randn(1, 100, S, generator=g)
     step_noise = torch.randn(DIFF_STEPS, 1, 100, S, generator=g)
     return S, latents, cond, x, step_noise
+
+
+def cond_inputs():
+    """Two voice clips as mel spectrograms for both conditioning encoders (api.py:258-299 builds these from audio)."""
+    g = torch.Generator().manual_seed(COND_SEED)
+    return (torch.randn(1, COND_CLIPS, 80, COND_T_AR, generator=g), torch.randn(1, COND_CLIPS, 100, COND_T_DIFF, generator=g))
 
 
 def voc_inputs():
@@ -178,6 +185,22 @@ def golden_vocoder(ref):
     np.savez_compressed(os.path.join(OUT, "vocoder.npz"), wav=wav.numpy())
 
 
+@torch.no_grad()
+def golden_conditioning(ref):
+    """get_conditioning of both models on the small AR / diffusion configurations."""
+    a_cfg, d_cfg = ARConfig(**AR_CFG), DiffusionConfig(**DIFF_CFG)
+    a_sd = W.synthetic_state_dict(W.ar_manifest(a_cfg), seed=COND_SEED)
+    d_sd = W.synthetic_state_dict(W.diffusion_manifest(d_cfg), seed=COND_SEED + 1)
+    m = build_ref_ar(ref, a_cfg, a_sd)
+    d = ref.DiffusionTts(model_channels=d_cfg.model_channels, num_layers=d_cfg.num_layers, in_channels=d_cfg.in_channels,
+                         out_channels=d_cfg.out_channels, in_latent_channels=d_cfg.in_latent_channels, in_tokens=d_cfg.in_tokens,
+                         dropout=0, use_fp16=False, num_heads=d_cfg.num_heads, layer_drop=0, unconditioned_percentage=0).eval()
+    d.load_state_dict(d_sd, strict=True)
+    mel_ar, mel_diff = cond_inputs()
+    np.savez_compressed(os.path.join(OUT, "conditioning.npz"), auto_latent=m.get_conditioning(mel_ar).numpy(),
+                        diffusion_latent=d.get_conditioning(mel_diff).numpy())
+
+
 def golden_integer():
     src = open(os.path.join(ref_shims.REFERENCE_ROOT, "tortoise", "api.py")).read()
     tree = ast.parse(src)
@@ -205,6 +228,7 @@ def main():
     golden_clvp(ref)
     golden_diffusion(ref)
     golden_vocoder(ref)
+    golden_conditioning(ref)
     golden_integer()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

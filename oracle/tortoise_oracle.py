@@ -380,6 +380,37 @@ def attention_block(sd, prefix, x, heads):
     return x + F.conv1d(a, sd[f"{prefix}.proj_out.weight"], sd[f"{prefix}.proj_out.bias"])
 
 
+def ar_get_conditioning(sd, cfg: ARConfig, mels):
+    """UnifiedVoice.get_conditioning over ConditioningEncoder (autoregressive.py:204-228, 444-452): per clip
+    conv1x1(80 -> D) -> 6 AttentionBlocks (no relative positions) -> time step 0; mean over clips.
+    mels f32 [1, n_clips, 80, T] -> [1, D].  (conditioning front-end, oracle side.)"""
+    conds = []
+    for j in range(mels.shape[1]):
+        h = F.conv1d(mels[:, j].float(), sd["conditioning_encoder.init.weight"], sd["conditioning_encoder.init.bias"])
+        i = 0
+        while f"conditioning_encoder.attn.{i}.norm.weight" in sd:
+            h = attention_block(sd, f"conditioning_encoder.attn.{i}", h, cfg.heads)
+            i += 1
+        conds.append(h[:, :, 0])
+    return torch.stack(conds, dim=1).mean(dim=1)
+
+
+def diffusion_get_conditioning(sd, cfg: DiffusionConfig, mels):
+    """DiffusionTts.get_conditioning over contextual_embedder (diffusion_decoder.py:186-192, 222-230): per clip
+    conv k3 stride 2 (100 -> C), conv k3 stride 2 (C -> 2C), 5 AttentionBlocks with relative positions; the clips are
+    concatenated along time and averaged.  mels f32 [1, n_clips, 100, T] -> [1, 2C]."""
+    outs = []
+    for j in range(mels.shape[1]):
+        h = F.conv1d(mels[:, j].float(), sd["contextual_embedder.0.weight"], sd["contextual_embedder.0.bias"], stride=2, padding=1)
+        h = F.conv1d(h, sd["contextual_embedder.1.weight"], sd["contextual_embedder.1.bias"], stride=2, padding=1)
+        i = 2
+        while f"contextual_embedder.{i}.norm.weight" in sd:
+            h = attention_block(sd, f"contextual_embedder.{i}", h, cfg.num_heads)
+            i += 1
+        outs.append(h)
+    return torch.cat(outs, dim=-1).mean(dim=-1)
+
+
 def res_block(sd, prefix, x, emb):
     """ResBlock(use_scale_shift_norm=True, efficient_config=True, kernel 3) (diffusion_decoder.py:60-120)."""
     h = F.silu(_gn(x, sd[f"{prefix}.in_layers.0.weight"], sd[f"{prefix}.in_layers.0.bias"]))

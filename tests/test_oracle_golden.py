@@ -79,6 +79,23 @@ def test_univnet_waveform():
     assert wav.shape == (1, 1, G.VOC_S * 256)  # the reference's own shape check (vocoder.py:318-324)
 
 
+@torch.no_grad()
+def test_conditioning_encoders():
+    """get_conditioning of both models: the oracle side of the next row, pinned against the
+    reference modules' outputs so the device path can be built against it."""
+    a_cfg, d_cfg = ARConfig(**G.AR_CFG), DiffusionConfig(**G.DIFF_CFG)
+    a_sd = W.synthetic_state_dict(W.ar_manifest(a_cfg), seed=G.COND_SEED)
+    d_sd = W.synthetic_state_dict(W.diffusion_manifest(d_cfg), seed=G.COND_SEED + 1)
+    mel_ar, mel_diff = G.cond_inputs()
+    g = gold("conditioning.npz")
+    close(O.ar_get_conditioning(a_sd, a_cfg, mel_ar), g["auto_latent"], 1e-4)
+    close(O.diffusion_get_conditioning(d_sd, d_cfg, mel_diff), g["diffusion_latent"], 1e-4)
+    # mean over clips: one clip repeated gives that clip's latent; clip order does not matter for the AR encoder
+    one = O.ar_get_conditioning(a_sd, a_cfg, mel_ar[:, :1])
+    assert torch.allclose(O.ar_get_conditioning(a_sd, a_cfg, mel_ar[:, :1].repeat(1, 3, 1, 1)), one, atol=1e-5)
+    assert torch.allclose(O.ar_get_conditioning(a_sd, a_cfg, mel_ar.flip(1)), O.ar_get_conditioning(a_sd, a_cfg, mel_ar), atol=1e-5)
+
+
 def test_fix_autoregressive_output_bit_exact():
     g = gold("integer.npz")
     for cin, cout in zip(g["codes_in"], g["codes_out"]):

@@ -162,6 +162,33 @@ def test_diffusion_network_and_sampler(ref):
 
 
 @torch.no_grad()
+def test_conditioning_encoders(ref):
+    """UnifiedVoice.get_conditioning / DiffusionTts.get_conditioning at the reference width of one block stack
+    (autoregressive.py:204-228, 444-452; diffusion_decoder.py:186-192, 222-230)."""
+    from oracle import make_golden as G
+    a_cfg = ARConfig(layers=1, model_dim=256, heads=4)
+    a_sd = W.synthetic_state_dict(W.ar_manifest(a_cfg), seed=31)
+    m = G.build_ref_ar(ref, a_cfg, a_sd)
+    g = torch.Generator().manual_seed(8)
+    mel = torch.randn(1, 3, 80, 50, generator=g)
+    want = m.get_conditioning(mel)
+    got = O.ar_get_conditioning(a_sd, a_cfg, mel)
+    assert got.shape == want.shape == (1, 256)
+    assert torch.allclose(got, want, atol=1e-5), (got - want).abs().max()
+    d_cfg = DiffusionConfig(model_channels=128, num_layers=1, in_latent_channels=128, num_heads=2)
+    d_sd = W.synthetic_state_dict(W.diffusion_manifest(d_cfg), seed=32)
+    d = ref.DiffusionTts(model_channels=d_cfg.model_channels, num_layers=d_cfg.num_layers, in_channels=d_cfg.in_channels,
+                         out_channels=d_cfg.out_channels, in_latent_channels=d_cfg.in_latent_channels, in_tokens=d_cfg.in_tokens,
+                         dropout=0, use_fp16=False, num_heads=d_cfg.num_heads, layer_drop=0, unconditioned_percentage=0).eval()
+    d.load_state_dict(d_sd, strict=True)
+    mel = torch.randn(1, 2, 100, 61, generator=g)  # odd length: the two stride-2 convolutions round up
+    want = d.get_conditioning(mel)
+    got = O.diffusion_get_conditioning(d_sd, d_cfg, mel)
+    assert got.shape == want.shape == (1, 256)
+    assert torch.allclose(got, want, atol=1e-5), (got - want).abs().max()
+
+
+@torch.no_grad()
 def test_univnet(ref):
     cfg = VocoderConfig()
     raw = W.synthetic_state_dict(W.vocoder_manifest(cfg), seed=15)
