@@ -201,6 +201,37 @@ def golden_conditioning(ref):
                         diffusion_latent=d.get_conditioning(mel_diff).numpy())
 
 
+def golden_text():
+    """Long-form chunking (tortoise/utils/text.py:4-72).  The three cases are the reference's OWN expectations
+    (text.py:82-130, which pass here: `python tortoise/utils/text.py`); inputs and outputs are stored so the GPU box,
+    which has no reference tree, can check them too."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("_ref_text", os.path.join(ref_shims.REFERENCE_ROOT, "tortoise", "utils", "text.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(os.path.join(ref_shims.REFERENCE_ROOT, "tortoise", "data", "riding_hood.txt")) as f:
+        riding_hood = f.read()
+    cases = [
+        {"text": """
+            This is a sample sentence.
+            This is another sample sentence.
+            This is a longer sample sentence that should force a split inthemiddlebutinotinthislongword.
+            "Don't split my quote... please"
+            """, "desired_length": 20, "max_length": 40},
+        {"text": """
+            When you are really angry sometimes you use consecutive exclamation marks!!!!!! Is this a good thing to do?!?!?!
+            I don't know but we should handle this situation..........................
+            """, "desired_length": 30, "max_length": 50},
+        {"text": riding_hood, "desired_length": 200, "max_length": 300},
+    ]
+    for c in cases:
+        c["chunks"] = mod.split_and_recombine_text(c["text"], c["desired_length"], c["max_length"])
+    assert cases[0]["chunks"][2] == "This is a longer sample sentence that" and len(cases[2]["chunks"]) == 15
+    with open(os.path.join(OUT, "text_split.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+
+
 def golden_integer():
     src = open(os.path.join(ref_shims.REFERENCE_ROOT, "tortoise", "api.py")).read()
     tree = ast.parse(src)
@@ -229,6 +260,7 @@ def main():
     golden_diffusion(ref)
     golden_vocoder(ref)
     golden_conditioning(ref)
+    golden_text()
     golden_integer()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -113,3 +113,47 @@ def test_multinomial_equals_argmax_exponential():
         want = torch.multinomial(p, 1, generator=g1)[:, 0]
         q = torch.empty_like(p).exponential_(1, generator=g2)
         assert torch.equal(O.multinomial_from_exponential(p, q), want)
+
+
+def test_split_and_recombine_text_reference_expectations():
+    """The reference's own known-answer tests for long-form chunking (tortoise/utils/text.py:82-130), stored with
+    their inputs in tests/golden/text_split.json by oracle/make_golden.py."""
+    import json
+    from tortoise_tts_amd.text import split_and_recombine_text
+    with open(os.path.join(os.path.dirname(__file__), "golden", "text_split.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 3
+    for c in cases:
+        assert split_and_recombine_text(c["text"], c["desired_length"], c["max_length"]) == c["chunks"]
+    assert len(cases[2]["chunks"]) == 15  # riding_hood.txt -> 15 utterances (SURVEY.md §8d, config #4)
+    # edge cases: empty / whitespace / punctuation-only input, one over-long word, no terminal punctuation
+    assert split_and_recombine_text("") == []
+    assert split_and_recombine_text("  \n\n ... !!! ") == []
+    assert split_and_recombine_text("word") == ["word"]
+    # a word longer than max_length has no break to fall back to: it is cut back to desired_length pieces
+    assert split_and_recombine_text("x" * 50, desired_length=10, max_length=20) == ["x" * 10] * 5
+    for chunk in split_and_recombine_text("one two three four five six seven eight nine ten " * 20, 40, 60):
+        assert 0 < len(chunk) <= 60
+
+
+def test_split_and_recombine_text_against_reference_source():
+    """Randomised cross-check against the reference function itself (build container only)."""
+    import importlib.util
+    import random
+    from oracle import ref_shims
+    from tortoise_tts_amd.text import split_and_recombine_text
+    path = os.path.join(ref_shims.REFERENCE_ROOT, "tortoise", "utils", "text.py")
+    if not os.path.exists(path):
+        pytest.skip("reference tree not available")
+    spec = importlib.util.spec_from_file_location("_ref_text", path)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = random.Random(1)
+    words = ["alpha", "be", "c", "delta-epsilon", "z" * 44, "It's", "ok"]
+    punct = [". ", "! ", "? ", "... ", "?! ", ", ", "; ", "\n", "\n\n", ' "', '" ', "\u201c", "\u201d ", " ", ".", '"']
+    for _ in range(500):
+        s = "".join(rng.choice(words) + rng.choice(punct) for _ in range(rng.randint(0, 60)))
+        d = rng.choice([10, 20, 50, 200])
+        m = d + rng.choice([1, 10, 30, 100])
+        assert split_and_recombine_text(s, d, m) == ref.split_and_recombine_text(s, d, m), repr(s)
+
