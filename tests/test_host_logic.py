@@ -157,3 +157,24 @@ def test_split_and_recombine_text_against_reference_source():
         m = d + rng.choice([1, 10, 30, 100])
         assert split_and_recombine_text(s, d, m) == ref.split_and_recombine_text(s, d, m), repr(s)
 
+
+def test_tokenizer_contract_on_reference_vocabulary():
+    """VoiceBpeTokenizer over the vocabulary file the reference ships (tortoise/data/tokenizer.json is data the user
+    already has; it is located, not copied - so this runs only where the reference tree is).  The do_tts.py default
+    sentence gives 54 ids, spaces map to the [SPACE] token and decode() inverts encode()."""
+    from oracle import ref_shims
+    from tortoise_tts_amd.text import VoiceBpeTokenizer
+    vocab = os.path.join(ref_shims.REFERENCE_ROOT, "tortoise", "data", "tokenizer.json")
+    if not os.path.exists(vocab):
+        pytest.skip("reference vocabulary not available")
+    tok = VoiceBpeTokenizer(vocab, use_basic_cleaners=True)
+    text = "The expressiveness of autoregressive transformers is literally nuts! I absolutely adore them."
+    ids = tok.encode(text)
+    assert len(ids) == 54 and max(ids) < 255 and min(ids) >= 0
+    space = tok.tokenizer.token_to_id("[SPACE]")
+    assert ids.count(space) == text.count(" ")
+    assert tok.decode(ids) == text.lower()
+    assert tok.encode("  Mixed   CASE\tand\nwhitespace ") == tok.encode(" mixed case and whitespace ")
+    with pytest.raises(FileNotFoundError):
+        VoiceBpeTokenizer(os.path.join(os.path.dirname(vocab), "missing.json"), use_basic_cleaners=True, models_dir="/nonexistent")
+
