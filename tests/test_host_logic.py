@@ -32,6 +32,22 @@ def test_fix_autoregressive_output_matches_reference_golden():
     assert np.array_equal(api.fix_autoregressive_output(rows, 8193).numpy(), want)
 
 
+def test_fix_autoregressive_output_randomised_ragged_rows():
+    """Ragged batches: stop tokens at random positions (including 0, the last three slots, repeated, absent);
+    the batched device-side form must equal the row-wise restatement of api.py:87-114 bit for bit."""
+    api = _api_helpers()
+    rng = np.random.default_rng(7)
+    for trial in range(300):
+        B, n = int(rng.integers(1, 9)), int(rng.integers(3, 40))
+        rows = rng.integers(0, 8192, (B, n))
+        for b in range(B):
+            for _ in range(int(rng.integers(0, 4))):
+                rows[b, int(rng.integers(0, n))] = 8193
+        want = np.stack([O.fix_autoregressive_output(r, 8193) for r in rows])
+        got = api.fix_autoregressive_output(torch.from_numpy(rows), 8193).numpy()
+        assert np.array_equal(got, want), rows
+
+
 def test_calm_trim_matches_oracle():
     api = _api_helpers()
     rng = np.random.default_rng(1)
