@@ -24,7 +24,7 @@ namespace tt {
 //                (max, sum, O) states are merged through LDS.  4x the resident waves for the same work, which is
 //                what hides the per-tile dependency chain (MFMA -> softmax -> MFMA) when batch*heads is small.
 template <typename T, int NQ, bool SPLIT>
-__global__ __launch_bounds__(256) void flash_kernel(FlashArgs a) {
+__global__ __launch_bounds__(256, 2) void flash_kernel(FlashArgs a) {  // 2 waves per SIMD: <= 256 VGPRs (NQ = 4 took 308 => one workgroup per CU)
   typedef typename Vec<T>::x8 x8;
   typedef typename Vec<T>::x4 x4;
   __shared__ float rp[132];
