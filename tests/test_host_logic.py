@@ -194,3 +194,29 @@ def test_tokenizer_contract_on_reference_vocabulary():
     with pytest.raises(FileNotFoundError):
         VoiceBpeTokenizer(os.path.join(os.path.dirname(vocab), "missing.json"), use_basic_cleaners=True, models_dir="/nonexistent")
 
+
+def test_committed_bench_line_follows_the_contract():
+    """The bench line committed under profiles/ carries every field the measurement contract names, the roofline
+    fraction is achieved / peak, and roofline.traffic is what bench.pmc_traffic derives from the committed PMC pass."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r01_final_bench_1gpu.json")) as f:
+        d = json.loads([ln for ln in f.read().splitlines() if ln.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r, c = d["roofline"], d["cpu_baseline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert abs(d["value"] - d["audio_seconds_per_step"] / (d["ms_per_step"] / 1e3)) < 1e-6
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    traffic, src = bench.pmc_traffic(r["kernel"])
+    assert src and abs(traffic - r["traffic"]) < 1.0
+    assert bench.pmc_traffic("no_such_kernel") == (None, None)
+
