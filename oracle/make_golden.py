@@ -32,6 +32,9 @@ DIFF_CFG = dict(model_channels=128, num_layers=2, in_latent_channels=128, num_he
 DIFF_SEED, DIFF_M, DIFF_STEPS, DIFF_TS = 14, 12, 5, 2999
 VOC_SEED, VOC_S = 15, 6
 COND_SEED, COND_CLIPS, COND_T_AR, COND_T_DIFF = 16, 2, 37, 44
+# HF generate() cases pinning the sampling loop: (kv_cache, logit boost of the stop token); B rows x up to N tokens
+SAMPLE_SEED, SAMPLE_B, SAMPLE_N = 5, 6, 24
+SAMPLE_CASES = [(True, None), (True, 3.0), (True, 5.0), (False, None), (False, 3.0), (False, 5.0)]
 
 
 def ar_inputs(cfg):
@@ -79,14 +82,53 @@ def voc_inputs():
     return mel, z
 
 
-def build_ref_ar(ref, cfg, sd):
+def sampling_state_dict(cfg, eos_boost):
+    """AR weights of the sampling cases: the small AR golden weights with the stop-token logit raised by `eos_boost`
+    (None: untouched) so rows finish at different steps (ragged EOS) or the whole batch stops early."""
+    sd = W.synthetic_state_dict(W.ar_manifest(cfg), seed=AR_SEED)
+    if eos_boost is not None:
+        b = sd["mel_head.bias"].clone()
+        b[cfg.stop_mel_token] += eos_boost
+        sd["mel_head.bias"] = b
+    return sd
+
+
+def sampling_noise(cfg):
+    """Exp(1) draws [N, B, V] that torch.multinomial consumes under torch.manual_seed(SAMPLE_SEED): multinomial(p, 1) on
+    CPU == argmax(p / q) with q = empty_like(p).exponential_() from the same generator state."""
+    torch.manual_seed(SAMPLE_SEED)
+    return torch.stack([torch.empty(SAMPLE_B, cfg.number_mel_codes).exponential_(1) for _ in range(SAMPLE_N)])
+
+
+def build_ref_ar(ref, cfg, sd, kv_cache=True):
     m = ref.UnifiedVoice(max_mel_tokens=cfg.max_mel_tokens, max_text_tokens=cfg.max_text_tokens,
                          max_conditioning_inputs=cfg.max_conditioning_inputs, layers=cfg.layers, model_dim=cfg.model_dim,
                          heads=cfg.heads, number_text_tokens=cfg.number_text_tokens, start_text_token=cfg.start_text_token,
                          checkpointing=False, train_solo_embeddings=False).eval()
     m.load_state_dict(sd, strict=True)
-    m.post_init_gpt2_config(kv_cache=True)
+    m.post_init_gpt2_config(kv_cache=kv_cache)
     return m
+
+
+@torch.no_grad()
+def hf_generate_codes(ref, cfg, sd, kv_cache):
+    """Codes of a real HF `generate(do_sample=True, ...)` run of the reference model through its own
+    UnifiedVoice.inference_speech (autoregressive.py:535-563) with the api.py:416-424 arguments, on CPU."""
+    m = ref_shims.enable_generate(build_ref_ar(ref, cfg, sd, kv_cache))
+    cond, text = ar_inputs(cfg)
+    torch.manual_seed(SAMPLE_SEED)
+    return m.inference_speech(cond, text, do_sample=True, top_p=0.8, temperature=0.8, num_return_sequences=SAMPLE_B,
+                              length_penalty=1, repetition_penalty=2.0, max_generate_length=SAMPLE_N)
+
+
+@torch.no_grad()
+def golden_sampling(ref):
+    cfg = ARConfig(**AR_CFG)
+    out = {}
+    for kv, boost in SAMPLE_CASES:
+        codes = hf_generate_codes(ref, cfg, sampling_state_dict(cfg, boost), kv)
+        out[f"codes_kv{int(kv)}_eos{boost}"] = codes.numpy()
+    np.savez_compressed(os.path.join(OUT, "sampling.npz"), **out)
 
 
 @torch.no_grad()
@@ -256,6 +298,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_shims.import_reference()
     golden_ar(ref)
+    golden_sampling(ref)
     golden_clvp(ref)
     golden_diffusion(ref)
     golden_vocoder(ref)

@@ -81,3 +81,29 @@ def import_reference():
     ns.space_timesteps = space_timesteps
     ns.get_named_beta_schedule = get_named_beta_schedule
     return ns
+
+
+def enable_generate(unified_voice):
+    """Give the reference's GPT2InferenceModel back the `generate` it had under transformers 4.31 by mixing the
+    INSTALLED GenerationMixin into a test-only subclass (5.x dropped the mixin from PreTrainedModel).
+
+    One compatibility fix-up, nothing else: 5.x hands an empty Cache object to the first decoding step where 4.31
+    passed `past_key_values=None`, and the reference's `if past_key_values:` (autoregressive.py:83, 93) would then
+    feed only the last token to the prefill.  The subclass makes that first call see "no past", exactly as 4.31 did.
+    Used by tests/test_oracle_vs_reference.py and oracle/make_golden.py to pin oracle.ar_sample_loop against a real
+    HF `generate(do_sample=True, ...)` run of the reference model."""
+    from transformers import GenerationConfig, GenerationMixin
+    im = unified_voice.inference_model
+
+    class _GenerativeInferenceModel(type(im), GenerationMixin):
+        def prepare_inputs_for_generation(self, input_ids, past_key_values=None, **kwargs):
+            empty = (past_key_values is not None and hasattr(past_key_values, "get_seq_length")
+                     and past_key_values.get_seq_length() == 0)
+            out = super().prepare_inputs_for_generation(input_ids, past_key_values=None if empty else past_key_values, **kwargs)
+            if empty and self.kv_cache:
+                out["past_key_values"] = past_key_values  # the (empty) cache object the model fills in
+            return out
+
+    im.__class__ = _GenerativeInferenceModel
+    im.generation_config = GenerationConfig.from_model_config(im.config)
+    return unified_voice

@@ -8,10 +8,16 @@ nn.Modules, run in the build container) and tests/test_oracle_golden.py (committ
 vectors produced from the reference's modules by oracle/make_golden.py).  The reference holds
 no numeric golden vectors of its own, so that is the strongest pin available.
 
-The AR sampling loop is a restatement of HF transformers==4.31.0 `GenerationMixin.sample`
-(third-party, pinned in the reference's setup.py:30; not vendored, not runnable here) following
-the in-repo fork tortoise/models/stream_generator.py:916-1000 and the 4.31 logits processors.
-Parity for that loop is therefore "unpinned" beyond hand-computed cases.
+The AR sampling loop is a restatement of HF transformers `GenerationMixin.sample` (third-party; the
+reference pins ==4.31.0 in setup.py:30, not vendored) following the in-repo fork
+tortoise/models/stream_generator.py:916-1000 and the logits processors.  It is pinned against a REAL
+`generate(do_sample=True, ...)` run of the reference's GPT2InferenceModel through the reference's own
+`UnifiedVoice.inference_speech`, with the INSTALLED transformers (5.15) GenerationMixin mixed back in
+(oracle/ref_shims.enable_generate): identical codes bit for bit for both position rules, ragged stop
+rows and whole-batch early exit (tests/test_oracle_vs_reference.py::test_sampling_loop_equals_hf_generate,
+committed as tests/golden/sampling.npz).  What stays unpinned: 4.31.0 itself cannot be installed offline, so
+agreement is with 5.15's sampler, whose processor semantics for these options equal 4.31's by inspection of
+stream_generator.py and the processors' documented behaviour.
 
 All state is passed as reference-layout state_dicts (see tortoise_tts_amd/weights.py).
 """

@@ -45,6 +45,19 @@ def test_ar_logits_and_latents():
     close(lat, g["latents"], 2e-4)
 
 
+@pytest.mark.parametrize("kv_cache,eos_boost", G.SAMPLE_CASES)
+@torch.no_grad()
+def test_sampling_loop_equals_hf_generate_golden(kv_cache, eos_boost):
+    """oracle.ar_sample_loop == the committed codes of HF generate() run on the reference model (tests/golden/sampling.npz,
+    oracle/make_golden.py:golden_sampling), bit for bit; runs without the reference tree (GPU box included)."""
+    cfg = ARConfig(**G.AR_CFG)
+    want = gold("sampling.npz")[f"codes_kv{int(kv_cache)}_eos{eos_boost}"]
+    sd = G.sampling_state_dict(cfg, eos_boost)
+    cond, text = G.ar_inputs(cfg)
+    got = O.ar_sample_loop(sd, cfg, cond, text, G.SAMPLE_B, G.SAMPLE_N, G.sampling_noise(cfg), kv_cache=kv_cache)
+    assert got.shape == want.shape and np.array_equal(got.numpy(), want)
+
+
 @torch.no_grad()
 def test_clvp_scores():
     cfg = CLVPConfig(**G.CLVP_CFG)

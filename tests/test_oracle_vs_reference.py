@@ -72,6 +72,30 @@ def test_ar_prefill_and_cached_steps(ref):
         assert torch.allclose(a, b, atol=2e-4, rtol=1e-4), (a - b).abs().max()
 
 
+@pytest.mark.parametrize("kv_cache,eos_boost", [(True, None), (True, 3.0), (True, 5.0), (False, None), (False, 3.0), (False, 5.0)])
+@torch.no_grad()
+def test_sampling_loop_equals_hf_generate(ref, kv_cache, eos_boost):
+    """oracle.ar_sample_loop against a REAL `generate(do_sample=True, top_p, temperature,
+    repetition_penalty, num_return_sequences)` run of the reference's GPT2InferenceModel, driven through the reference's
+    own UnifiedVoice.inference_speech (autoregressive.py:535-563) with the installed transformers' GenerationMixin mixed
+    back in (oracle/ref_shims.enable_generate).  Same generator state => identical codes, bit for bit, including rows
+    that hit the stop token at different steps (pad rule), whole-batch early exit, and both position rules
+    (kv_cache=True: mel positions 0,2,3,...; kv_cache=False: 0,1,2,..., autoregressive.py:134-149)."""
+    from oracle import make_golden as G
+    cfg = small_ar()
+    sd = G.sampling_state_dict(cfg, eos_boost)
+    want = G.hf_generate_codes(ref, cfg, sd, kv_cache)
+    cond, text = G.ar_inputs(cfg)
+    got = O.ar_sample_loop(sd, cfg, cond, text, G.SAMPLE_B, G.SAMPLE_N, G.sampling_noise(cfg), kv_cache=kv_cache)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert torch.equal(got, want)
+    if eos_boost == 3.0:
+        stops = (want == cfg.stop_mel_token).sum(1)
+        assert stops.max() == G.SAMPLE_N and stops.min() == 0  # ragged: one row finished at step 0, others never
+    if eos_boost == 5.0:
+        assert want.shape[1] < G.SAMPLE_N  # every row finished: generate() returned early
+
+
 @torch.no_grad()
 def test_ar_latents(ref):
     cfg = small_ar()
