@@ -1,6 +1,6 @@
-"""-m gpu: BASELINE-size checks (reference hyper-parameters: 30x1024 GPT-2, 10-layer 1024-wide DiffusionTts,
-20-layer CLVP towers, UnivNet) through size-independent properties, because the CPU oracle cannot finish
-these sizes in seconds:
+"""-m gpu: BASELINE-size PROPERTY checks (reference hyper-parameters: 30x1024 GPT-2, 10-layer 1024-wide DiffusionTts,
+20-layer CLVP towers, UnivNet).  Numerical parity at these sizes against the reference modules and the oracle lives in
+tests/test_gpu_fullsize.py; this file adds the size-independent properties:
   * KV-cached decode == teacher-forced full pass fed the same position rows (two different kernel paths);
   * sampled codes: in range, never the suppressed stop token, bit-reproducible, invariant to candidate sharding;
   * batched cond/uncond denoiser row == stand-alone conditioned evaluation; hipGraph replay == eager launches;

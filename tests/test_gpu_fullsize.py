@@ -1,0 +1,185 @@
+"""-m gpu: the BENCHMARKED configuration against the reference's own modules and the oracle.
+
+Every engine here is built at the api.py:217-236 hyper-parameters with bench.py's synthetic weights and prompt, at the
+shapes bench.py times: 55 text tokens, AR batch 16 (reference default) and 256 (the engine's batch), 200 mel codes ->
+S = 870 denoiser positions (M = 1740 rows with the conditioning-free row: the 128x64 conv-GEMM with the GroupNorm
+statistics epilogue straddling the sequence boundary, flash attention with relative-position bias at n = 870),
+768-wide / 12-head / 20-layer CLVP at 4 and at 256 candidates, 870 vocoder frames.
+  (a) vs tests/golden/full_*.npz = outputs of the reference nn.Modules in fp32 (oracle/make_golden_full.py);
+  (b) vs the CPU oracle evaluated on the same operand-rounded weights (a few seconds per stage on the host cores).
+Tolerances (relative L2 of the stage output): vs (a) bf16 4e-2 / fp16 6.4e-3; vs (b) bf16 2.5e-2 / fp16 4e-3.
+The drift test runs the full 200-iteration 'standard' schedule (conditioning-free guidance on) on the reduced-width
+denoiser in both operand types against the reference's own p_sample_loop and reports mel rel-L2 and max-abs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import make_golden as G
+from oracle import make_golden_full as GF
+from oracle import tortoise_oracle as O
+from tortoise_tts_amd import engine as E
+from tortoise_tts_amd import stages
+from tortoise_tts_amd import weights as W
+from tortoise_tts_amd.config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig, TACOTRON_MEL_MAX, TACOTRON_MEL_MIN
+from tortoise_tts_amd.schedule import Schedule
+from tests.gpu_util import DTYPES, quantize_sd, report, rel_err, max_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+@pytest.fixture(scope="module")
+def sds():
+    import bench
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    return bench.synthetic_weights()
+
+
+def denorm(x):
+    return (x + 1) / 2 * (TACOTRON_MEL_MAX - TACOTRON_MEL_MIN) + TACOTRON_MEL_MIN
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@torch.no_grad()
+def test_full_ar_prefill_and_cached_steps(sds, name, dt, tdt, tol):
+    """30 x 1024 x 16-head trunk: prefill + 3 KV-cached steps.  Batch 16 = the reference's default batch (golden rows);
+    batch 256 = the engine's decode batch (decode_attn_kernel at 16 heads x 256 sequences, 64x64 decode GEMMs with split-K),
+    fed the golden tokens cyclically so every one of the 256 rows has a reference row to match."""
+    g = gold("full_ar.npz")
+    cfg = ARConfig()
+    text, auto, _ = GF.prompt()
+    toks = GF.ar_tokens()
+    keep = torch.ones(cfg.number_mel_codes, dtype=torch.bool)
+    keep[cfg.stop_mel_token] = False  # suppressed (-1e9) in the benchmark weights: would dominate every norm
+    st = stages.ArStage(sds["autoregressive"], cfg, dtype=dt, max_batch=256, max_text=80, max_new_tokens=32, max_latent_candidates=1)
+    # (b) the oracle on operand-rounded weights, batch 16
+    sdq = quantize_sd(sds["autoregressive"], tdt)
+    prefix = O.ar_prefix(sdq, cfg, auto, text)
+    lg, kv = O.ar_prefill(sdq, cfg, prefix, GF.AR_B)
+    oracle_lg = [lg]
+    for s, tk in enumerate(toks):
+        lg, kv = O.ar_step(sdq, cfg, tk, s + 1, kv)
+        oracle_lg.append(lg)
+    for B in (GF.AR_B, 256):
+        rep = B // GF.AR_B
+        st.prefill(auto, text)
+        got = st.logits(1).cpu()
+        report(f"FULL AR prefill logits {name} B={B} vs reference golden", got[0, keep], torch.from_numpy(g["logits"][0][0])[keep], tol * 1.6)
+        if B == GF.AR_B:
+            report(f"FULL AR prefill logits {name} vs oracle", got[0, keep], oracle_lg[0][0, keep], tol)
+        st.begin(B)
+        for s, tk in enumerate(toks):
+            st.decode_step(tk.repeat(rep))
+            got = st.logits(B).cpu()
+            want = torch.from_numpy(g["logits"][s + 1]).repeat(rep, 1)
+            report(f"FULL AR cached step {s + 1} logits {name} B={B} vs reference golden", got[:, keep], want[:, keep], tol * 1.6)
+            if B == GF.AR_B:
+                report(f"FULL AR cached step {s + 1} logits {name} vs oracle", got[:, keep], oracle_lg[s + 1][:, keep], tol)
+            else:  # identical tokens => identical rows whatever the row's position in the batch (tile / split-K independent of B)
+                assert torch.equal(got[:GF.AR_B], got[-GF.AR_B:]), "a row's logits depend on its position in the decode batch"
+    # latent re-pass of one winner at the benchmarked length
+    lat = st.latents(auto, text, GF.latent_codes())
+    report(f"FULL AR latents {name} vs reference golden", lat, torch.from_numpy(g["latents"]), tol * 1.6)
+    st.close()
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@torch.no_grad()
+def test_full_clvp_production_config(sds, name, dt, tdt, tol):
+    """768-d / 12 heads / 20 layers, 200 codes per candidate.  4 candidates (golden) and 256 candidates (the production
+    batch: flash_kernel<2,false>, 128x128 GEMMs), the latter fed the golden candidates cyclically."""
+    cfg = CLVPConfig()
+    text, _, _ = GF.prompt()
+    codes = GF.clvp_codes()
+    want = torch.from_numpy(gold("full_clvp.npz")["scores"])
+    st = stages.ClvpStage(sds["clvp"], cfg, dtype=dt, max_rows=256 * GF.CLVP_N)
+    got4 = st.score(text, codes).cpu()
+    got256 = st.score(text, codes.repeat(64, 1)).cpu()
+    sdq = quantize_sd(sds["clvp"], tdt)
+    orc = O.clvp_score(sdq, cfg, text.long().repeat(GF.CLVP_B, 1), codes)
+    # scores are cosine similarities * exp(temperature): O(1) numbers whose spread across candidates is what ranks them
+    print(f"[parity] FULL CLVP scores {name}: reference {want.tolist()} engine {got4.tolist()}")
+    scale = float(want.abs().max())
+    for label, got, ref_, t in (("4 cand vs reference golden", got4, want, tol * 1.6), ("4 cand vs oracle", got4, orc, tol),
+                                ("256 cand vs reference golden", got256, want.repeat(64), tol * 1.6)):
+        err = float((got - ref_).abs().max()) / scale
+        print(f"[parity] FULL CLVP {name} {label}: max_abs/scale={err:.3e} (tol {t:.1e})")
+        assert err < t
+    assert torch.equal(got256[:4], got256[-4:]), "a candidate's score depends on its position in the batch"
+    st.close()
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@torch.no_grad()
+def test_full_diffusion_s870(sds, name, dt, tdt, tol):
+    """DiffusionTts at S = 870 with both guidance rows batched (M = 1740): code_emb, eps at one timestep (vs the reference
+    module and vs the oracle on rounded weights), and an 8-iteration p_sample_loop vs the reference's own loop."""
+    g = gold("full_diffusion.npz")
+    cfg = DiffusionConfig()
+    _, _, cond = GF.prompt()
+    S, latents, x, step_noise = GF.diff_inputs(cfg)
+    st = stages.DiffusionStage(sds["diffusion"], cfg, dtype=dt, max_seq=S + 8, max_codes=GF.DIFF_M + 8, max_steps=16)
+    st.condition(latents, cond, S)
+    emb = st.code_emb().cpu()
+    report(f"FULL diffusion code_emb {name} vs reference golden", emb[:, :, ::GF.CODE_EMB_STRIDE], torch.from_numpy(g["code_emb_strided"]), tol * 1.6)
+    out = st.forward(x, GF.DIFF_TS, cond_free=True).cpu()
+    report(f"FULL diffusion eps cond S=870 {name} vs reference golden", out[0], torch.from_numpy(g["eps_cond"])[0], tol * 1.6)
+    report(f"FULL diffusion eps uncond S=870 {name} vs reference golden", out[1], torch.from_numpy(g["eps_uncond"])[0], tol * 1.6)
+    sdq = quantize_sd(sds["diffusion"], tdt)
+    oemb = O.diffusion_timestep_independent(sdq, cfg, latents, cond, S)
+    ts = torch.tensor([GF.DIFF_TS])
+    report(f"FULL diffusion eps cond S=870 {name} vs oracle", out[0], O.diffusion_forward(sdq, cfg, x, ts, oemb, False)[0], tol)
+    report(f"FULL diffusion eps uncond S=870 {name} vs oracle", out[1], O.diffusion_forward(sdq, cfg, x, ts, oemb, True)[0], tol)
+    sched = Schedule(GF.DIFF_LOOP_STEPS, 4000, True, 2.0)
+    mel = st.sample(sched, x, step_noise).cpu()
+    want = denorm(torch.from_numpy(g["x0"]))
+    r, m = rel_err(mel, want), max_err(mel, want)
+    print(f"[parity] FULL diffusion {GF.DIFF_LOOP_STEPS}-step p_sample_loop S=870 {name} vs reference loop: mel rel_l2={r:.3e} max_abs={m:.3e}")
+    assert r < (8e-2 if name == "bf16" else 1.6e-2)
+    st.close()
+
+
+@torch.no_grad()
+def test_drift_over_the_real_schedule_bf16_vs_fp16():
+    """SURVEY hard part (e): rounding drift over the REAL schedule length.  200 iterations with conditioning-free guidance on
+    the reduced-width denoiser, both operand types, against the reference's own fp32 p_sample_loop (tests/golden
+    full_diffusion.npz: drift_x0).  Reports mel rel-L2 and max-abs; this measurement is what DESIGN.md's default-dtype
+    argument cites."""
+    g = gold("full_diffusion.npz")
+    cfg = DiffusionConfig(**G.DIFF_CFG)
+    sd = W.synthetic_state_dict(W.diffusion_manifest(cfg), seed=G.DIFF_SEED)
+    S, lat, x, noise = GF.diff_inputs(cfg, M=G.DIFF_M, seed=GF.DRIFT_SEED, steps=GF.DRIFT_STEPS)
+    cond = torch.as_tensor(g["drift_cond"])
+    want = denorm(torch.from_numpy(g["drift_x0"]))
+    sched = Schedule(GF.DRIFT_STEPS, 4000, True, 2.0)
+    res = {}
+    for name, dt, tdt, tol in DTYPES:
+        st = stages.DiffusionStage(sd, cfg, dtype=dt, max_seq=S + 8, max_codes=G.DIFF_M + 8, max_steps=GF.DRIFT_STEPS)
+        st.condition(lat, cond, S)
+        mel = st.sample(sched, x, noise).cpu()
+        res[name] = (rel_err(mel, want), max_err(mel, want))
+        print(f"[parity] DRIFT {GF.DRIFT_STEPS}-step schedule {name} vs reference fp32 loop: mel rel_l2={res[name][0]:.3e} "
+              f"max_abs={res[name][1]:.3e} (mel range [{float(want.min()):.2f}, {float(want.max()):.2f}])")
+        assert torch.isfinite(mel).all()
+        st.close()
+    assert res["f16"][0] < 0.1 and res["bf16"][0] < 0.5
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@torch.no_grad()
+def test_full_vocoder_870_frames(sds, name, dt, tdt, tol):
+    """UnivNet at the benchmarked length (the kernel predictor's GEMMs run in the operand type, everything else f32)."""
+    mel, z = GF.voc_inputs()
+    st = stages.VocoderStage(sds["vocoder"], VocoderConfig(), dtype=dt, max_frames=GF.VOC_S + 16)
+    got = st.inference(mel, z).cpu()
+    want = torch.from_numpy(gold("full_vocoder.npz")["wav"])
+    assert got.shape == want.shape
+    report(f"FULL UnivNet 870 frames {name} vs reference golden", got, want, tol * 3)
+    st.close()

@@ -84,7 +84,7 @@ def test_ar_generate_injected_noise_and_sharding_invariance():
     first = float((got.cpu()[:, 0] == want[:, 0]).float().mean())
     print(f"[parity] AR free-running codes vs oracle (injected Exp(1) noise): agreement {agree:.3f}, first token {first:.3f}")
     assert got.min() >= 0 and got.max() < cfg.number_mel_codes and (got != cfg.stop_mel_token).all()
-    assert first >= 0.75 and agree >= 0.5
+    assert first == 1.0 and agree == 1.0  # measured 1.000 on MI355X (profiles/r01_parity_gpu.txt); any flip is a regression
     # every sampled token must lie in the oracle's nucleus when the oracle is teacher-forced with OUR tokens
     ids = torch.full((B, st.P + 1), 1, dtype=torch.long)
     ids[:, -1] = cfg.start_mel_token
@@ -227,9 +227,11 @@ def test_univnet(name, dt, tdt, tol):
 
 @torch.no_grad()
 def test_diffusion_full_width_short_sequence():
-    """1024 channels / 16 heads (the reference width) with 2 layers and a short sequence: exercises the kernels the
-    128-channel configuration cannot reach (GroupNorm statistics fused into the GEMM epilogue, 128-row tiles,
-    the C == 1024 GroupNorm fast path) against the CPU oracle."""
+    """1024 channels / 16 heads (the reference width) with 2 layers and a SHORT sequence (S = 43, M = 86 rows): exercises
+    the GroupNorm statistics fused into the GEMM epilogue and the C == 1024 GroupNorm fast path against the CPU oracle.
+    At M = 86 the 64x64 tile and the 16-query flash variant are selected; the production variants (128x64 conv-GEMM at
+    M = 1740, flash 64 queries per wave with key split at n = 870) are compared with the reference in
+    tests/test_gpu_fullsize.py::test_full_diffusion_s870."""
     cfg = DiffusionConfig(model_channels=1024, num_layers=2, in_latent_channels=1024, num_heads=16)
     tdt, dt, tol = torch.bfloat16, E.TT_BF16, 2.5e-2
     sd = quantize_sd(W.synthetic_state_dict(W.diffusion_manifest(cfg), seed=21), tdt)
