@@ -113,14 +113,12 @@ def roofline_leg(tts, run_step):
     from tortoise_tts_amd import engine as E
     lib = E.load_library()
     os.environ["TT_NO_GRAPH"] = "1"
-    saved_streams, tts.decode_streams = tts.decode_streams, 1  # the event recorder is single-threaded
     lib.tt_prof_enable(1)
     try:
         run_step()
         torch.cuda.synchronize()
     finally:
         lib.tt_prof_enable(0)
-        tts.decode_streams = saved_streams
         os.environ.pop("TT_NO_GRAPH", None)
     rows = []
     buf = (C.c_double * 4)()
@@ -179,7 +177,6 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--decode-streams", type=int, default=1, help="concurrent AR decode sub-batches per GPU")
     args = ap.parse_args()
 
     from tortoise_tts_amd import dist as tdist
@@ -196,8 +193,7 @@ def main():
     t_build = time.perf_counter()
     sds = synthetic_weights()
     text, latents = synthetic_prompt()
-    tts = TextToSpeech(state_dicts=sds, dtype=args.dtype, max_candidates=N // world, max_mel_tokens=max(M, 32),
-                       decode_streams=args.decode_streams)
+    tts = TextToSpeech(state_dicts=sds, dtype=args.dtype, max_candidates=N // world, max_mel_tokens=max(M, 32))
     t_build = time.perf_counter() - t_build
 
     def run_step(i=0):
@@ -239,7 +235,7 @@ def main():
                                    f"CLVP top-1, {preset_kw['diffusion_iterations']} diffusion iterations cond_free={preset_kw.get('cond_free', True)}, "
                                    f"UnivNet; 55 text tokens; {audio_s:.2f} s of 24 kHz audio per step",
                        "weights": "seeded synthetic at the reference hyper-parameters (no checkpoints offline)",
-                       "parallelism": f"candidates sharded {N // world}/GPU ({args.decode_streams} concurrent decode streams per GPU), 1 all_gather of scores+codes, "
+                       "parallelism": f"candidates sharded {N // world}/GPU, 1 all_gather of scores+codes, "
                                       + ("winner's diffusion tail split over ranks 0/1 (one denoiser row each, 1 exchange per step), vocoder on rank 0"
                                          if tts.split_diffusion else "winner rendered on rank 0")},
             "stages_s_per_step": {k_: v / args.steps for k_, v in stage_acc.items()},

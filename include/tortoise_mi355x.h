@@ -59,6 +59,9 @@ typedef struct tt_ar_config {
   int max_new_tokens;    /* per-sequence KV slots */
   int max_full_rows;     /* rows of the largest teacher-forced pass (k * (1 + T+2 + M+2)) */
   int weights_tile_packed; /* 1: the five GEMM weight matrices are [ceil(N/64)][K/64][64][64] tile-packed (pack.py) */
+  int mel_pos_offset;    /* mel position row of generated token i (i >= 0; the start token uses row 0) = i + mel_pos_offset:
+                          * 2 = TextToSpeech(kv_cache=True): rows 0,2,3,... (autoregressive.py:145-149, attention_mask.shape[1] - mel_len)
+                          * 1 = TextToSpeech(kv_cache=False), the reference DEFAULT: rows 0,1,2,... (autoregressive.py:134-144) */
 } tt_ar_config;
 
 typedef struct tt_ar_weights {
@@ -102,7 +105,7 @@ int tt_ar_generate(tt_ar* h, int B, int max_new, const tt_sampling* s, int* code
 /* Teacher-forced single steps for parity tests: tt_ar_begin resets per-sequence state for B rows
  * after a prefill; tt_ar_decode_step feeds tokens int32 [B] (KV-cached position rule of
  * autoregressive.py:145-149: mel position row = index + 1 for index >= 1) and leaves the logits for
- * tt_ar_get_logits. */
+ * tt_ar_get_logits.  At most max_new_tokens - 1 steps per tt_ar_begin (one KV slot each); more is an error. */
 int tt_ar_begin(tt_ar* h, int B, void* stream);
 int tt_ar_decode_step(tt_ar* h, const int* tokens, void* stream);
 

@@ -243,6 +243,35 @@ def golden_conditioning(ref):
                         diffusion_latent=d.get_conditioning(mel_diff).numpy())
 
 
+RLG_SEED = 17
+
+
+def rlg_inputs(channels):
+    g = torch.Generator().manual_seed(RLG_SEED + channels)
+    return torch.randn(1, channels, generator=g)
+
+
+@torch.no_grad()
+def golden_rlg():
+    """get_random_conditioning_latents (api.py:301-309): the reference's RandomLatentConverter at both widths, with the
+    Gaussian input its forward draws (random_latent_generator.py:50) pinned by seeding the global generator."""
+    ref_shims.install()
+    from tortoise.models.random_latent_generator import RandomLatentConverter
+    out = {}
+    for ch in (1024, 2048):
+        sd = W.synthetic_state_dict(W.rlg_manifest(ch), seed=RLG_SEED, gain=3.0)
+        m = RandomLatentConverter(ch).eval()
+        m.load_state_dict(sd, strict=True)
+        r = rlg_inputs(ch)
+        orig = torch.randn
+        torch.randn = lambda *a, **k: r.clone()
+        try:
+            out[f"latent_{ch}"] = m(torch.tensor([0.0])).numpy()
+        finally:
+            torch.randn = orig
+    np.savez_compressed(os.path.join(OUT, "rlg.npz"), **out)
+
+
 def golden_text():
     """Long-form chunking (tortoise/utils/text.py:4-72).  The three cases are the reference's OWN expectations
     (text.py:82-130, which pass here: `python tortoise/utils/text.py`); inputs and outputs are stored so the GPU box,
@@ -303,6 +332,7 @@ def main():
     golden_diffusion(ref)
     golden_vocoder(ref)
     golden_conditioning(ref)
+    golden_rlg()
     golden_text()
     golden_integer()
     for f in sorted(os.listdir(OUT)):

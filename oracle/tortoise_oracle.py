@@ -206,6 +206,20 @@ def ar_sample_loop(sd, cfg: ARConfig, cond_latent, text_tokens, batch, max_new, 
     return codes
 
 
+# =============================================================================== random-voice latents
+def random_latent_converter(sd, r, lr_mul=0.1):
+    """RandomLatentConverter.forward with the Gaussian input `r` [B, C] injected (random_latent_generator.py:8-55):
+    5 x EqualLinear (F.linear(x, W * scale), scale = lr_mul / sqrt(C); leaky_relu(. + b * lr_mul, 0.2) * sqrt(2)) and one
+    plain Linear.  api.py:301-309 calls it with C = 1024 (rlg_auto) and 2048 (rlg_diffuser)."""
+    x = r.float()
+    C = x.shape[1]
+    scale = (1.0 / math.sqrt(C)) * lr_mul
+    for i in range(5):
+        x = F.linear(x, sd[f"layers.{i}.weight"] * scale)
+        x = F.leaky_relu(x + (sd[f"layers.{i}.bias"] * lr_mul)[None], negative_slope=0.2) * (2 ** 0.5)
+    return F.linear(x, sd["layers.5.weight"], sd["layers.5.bias"])
+
+
 # =============================================================================== integer post-processing
 def fix_autoregressive_output(codes, stop_token=8193):
     """api.py:87-114 on one row (numpy int64 [n]); returns a new array.  Integer path: bit-exact."""

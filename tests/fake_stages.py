@@ -1,0 +1,104 @@
+"""TEST INFRASTRUCTURE ONLY — CPU stand-ins for tortoise_tts_amd.stages backed by the ORACLE, so the host logic of the
+drop-in class (tortoise_tts_amd/api.py: tokenisation, padding, candidate sharding, fix_autoregressive_output, CLVP top-k,
+calm-token trim, return conventions, flag handling) can be driven end to end without a GPU.  The product never imports
+this; tests install it with pytest's monkeypatch."""
+import time
+
+import numpy as np
+import torch
+
+from oracle import tortoise_oracle as O
+
+
+class FakeTimer:
+    def __init__(self, n):
+        self.t = [0.0] * n
+
+    def mark(self, i):
+        self.t[i] = time.perf_counter()
+
+    def seconds(self, i, j):
+        return self.t[j] - self.t[i]
+
+    @staticmethod
+    def synchronize():
+        pass
+
+
+class FakeArStage:
+    def __init__(self, sd, cfg, device="cpu", dtype=0, max_batch=256, max_text=402, max_new_tokens=500, max_latent_candidates=4,
+                 share_weights_with=None, kv_cache=True):
+        self.sd = sd if sd is not None else share_weights_with.sd
+        self.cfg, self.kv_cache, self.max_batch = cfg, kv_cache, max_batch
+
+    def prefill(self, cond_latent, text_tokens):
+        self.cond, self.text = cond_latent[:1].float().cpu(), text_tokens[:1].cpu()
+
+    def generate(self, B, max_new, temperature=0.8, top_p=0.8, repetition_penalty=2.0, top_k=50, seed=0, row_offset=0, exp_noise=None):
+        assert B <= self.max_batch
+        V = self.cfg.number_mel_codes
+        if exp_noise is None:  # one generator per GLOBAL candidate: sharding-invariant like the engine's Philox streams
+            rows = []
+            for r in range(B):
+                g = torch.Generator().manual_seed(int(seed) * 1000003 + row_offset + r)
+                rows.append(torch.empty(max_new, V).exponential_(1, generator=g))
+            exp_noise = torch.stack(rows, dim=1)
+        codes = O.ar_sample_loop(self.sd, self.cfg, self.cond, self.text, B, max_new, exp_noise.cpu(), repetition_penalty, temperature,
+                                 top_k, top_p, kv_cache=self.kv_cache)
+        return codes, codes.shape[1]
+
+    def latents(self, cond_latent, text_tokens, codes):
+        k = codes.shape[0]
+        return O.ar_latents(self.sd, self.cfg, cond_latent.float().cpu().expand(k, -1), text_tokens.cpu().expand(k, -1), codes.cpu())
+
+
+class FakeClvpStage:
+    def __init__(self, sd, cfg, device="cpu", dtype=0, max_rows=0):
+        self.sd, self.cfg = sd, cfg
+
+    def score(self, text_tokens, codes):
+        B = codes.shape[0]
+        return O.clvp_score(self.sd, self.cfg, text_tokens[:1].long().cpu().repeat(B, 1), codes.long().cpu())
+
+
+class FakeDiffusionStage:
+    def __init__(self, sd, cfg, device="cpu", dtype=0, max_seq=0, max_codes=0, max_steps=0):
+        self.sd, self.cfg = sd, cfg
+
+    def condition(self, latents, cond_latent, S):
+        self.S = S
+        self.emb = O.diffusion_timestep_independent(self.sd, self.cfg, latents.float().cpu(), cond_latent.float().cpu(), S)
+
+    def sample(self, sched, x_T, step_noise):
+        osched = O.Schedule(sched.num_timesteps, self.cfg.trained_steps, sched.cond_free, sched.cond_free_k)
+        assert np.array_equal(osched.timestep_map, sched.timestep_map)
+        return O.denormalize_tacotron_mel(O.p_sample_loop(self.sd, self.cfg, osched, self.emb, x_T.float().cpu(), step_noise.float().cpu()))
+
+
+class FakeVocoderStage:
+    def __init__(self, sd_folded, cfg, device="cpu", dtype=0, max_frames=0):
+        self.sd, self.cfg = sd_folded, cfg
+
+    def inference(self, mel, z):
+        return O.univnet_inference(self.sd, self.cfg, mel.float().cpu(), z.float().cpu())
+
+
+class FakeRandomLatentStage:
+    def __init__(self, sd_auto, sd_diffuser, device="cpu", dtype=0):
+        self.sds = (sd_auto, sd_diffuser)
+        self.channels = (sd_auto["layers.0.weight"].shape[0], sd_diffuser["layers.0.weight"].shape[0])
+
+    def latents(self, r_auto, r_diffuser):
+        return O.random_latent_converter(self.sds[0], r_auto), O.random_latent_converter(self.sds[1], r_diffuser)
+
+
+def install(monkeypatch):
+    """Route tortoise_tts_amd.api onto the CPU stand-ins (and a CPU 'device')."""
+    from tortoise_tts_amd import api
+    monkeypatch.setattr(api.stages, "ArStage", FakeArStage)
+    monkeypatch.setattr(api.stages, "ClvpStage", FakeClvpStage)
+    monkeypatch.setattr(api.stages, "DiffusionStage", FakeDiffusionStage)
+    monkeypatch.setattr(api.stages, "VocoderStage", FakeVocoderStage)
+    monkeypatch.setattr(api.stages, "RandomLatentStage", FakeRandomLatentStage)
+    monkeypatch.setattr(api.E, "require_gpu", lambda device=None: torch.device("cpu"))
+    monkeypatch.setattr(api, "_StageTimer", FakeTimer)

@@ -1,0 +1,115 @@
+"""Host logic of the drop-in class, driven on CPU with the exact call sequence of the reference's CLI
+(tortoise/do_tts.py:31-47) and oracle-backed stand-ins for the GPU stages (tests/fake_stages.py).  What is checked is
+everything api.py does BETWEEN the stage calls - flags, tokenisation, padding, fix_autoregressive_output, CLVP top-k,
+calm-token trim, the return conventions of api.py:589-595 - plus the reference's error behaviour."""
+import os
+
+import pytest
+import torch
+
+from oracle import make_golden as G
+from oracle import ref_shims
+from tests import fake_stages
+from tortoise_tts_amd import weights as W
+from tortoise_tts_amd.config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
+
+VOCAB = os.path.join(ref_shims.REFERENCE_ROOT, "tortoise", "data", "tokenizer.json")
+PAT = os.path.join(ref_shims.REFERENCE_ROOT, "tortoise", "voices", "cond_latent_example", "pat.pth")
+DEFAULT_TEXT = "The expressiveness of autoregressive transformers is literally nuts! I absolutely adore them."  # do_tts.py:12
+
+
+def small_setup():
+    ar, clvp, diff = ARConfig(**G.AR_CFG), CLVPConfig(**G.CLVP_CFG), DiffusionConfig(**G.DIFF_CFG)
+    sds = {"autoregressive": G.sampling_state_dict(ar, 2.0),  # stop token reachable: ragged candidates
+           "clvp": W.synthetic_state_dict(W.clvp_manifest(clvp), seed=G.CLVP_SEED),
+           "diffusion": W.synthetic_state_dict(W.diffusion_manifest(diff), seed=G.DIFF_SEED),
+           "vocoder": W.fold_weight_norm(W.synthetic_state_dict(W.vocoder_manifest(VocoderConfig()), seed=G.VOC_SEED)),
+           "rlg_auto": W.synthetic_state_dict(W.rlg_manifest(ar.model_dim), seed=G.RLG_SEED, gain=3.0),
+           "rlg_diffuser": W.synthetic_state_dict(W.rlg_manifest(2 * diff.model_channels), seed=G.RLG_SEED + 1, gain=3.0)}
+    return sds, {"ar": ar, "clvp": clvp, "diffusion": diff}
+
+
+def voice_latents(cfgs):
+    """do_tts.py:39 `load_voices` on a .pth voice returns (None, latents) (utils/audio.py:104-124): the reference's own
+    example file when the tree is here (1024 / 2048 wide), cut to the small test widths."""
+    D, C2 = cfgs["ar"].model_dim, 2 * cfgs["diffusion"].model_channels
+    if os.path.exists(PAT):
+        a, d = torch.load(PAT, map_location="cpu")
+        return a[:, :D].contiguous(), d[:, :C2].contiguous()
+    g = torch.Generator().manual_seed(9)
+    return torch.randn(1, D, generator=g) * 0.5, torch.randn(1, C2, generator=g) * 0.5
+
+
+@pytest.fixture()
+def tts(monkeypatch):
+    if not os.path.exists(VOCAB):
+        pytest.skip("tokenizer.json (reference data file) not present")
+    fake_stages.install(monkeypatch)
+    from tortoise_tts_amd.api import TextToSpeech
+    sds, cfgs = small_setup()
+    # do_tts.py:31: TextToSpeech(models_dir=..., use_deepspeed=..., kv_cache=..., half=...)  (+ engine-only keywords for the test sizes)
+    t = TextToSpeech(models_dir="/nonexistent", use_deepspeed=False, kv_cache=True, half=True, tokenizer_vocab_file=VOCAB,
+                     tokenizer_basic=True, state_dicts=sds, configs=cfgs, max_candidates=32, max_mel_tokens=48)
+    t._cfgs = cfgs
+    return t
+
+
+@torch.no_grad()
+def test_do_tts_call_sequence(tts):
+    from tortoise_tts_amd import engine as E
+    assert tts.dtype == E.TT_F16 and tts.kv_cache is True and tts.enable_redaction is True  # flags honoured, not ignored
+    voice_samples, conditioning_latents = None, voice_latents(tts._cfgs)
+    kw = dict(k=3, voice_samples=voice_samples, conditioning_latents=conditioning_latents, preset="ultra_fast",
+              use_deterministic_seed=11, return_deterministic_state=True, cvvp_amount=0.0)
+    gen, dbg = tts.tts_with_preset(DEFAULT_TEXT, max_mel_tokens=48, **kw)  # do_tts.py:41-42 (+ a short decode for CPU time)
+    assert isinstance(gen, list) and len(gen) == 3  # api.py:589-592: k > 1 -> list of k clips
+    for g_ in gen:
+        assert g_.dim() == 3 and g_.shape[:2] == (1, 1) and g_.dtype == torch.float32 and g_.device.type == "cpu"
+        assert g_.shape[-1] % 256 == 0 and g_.shape[-1] > 0 and torch.isfinite(g_).all() and g_.abs().max() <= 1.0
+        assert g_.squeeze(0).cpu().shape[0] == 1  # what do_tts.py:45 hands torchaudio.save
+    seed, text, vs, lat = dbg  # api.py:594-595
+    assert seed == 11 and text == DEFAULT_TEXT and vs is None and lat is conditioning_latents
+    # the ranked winners are fix_autoregressive_output'ed rows padded to max_mel_tokens (api.py:425-426, 459)
+    best = tts.last_best_codes
+    assert best.shape == (3, 48) and best.max() < 8193
+    # same seed -> same audio; k = 1 returns a bare tensor (api.py:591-592)
+    again = tts.tts_with_preset(DEFAULT_TEXT, max_mel_tokens=48, **dict(kw, k=1, return_deterministic_state=False))
+    assert torch.is_tensor(again) and torch.equal(again, gen[0])
+
+
+@torch.no_grad()
+def test_random_voice_and_error_behaviour(tts):
+    # voice='random' (do_tts.py default): no samples, no latents -> RandomLatentConverter pair (api.py:398-399, 301-309)
+    torch.manual_seed(3)
+    a, d = tts.get_random_conditioning_latents()
+    assert a.shape == (1, tts._cfgs["ar"].model_dim) and d.shape == (1, 2 * tts._cfgs["diffusion"].model_channels)
+    torch.manual_seed(3)
+    a2, _ = tts.get_random_conditioning_latents()
+    assert torch.equal(a, a2)
+    wav = tts.tts("hello there", num_autoregressive_samples=4, diffusion_iterations=4, max_mel_tokens=24, use_deterministic_seed=1)
+    assert torch.is_tensor(wav) and wav.shape[:2] == (1, 1)
+    with pytest.raises(ValueError, match="Too much text"):  # api.py:392
+        tts.tts(list(range(1, 255)) * 2, conditioning_latents=(a, d))
+    with pytest.raises(NotImplementedError, match="bracket"):
+        tts.tts("[I am so sad,] hello", conditioning_latents=(a, d))
+    with pytest.raises(NotImplementedError):
+        tts.tts("hello", conditioning_latents=(a, d), cvvp_amount=0.5)
+    with pytest.raises(ValueError, match="max_mel_tokens"):
+        tts.tts("hello", conditioning_latents=(a, d), max_mel_tokens=500)
+
+
+def test_constructor_flags(monkeypatch):
+    fake_stages.install(monkeypatch)
+    from tortoise_tts_amd.api import TextToSpeech
+    from tortoise_tts_amd import engine as E
+    sds, cfgs = small_setup()
+    kw = dict(state_dicts=sds, configs=cfgs, max_candidates=8, max_mel_tokens=16)
+    t = TextToSpeech(**kw)  # reference defaults: kv_cache=False, half=False
+    assert t.kv_cache is False and t.ar.kv_cache is False and t.dtype == E.TT_BF16
+    assert TextToSpeech(half=True, **kw).dtype == E.TT_F16
+    assert TextToSpeech(dtype="fp16", **kw).dtype == E.TT_F16
+    with pytest.raises(ValueError):
+        TextToSpeech(half=True, dtype="bf16", **kw)
+    with pytest.raises(NotImplementedError):
+        TextToSpeech(use_deepspeed=True, **kw)
+    assert TextToSpeech(autoregressive_batch_size=64, **kw).autoregressive_batch_size == 8  # clamped to the handle's capacity

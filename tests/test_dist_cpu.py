@@ -99,3 +99,28 @@ def test_split_tail_protocol_keeps_pair_in_lockstep(tmp_path):
         x = 0.5 * x + 0.25 * ((x * 1 + step) - (x * 2 + step))
     assert np.array_equal(x0, x.numpy())
 
+
+
+def _collect_worker(rank, world, port, out_dir):
+    """k = 3 winners over 2 ranks: winner i is rendered on rank i % 2; rank 0 must end up with all three waveforms (two
+    of its own + one point-to-point receive), rank 1 with None."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    tdist.init_from_env()
+    k = 3
+    mine = {i: torch.full((1, 1, 10 + i), float(i)) for i in range(k) if i % world == rank}
+    got = tdist.collect_on_rank0(mine, k)
+    if rank == 0:
+        assert sorted(got) == [0, 1, 2]
+        for i in range(k):
+            assert got[i].shape == (1, 1, 10 + i) and bool((got[i] == float(i)).all())
+    else:
+        assert got is None
+    # k = 1: the winner is on rank 0, nothing is sent
+    got = tdist.collect_on_rank0({0: torch.zeros(1, 1, 4)} if rank == 0 else {}, 1)
+    assert (got is not None) == (rank == 0)
+    tdist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rendered_winners_are_collected_on_rank0_only():
+    mp.spawn(_collect_worker, args=(2, _free_port(), ""), nprocs=2, join=True)

@@ -302,3 +302,16 @@ def test_diffusion_split_rows_match_batched_sampling():
     for st in parts:
         st.close()
 
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@torch.no_grad()
+def test_random_conditioning_latents(name, dt, tdt, tol):
+    """get_random_conditioning_latents (api.py:301-309) on the engine vs the oracle and the reference golden."""
+    g = gold("rlg.npz")
+    sds = {ch: W.synthetic_state_dict(W.rlg_manifest(ch), seed=G.RLG_SEED, gain=3.0) for ch in (1024, 2048)}
+    st = stages.RandomLatentStage(sds[1024], sds[2048], dtype=dt)
+    a, d = st.latents(G.rlg_inputs(1024), G.rlg_inputs(2048))
+    for ch, got in ((1024, a), (2048, d)):
+        report(f"random latent {ch} {name} vs oracle", got, O.random_latent_converter(quantize_sd(sds[ch], tdt), G.rlg_inputs(ch)), tol)
+        report(f"random latent {ch} {name} vs reference golden", got, torch.from_numpy(g[f"latent_{ch}"]), tol * 1.6)

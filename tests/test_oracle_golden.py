@@ -113,3 +113,14 @@ def test_fix_autoregressive_output_bit_exact():
     g = gold("integer.npz")
     for cin, cout in zip(g["codes_in"], g["codes_out"]):
         assert np.array_equal(O.fix_autoregressive_output(cin, 8193), cout)
+
+
+@torch.no_grad()
+def test_random_latent_converter():
+    """oracle.random_latent_converter vs outputs of the reference's RandomLatentConverter (tests/golden/rlg.npz)."""
+    g = gold("rlg.npz")
+    for ch in (1024, 2048):
+        sd = W.synthetic_state_dict(W.rlg_manifest(ch), seed=G.RLG_SEED, gain=3.0)
+        got = O.random_latent_converter(sd, G.rlg_inputs(ch))
+        assert got.shape == (1, ch) and float(got.abs().mean()) > 1e-3
+        close(got, g[f"latent_{ch}"], 1e-5)

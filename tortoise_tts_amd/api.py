@@ -9,8 +9,15 @@ What changed behind the signature
   * candidates shard across the GPUs of a node, one all_gather picks the CLVP top-k (dist.py);
   * stage 2 evaluates conditioned + unconditioned denoiser rows in one pass per step;
   * integer post-processing (api.py:87-114, 547-556) is vectorised on device and bit-exact.
-Out of scope this round (raise, never silently fall back): voice_samples -> conditioning latents
-(SURVEY.md §8f-3), CVVP (cvvp_amount != 0, removed upstream), wav2vec redaction, DeepSpeed flag.
+Constructor flags of the reference and what they mean here:
+  * kv_cache   the engine always keeps a KV cache; the flag selects the reference's mel POSITION rule, which is the
+               only numerical difference between its two code paths (kv_cache=False, the reference default: rows
+               0,1,2,...; kv_cache=True: rows 0,2,3,...; autoregressive.py:134-149);
+  * half       True selects fp16 MFMA operands (the reference's fp16 autocast), False the engine default (bf16) unless
+               the engine-only `dtype=` says otherwise;
+  * enable_redaction  bracketed text needs the wav2vec2 aligner (out of scope): such text raises, other text is unaffected.
+Out of scope (raise, never silently fall back): CVVP (cvvp_amount != 0, removed upstream), wav2vec redaction of
+bracketed text, DeepSpeed flag, wav -> mel front-end of voice_samples (pass mel spectrograms or conditioning_latents).
 """
 import os
 import random
@@ -28,7 +35,24 @@ from .schedule import Schedule
 
 MODELS_DIR = os.environ.get("TORTOISE_MODELS_DIR", os.path.join(os.path.expanduser("~"), ".cache", "tortoise", "models"))
 MODEL_FILES = {"autoregressive": "autoregressive.pth", "clvp": "clvp2.pth", "diffusion": "diffusion_decoder.pth",
-               "vocoder": "vocoder.pth"}
+               "vocoder": "vocoder.pth", "rlg_auto": "rlg_auto.pth", "rlg_diffuser": "rlg_diffuser.pth"}
+
+
+class _StageTimer:
+    """Stage boundaries of one tts() call as HIP events on the current stream (no host synchronisation until read)."""
+
+    def __init__(self, n):
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+
+    def mark(self, i):
+        self.ev[i].record()
+
+    def seconds(self, i, j):
+        return self.ev[i].elapsed_time(self.ev[j]) / 1e3
+
+    @staticmethod
+    def synchronize():
+        torch.cuda.synchronize()
 
 
 def fix_autoregressive_output(codes, stop_token, calm_token=CALM_TOKEN):
@@ -78,24 +102,27 @@ class TextToSpeech:
 
     def __init__(self, autoregressive_batch_size=None, models_dir=MODELS_DIR, enable_redaction=True, kv_cache=False,
                  use_deepspeed=False, half=False, device=None, tokenizer_vocab_file=None, tokenizer_basic=False, *,
-                 state_dicts=None, dtype="bf16", max_candidates=256, configs=None, max_mel_tokens=500, max_text_tokens=402,
-                 decode_streams=1):
+                 state_dicts=None, dtype=None, max_candidates=256, configs=None, max_mel_tokens=500, max_text_tokens=402):
         self.models_dir = models_dir
         if use_deepspeed:
             raise NotImplementedError("use_deepspeed: DeepSpeed kernel injection is a CUDA-only reference option; the MI355X engine "
                                       "always runs its own fused HIP path")
-        self.enable_redaction = False  # wav2vec2 redaction is outside the hot path
+        # wav2vec2 redaction is outside the hot path.  The flag is kept (reference default True): text
+        # without [brackets] is unaffected by it in the reference too; bracketed text raises in tts() instead of being spoken.
+        self.enable_redaction = bool(enable_redaction)
+        self.kv_cache = bool(kv_cache)
+        self.half = bool(half)
         self.rank, self.world = tdist.world()
         # With >= 2 ranks a single winner's diffusion tail is split over ranks 0 and 1 (conditioned / conditioning-free
         # row each, one exchange per step).  TT_SPLIT_DIFFUSION=0 keeps the whole tail on rank 0.
         self.split_diffusion = self.world >= 2 and os.environ.get("TT_SPLIT_DIFFUSION", "1") != "0"
         if self.split_diffusion:
             tdist.pair_group()  # collective over all ranks: create it once, here, where every rank passes
-        if device is None:
-            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
-        if device is None or torch.device(device).type != "cuda":
-            raise E.EngineError("TextToSpeech needs an MI355X (gfx950) device; the engine has no CPU path")
-        self.device = torch.device(device)
+        self.device = E.require_gpu(device)
+        if dtype is None:
+            dtype = "fp16" if half else "bf16"  # half=True is the reference's fp16 autocast (api.py:180, autoregressive.py:561)
+        elif half and dtype not in ("fp16", "f16"):
+            raise ValueError(f"half=True asks for fp16 operands but dtype={dtype!r} was also given")
         self.dtype = {"bf16": E.TT_BF16, "fp16": E.TT_F16, "f16": E.TT_F16}[dtype]
         cfgs = configs or {}
         self.ar_cfg = cfgs.get("ar", ARConfig())
@@ -109,22 +136,14 @@ class TextToSpeech:
 
         # the reference's default AR batch is 16 on a >=14 GB GPU (api.py:148-172); 288 GB of HBM3E decodes
         # every candidate of this rank in one batch unless the caller asks for smaller batches.
-        self.autoregressive_batch_size = int(autoregressive_batch_size or max_candidates)
-        cap = min(self.autoregressive_batch_size, max_candidates)
+        cap = min(int(autoregressive_batch_size or max_candidates), max_candidates)
+        self.autoregressive_batch_size = cap  # never above the handle's decode capacity
         self.tokenizer_args = (tokenizer_vocab_file, tokenizer_basic)
         self._tokenizer = None
         self.max_mel_tokens_cap = max_mel_tokens
         max_S = max_mel_tokens * 4 * 24000 // 22050 + 8
         self.ar = stages.ArStage(sd("autoregressive"), self.ar_cfg, self.device, self.dtype, max_batch=cap,
-                                 max_text=max_text_tokens, max_new_tokens=max_mel_tokens, max_latent_candidates=4)
-        # Optional: decode several candidate sub-batches concurrently on their own streams (shared weights; sampled
-        # codes do not change because Philox streams are keyed by the global candidate index).  Measured on MI355X:
-        # no gain (1 stream 0.505 s, 2 streams 0.515 s, 4 streams 0.915 s for 256 x 200 tokens) - the decode GEMMs
-        # are weight-streaming bound, so splitting the batch only streams the weights more often.  Default 1.
-        self.decode_streams = max(1, int(decode_streams))
-        self.ar_extra = [stages.ArStage(None, self.ar_cfg, self.device, self.dtype, max_batch=-(-cap // self.decode_streams),
-                                        max_text=max_text_tokens, max_new_tokens=max_mel_tokens, max_latent_candidates=1,
-                                        share_weights_with=self.ar) for _ in range(self.decode_streams - 1)]
+                                 max_text=max_text_tokens, max_new_tokens=max_mel_tokens, max_latent_candidates=4, kv_cache=self.kv_cache)
         self.clvp = stages.ClvpStage(sd("clvp"), self.clvp_cfg, self.device, self.dtype, max_rows=max(cap, 8) * max_mel_tokens)
         self.diffusion = stages.DiffusionStage(sd("diffusion"), self.diff_cfg, self.device, self.dtype, max_seq=max_S,
                                                max_codes=max_mel_tokens + 8, max_steps=512)
@@ -132,6 +151,9 @@ class TextToSpeech:
         if any(k.endswith("weight_v") for k in voc_sd):
             voc_sd = W.fold_weight_norm(voc_sd)  # UnivNetGenerator.eval(inference=True), vocoder.py:284-298
         self.vocoder = stages.VocoderStage(voc_sd, self.voc_cfg, self.device, self.dtype, max_frames=max_S)
+        self._state_dicts = sds
+        self.rlg = None         # random-voice latent MLPs, built lazily like the reference (api.py:301-309)
+        self.conditioning = None  # conditioning encoders (voice_samples path), built lazily
         # attributes the reference exposes and callers touch (api.py:408, 523)
         self.stop_mel_token = self.ar_cfg.stop_mel_token
         self.mel_length_compression = self.ar_cfg.mel_length_compression
@@ -146,13 +168,38 @@ class TextToSpeech:
         return self._tokenizer
 
     def get_conditioning_latents(self, voice_samples, return_mels=False):
-        raise NotImplementedError("voice_samples -> conditioning latents (ConditioningEncoder / contextual_embedder / STFT front-end, "
-                                  "api.py:258-299) is not on the accelerated path yet (SURVEY.md §8f-3); pass conditioning_latents= "
-                                  "(e.g. the .pth latent files the reference caches per voice)")
+        """api.py:258-299 on the engine: ConditioningEncoder (autoregressive.py:204-228) and contextual_embedder
+        (diffusion_decoder.py:186-192, 222-230) run on the device.  The wav -> mel front-end (TacotronSTFT /
+        torchaudio resample + TorchMelSpectrogram) stays with the caller: voice_samples is a list of (auto_mel f32 [1, 80, T_a],
+        diffusion_mel f32 [1, 100, T_d]) pairs, one per clip, i.e. what api.py:271-289 computes from the raw clips."""
+        if self.conditioning is None:
+            self.conditioning = stages.ConditioningStage(self._sd("autoregressive"), self._sd("diffusion"), self.ar_cfg, self.diff_cfg,
+                                                         self.device, self.dtype)
+        auto_mels, diff_mels = [], []
+        for vs in voice_samples:
+            if not (isinstance(vs, (tuple, list)) and len(vs) == 2):
+                raise NotImplementedError("voice_samples must be (auto_mel [1, 80, T], diffusion_mel [1, 100, T]) pairs: the STFT / mel "
+                                          "front-end of raw clips (torchaudio, librosa) is outside the accelerated path; or pass "
+                                          "conditioning_latents= (the .pth files the reference caches per voice)")
+            auto_mels.append(vs[0])
+            diff_mels.append(vs[1])
+        auto_latent = self.conditioning.auto_latent(auto_mels)
+        diffusion_latent = self.conditioning.diffusion_latent(diff_mels)
+        if return_mels:
+            return auto_latent, diffusion_latent, torch.stack(auto_mels, dim=1), torch.stack(diff_mels, dim=1)
+        return auto_latent, diffusion_latent
+
+    def _sd(self, name):
+        return self._state_dicts[name] if name in self._state_dicts else _load_state_dict(self.models_dir, name)
 
     def get_random_conditioning_latents(self):
-        raise NotImplementedError("random-voice latents need the reference's rlg_auto.pth / rlg_diffuser.pth MLPs (api.py:301-309), "
-                                  "which are outside the hot path; pass conditioning_latents=")
+        """api.py:301-309: two RandomLatentConverter MLPs (random_latent_generator.py:42-55) on the device.  Like the
+        reference, the Gaussian inputs are drawn from torch's CPU generator (it evaluates the MLPs on a CPU tensor), so the
+        same torch.manual_seed gives the same random voice."""
+        if self.rlg is None:
+            self.rlg = stages.RandomLatentStage(self._sd("rlg_auto"), self._sd("rlg_diffuser"), self.device, self.dtype)
+        ca, cd = self.rlg.channels  # 1024 / 2048 for the released rlg_auto.pth / rlg_diffuser.pth
+        return self.rlg.latents(torch.randn(1, ca), torch.randn(1, cd))
 
     def deterministic_state(self, seed=None):
         """api.py:598-609."""
@@ -188,16 +235,21 @@ class TextToSpeech:
         if cvvp_amount != 0:
             raise NotImplementedError("CVVP was removed upstream (CHANGELOG) and is not part of the accelerated path")
         dev = self.device
+        if self.enable_redaction and isinstance(text, str) and "[" in text and "]" in text:
+            raise NotImplementedError("text with [bracketed] passages needs the wav2vec2 aligner to redact them from the audio "
+                                      "(api.py:583-587), which is outside the accelerated path; remove the brackets or construct "
+                                      "TextToSpeech(enable_redaction=False) to have them spoken")
         seed = self.deterministic_state(seed=use_deterministic_seed)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
-        ev[0].record()
+        ev = _StageTimer(6)
+        ev.mark(0)
 
         if isinstance(text, str):
             text_tokens = torch.IntTensor(self.tokenizer.encode(text)).unsqueeze(0)
         else:  # pre-tokenised ids (synthetic prompts): int sequence / tensor [T]
             text_tokens = torch.as_tensor(text, dtype=torch.int32).reshape(1, -1)
         text_tokens = F.pad(text_tokens.to(dev), (0, 1))  # api.py:391
-        assert text_tokens.shape[-1] < 400, "Too much text provided. Break the text up into separate segments and re-try inference."
+        if text_tokens.shape[-1] >= 400:  # api.py:392
+            raise ValueError("Too much text provided. Break the text up into separate segments and re-try inference.")
         if voice_samples is not None:
             auto_conditioning, diffusion_conditioning = self.get_conditioning_latents(voice_samples)
         elif conditioning_latents is not None:
@@ -206,7 +258,9 @@ class TextToSpeech:
             auto_conditioning, diffusion_conditioning = self.get_random_conditioning_latents()
         auto_conditioning = auto_conditioning.to(dev).float()
         diffusion_conditioning = diffusion_conditioning.to(dev).float()
-        assert max_mel_tokens <= self.max_mel_tokens_cap
+        if max_mel_tokens > self.max_mel_tokens_cap:
+            raise ValueError(f"max_mel_tokens={max_mel_tokens} exceeds the capacity this engine was built with "
+                             f"(TextToSpeech(max_mel_tokens={self.max_mel_tokens_cap}))")
         sched = Schedule(diffusion_iterations, self.diff_cfg.trained_steps, cond_free, cond_free_k)
 
         # ---- stage 1: this rank's share of the candidates (api.py:407-427)
@@ -214,46 +268,16 @@ class TextToSpeech:
         lo, hi = tdist.shard_range(N, self.rank, self.world)
         stop = self.ar_cfg.stop_mel_token
         exp_noise = noise.get("exp_noise")
-        jobs = []  # (first global candidate, count)
-        for b0 in range(lo, hi, self.autoregressive_batch_size):
-            B = min(self.autoregressive_batch_size, hi - b0)
-            nsub = self.decode_streams if B >= 32 * self.decode_streams else 1
-            per = -(-B // nsub)
-            for j in range(nsub):
-                c0 = b0 + j * per
-                if c0 < b0 + B:
-                    jobs.append((c0, min(per, b0 + B - c0)))
-
-        def decode(stage, c0, B, out, idx, stream):
-            with torch.cuda.stream(stream):
-                stage.prefill(auto_conditioning, text_tokens)
-                en = exp_noise[:, c0 - lo:c0 - lo + B] if exp_noise is not None else None
-                codes, n = stage.generate(B, max_mel_tokens, temperature=temperature, top_p=top_p, repetition_penalty=repetition_penalty,
-                                          top_k=top_k, seed=seed, row_offset=c0, exp_noise=en)
-                out[idx] = F.pad(codes, (0, max_mel_tokens - codes.shape[1]), value=stop)  # api.py:425-426
-
-        batches = [None] * len(jobs)
-        handles = [self.ar] + self.ar_extra
-        cur = torch.cuda.current_stream()
-        for w0 in range(0, len(jobs), len(handles)):
-            wave = jobs[w0:w0 + len(handles)]
-            if len(wave) == 1:
-                decode(handles[0], wave[0][0], wave[0][1], batches, w0, cur)
-                continue
-            import threading
-            streams = [torch.cuda.Stream(device=dev) for _ in wave]
-            for st_ in streams:
-                st_.wait_stream(cur)
-            threads = [threading.Thread(target=decode, args=(handles[i], c0, B, batches, w0 + i, streams[i]))
-                       for i, (c0, B) in enumerate(wave)]
-            for t_ in threads:
-                t_.start()
-            for t_ in threads:
-                t_.join()
-            for st_ in streams:
-                cur.wait_stream(st_)
+        batches = []
+        for c0 in range(lo, hi, self.autoregressive_batch_size):
+            B = min(self.autoregressive_batch_size, hi - c0)
+            self.ar.prefill(auto_conditioning, text_tokens)
+            en = exp_noise[:, c0 - lo:c0 - lo + B] if exp_noise is not None else None
+            codes, n = self.ar.generate(B, max_mel_tokens, temperature=temperature, top_p=top_p, repetition_penalty=repetition_penalty,
+                                        top_k=top_k, seed=seed, row_offset=c0, exp_noise=en)
+            batches.append(F.pad(codes, (0, max_mel_tokens - codes.shape[1]), value=stop))  # api.py:425-426
         samples = torch.cat(batches, dim=0)
-        ev[1].record()
+        ev.mark(1)
 
         # ---- CLVP ranking (api.py:447-477) + the one collective of the path
         fixed = fix_autoregressive_output(samples, stop)
@@ -262,11 +286,11 @@ class TextToSpeech:
         best = tdist.topk_lowest_index(scores_all, k)
         best_results = codes_all[best].long()
         self.last_best_codes = best_results  # the k ranked winners' codes (tests, sharding checks)
-        ev[2].record()
+        ev.mark(2)
 
         # ---- AR latent re-pass for the winners (api.py:516-524)
         best_latents = self.ar.latents(auto_conditioning, text_tokens, best_results)
-        ev[3].record()
+        ev.mark(3)
 
         # ---- stage 2 + 3 per winner; winners are spread round-robin over the ranks.  A single winner with
         # conditioning_free is rendered by ranks 0 and 1 together: rank r evaluates denoiser row r of every step.
@@ -296,22 +320,21 @@ class TextToSpeech:
                     continue  # rank 1 only lends its GPU to the tail; rank 0 holds the same mel and runs the vocoder
             else:
                 mel = self.diffusion.sample(sched, x_T, step_noise)
-            ev[4].record()
+            ev.mark(4)
             z = noise.get("z")
             z = torch.randn(1, self.voc_cfg.noise_dim, S + 10, device=dev, generator=gen) if z is None else z.to(dev)
             wavs[i] = self.vocoder.inference(mel, z).cpu()
         if not wavs:  # this rank had no winner to render
-            ev[4].record()
-        ev[5].record()
-        torch.cuda.synchronize()
-        self.timings = {"ar_s": ev[0].elapsed_time(ev[1]) / 1e3, "clvp_s": ev[1].elapsed_time(ev[2]) / 1e3,
-                        "latents_s": ev[2].elapsed_time(ev[3]) / 1e3, "diffusion_s": ev[3].elapsed_time(ev[4]) / 1e3,
-                        "vocoder_s": ev[4].elapsed_time(ev[5]) / 1e3, "total_s": ev[0].elapsed_time(ev[5]) / 1e3}
-        if self.world > 1:
-            import torch.distributed as tdd
-            gathered = [None] * self.world
-            tdd.all_gather_object(gathered, wavs)
-            wavs = {i: w for d in gathered for i, w in d.items()}
+            ev.mark(4)
+        ev.mark(5)
+        ev.synchronize()
+        self.timings = {"ar_s": ev.seconds(0, 1), "clvp_s": ev.seconds(1, 2), "latents_s": ev.seconds(2, 3),
+                        "diffusion_s": ev.seconds(3, 4), "vocoder_s": ev.seconds(4, 5), "total_s": ev.seconds(0, 5)}
+        # Rendered winners go to rank 0 only (the reference returns the audio to ONE caller); other ranks get None entries.
+        wavs = tdist.collect_on_rank0(wavs, k)
+        if wavs is None:
+            res = None
+            return (res, (seed, text, voice_samples, conditioning_latents)) if return_deterministic_state else res
         wav_candidates = [wavs[i] for i in range(k)]
         res = wav_candidates if len(wav_candidates) > 1 else wav_candidates[0]
         if return_deterministic_state:

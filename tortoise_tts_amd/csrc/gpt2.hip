@@ -130,7 +130,7 @@ static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, 
 // One KV-cached decode step for e->B sequences; the fed tokens are in e->next_tok.
 static int decode_step_enqueue(tt_ar* e, hipStream_t s) {
   const int D = e->D, H = e->H, B = e->B, dt = e->cfg.dtype;
-  TT_TRY(ar_embed_launch(e->next_tok, e->state, e->w.mel_emb, e->w.mel_pos, e->x, B, D, s));
+  TT_TRY(ar_embed_launch(e->next_tok, e->state, e->w.mel_emb, e->w.mel_pos, e->x, B, D, e->cfg.mel_pos_offset, s));
   const float* pend_bias = nullptr;
   int pend_slabs = 0;
   for (int l = 0; l < e->cfg.layers; ++l) {
@@ -178,6 +178,7 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
   TT_REQUIRE(cfg->model_dim % 64 == 0 && cfg->model_dim <= 4096, "tt_ar_create: unsupported model_dim %d", cfg->model_dim);
   TT_REQUIRE(cfg->max_batch > 0 && cfg->max_prefix > 1 && cfg->max_new_tokens > 0, "tt_ar_create: bad capacity");
   TT_REQUIRE(cfg->vocab <= 10240, "tt_ar_create: vocab %d exceeds the sampler's 10240 limit", cfg->vocab);
+  TT_REQUIRE(cfg->mel_pos_offset == 1 || cfg->mel_pos_offset == 2, "tt_ar_create: mel_pos_offset must be 2 (kv_cache=True rule) or 1 (kv_cache=False rule), got %d", cfg->mel_pos_offset);
   tt_ar* e = new tt_ar();
   e->cfg = *cfg;
   e->w = *w;
@@ -281,6 +282,9 @@ int tt_ar_begin(tt_ar* e, int B, void* stream) {
 
 int tt_ar_decode_step(tt_ar* e, const int* tokens, void* stream) {
   TT_REQUIRE(e && tokens && e->B > 0, "tt_ar_decode_step: call tt_ar_begin first");
+  // the step about to run writes KV slot host_slot + 1 and reads mel position row host_slot + 1 + mel_pos_offset
+  TT_REQUIRE(e->host_slot + 1 < e->tmax, "tt_ar_decode_step: all %d KV slots of this handle are used", e->tmax);
+  TT_REQUIRE(e->host_slot + 1 + e->cfg.mel_pos_offset < e->cfg.mel_pos_len, "tt_ar_decode_step: step %d is beyond the mel position table (%d rows)", e->host_slot + 1, e->cfg.mel_pos_len);
   hipStream_t us = (hipStream_t)stream, s = e->sb.own;
   TT_TRY(e->sb.enter(us));
   TT_CHECK_HIP(hipMemcpyAsync(e->next_tok, tokens, (size_t)e->B * sizeof(int), hipMemcpyDeviceToDevice, s));
@@ -295,7 +299,7 @@ int tt_ar_generate(tt_ar* e, int B, int max_new, const tt_sampling* sp, int* cod
   TT_REQUIRE(e && sp && codes, "tt_ar_generate: null argument");
   TT_REQUIRE(B >= 1 && B <= e->cfg.max_batch, "tt_ar_generate: batch %d exceeds capacity %d", B, e->cfg.max_batch);
   TT_REQUIRE(max_new >= 1 && max_new <= e->tmax, "tt_ar_generate: max_new %d exceeds capacity %d", max_new, e->tmax);
-  TT_REQUIRE(max_new + 1 < e->cfg.mel_pos_len, "tt_ar_generate: max_new %d exceeds the mel position table", max_new);
+  TT_REQUIRE(max_new - 2 + e->cfg.mel_pos_offset < e->cfg.mel_pos_len, "tt_ar_generate: max_new %d exceeds the mel position table", max_new);
   TT_REQUIRE(e->P1 > 0, "tt_ar_generate: call tt_ar_prefill first");
   hipStream_t us = (hipStream_t)stream, s = e->sb.own;
   TT_TRY(e->sb.enter(us));
@@ -331,8 +335,12 @@ int tt_ar_generate(tt_ar* e, int B, int max_new, const tt_sampling* sp, int* cod
       if (graph) (void)hipGraphDestroy(graph);
       return rc;
     }
-    TT_CHECK_HIP(ce);
-    TT_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    if (ce == hipSuccess) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (ce != hipSuccess) {
+      if (graph) (void)hipGraphDestroy(graph);
+      set_error("tt_ar_generate: graph capture / instantiate failed: %s", hipGetErrorString(ce));
+      return -2;
+    }
   }
   int steps_done = 1;
   bool finished = false;

@@ -110,8 +110,8 @@ int ar_state_advance_launch(int* state, hipStream_t stream);
 int ar_begin_launch(int* state, unsigned* seen, int* unfinished, int* unfinished_count, int B, int V, int max_steps,
                     int start_token, hipStream_t stream);
 
-// x[b][:] = tok_emb[tok[b]][:] + pos_emb[state[1] + 2][:]   (kv_cache=True position rule)
-int ar_embed_launch(const int* tok, const int* state, const float* tok_emb, const float* pos_emb, float* x, int B, int D,
+// x[b][:] = tok_emb[tok[b]][:] + pos_emb[state[1] + pos_offset][:]   (pos_offset 2: kv_cache=True rule, 1: kv_cache=False rule)
+int ar_embed_launch(const int* tok, const int* state, const float* tok_emb, const float* pos_emb, float* x, int B, int D, int pos_offset,
                     hipStream_t stream);
 
 // ------------------------------------------------------------------------------ small fused ops

@@ -260,20 +260,20 @@ int ar_begin_launch(int* state, unsigned* seen, int* unfinished, int* unfinished
 }
 
 __global__ __launch_bounds__(256) void ar_embed_kernel(const int* tok, const int* state, const float* tok_emb, const float* pos_emb,
-                                                       float* x, int D) {
+                                                       float* x, int D, int pos_offset) {
   const int b = blockIdx.x;
   const int t = tok[b];
-  const int pos = state[1] + 2;
+  const int pos = state[1] + pos_offset;
   for (int c = threadIdx.x * 4; c < D; c += 1024) {
     const float4 e = *(const float4*)(tok_emb + (size_t)t * D + c);
     const float4 p = *(const float4*)(pos_emb + (size_t)pos * D + c);
     *(float4*)(x + (size_t)b * D + c) = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
   }
 }
-int ar_embed_launch(const int* tok, const int* state, const float* tok_emb, const float* pos_emb, float* x, int B, int D,
+int ar_embed_launch(const int* tok, const int* state, const float* tok_emb, const float* pos_emb, float* x, int B, int D, int pos_offset,
                     hipStream_t stream) {
   TT_REQUIRE(D % 4 == 0, "ar_embed: D must be a multiple of 4");
-  ar_embed_kernel<<<B, 256, 0, stream>>>(tok, state, tok_emb, pos_emb, x, D);
+  ar_embed_kernel<<<B, 256, 0, stream>>>(tok, state, tok_emb, pos_emb, x, D, pos_offset);
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }

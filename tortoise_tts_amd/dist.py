@@ -4,8 +4,9 @@ The reference has no multi-GPU path: it loops `num_autoregressive_samples // bat
 device (tortoise/api.py:407-427) and ranks them with CLVP (api.py:447-477).  Candidates are i.i.d.
 given (voice latent, text), so rank r decodes and scores N/R of them with replicated weights and a
 single all_gather of (scores, codes) lets every rank compute the identical top-k.
-Payload: N/R f32 scores + N/R x 500 int32 codes per rank (64 KB at 32 candidates) — latency-bound,
-one collective per utterance; nothing else on the path communicates.
+Payload: N/R f32 scores + N/R x M int16 codes per rank (codes < 8194; 32 KB at 32 candidates x 500) — latency-bound,
+one collective per utterance.  Rendered audio leaves the rank that rendered it only when that rank is not rank 0
+(k > 1 winners spread round-robin): a point-to-point send to rank 0, never a gather to everyone.
 """
 import os
 
@@ -31,8 +32,23 @@ def init_from_env(device_index=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = "nccl" if torch.cuda.is_available() and not share else "gloo"
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if backend == "nccl":  # force communicator creation now: RCCL failures (IPC, topology) surface here, not mid-utterance
+                dist.all_reduce(torch.zeros(1, device="cuda"))
+        except Exception as e:  # a node whose RCCL cannot initialise still serves from one GPU
+            import sys
+            print(f"[tortoise_tts_amd.dist] rank {rank}: {backend} initialisation failed ({type(e).__name__}: {e}); "
+                  f"falling back to single-GPU operation on rank 0", file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            global FALLBACK_SINGLE
+            FALLBACK_SINGLE = True
+            return rank, 1, local
     return rank, world, local
+
+
+FALLBACK_SINGLE = False  # set when a multi-rank launch could not initialise its collectives (ranks != 0 should exit)
 
 
 def _host_staged():
@@ -53,21 +69,57 @@ def shard_range(n, rank, world_size):
 
 
 def gather_candidates(scores_local, codes_local):
-    """all_gather of CLVP scores f32 [n] and codes int32 [n, M] -> global ([N], [N, M]) on every rank,
-    ordered by global candidate index."""
+    """all_gather of CLVP scores f32 [n] and codes [n, M] (sent as int16: mel codes are < 8194) -> global
+    ([N] f32, [N, M] int32) on every rank, ordered by global candidate index."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return scores_local, codes_local
     ws = dist.get_world_size()
     scores_local = scores_local.contiguous()
-    codes_local = codes_local.to(torch.int32).contiguous()
+    if codes_local.numel() and (int(codes_local.max()) > 32767 or int(codes_local.min()) < 0):
+        raise ValueError("gather_candidates: codes do not fit int16")
+    n_loc, M = codes_local.shape
+    # int16 payload moved as int32 words (two codes per word; gloo has no int16 all_gather): pad each rank's block to even length
+    flat = codes_local.to(torch.int16).reshape(-1)
+    if flat.numel() % 2:
+        flat = torch.cat([flat, flat.new_zeros(1)])
+    words_local = flat.contiguous().view(torch.int32)
     dev = scores_local.device
     if _host_staged() and dev.type != "cpu":
-        scores_local, codes_local = scores_local.cpu(), codes_local.cpu()
+        scores_local, words_local = scores_local.cpu(), words_local.cpu()
     s_all = torch.empty(ws * scores_local.shape[0], dtype=scores_local.dtype, device=scores_local.device)
-    c_all = torch.empty(ws * codes_local.shape[0], codes_local.shape[1], dtype=torch.int32, device=codes_local.device)
+    w_all = torch.empty(ws * words_local.shape[0], dtype=torch.int32, device=words_local.device)
     dist.all_gather_into_tensor(s_all, scores_local)
-    dist.all_gather_into_tensor(c_all, codes_local)
-    return s_all.to(dev), c_all.to(dev)
+    dist.all_gather_into_tensor(w_all, words_local)
+    c_all = w_all.view(ws, -1).view(torch.int16)[:, :n_loc * M].reshape(ws * n_loc, M)
+    return s_all.to(dev), c_all.to(dev).to(torch.int32)
+
+
+def collect_on_rank0(wavs, k):
+    """wavs: {winner index: CPU waveform} rendered on THIS rank (winner i is rendered by rank i % world, or by rank 0 when
+    the diffusion tail is split).  Rank 0 receives the ones it does not hold by point-to-point sends and returns the full
+    dict; every other rank returns None.  With k == 1 nothing is communicated at all."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return wavs
+    rank, ws = dist.get_rank(), dist.get_world_size()
+    gpu_backend = not _host_staged()
+    for i in range(k):
+        owner = i % ws
+        if owner == 0 or (rank == 0 and i in wavs):
+            continue  # rank 0 rendered it (round-robin owner 0, or the split tail)
+        if rank == owner and i in wavs:
+            w = wavs[i].contiguous()
+            n = torch.tensor([w.numel()], dtype=torch.int64)
+            if gpu_backend:
+                n, w = n.cuda(), w.cuda()
+            dist.send(n, dst=0)
+            dist.send(w.view(-1), dst=0)
+        elif rank == 0:
+            n = torch.zeros(1, dtype=torch.int64, device="cuda" if gpu_backend else "cpu")
+            dist.recv(n, src=owner)
+            buf = torch.empty(int(n.item()), dtype=torch.float32, device=n.device)
+            dist.recv(buf, src=owner)
+            wavs[i] = buf.cpu().view(1, 1, -1)
+    return wavs if rank == 0 else None
 
 
 def topk_lowest_index(scores, k):

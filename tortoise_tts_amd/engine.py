@@ -26,7 +26,8 @@ class GptLayer(C.Structure):
 
 class ArConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("dtype", "layers", "model_dim", "heads", "vocab", "start_mel_token", "stop_mel_token",
-                                       "mel_pos_len", "max_batch", "max_prefix", "max_new_tokens", "max_full_rows", "weights_tile_packed")]
+                                       "mel_pos_len", "max_batch", "max_prefix", "max_new_tokens", "max_full_rows", "weights_tile_packed",
+                                       "mel_pos_offset")]
 
 
 class ArWeights(C.Structure):
@@ -178,6 +179,16 @@ def init():
         check(lib.tt_init())
         _initialised = True
     return lib
+
+
+def require_gpu(device=None):
+    """The torch.device the engine will run on; raises EngineError unless it is a HIP/ROCm GPU (there is no CPU path)."""
+    import torch
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    if device is None or torch.device(device).type != "cuda":
+        raise EngineError("TextToSpeech needs an MI355X (gfx950) device; the engine has no CPU path")
+    return torch.device(device)
 
 
 def check(rc):

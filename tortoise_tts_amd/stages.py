@@ -23,7 +23,7 @@ class ArStage:
     """UnifiedVoice hot path: prefill + sampling loop + latent re-pass (autoregressive.py:454-563)."""
 
     def __init__(self, sd, cfg: ARConfig = ARConfig(), device="cuda", dtype=E.TT_BF16, max_batch=256, max_text=402,
-                 max_new_tokens=500, max_latent_candidates=4, share_weights_with=None):
+                 max_new_tokens=500, max_latent_candidates=4, share_weights_with=None, kv_cache=True):
         self.lib = E.init()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -41,6 +41,9 @@ class ArStage:
         c.max_new_tokens = max_new_tokens + 2
         c.max_full_rows = max_latent_candidates * (1 + max_text + 2 + max_new_tokens + 2)
         c.weights_tile_packed = int(getattr(self.w, "tile_packed", False))
+        # TextToSpeech(kv_cache=...) only changes WHICH mel position row a generated token gets (autoregressive.py:134-149):
+        # the engine always keeps a KV cache; kv_cache=False (the reference default) selects rows 0,1,2,... instead of 0,2,3,...
+        c.mel_pos_offset = 2 if kv_cache else 1
         self.max_latent_candidates = max_latent_candidates
         self.ccfg = c
         self.h = E.vp()
@@ -292,6 +295,57 @@ class DiffusionStage:
             exchange(rows, self.split_forward())
             self.split_update(rows)
         return self.split_end()
+
+
+class ConditioningStage:
+    """Conditioning encoders of the voice_samples path: UnifiedVoice.get_conditioning
+    (ConditioningEncoder, autoregressive.py:204-228) and DiffusionTts.get_conditioning (contextual_embedder,
+    diffusion_decoder.py:186-192, 222-230).  Not on the device yet: the oracle side exists and is pinned
+    (oracle.ar_get_conditioning / diffusion_get_conditioning, tests/golden/conditioning.npz); constructing this stage
+    refuses loudly so voice_samples= never silently runs somewhere else."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("voice_samples -> conditioning latents (ConditioningEncoder / contextual_embedder, api.py:258-299) "
+                                  "is not on the accelerated path yet (SURVEY.md §8f-3); pass conditioning_latents= (e.g. the .pth "
+                                  "latent files the reference caches per voice) or use the random voice")
+
+
+class RandomLatentStage:
+    """get_random_conditioning_latents (api.py:301-309): the two RandomLatentConverter MLPs as six M = 1 GEMMs each.
+    EqualLinear's constants are folded at pack time: leaky_relu is positively homogeneous, so
+    leaky_relu(x W^T s + b l) * sqrt2 == leaky_relu(x (W s sqrt2)^T + b l sqrt2)."""
+
+    def __init__(self, sd_auto, sd_diffuser, device="cuda", dtype=E.TT_BF16, lr_mul=0.1):
+        self.lib = E.init()
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.h = pack.Holder(self.device, dtype)
+        self.nets = []
+        for sd in (sd_auto, sd_diffuser):
+            C_ = sd["layers.0.weight"].shape[0]
+            scale = (1.0 / np.sqrt(C_)) * lr_mul * np.sqrt(2.0)
+            layers = [(self.h.op(sd[f"layers.{i}.weight"].float() * scale), self.h.f32(sd[f"layers.{i}.bias"].float() * (lr_mul * np.sqrt(2.0))))
+                      for i in range(5)]
+            layers.append((self.h.op(sd["layers.5.weight"]), self.h.f32(sd["layers.5.bias"])))
+            self.nets.append((C_, layers))
+        self.channels = tuple(n[0] for n in self.nets)
+
+    def _run(self, net, r):
+        C_, layers = net
+        x = r.to(self.device).float().reshape(1, C_).to(self.h.tdtype).contiguous()
+        out = None
+        for i, (w, b) in enumerate(layers):
+            last = i == len(layers) - 1
+            nxt = None if last else torch.empty(1, C_, device=self.device, dtype=self.h.tdtype)
+            out = torch.empty(1, C_, device=self.device, dtype=torch.float32) if last else None
+            E.check(self.lib.tt_op_gemm(self.dtype, E.ptr(x), C_, E.ptr(w), C_, 1, C_, C_, 1, 0, 1, E.ptr(b),
+                                        E.ACT_NONE if last else E.ACT_LRELU, None, E.ptr(out), E.ptr(nxt), E.stream_ptr()))
+            x = nxt
+        return out
+
+    def latents(self, r_auto, r_diffuser):
+        """r_auto f32 [1, 1024], r_diffuser f32 [1, 2048] standard-normal draws -> (auto latent, diffusion latent)."""
+        return self._run(self.nets[0], r_auto), self._run(self.nets[1], r_diffuser)
 
 
 class VocoderStage:

@@ -4,9 +4,10 @@ entries).  The vocabulary file is data the user already has with the reference c
 located, not copied: explicit path -> $TORTOISE_TOKENIZER -> <models_dir>/tokenizer.json ->
 an installed `tortoise` package's data directory.
 
-CPU string work is outside the hot path; english_cleaners needs `inflect` and
-`unidecode` exactly like the reference and is refused loudly when they are missing rather than
-silently changing the token stream.
+CPU string work is outside the hot path ("reuse as-is"): `english_cleaners` is NOT
+re-implemented here.  With tokenizer_basic=False the reference's own module (tortoise/utils/tokenizer.py:122-150,
+which needs `inflect` and `unidecode`) is imported from an installed `tortoise` package; when it is not importable the
+constructor refuses loudly instead of silently changing the token stream.
 """
 import os
 import re
@@ -45,19 +46,19 @@ class VoiceBpeTokenizer:
         from tokenizers import Tokenizer
         self.tokenizer = Tokenizer.from_file(path)
         self.use_basic = use_basic_cleaners
+        self._english_cleaners = None
         if not use_basic_cleaners:
             try:
-                import inflect  # noqa: F401
-                import unidecode  # noqa: F401
+                from tortoise.utils.tokenizer import english_cleaners  # the reference's own cleaners, reused as-is
             except ImportError as e:
-                raise ImportError("english_cleaners needs `inflect` and `unidecode` (as in the reference); install them or "
-                                  "construct TextToSpeech(tokenizer_basic=True)") from e
+                raise ImportError("english_cleaners come from the reference package (tortoise.utils.tokenizer, which needs `inflect` "
+                                  "and `unidecode`); install it or construct TextToSpeech(tokenizer_basic=True)") from e
+            self._english_cleaners = english_cleaners
 
     def preprocess_text(self, txt):
         if self.use_basic:
             return basic_cleaners(txt)
-        from .text_english import english_cleaners
-        return english_cleaners(txt)
+        return self._english_cleaners(txt)
 
     def encode(self, txt):
         txt = self.preprocess_text(txt)

@@ -192,6 +192,16 @@ def vocoder_manifest(cfg: VocoderConfig = VocoderConfig()):
     return d
 
 
+def rlg_manifest(channels):
+    """RandomLatentConverter(channels) (random_latent_generator.py:42-55): 5 EqualLinear + 1 Linear; rlg_auto.pth is
+    channels = 1024, rlg_diffuser.pth 2048 (api.py:301-309)."""
+    m = OrderedDict()
+    for i in range(6):
+        m[f"layers.{i}.weight"] = (channels, channels)
+        m[f"layers.{i}.bias"] = (channels,)
+    return m
+
+
 # ----------------------------------------------------------------------------- synthetic weights
 def _is_norm_gain(key):
     k = key
