@@ -1,153 +1,95 @@
 #!/usr/bin/env python
-"""Micro-benchmarks of the hot kernels at the shapes the 'standard' preset produces (run on the MI355X).
-Prints one line per case: average microseconds over graph-free back-to-back launches, TFLOP/s and GB/s."""
-import math
-import sys
+"""Kernel experiments on the MI355X (run through gpurun): drives tortoise_tts_amd/lib/libtortoise_kbench.so
+(`python -m tortoise_tts_amd.build --kbench`; sources in tortoise_tts_amd/csrc/kbench/).  Every number is device time per
+launch from a replayed hipGraph of a launch chain, on pseudo-random (full-sign) operands.
+usage: scripts/kbench.py [gemm_denoiser] [gemm_decode] [attn] ..."""
+import ctypes as C
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch  # noqa: E402
-from tortoise_tts_amd import engine as E  # noqa: E402
+import torch  # noqa: E402,F401  (binds the HIP runtime the library links against)
 
-lib = E.init()
-T = torch.bfloat16
-DT = E.TT_BF16
-
-
-def timeit(fn, iters=50, warm=5):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(iters):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) * 1e3 / iters  # us
+lib = C.CDLL(os.path.join(ROOT, "tortoise_tts_amd", "lib", "libtortoise_kbench.so"))
+lib.tt_last_error.restype = C.c_char_p
+D = C.c_double
 
 
-def gemm_case(name, M, N, K, taps=1, seq=0, splitk=1):
-    A = torch.randn(M, K // taps, device="cuda").to(T)
-    W = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(T)
-    bias = torch.randn(N, device="cuda")
-    out = torch.zeros(max(splitk, 1), M, N, device="cuda")
-    us = timeit(lambda: E.check(lib.tt_op_gemm(DT, E.ptr(A), K // taps, E.ptr(W), K, M, N, K, taps, seq, splitk,
-                                               E.ptr(bias) if splitk == 1 else None, 0, None, E.ptr(out), None, None)))
-    fl = 2.0 * M * N * K
-    by = (N * K + M * K / taps) * 2 + M * N * 4 * splitk
-    print(f"gemm {name:28s} M={M:5d} N={N:5d} K={K:5d} sk={splitk}: {us:8.2f} us  {fl / us / 1e6:8.1f} TFLOP/s  {by / us / 1e3:8.1f} GB/s")
+def chk(rc):
+    if rc != 0:
+        raise RuntimeError(lib.tt_last_error().decode())
+
+
+def gemm_exp(variant, M, N, K, taps=1, seq=0, nw=1, chain=32, prefetch=0, reps=10):
+    us = D(0)
+    chk(lib.tt_kb_gemm_exp(variant, M, N, K, taps, seq, nw, chain, prefetch, reps, C.byref(us)))
+    return us.value
+
+
+def gemm_prod(M, N, K, taps=1, seq=0, splitk=1, packed=0, nw=1, chain=32, reps=10):
+    us = D(0)
+    chk(lib.tt_kb_gemm_prod(M, N, K, taps, seq, splitk, packed, nw, chain, reps, C.byref(us)))
+    return us.value
+
+
+def attn(variant, B, H, P1, tgen, tmax, nl, chain=16, reps=10):
+    us, md = D(0), D(0)
+    chk(lib.tt_kb_decode_attn(variant, B, H, P1, tgen, tmax, nl, chain, reps, C.byref(us), C.byref(md)))
+    return us.value, md.value
+
+
+CFG = {0: "128x64 8w(2x4) ring4 [product tile]", 1: "128x64 4w(2x2) ring4", 3: "128x64 8w(4x2) ring4", 4: "64x64 4w ring4 [product decode tile]",
+       6: "128x128 8w(2x4) ring3", 7: "128x128 4w(2x2) ring3", 8: "256x64 8w(4x2) ring3", 9: "128x64 8w(2x4) ring6"}
+MODE = {0: "full", 1: "no loads in k-loop", 2: "no LDS reads / MFMA"}
+
+
+def tf(M, N, K, us):
+    return 2.0 * M * N * K / us / 1e6
 
 
 def main():
-    which = sys.argv[1:] or ["gemm", "gn", "flash", "ln"]
-    if "gemm" in which:
+    which = sys.argv[1:] or ["gemm_denoiser", "gemm_decode", "attn"]
+    lib.tt_init()
+    if "gemm_denoiser" in which:
+        shapes = [("1x1 1024->1024", 1740, 1024, 1024, 1, 0, 150), ("k3 1024->1024", 1740, 1024, 3072, 3, 870, 56), ("qkv 1024->3072", 1740, 3072, 1024, 1, 0, 56)]
+        for name, M, N, K, taps, seq, nwc in shapes:
+            for nw, tag in ((1, "hot W"), (nwc, "cold W")):
+                us = gemm_prod(M, N, K, taps, seq, nw=nw)
+                print(f"denoiser {name} M={M} PRODUCT gemm_launch ({tag}): {us:7.2f} us {tf(M, N, K, us):7.1f} TFLOP/s", flush=True)
+                for cfg in (0, 1, 3, 9, 6, 7, 8, 4):
+                    modes = (0, 1, 2) if cfg in (0, 1, 6) else (0,)
+                    for mode in modes:
+                        us = gemm_exp(cfg * 100 + mode, M, N, K, taps, seq, nw=nw)
+                        print(f"denoiser {name} M={M} exp {CFG[cfg]:38s} {MODE[mode]:22s} ({tag}): {us:7.2f} us {tf(M, N, K, us):7.1f} TFLOP/s", flush=True)
+                for v, label in ((200, "128x64 4w ring3 2 blocks/CU"), (500, "64x64 4w ring3 2 blocks/CU")):
+                    us = gemm_exp(v, M, N, K, taps, seq, nw=nw)
+                    print(f"denoiser {name} M={M} exp {label:38s} {'full':22s} ({tag}): {us:7.2f} us {tf(M, N, K, us):7.1f} TFLOP/s", flush=True)
+            # cross-kernel prefetch of the next launch's weights on the product tile
+            for pf in (0, 1):
+                us = gemm_exp(0, M, N, K, taps, seq, nw=nwc, prefetch=pf)
+                print(f"denoiser {name} M={M} exp {CFG[0]:38s} prefetch_next={pf} (cold W): {us:7.2f} us", flush=True)
+    if "gemm_decode" in which:
+        for name, N, K, sk in (("qkv", 3072, 1024, 1), ("proj", 1024, 1024, 4), ("fc", 4096, 1024, 1), ("proj2", 1024, 4096, 4), ("mel_head", 8194, 1024, 1)):
+            nw = max(8, int(700e6 // (N * K * 2)))
+            for M in (256, 32):
+                for packed in (0, 1):
+                    us = gemm_prod(M, N, K, splitk=sk, packed=packed, nw=nw)
+                    print(f"decode {name:8s} M={M:3d} N={N} K={K} PRODUCT splitk={sk} packed={packed} cold W: {us:7.2f} us {N * K * 2 / us / 1e3:7.1f} GB/s weights", flush=True)
+                if N % 64 == 0:
+                    for cfg in (4, 0, 8):
+                        for pf in (0, 1):
+                            us = gemm_exp(cfg * 100, M, N, K, nw=nw, prefetch=pf)
+                            print(f"decode {name:8s} M={M:3d} N={N} K={K} exp {CFG[cfg]:38s} prefetch_next={pf} cold W: {us:7.2f} us {N * K * 2 / us / 1e3:7.1f} GB/s weights", flush=True)
+                    us = gemm_exp(400, M, N, K, nw=1)
+                    print(f"decode {name:8s} M={M:3d} N={N} K={K} exp {CFG[4]:38s} hot W: {us:7.2f} us", flush=True)
+    if "attn" in which:
         for B in (256, 32):
-            gemm_case(f"decode qkv B={B}", B, 3072, 1024)
-            gemm_case(f"decode fc B={B}", B, 4096, 1024)
-            for sk in (1, 2, 4, 8):
-                gemm_case(f"decode proj B={B}", B, 1024, 1024, splitk=sk)
-                gemm_case(f"decode proj2 B={B}", B, 1024, 4096, splitk=sk)
-            gemm_case(f"mel_head B={B}", B, 8194, 1024)
-        gemm_case("diff 1x1 S=870x2", 1740, 1024, 1024)
-        gemm_case("diff k3 S=870x2", 1740, 1024, 3072, taps=3, seq=870)
-        gemm_case("diff qkv S=870x2", 1740, 3072, 1024)
-        gemm_case("diff integ S=870x2", 1740, 1024, 2048)
-        gemm_case("diff 1x1 S=2176x2", 4352, 1024, 1024)
-        gemm_case("clvp ff1 256x200", 51200, 3072, 768)
-        gemm_case("clvp out 256x200", 51200, 768, 768)
-        gemm_case("square 4096", 4096, 4096, 4096)
-    if "tiles" in which:
-        for M, N, K, taps, seq in ((1740, 1024, 1024, 1, 0), (1740, 1024, 3072, 3, 870), (1740, 3072, 1024, 1, 0), (256, 4096, 1024, 1, 0),
-                                   (256, 1024, 4096, 1, 0), (4096, 4096, 4096, 1, 0)):
-            gemm_case(f"tile={os.environ.get('TT_GEMM_TILE', 'auto')}", M, N, K, taps=taps, seq=seq)
-    if "cold" in which:
-        # decode GEMMs with HBM-cold weights: cycle through enough distinct weight matrices to defeat the 256 MB Infinity Cache
-        for (name, M, N, K, sk) in (("qkv", 256, 3072, 1024, 1), ("fc", 256, 4096, 1024, 1), ("proj", 256, 1024, 1024, 4),
-                                    ("proj2", 256, 1024, 4096, 4), ("qkv32", 32, 3072, 1024, 1), ("fc32", 32, 4096, 1024, 1)):
-            nW = max(8, int(600e6 // (N * K * 2)))
-            Ws = [(torch.randn(N, K, device="cuda") / math.sqrt(K)).to(T) for _ in range(nW)]
-            A = torch.randn(M, K, device="cuda").to(T)
-            bias = torch.randn(N, device="cuda")
-            out = torch.zeros(max(sk, 1), M, N, device="cuda")
-            it = [0]
-
-            def fn():
-                W = Ws[it[0] % nW]
-                it[0] += 1
-                E.check(lib.tt_op_gemm(DT, E.ptr(A), K, E.ptr(W), K, M, N, K, 1, 0, sk, E.ptr(bias) if sk == 1 else None, 0, None,
-                                       E.ptr(out), None, None))
-            us = timeit(fn, iters=4 * nW, warm=nW)
-            print(f"cold gemm {name:6s} tile={os.environ.get('TT_GEMM_TILE', 'auto'):4s} M={M} N={N} K={K} sk={sk}: {us:8.2f} us  {N * K * 2 / us / 1e3:8.1f} GB/s weights")
-            del Ws
-    if "coldpacked" in which:
-        from tortoise_tts_amd.pack import Holder
-        hold = Holder(torch.device("cuda"), DT)
-        for (name, M, N, K, sk) in (("qkv", 256, 3072, 1024, 1), ("fc", 256, 4096, 1024, 1), ("proj", 256, 1024, 1024, 4),
-                                    ("proj2", 256, 1024, 4096, 4), ("fc32", 32, 4096, 1024, 1)):
-            nW = max(8, int(600e6 // (N * K * 2)))
-            Ws = []
-            for _ in range(nW):
-                hold.keep.clear()
-                Ws.append(hold.op_packed(torch.randn(N, K, device="cuda") / math.sqrt(K)))
-            A = torch.randn(M, K, device="cuda").to(T)
-            out = torch.zeros(max(sk, 1), M, N, device="cuda")
-            it = [0]
-
-            def fn():
-                W = Ws[it[0] % nW]
-                it[0] += 1
-                E.check(lib.tt_op_gemm_packed(DT, E.ptr(A), K, E.ptr(W), M, N, K, sk, None, 0, None, E.ptr(out), None, None))
-            us = timeit(fn, iters=4 * nW, warm=nW)
-            print(f"cold packed gemm {name:6s} M={M} N={N} K={K} sk={sk}: {us:8.2f} us  {N * K * 2 / us / 1e3:8.1f} GB/s weights")
-            del Ws
-    if "kscale" in which:
-        for M in (32, 256):
-            for K in (64, 256, 1024, 4096):
-                N = 4096
-                nW = max(8, int(600e6 // (N * K * 2)))
-                nW = min(nW, 256)
-                Ws = [(torch.randn(N, K, device="cuda") / math.sqrt(K)).to(T) for _ in range(nW)]
-                A = torch.randn(M, K, device="cuda").to(T)
-                out_t = torch.zeros(M, N, device="cuda", dtype=T)
-                it = [0]
-
-                def fn():
-                    W = Ws[it[0] % nW]
-                    it[0] += 1
-                    E.check(lib.tt_op_gemm(DT, E.ptr(A), K, E.ptr(W), K, M, N, K, 1, 0, 1, None, 0, None, None, E.ptr(out_t), None))
-                us = timeit(fn, iters=4 * nW, warm=nW)
-                print(f"kscale M={M} N={N} K={K}: {us:8.2f} us  ({N * K * 2 / 1e6:.1f} MB weights, {N * K * 2 / us / 1e3:8.1f} GB/s)")
-                del Ws
-    if "gn" in which:
-        for (B, S, C_) in ((2, 870, 1024), (2, 2176, 1024)):
-            x = torch.randn(B, S, C_, device="cuda")
-            g, b = torch.randn(C_, device="cuda"), torch.randn(C_, device="cuda")
-            ws = torch.zeros(lib.tt_op_groupnorm_workspace(B, S) // 4 + 16, device="cuda")
-            o = torch.zeros(B, S, C_, device="cuda", dtype=T)
-            us = timeit(lambda: E.check(lib.tt_op_groupnorm(DT, E.ptr(x), B, S, C_, E.ptr(g), E.ptr(b), None, E.ACT_SILU, E.ptr(o), None,
-                                                            E.ptr(ws), None)))
-            print(f"groupnorm B={B} S={S} C={C_}: {us:8.2f} us  {B * S * C_ * 10 / us / 1e3:8.1f} GB/s")
-    if "ln" in which:
-        for M in (256, 1740):
-            x = torch.randn(M, 1024, device="cuda")
-            g, b = torch.randn(1024, device="cuda"), torch.randn(1024, device="cuda")
-            o = torch.zeros(M, 1024, device="cuda", dtype=T)
-            us = timeit(lambda: E.check(lib.tt_op_layernorm(DT, E.ptr(x), M, 1024, E.ptr(g), E.ptr(b), 1e-5, 0, E.ptr(o), None, None)))
-            print(f"layernorm M={M}: {us:8.2f} us")
-    if "flash" in which:
-        for (B, H, n, causal) in ((2, 16, 870, 0), (2, 16, 2176, 0), (256, 12, 200, 0), (1, 16, 260, 1)):
-            n_pad = (n + 31) // 32 * 32
-            q = (torch.randn(B, H, n, 64, device="cuda") * 0.2).to(T)
-            k = torch.randn(B, H, n, 64, device="cuda").to(T)
-            vt = torch.randn(B, H, 64, n_pad, device="cuda").to(T)
-            rp = torch.randn(H, 129, device="cuda")
-            o = torch.zeros(B, n, H * 64, device="cuda", dtype=T)
-            us = timeit(lambda: E.check(lib.tt_op_flash_attention(DT, E.ptr(q), E.ptr(k), E.ptr(vt), E.ptr(o), B, H, n, n_pad, causal,
-                                                                  E.ptr(rp) if not causal else None, None)))
-            fl = 4.0 * B * H * n * n * 64 * (0.5 if causal else 1.0)
-            print(f"flash B={B} H={H} n={n} causal={causal}: {us:8.2f} us  {fl / us / 1e6:8.1f} TFLOP/s")
+            for tgen in (50, 100, 200):
+                for v, label in ((0, "product (8-byte V loads)"), (1, "v2 16-byte V loads, 32 keys/iter"), (2, "v2 16-byte V loads, 48 keys/iter")):
+                    us, md = attn(v, B, 16, 59, tgen, 202, 8)
+                    by = (B * tgen + 59) * 16 * 64 * 2 * 2
+                    print(f"decode_attn B={B} tgen={tgen} {label:36s}: {us:7.2f} us {by / us / 1e3:7.1f} GB/s  max|diff| vs product {md:.3e}", flush=True)
 
 
 if __name__ == "__main__":

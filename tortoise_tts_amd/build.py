@@ -17,6 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtortoise_mi355x.so")
+KBENCH_LIB = os.path.join(LIBDIR, "libtortoise_kbench.so")  # experiments only (scripts/kbench.py); never loaded by the product
 SOURCES = ["common.hip", "gemm.hip", "norm.hip", "attention.hip", "sampling.hip", "misc.hip", "univnet.hip",
            "gpt2.hip", "clvp.hip", "diffusion.hip", "vocoder.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-ffp-contract=on"]
@@ -86,5 +87,26 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_kbench(verbose=True):
+    """Kernel experiments / microbenchmarks (csrc/kbench/kbench.hip) linked with the product objects into a SEPARATE library."""
+    build(verbose=verbose)
+    hipcc = _hipcc()
+    src = os.path.join(CSRC, "kbench", "kbench.hip")
+    obj = os.path.join(OBJ, "kbench.o")
+    r = subprocess.run([hipcc] + FLAGS + ["-DTT_KBENCH", "-c", src, "-o", obj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    objs = [os.path.join(OBJ, s_.replace(".hip", ".o")) for s_ in SOURCES] + [obj]
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", KBENCH_LIB] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("[build] linked %s" % KBENCH_LIB, file=sys.stderr)
+    return KBENCH_LIB
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--kbench" in sys.argv:
+        build_kbench()
+    else:
+        build(force="--force" in sys.argv)

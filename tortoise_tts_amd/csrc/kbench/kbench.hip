@@ -1,0 +1,532 @@
+// Kernel microbenchmarks and A/B experiments (NOT part of the product library).  Built into
+// tortoise_tts_amd/lib/libtortoise_kbench.so by `python -m tortoise_tts_amd.build --kbench` together with the product
+// sources, and driven by scripts/kbench.py on the MI355X.  Every case captures a chain of launches into a hipGraph and
+// replays it, so the reported time is device time per launch, not host launch rate.
+#include "../runtime.h"
+#include <vector>
+#include <string>
+
+using namespace tt;
+
+namespace {
+
+struct GraphTimer {
+  hipStream_t s = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  int init() {
+    TT_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    TT_CHECK_HIP(hipEventCreate(&a));
+    TT_CHECK_HIP(hipEventCreate(&b));
+    return 0;
+  }
+  // enqueue(stream) is captured once; the graph is replayed `reps` times; returns microseconds per replay
+  template <typename F> int run(F enqueue, int reps, double* us_out) {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ex = nullptr;
+    TT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue(s);
+    hipError_t ce = hipStreamEndCapture(s, &g);
+    if (rc) return rc;
+    TT_CHECK_HIP(ce);
+    TT_CHECK_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+    for (int i = 0; i < 2; ++i) TT_CHECK_HIP(hipGraphLaunch(ex, s));
+    TT_CHECK_HIP(hipStreamSynchronize(s));
+    TT_CHECK_HIP(hipEventRecord(a, s));
+    for (int i = 0; i < reps; ++i) TT_CHECK_HIP(hipGraphLaunch(ex, s));
+    TT_CHECK_HIP(hipEventRecord(b, s));
+    TT_CHECK_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    TT_CHECK_HIP(hipEventElapsedTime(&ms, a, b));
+    *us_out = 1e3 * ms / reps;
+    (void)hipGraphExecDestroy(ex);
+    (void)hipGraphDestroy(g);
+    return 0;
+  }
+  void destroy() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    if (s) (void)hipStreamDestroy(s);
+  }
+};
+
+__global__ void fill_kernel(unsigned short* p, size_t n, unsigned seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u + seed;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+    const float f = ((float)(x & 0xFFFF) / 65536.f - 0.5f) * 0.25f;  // full-range signs (DVFS: never bench on zeros)
+    __bf16 h = (__bf16)f;
+    p[i] = *(unsigned short*)&h;
+  }
+}
+__global__ void fill_f32_kernel(float* p, size_t n, unsigned seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u + seed;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+    p[i] = ((float)(x & 0xFFFF) / 65536.f - 0.5f);
+  }
+}
+static int dev_bf16(Arena& ar, void** p, size_t n, unsigned seed) {
+  TT_TRY(ar.alloc(p, n * 2, false));
+  fill_kernel<<<1024, 256>>>((unsigned short*)*p, n, seed);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+static int dev_f32(Arena& ar, float** p, size_t n, unsigned seed) {
+  TT_TRY(ar.alloc((void**)p, n * 4, false));
+  fill_f32_kernel<<<1024, 256>>>(*p, n, seed);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------------------------------------
+// Experimental GEMM: same data path as the product's direct-to-LDS kernel with the degrees of freedom exposed:
+// wave grid WM x WN over the BM x BN tile, ring depth ST, min waves per SIMD (blocks per CU), and ablation modes
+//   MODE 0 full | 1 no loads inside the k-loop (LDS + MFMA + barrier floor) | 2 no LDS reads / MFMA (memory pipeline floor).
+// out[m][n] (bf16) = sum_k A[m][k] W[n][k].  Optional 3-tap conv addressing (CONV) like the product kernel.
+__device__ __attribute__((aligned(16))) unsigned int kb_zero_page[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+typedef __attribute__((address_space(3))) void lds_void_k;
+typedef __attribute__((address_space(1))) const void gbl_void_k;
+
+struct ExpArgs {
+  const bf16* A; const bf16* W; bf16* out; int M, N, K, lda, ldw, ldo, taps, seq_len, cin;
+  const char* pf; size_t pf_bytes;  // optional: region the NEXT kernel will stream (prefetched into this XCD's L2)
+};
+
+template <int BM, int BN, int WM, int WN, int ST, int MODE, int MINW, bool CONV>
+__global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_exp_kernel(ExpArgs g) {
+  typedef Vec<bf16>::x8 x8;
+  constexpr int NW = WM * WN, BK = 64;
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int PA = BM / 8 / NW, PW = BN / 8 / NW;
+  static_assert(PA >= 1 && PW >= 1 && FM >= 1 && FN >= 1, "bad tile");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16* As = (bf16*)smem_raw;
+  bf16* Ws = As + ST * BM * BK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  int bx, by;
+  {
+    const int gx = gridDim.x, nwg = gx * gridDim.y, id = blockIdx.x + gx * blockIdx.y;
+    const int xcd = id & 7, loc = id >> 3, q = nwg >> 3, r = nwg & 7;
+    const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    bx = nid % gx; by = nid / gx;
+  }
+  const int m0 = bx * BM, n0 = by * BN;
+  const int nk = g.K / BK;
+  const bf16* zero = (const bf16*)kb_zero_page;
+  const int lr = lane >> 3, lc = lane & 7;
+  int a_b[PA], a_s[PA], a_src[PA];
+  bool a_ok[PA];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int row = (wave + NW * p) * 8 + lr;
+    a_src[p] = (lc ^ ((row >> 1) & 7)) * 8;
+    const int m = m0 + row;
+    a_ok[p] = m < g.M;
+    if (CONV) { a_b[p] = m / g.seq_len; a_s[p] = m - a_b[p] * g.seq_len; }
+    else { a_b[p] = 0; a_s[p] = a_ok[p] ? m : 0; }
+  }
+  const bf16* w_ptr[PW];
+#pragma unroll
+  for (int p = 0; p < PW; ++p) {
+    const int row = (wave + NW * p) * 8 + lr;
+    const int n = n0 + row;
+    w_ptr[p] = g.W + (size_t)(n < g.N ? n : g.N - 1) * g.ldw + (lc ^ ((row >> 1) & 7)) * 8;
+  }
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    int tap = 0, kin = k0;
+    if (CONV) { tap = k0 / g.cin; kin = k0 - tap * g.cin; }
+    const int shift = tap - (g.taps >> 1);
+    bf16* as = As + buf * BM * BK;
+    bf16* ws = Ws + buf * BN * BK;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const bf16* src;
+      if (CONV) {
+        const int s2 = a_s[p] + shift;
+        const bool ok = a_ok[p] && s2 >= 0 && s2 < g.seq_len;
+        src = ok ? g.A + ((size_t)a_b[p] * g.seq_len + s2) * g.lda + kin + a_src[p] : zero;
+      } else {
+        src = g.A + (size_t)a_s[p] * g.lda + kin + a_src[p];
+      }
+      __builtin_amdgcn_global_load_lds((gbl_void_k*)src, (lds_void_k*)(as + (wave + NW * p) * 8 * BK), 16, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < PW; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_void_k*)(w_ptr[p] + (size_t)kt * BK), (lds_void_k*)(ws + (wave + NW * p) * 8 * BK), 16, 0, 0);
+  };
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+  auto compute = [&](int buf) {
+    const bf16* as = As + buf * BM * BK;
+    const bf16* ws = Ws + buf * BN * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      x8 fa[FM], fw[FN];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int r = wm * TM + j * 16 + fr;
+        fa[j] = *(const x8*)(as + r * BK + (((ks * 4 + fg) ^ ((r >> 1) & 7)) * 8));
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int r = wn * TN + i * 16 + fr;
+        fw[i] = *(const x8*)(ws + r * BK + (((ks * 4 + fg) ^ ((r >> 1) & 7)) * 8));
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
+    }
+  };
+  constexpr int G = PA + PW;
+  const int last = nk - 1;
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s) issue(min(s, last), s);
+  if (g.pf_bytes) {  // cross-kernel weight prefetch: touch one 128-B line per load, result never used, never waited for
+    const int gx = gridDim.x, id = blockIdx.x + gx * blockIdx.y, nwg = gx * gridDim.y;
+    const int xcd = id & 7, loc = id >> 3, per_xcd = (nwg + 7) >> 3;
+    const size_t share = (g.pf_bytes / 8 + 127) & ~(size_t)127;
+    const char* base = g.pf + (size_t)xcd * share;
+    const size_t lim = min(share, g.pf_bytes > (size_t)xcd * share ? g.pf_bytes - (size_t)xcd * share : 0);
+    for (size_t off = ((size_t)loc * (NW * 64) + tid) * 128; off < lim; off += (size_t)per_xcd * (NW * 64) * 128) {
+      unsigned tmp;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(base + off) : "memory");
+    }
+  }
+  int slot = 0;
+  if (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int kt = 0; kt < nk; ++kt) {
+    if (MODE != 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * G) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int nslot = slot + ST - 1;
+    if (nslot >= ST) nslot -= ST;
+    if (MODE != 1) issue(min(kt + ST - 1, last), nslot);
+    if (MODE != 2) compute(slot);
+    slot = slot + 1 == ST ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // epilogue: bf16 stores, 8 B per lane
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = m0 + wm * TM + j * 16 + fr, n = n0 + wn * TN + i * 16 + fg * 4;
+      if (m < g.M && n < g.N) *(Vec<bf16>::x4*)(g.out + (size_t)m * g.ldo + n) = pack4<bf16>(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int ST, int MODE, int MINW>
+static int launch_exp(const ExpArgs& a, hipStream_t s) {
+  constexpr int smem = ST * (BM + BN) * 64 * 2;
+  dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN));
+  if (a.taps > 1) {
+    auto fn = gemm_exp_kernel<BM, BN, WM, WN, ST, MODE, MINW, true>;
+    TT_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    fn<<<grid, WM * WN * 64, smem, s>>>(a);
+  } else {
+    auto fn = gemm_exp_kernel<BM, BN, WM, WN, ST, MODE, MINW, false>;
+    TT_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    fn<<<grid, WM * WN * 64, smem, s>>>(a);
+  }
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// variant ids: 100*config + mode
+//   config 0: 128x64 8 waves 2x4 ring 4 (the product's denoiser tile)      1: 128x64 4 waves 2x2 ring 4
+//          2: 128x64 4 waves 2x2 ring 3, 2 blocks/CU                        3: 128x64 8 waves 4x2 ring 4
+//          4: 64x64 4 waves 2x2 ring 4 (the product's decode tile)          5: 64x64 4 waves ring 3, 2 blocks/CU
+//          6: 128x128 8 waves 2x4 ring 3                                    7: 128x128 4 waves 2x2 ring 3
+//          8: 256x64 8 waves 4x2 ring 3                                     9: 128x64 8 waves 2x4 ring 6
+static int launch_variant(int variant, const ExpArgs& a, hipStream_t s) {
+  switch (variant) {
+#define V3(cfg, ...) \
+    case cfg * 100 + 0: return launch_exp<__VA_ARGS__, 0, 1>(a, s); \
+    case cfg * 100 + 1: return launch_exp<__VA_ARGS__, 1, 1>(a, s); \
+    case cfg * 100 + 2: return launch_exp<__VA_ARGS__, 2, 1>(a, s);
+    V3(0, 128, 64, 2, 4, 4)
+    V3(1, 128, 64, 2, 2, 4)
+    V3(3, 128, 64, 4, 2, 4)
+    V3(4, 64, 64, 2, 2, 4)
+    V3(6, 128, 128, 2, 4, 3)
+    V3(7, 128, 128, 2, 2, 3)
+    V3(8, 256, 64, 4, 2, 3)
+    V3(9, 128, 64, 2, 4, 6)
+    case 200: return launch_exp<128, 64, 2, 2, 3, 0, 2>(a, s);
+    case 500: return launch_exp<64, 64, 2, 2, 3, 0, 2>(a, s);
+#undef V3
+  }
+  set_error("kbench: unknown gemm variant %d", variant);
+  return -1;
+}
+
+extern "C" {
+
+// One GEMM shape, `nw` distinct weight matrices visited round-robin (nw large => HBM-cold weights), `chain` launches per
+// graph.  prefetch: every launch also touches the NEXT launch's weights.  us_out = microseconds per launch.
+int tt_kb_gemm_exp(int variant, int M, int N, int K, int taps, int seq_len, int nw, int chain, int prefetch, int reps, double* us_out) {
+  Arena ar;
+  GraphTimer gt;
+  TT_TRY(gt.init());
+  void* A = nullptr; void* out = nullptr;
+  std::vector<void*> W(nw);
+  int rc = dev_bf16(ar, &A, (size_t)(M + 8) * (K / taps), 1u);
+  if (!rc) rc = ar.alloc(&out, (size_t)M * N * 2);
+  for (int i = 0; i < nw && !rc; ++i) rc = dev_bf16(ar, &W[i], (size_t)N * K, 77u + i);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
+  if (!rc) rc = gt.run([&](hipStream_t s) -> int {
+    for (int i = 0; i < chain; ++i) {
+      ExpArgs a;
+      memset(&a, 0, sizeof(a));
+      a.A = (const bf16*)A; a.W = (const bf16*)W[i % nw]; a.out = (bf16*)out; a.M = M; a.N = N; a.K = K; a.lda = K / taps; a.ldw = K; a.ldo = N;
+      a.taps = taps; a.seq_len = seq_len > 0 ? seq_len : M; a.cin = K / taps;
+      if (prefetch) { a.pf = (const char*)W[(i + 1) % nw]; a.pf_bytes = (size_t)N * K * 2; }
+      TT_TRY(launch_variant(variant, a, s));
+    }
+    return 0;
+  }, reps, us_out);
+  if (!rc) *us_out /= chain;
+  gt.destroy();
+  ar.release();
+  return rc;
+}
+
+// The product GEMM (gemm_launch) on the same harness: one shape, nw weight copies, optional split-K, f32 or T output.
+int tt_kb_gemm_prod(int M, int N, int K, int taps, int seq_len, int splitk, int packed, int nw, int chain, int reps, double* us_out) {
+  Arena ar;
+  GraphTimer gt;
+  TT_TRY(gt.init());
+  void* A = nullptr; void* out_t = nullptr; float* out32 = nullptr; float* bias = nullptr;
+  std::vector<void*> W(nw);
+  const int npad = (N + 63) / 64 * 64;
+  int rc = dev_bf16(ar, &A, (size_t)(M + 8) * (K / taps), 1u);
+  if (!rc) rc = ar.alloc(&out_t, (size_t)M * N * 2);
+  if (!rc) rc = ar.alloc_t(&out32, (size_t)std::max(splitk, 1) * M * N);
+  if (!rc) rc = dev_f32(ar, &bias, N, 5u);
+  for (int i = 0; i < nw && !rc; ++i) rc = dev_bf16(ar, &W[i], (size_t)npad * K, 77u + i);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
+  if (!rc) rc = gt.run([&](hipStream_t s) -> int {
+    for (int i = 0; i < chain; ++i) {
+      GemmArgs g = gemm_args(A, K / taps, W[i % nw], K, M, N, K);
+      g.taps = taps; g.seq_len = seq_len > 0 ? seq_len : M; g.splitk = splitk; g.w_packed = packed;
+      if (splitk > 1) { g.out_f32 = out32; g.ldo32 = N; }
+      else { g.bias = bias; g.out_t = out_t; g.ldot = N; }
+      TT_TRY(gemm_launch(DT_BF16, EPI_STD, g, s));
+    }
+    return 0;
+  }, reps, us_out);
+  if (!rc) *us_out /= chain;
+  gt.destroy();
+  ar.release();
+  return rc;
+}
+
+}  // extern "C"
+
+
+// --------------------------------------------------------------------------------------------------------------------
+// Decode attention experiment: same score phase as the product kernel; PV phase with 16-byte V loads (8 lanes per key
+// row of 128 B, 8 keys per wave instruction = 1 KiB like the K loads) instead of 8-byte loads (512 B per instruction).
+__device__ __forceinline__ float kb_dot8(Vec<bf16>::x8 a, Vec<bf16>::x8 b, float acc) {
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), acc, false);
+  return acc;
+}
+
+template <int VU>  // V row sets of 8 keys per register set
+__global__ __launch_bounds__(256, 4) void decode_attn_v2_kernel(DecodeAttnArgs a, int ctx_cap) {
+  typedef Vec<bf16>::x8 x8;
+  typedef bf16 T;
+  extern __shared__ __attribute__((aligned(16))) float sc_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = min((int)blockIdx.x * 4 + wave, a.B * a.heads - 1);
+  const int b = pair / a.heads, h = pair % a.heads;
+  const int tgen = *a.step + 1;
+  const int P1 = a.P1;
+  const int ctx = P1 + tgen;
+  float* sc = sc_all + (size_t)wave * ctx_cap;
+  const T* kp = (const T*)a.kp + (size_t)h * P1 * 64;
+  const T* vp = (const T*)a.vp + (size_t)h * P1 * 64;
+  const size_t bh = (size_t)b * a.heads + h;
+  const T* kc = (const T*)a.kc + bh * 8 * a.tmax * 8;
+  const T* vc = (const T*)a.vc + bh * a.tmax * 64;
+  float mx = -1e30f;
+  {
+    x8 qk[8];
+    const T* qp = (const T*)a.q + (size_t)b * a.heads * 64 + h * 64;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) qk[c] = *(const x8*)(qp + c * 8);
+    const int nsp = (P1 + 63) >> 6, nso = (tgen + 63) >> 6;
+#pragma unroll 1
+    for (int sl0 = 0; sl0 < nsp + nso; sl0 += 2) {
+      x8 kk[2][8];
+      int key[2];
+      bool live[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int slot = min(sl0 + u, nsp + nso - 1);
+        const bool pre = slot < nsp;
+        const int k = (pre ? slot : slot - nsp) * 64 + lane;
+        const int lim = pre ? P1 : tgen;
+        const int kcl = min(k, lim - 1);
+        const char* base = (const char*)(pre ? kp : kc);
+        const unsigned off = (pre ? (unsigned)kcl * 64u : (unsigned)kcl * 8u) * 2u;
+        const unsigned cs = (pre ? 8u : (unsigned)a.tmax * 8u) * 2u;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) kk[u][c] = *(const x8*)(base + (off + c * cs));
+        key[u] = (pre ? 0 : P1) + k;
+        live[u] = k < lim && sl0 + u < nsp + nso;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float sv = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sv = kb_dot8(qk[c], kk[u][c], sv);
+        if (live[u]) { sc[key[u]] = sv; mx = fmaxf(mx, sv); }
+      }
+    }
+  }
+  // PV: lane -> (key sub-index kk = lane >> 3, channel group cg = lane & 7: 8 channels = 16 bytes)
+  const int kk8 = lane >> 3, cg = lane & 7;
+  constexpr int KEYS = 8 * VU;
+  const int nvp = (P1 + KEYS - 1) / KEYS, nvo = (tgen + KEYS - 1) / KEYS, nit = nvp + nvo;
+  auto load_v = [&](x8 (&t)[VU], int it) {
+    const int itc = min(it, nit - 1);
+    const bool pre = itc < nvp;
+    const char* base = (const char*)(pre ? vp : vc);
+    const int k0 = (pre ? itc : itc - nvp) * KEYS + kk8, lim = pre ? P1 : tgen;
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const unsigned jc = (unsigned)min(k0 + 8 * u, lim - 1);
+      t[u] = *(const x8*)(base + (jc * 64u + (unsigned)cg * 8u) * 2u);
+    }
+  };
+  x8 ta[VU], tb[VU];
+  load_v(ta, 0);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < ctx; j += 64) {
+    const float e = __expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  float o[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) o[c] = 0.f;
+  auto consume = [&](const x8 (&t)[VU], int it) {
+    const bool pre = it < nvp;
+    const int k0 = (pre ? it : it - nvp) * KEYS + kk8, lim = it < nit ? (pre ? P1 : tgen) : 0;
+    const float* scs = sc + (pre ? 0 : P1);
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const int j = k0 + 8 * u;
+      const float pj = j < lim ? scs[j] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] += pj * (float)t[u][c];
+    }
+  };
+#pragma unroll 1
+  for (int it = 0; it < nit; it += 2) {
+    load_v(tb, it + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(ta, it);
+    __builtin_amdgcn_sched_barrier(0);
+    load_v(ta, it + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(tb, it + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    o[c] += __shfl_xor(o[c], 8, 64);
+    o[c] += __shfl_xor(o[c], 16, 64);
+    o[c] += __shfl_xor(o[c], 32, 64);
+  }
+  if ((int)blockIdx.x * 4 + wave < a.B * a.heads && kk8 == 0) {
+    const float inv = 1.0f / sum;
+    x8 r;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) r[c] = (T)(o[c] * inv);
+    *(x8*)((T*)a.out + (size_t)b * a.heads * 64 + h * 64 + cg * 8) = r;
+  }
+}
+
+extern "C" {
+// B sequences x heads, tgen generated keys, prefix P1; `nl` distinct per-layer caches visited round-robin (cold KV).
+// variant 0 = product kernel, 1 = v2 with 4 row sets (32 keys / iteration), 2 = v2 with 6 row sets (48 keys / iteration).
+int tt_kb_decode_attn(int variant, int B, int heads, int P1, int tgen, int tmax, int nl, int chain, int reps, double* us_out, double* maxdiff) {
+  Arena ar;
+  GraphTimer gt;
+  TT_TRY(gt.init());
+  void* q = nullptr; void* kp = nullptr; void* vp = nullptr; void* out = nullptr; void* out_ref = nullptr; int* step = nullptr;
+  std::vector<void*> kc(nl), vc(nl);
+  const size_t per = (size_t)B * heads * tmax * 64;
+  int rc = dev_bf16(ar, &q, (size_t)B * heads * 64, 3u);
+  if (!rc) rc = dev_bf16(ar, &kp, (size_t)heads * P1 * 64 + 64, 4u);
+  if (!rc) rc = dev_bf16(ar, &vp, (size_t)heads * P1 * 64 + 64, 5u);
+  if (!rc) rc = ar.alloc(&out, (size_t)B * heads * 64 * 2);
+  if (!rc) rc = ar.alloc(&out_ref, (size_t)B * heads * 64 * 2);
+  if (!rc) rc = ar.alloc_t(&step, 4);
+  for (int i = 0; i < nl && !rc; ++i) {
+    rc = dev_bf16(ar, &kc[i], per + 64, 100u + i);
+    if (!rc) rc = dev_bf16(ar, &vc[i], per + 64, 200u + i);
+  }
+  const int st = tgen - 1;
+  if (!rc) TT_CHECK_HIP(hipMemcpy(step, &st, sizeof(int), hipMemcpyHostToDevice));
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
+  auto launch = [&](int var, int layer, void* o, hipStream_t s) -> int {
+    DecodeAttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = q; a.kp = kp; a.vp = vp; a.P1 = P1; a.kc = kc[layer]; a.vc = vc[layer]; a.tmax = tmax; a.step = step; a.host_tgen = tgen;
+    a.out = o; a.B = B; a.heads = heads;
+    if (var == 0) return decode_attention_launch(DT_BF16, a, s);
+    const int ctx_cap = P1 + tmax;
+    const size_t smem = (size_t)4 * ctx_cap * sizeof(float);
+    const int blocks = cdiv(B * heads, 4);
+    if (var == 1) decode_attn_v2_kernel<4><<<blocks, 256, smem, s>>>(a, ctx_cap);
+    else decode_attn_v2_kernel<6><<<blocks, 256, smem, s>>>(a, ctx_cap);
+    TT_CHECK_HIP(hipGetLastError());
+    return 0;
+  };
+  if (!rc) rc = gt.run([&](hipStream_t s) -> int {
+    for (int i = 0; i < chain; ++i) TT_TRY(launch(variant, i % nl, out, s));
+    return 0;
+  }, reps, us_out);
+  if (!rc) *us_out /= chain;
+  if (!rc && maxdiff) {  // agreement with the product kernel on layer 0
+    rc = launch(0, 0, out_ref, gt.s);
+    if (!rc) rc = launch(variant, 0, out, gt.s);
+    if (!rc && hipStreamSynchronize(gt.s) != hipSuccess) rc = -2;
+    if (!rc) {
+      std::vector<unsigned short> x((size_t)B * heads * 64), y(x.size());
+      TT_CHECK_HIP(hipMemcpy(x.data(), out, x.size() * 2, hipMemcpyDeviceToHost));
+      TT_CHECK_HIP(hipMemcpy(y.data(), out_ref, y.size() * 2, hipMemcpyDeviceToHost));
+      double md = 0;
+      for (size_t i = 0; i < x.size(); ++i) {
+        unsigned ux = (unsigned)x[i] << 16, uy = (unsigned)y[i] << 16;
+        float fx, fy;
+        memcpy(&fx, &ux, 4); memcpy(&fy, &uy, 4);
+        md = std::max(md, (double)fabsf(fx - fy));
+      }
+      *maxdiff = md;
+    }
+  }
+  gt.destroy();
+  ar.release();
+  return rc;
+}
+}  // extern "C"
