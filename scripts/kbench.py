@@ -21,15 +21,15 @@ def chk(rc):
         raise RuntimeError(lib.tt_last_error().decode())
 
 
-def gemm_exp(variant, M, N, K, taps=1, seq=0, nw=1, chain=32, prefetch=0, reps=10):
+def gemm_exp(variant, M, N, K, taps=1, seq=0, nw=1, chain=32, pad=0, reps=10):
     us = D(0)
-    chk(lib.tt_kb_gemm_exp(variant, M, N, K, taps, seq, nw, chain, prefetch, reps, C.byref(us)))
+    chk(lib.tt_kb_gemm_exp(variant, M, N, K, taps, seq, nw, chain, pad, reps, C.byref(us)))
     return us.value
 
 
-def gemm_prod(M, N, K, taps=1, seq=0, splitk=1, packed=0, nw=1, chain=32, reps=10):
+def gemm_prod(M, N, K, taps=1, seq=0, splitk=1, packed=0, nw=1, na=1, xcd_rows=0, chain=32, reps=10):
     us = D(0)
-    chk(lib.tt_kb_gemm_prod(M, N, K, taps, seq, splitk, packed, nw, chain, reps, C.byref(us)))
+    chk(lib.tt_kb_gemm_prod(M, N, K, taps, seq, splitk, packed, nw, na, xcd_rows, chain, reps, C.byref(us)))
     return us.value
 
 
@@ -48,9 +48,46 @@ def tf(M, N, K, us):
     return 2.0 * M * N * K / us / 1e6
 
 
+def bw_probe(mode, waves, nblocks, footprint, bytes_per_wg, reps=10):
+    us = D(0)
+    lib.tt_kb_bw_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(D)]
+    chk(lib.tt_kb_bw_probe(mode, waves, nblocks, footprint, bytes_per_wg, reps, C.byref(us)))
+    return us.value
+
+
+EXTRA = {200: "128x64 4w ring3 2 blocks/CU", 500: "64x64 4w ring3 2 blocks/CU", 501: "64x64 4w ring2 4 blocks/CU", 502: "64x64 4w ring3 3 blocks/CU",
+         1300: "128x64 8w(2x4) ring3 2 blocks/CU", 1301: "128x64 8w(4x2) ring3 2 blocks/CU", 1600: "128x128 8w ring2 2 blocks/CU"}
+
+
 def main():
-    which = sys.argv[1:] or ["gemm_denoiser", "gemm_decode", "attn"]
+    which = sys.argv[1:] or ["bw", "gemm2", "gemm_decode", "attn"]
     lib.tt_init()
+    if "bw" in which:
+        for fp, tag in ((2 << 20, "2 MiB (one L2)"), (24 << 20, "24 MiB (all L2s)"), (160 << 20, "160 MiB (Infinity Cache)"), (2 << 30, "2 GiB (HBM)")):
+            for mode, mtag in ((0, "global_load_lds 16B"), (1, "global_load_dwordx4 -> VGPR, full lines"), (2, "global_load_dwordx4 -> VGPR, fragment shaped")):
+                for waves in (4, 8):
+                    for nb in (256, 512):
+                        per = 1 << 20
+                        us = bw_probe(mode, waves, nb, fp, per)
+                        print(f"bw_probe {tag:24s} {mtag:44s} {waves} waves x {nb} blocks: {us:8.2f} us  {nb * per / us / 1e6:7.2f} TB/s  {per * (nb / 256) / us / 1e3:6.1f} GB/s per CU", flush=True)
+    if "xcd" in which:
+        shapes = [("1x1 1024->1024", 1740, 1024, 1024, 1, 0, 40), ("k3 1024->1024", 1740, 1024, 3072, 3, 870, 16), ("qkv 1024->3072", 1740, 3072, 1024, 1, 0, 16),
+                  ("integ 2048->1024", 1740, 1024, 2048, 1, 0, 20), ("decode fc M=256", 256, 4096, 1024, 1, 0, 40), ("clvp ff1", 51200, 3072, 768, 1, 0, 2)]
+        for name, M, N, K, taps, seq, nw in shapes:
+            for na in (1, 8):
+                for xr in (1, 2, 4, 8, 0):
+                    us = gemm_prod(M, N, K, taps, seq, nw=nw, na=na, xcd_rows=xr, chain=max(nw, 16))
+                    print(f"xcd bands {name:18s} M={M} rotating A x{na} W x{nw}  xcd_rows={xr if xr else 'auto'}: {us:7.2f} us {tf(M, N, K, us):7.1f} TFLOP/s", flush=True)
+    if "gemm2" in which:
+        shapes = [("1x1 1024->1024", 1740, 1024, 1024, 1, 0), ("k3 1024->1024", 1740, 1024, 3072, 3, 870), ("qkv 1024->3072", 1740, 3072, 1024, 1, 0)]
+        for name, M, N, K, taps, seq in shapes:
+            us = gemm_prod(M, N, K, taps, seq)
+            print(f"denoiser {name} M={M} PRODUCT gemm_launch (bias fetched before the k-loop): {us:7.2f} us {tf(M, N, K, us):7.1f} TFLOP/s", flush=True)
+            for v in (0, 300, 400, 500, 501, 502, 200, 1300, 1301, 600, 1600):
+                for pad in (0, 64):
+                    us = gemm_exp(v, M, N, K, taps, seq, pad=pad)
+                    label = EXTRA.get(v) or CFG[v // 100]
+                    print(f"denoiser {name} M={M} exp {label:38s} row pad {pad:3d}: {us:7.2f} us {tf(M, N, K, us):7.1f} TFLOP/s", flush=True)
     if "gemm_denoiser" in which:
         shapes = [("1x1 1024->1024", 1740, 1024, 1024, 1, 0, 150), ("k3 1024->1024", 1740, 1024, 3072, 3, 870, 56), ("qkv 1024->3072", 1740, 3072, 1024, 1, 0, 56)]
         for name, M, N, K, taps, seq, nwc in shapes:
@@ -65,10 +102,6 @@ def main():
                 for v, label in ((200, "128x64 4w ring3 2 blocks/CU"), (500, "64x64 4w ring3 2 blocks/CU")):
                     us = gemm_exp(v, M, N, K, taps, seq, nw=nw)
                     print(f"denoiser {name} M={M} exp {label:38s} {'full':22s} ({tag}): {us:7.2f} us {tf(M, N, K, us):7.1f} TFLOP/s", flush=True)
-            # cross-kernel prefetch of the next launch's weights on the product tile
-            for pf in (0, 1):
-                us = gemm_exp(0, M, N, K, taps, seq, nw=nwc, prefetch=pf)
-                print(f"denoiser {name} M={M} exp {CFG[0]:38s} prefetch_next={pf} (cold W): {us:7.2f} us", flush=True)
     if "gemm_decode" in which:
         for name, N, K, sk in (("qkv", 3072, 1024, 1), ("proj", 1024, 1024, 4), ("fc", 4096, 1024, 1), ("proj2", 1024, 4096, 4), ("mel_head", 8194, 1024, 1)):
             nw = max(8, int(700e6 // (N * K * 2)))
@@ -77,10 +110,11 @@ def main():
                     us = gemm_prod(M, N, K, splitk=sk, packed=packed, nw=nw)
                     print(f"decode {name:8s} M={M:3d} N={N} K={K} PRODUCT splitk={sk} packed={packed} cold W: {us:7.2f} us {N * K * 2 / us / 1e3:7.1f} GB/s weights", flush=True)
                 if N % 64 == 0:
-                    for cfg in (4, 0, 8):
-                        for pf in (0, 1):
-                            us = gemm_exp(cfg * 100, M, N, K, nw=nw, prefetch=pf)
-                            print(f"decode {name:8s} M={M:3d} N={N} K={K} exp {CFG[cfg]:38s} prefetch_next={pf} cold W: {us:7.2f} us {N * K * 2 / us / 1e3:7.1f} GB/s weights", flush=True)
+                    for v in (400, 500, 501):
+                        for pad in (0, 64):
+                            us = gemm_exp(v, M, N, K, nw=nw, pad=pad)
+                            label = EXTRA.get(v) or CFG[v // 100]
+                            print(f"decode {name:8s} M={M:3d} N={N} K={K} exp {label:38s} row pad {pad:3d} cold W: {us:7.2f} us {N * K * 2 / us / 1e3:7.1f} GB/s weights", flush=True)
                     us = gemm_exp(400, M, N, K, nw=1)
                     print(f"decode {name:8s} M={M:3d} N={N} K={K} exp {CFG[4]:38s} hot W: {us:7.2f} us", flush=True)
     if "attn" in which:

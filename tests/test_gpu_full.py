@@ -22,7 +22,7 @@ def full():
     from tortoise_tts_amd.api import TextToSpeech
     sds = bench.synthetic_weights()
     text, latents = bench.synthetic_prompt()
-    tts = TextToSpeech(state_dicts=sds, dtype="bf16", max_candidates=32, max_mel_tokens=200)
+    tts = TextToSpeech(state_dicts=sds, dtype="bf16", max_candidates=32, max_mel_tokens=200, kv_cache=True)
     return tts, sds, text, latents
 
 

@@ -58,7 +58,7 @@ def test_full_ar_prefill_and_cached_steps(sds, name, dt, tdt, tol):
     toks = GF.ar_tokens()
     keep = torch.ones(cfg.number_mel_codes, dtype=torch.bool)
     keep[cfg.stop_mel_token] = False  # suppressed (-1e9) in the benchmark weights: would dominate every norm
-    st = stages.ArStage(sds["autoregressive"], cfg, dtype=dt, max_batch=256, max_text=80, max_new_tokens=32, max_latent_candidates=1)
+    st = stages.ArStage(sds["autoregressive"], cfg, dtype=dt, max_batch=256, max_text=80, max_new_tokens=GF.LAT_N + 8, max_latent_candidates=1)
     # (b) the oracle on operand-rounded weights, batch 16
     sdq = quantize_sd(sds["autoregressive"], tdt)
     prefix = O.ar_prefix(sdq, cfg, auto, text)

@@ -14,7 +14,7 @@
 // decode_attention: one wave per (sequence, head), one new query against [shared prefix | own
 // generated keys].  HBM-bound on the per-sequence cache: keys are stored in 16-byte dim-chunks
 // that are key-major so the lane-per-key dot product issues fully coalesced 1-KiB loads; values are
-// row-major and read 4 rows (512 B) per wave instruction.
+// row-major and read 8 whole rows (1 KiB) per wave instruction.
 #include "ops.h"
 
 namespace tt {
@@ -314,13 +314,12 @@ __device__ __forceinline__ float dot8(Vec<f16>::x8 a, Vec<f16>::x8 b, float acc)
 // segments: every load is then (wave-uniform base) + (32-bit lane offset) - no 64-bit address pairs held in VGPRs -
 // and unconditional (clamped key index), because a branch between two groups of loads makes the compiler drain the
 // first group before it issues the second.
-constexpr int DEC_VROWS = 8;             // V rows per lane group per register set (two sets in flight)
-constexpr int DEC_VKEYS = 4 * DEC_VROWS;  // keys per wave per PV iteration
+constexpr int DEC_VROWS = 4;             // V key rows per lane per register set (two sets in flight)
+constexpr int DEC_VKEYS = 8 * DEC_VROWS;  // keys per wave per PV iteration: 8 key sub-rows x DEC_VROWS
 
 template <typename T>
 __global__ __launch_bounds__(256, 4) void decode_attn_kernel(DecodeAttnArgs a, int ctx_cap) {  // 4 waves per SIMD => <= 128 VGPRs
   typedef typename Vec<T>::x8 x8;
-  typedef typename Vec<T>::x4 x4;
   extern __shared__ __attribute__((aligned(16))) float sc_all[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -337,7 +336,6 @@ __global__ __launch_bounds__(256, 4) void decode_attn_kernel(DecodeAttnArgs a, i
   const size_t bh = (size_t)b * a.heads + h;
   const T* kc = (const T*)a.kc + bh * 8 * a.tmax * 8;
   const T* vc = (const T*)a.vc + bh * a.tmax * 64;
-  const int fr = lane & 15, fg = lane >> 4;
 
   float mx = -1e30f;
   {
@@ -382,22 +380,25 @@ __global__ __launch_bounds__(256, 4) void decode_attn_kernel(DecodeAttnArgs a, i
     }
   }
 
-  // PV: iteration `it` covers DEC_VKEYS keys of one segment; lane group fg takes keys fg + 4u, lane fr 4 of the 64 channels
+  // PV: a V row is 128 bytes, read as 8 lanes x 16 bytes, so a wave instruction covers 8 whole key rows (1 KiB, like the K
+  // loads; 8-byte loads moved half as much per instruction and measured 6 % slower).  Lane -> (key sub-row kk8 = lane >> 3,
+  // channel group cg = lane & 7: 8 channels); iteration `it` covers DEC_VKEYS keys of one segment.
+  const int kk8 = lane >> 3, cg = lane & 7;
   const int nvp = (P1 + DEC_VKEYS - 1) / DEC_VKEYS, nvo = (tgen + DEC_VKEYS - 1) / DEC_VKEYS;
   const int nit = nvp + nvo;
-  auto load_v = [&](x4 (&t)[DEC_VROWS], int it) {
+  auto load_v = [&](x8 (&t)[DEC_VROWS], int it) {
     const int itc = min(it, nit - 1);  // past the end: repeat the last iteration's rows (cached), weighted 0
     const bool pre = itc < nvp;
     const char* base = (const char*)(pre ? vp : vc);
-    const int k0 = (pre ? itc : itc - nvp) * DEC_VKEYS + fg, lim = pre ? P1 : tgen;
+    const int k0 = (pre ? itc : itc - nvp) * DEC_VKEYS + kk8, lim = pre ? P1 : tgen;
 #pragma unroll
     for (int u = 0; u < DEC_VROWS; ++u) {
-      const unsigned jc = (unsigned)min(k0 + 4 * u, lim - 1);
-      t[u] = *(const x4*)(base + (jc * 64u + (unsigned)fr * 4u) * (unsigned)sizeof(T));  // uniform base + 32-bit byte offset
+      const unsigned jc = (unsigned)min(k0 + 8 * u, lim - 1);
+      t[u] = *(const x8*)(base + (jc * 64u + (unsigned)cg * 8u) * (unsigned)sizeof(T));  // uniform base + 32-bit byte offset
     }
   };
   // the first V rows do not depend on the scores: request them before the softmax
-  x4 ta[DEC_VROWS], tb[DEC_VROWS];
+  x8 ta[DEC_VROWS], tb[DEC_VROWS];
   load_v(ta, 0);
   mx = wave_max(mx);
   float sum = 0.f;
@@ -408,19 +409,19 @@ __global__ __launch_bounds__(256, 4) void decode_attn_kernel(DecodeAttnArgs a, i
   }
   sum = wave_sum(sum);
   __syncthreads();  // every lane's sc[] writes are visible to the whole wave (and block)
-  float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-  auto consume = [&](const x4 (&t)[DEC_VROWS], int it) {
+  float o[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) o[c] = 0.f;
+  auto consume = [&](const x8 (&t)[DEC_VROWS], int it) {
     const bool pre = it < nvp;
-    const int k0 = (pre ? it : it - nvp) * DEC_VKEYS + fg, lim = it < nit ? (pre ? P1 : tgen) : 0;
+    const int k0 = (pre ? it : it - nvp) * DEC_VKEYS + kk8, lim = it < nit ? (pre ? P1 : tgen) : 0;
     const float* scs = sc + (pre ? 0 : P1);
 #pragma unroll
     for (int u = 0; u < DEC_VROWS; ++u) {
-      const int j = k0 + 4 * u;
+      const int j = k0 + 8 * u;
       const float pj = j < lim ? scs[j] : 0.f;
-      o0 += pj * (float)t[u][0];
-      o1 += pj * (float)t[u][1];
-      o2 += pj * (float)t[u][2];
-      o3 += pj * (float)t[u][3];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] += pj * (float)t[u][c];
     }
   };
 #pragma unroll 1
@@ -434,14 +435,18 @@ __global__ __launch_bounds__(256, 4) void decode_attn_kernel(DecodeAttnArgs a, i
     consume(tb, it + 1);
     __builtin_amdgcn_sched_barrier(0);
   }
-  o0 += __shfl_xor(o0, 16, 64); o0 += __shfl_xor(o0, 32, 64);
-  o1 += __shfl_xor(o1, 16, 64); o1 += __shfl_xor(o1, 32, 64);
-  o2 += __shfl_xor(o2, 16, 64); o2 += __shfl_xor(o2, 32, 64);
-  o3 += __shfl_xor(o3, 16, 64); o3 += __shfl_xor(o3, 32, 64);
-  if ((int)blockIdx.x * 4 + wave < a.B * a.heads && fg == 0) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {  // sum the 8 key sub-rows (lanes with equal channel group)
+    o[c] += __shfl_xor(o[c], 8, 64);
+    o[c] += __shfl_xor(o[c], 16, 64);
+    o[c] += __shfl_xor(o[c], 32, 64);
+  }
+  if ((int)blockIdx.x * 4 + wave < a.B * a.heads && kk8 == 0) {
     const float inv = 1.0f / sum;
-    T* o = (T*)a.out + (size_t)b * a.heads * 64 + h * 64 + fr * 4;
-    *(x4*)o = pack4<T>(o0 * inv, o1 * inv, o2 * inv, o3 * inv);
+    x8 r;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) r[c] = (T)(o[c] * inv);
+    *(x8*)((T*)a.out + (size_t)b * a.heads * 64 + h * 64 + cg * 8) = r;
   }
 }
 

@@ -128,10 +128,10 @@ enum DType { DT_BF16 = 0, DT_F16 = 1 };
 // launch stream and accumulates the algorithmic flops / bytes of the launch.  Not used on the product
 // path (graphs stay enabled there); bench.py runs one extra un-captured step with it.
 namespace tt {
-enum ProfId {
-  PROF_GEMM_64x64_STD = 0, PROF_GEMM_64x64_QKV, PROF_GEMM_64x64_QKVDEC,
-  PROF_GEMM_128x64_STD, PROF_GEMM_128x64_QKV, PROF_GEMM_128x64_QKVDEC,
-  PROF_GEMM_128x128_STD, PROF_GEMM_128x128_QKV, PROF_GEMM_128x128_QKVDEC,
+enum ProfId {  // one class per kernel instantiation that actually runs (names: common.hip)
+  PROF_GEMM_64x64_STD = 0, PROF_GEMM_64x64_CONV, PROF_GEMM_64x64_QKV, PROF_GEMM_64x64_QKVDEC,
+  PROF_GEMM_128x64_STD, PROF_GEMM_128x64_CONV, PROF_GEMM_128x64_QKV, PROF_GEMM_128x64_QKVDEC,
+  PROF_GEMM_128x128_STD, PROF_GEMM_128x128_CONV, PROF_GEMM_128x128_QKV, PROF_GEMM_128x128_QKVDEC,
   PROF_FLASH, PROF_DECODE_ATTN, PROF_ROWNORM, PROF_GROUPNORM, PROF_SAMPLE, PROF_GLUE, PROF_CONV1D, PROF_CONVT, PROF_LVC,
   PROF_COUNT
 };

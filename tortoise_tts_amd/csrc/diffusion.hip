@@ -46,6 +46,8 @@ struct tt_diff {
   void* temb_t2 = nullptr;     // [steps][C] T
   float* temb_mid = nullptr;   // [steps][C]
   float* ss_all = nullptr;     // [steps][NR][2C]
+  float* ss_cur = nullptr;     // [NR][2C]: the CURRENT step's rows at a fixed address (staged by slot_advance_launch)
+  int n_steps_cur = 1;
   PSampleStep* steps_dev = nullptr;
   int* slot = nullptr;         // device step counter
   float* x = nullptr;          // [S][in]
@@ -57,13 +59,13 @@ struct tt_diff {
   int split_row = -1, split_steps = 0, split_done = 0;
 };
 
-static int run_gn(tt_diff* e, const float* x, int B, int S, const float* g, const float* b, const float* ss, bool ss_slotted,
+static int run_gn(tt_diff* e, const float* x, int B, int S, const float* g, const float* b, const float* ss, bool /*per_step*/,
                   int act, void* out_t, int ldot, float* out_f32, hipStream_t s) {
   GroupNormArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.B = B; a.S = S; a.C = e->C; a.gamma = g; a.beta = b; a.eps = 1e-5f;
   a.scale_shift = ss; a.ss_batch_stride = 0; a.act = act;
-  if (ss && ss_slotted) { a.ss_slot = e->slot; a.ss_slot_stride = (size_t)e->NR * 2 * e->C; }
+  // per-step scale / shift rows are staged at a fixed address (e->ss_cur): no step-dependent addressing in the kernel
   a.out_t = out_t; a.ldot = ldot; a.out_f32 = out_f32; a.ldo32 = e->C;
   a.partial = e->gn_partial;
   if (x == e->stats_ptr && e->stats_seq == S && S >= e->stats_rows) {
@@ -128,7 +130,7 @@ static int run_res_block(tt_diff* e, const tt_res_block& w, const float* ss, con
 // B batch rows starting at conditioning row `row0` (0 = conditioned embedding, 1 = unconditioned embedding)
 static int diff_forward(tt_diff* e, int B, hipStream_t s, int row0 = 0) {
   const int C = e->C, S = e->S, dt = e->cfg.dtype, M = B * S, L = e->cfg.num_layers;
-  const float* ss = e->ss_all;  // + *slot * NR*2C inside the GroupNorm kernel
+  const float* ss = e->ss_cur;  // the current step's [NR][2C] rows (staged by slot_advance_launch / diff_prepare_timesteps)
   e->stats_ptr = nullptr;       // no epilogue statistics are valid at the start of a pass
   // conditioning_timestep_integrator: 3 DiffusionLayers over the [cond | uncond] code embeddings
   const float* cur = e->code_emb + (size_t)row0 * S * C;
@@ -193,7 +195,10 @@ static int diff_prepare_timesteps(tt_diff* e, int n, hipStream_t s) {
   const int N = e->NR * 2 * C;
   g = gemm_args(e->temb_t, C, e->w.w_emb_all, C, n, N, C);
   g.bias = e->w.b_emb_all; g.out_f32 = e->ss_all; g.ldo32 = N;
-  return gemm_launch(dt, EPI_STD, g, s);
+  TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+  e->n_steps_cur = n;
+  TT_CHECK_HIP(hipMemcpyAsync(e->ss_cur, e->ss_all, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, s));  // step 0
+  return 0;
 }
 
 static void split_release(tt_diff* e) {
@@ -242,6 +247,7 @@ int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff*
   if (!rc) rc = e->arena.alloc(&e->temb_t2, (size_t)cfg->max_steps * C * 2);
   if (!rc) rc = e->arena.alloc_t(&e->temb_mid, (size_t)cfg->max_steps * C);
   if (!rc) rc = e->arena.alloc_t(&e->ss_all, (size_t)cfg->max_steps * e->NR * 2 * C);
+  if (!rc) rc = e->arena.alloc_t(&e->ss_cur, (size_t)e->NR * 2 * C);
   if (!rc) rc = e->arena.alloc_t(&e->steps_dev, cfg->max_steps);
   if (!rc) rc = e->arena.alloc_t(&e->slot, 4);
   if (!rc) rc = e->arena.alloc_t(&e->x, (size_t)cfg->max_seq * cfg->in_channels);
@@ -343,7 +349,7 @@ int tt_diff_sample(tt_diff* e, const float* x_T, const float* step_noise, const 
   auto one_step = [&]() -> int {
     TT_TRY(diff_forward(e, B, s));
     TT_TRY(psample_launch(dt, pa, s));
-    return slot_advance_launch(e->slot, s);
+    return slot_advance_launch(e->slot, e->ss_all, e->ss_cur, e->NR * 2 * e->C, e->n_steps_cur - 1, s);
   };
   int rc = 0;
   if (graphs_enabled() && n_steps > 2) {
@@ -435,7 +441,7 @@ int tt_diff_split_update(tt_diff* e, const float* rows, const float* step_noise,
   pa.mel_scale = 2.3143386840820312f - (-11.512925148010254f);
   pa.mel_shift = -11.512925148010254f;
   TT_TRY(psample_launch(e->cfg.dtype, pa, s));
-  TT_TRY(slot_advance_launch(e->slot, s));
+  TT_TRY(slot_advance_launch(e->slot, e->ss_all, e->ss_cur, e->NR * 2 * e->C, e->n_steps_cur - 1, s));
   e->split_done += 1;
   return e->sb.leave(us);
 }

@@ -25,7 +25,9 @@ struct GemmArgs {
   int seq_len;  // rows per sequence (conv boundary / head-layout epilogues)
   int cin;      // K / taps
   int splitk;   // >1: raw partial sums go to out_f32 + z * M * ldo32 (EPI_STD only)
-  int xcd_mode; // set by gemm_launch: workgroup -> tile order w.r.t. the 8 XCD L2s (0 none, 1 row-fastest runs, 2 col-fastest, 3 2-D)
+  int xcd_rows; // row bands the tile grid is cut into for XCD ownership (1, 2, 4 or 8); 0 = chosen by gemm_launch from the operand sizes
+  int xcd_band; // set by gemm_launch: row tiles per band
+  int sk_quot, sk_rem;  // set by gemm_launch: k-tiles per split-K slab (quotient, remainder)
   // EPI_STD
   const float* bias;
   int act;

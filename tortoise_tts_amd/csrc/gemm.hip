@@ -1,16 +1,17 @@
-// MFMA GEMM for gfx950 (see gemm.h).  256 threads = 4 waves in a 2x2 grid; each wave owns a
-// (BM/2)x(BN/2) sub-tile built from v_mfma_f32_16x16x32 fragments.  The MFMA is issued "swapped"
-// (W fragment as the A operand, activation fragment as B) so that a lane ends up holding four
-// consecutive output columns n..n+3 of one row m: epilogue stores are 16 B (f32) / 8 B (bf16).
-// Tiles move global -> registers -> LDS (double buffered, one barrier per 64-deep k-step); the
-// register stage is what lets the conv taps shift rows and zero-fill sequence edges for free.
+// MFMA GEMM for gfx950 (see gemm.h).  One kernel family, gemm_glds_kernel: NW waves in a 2 x NW/2 grid, each wave owns a
+// (BM/2) x (BN / (NW/2)) sub-tile built from v_mfma_f32_16x16x32 fragments.  The MFMA is issued "swapped" (W fragment as
+// the A operand, activation fragment as B) so that a lane ends up holding four consecutive output columns n..n+3 of one
+// row m: epilogue stores are 16 B (f32) / 8 B (bf16).  Tiles move global -> LDS directly (global_load_lds_dwordx4, no
+// register stage, no ds_write), XOR-swizzled on the source side; conv taps shift the source rows per k-tile and read a
+// zero page for the sequence-edge padding.  The tile is chosen from the problem shape only (pick_tile): there are no
+// run-time overrides in the product library; experiments live in csrc/kbench/ (built with `build.py --kbench`).
 #include "gemm.h"
 
-namespace tt {
+#ifndef TT_EPI_FETCH
+#define TT_EPI_FETCH 1  // 0: before the ring fill, 1: right after the ring fill (default), 2: after the k-loop (A/B builds only)
+#endif
 
-// BK (k-depth of one LDS stage) is a template parameter: 64 for the MFMA-bound shapes, 256 for the decode
-// shapes (M <= 256), where a block's k-loop is a chain of memory round trips and fewer, fatter stages win.
-// LDS row pitch = BK + 8 elements (keeps 16-B alignment, staggers banks).
+namespace tt {
 
 template <typename T>
 struct EpiStd {
@@ -26,10 +27,12 @@ struct EpiStd {
     }
     v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
   }
+  // AL (compile time): N % 4 == 0 and every operand / output row is 16-byte aligned, so every access is a whole quad
+  template <bool AL>
   __device__ __forceinline__ void store(const GemmArgs& g, int m, int n, const f32x4& v, int nvalid, int z) const {
     if (g.splitk > 1) {
       float* o = g.out_f32 + (size_t)z * g.M * g.ldo32 + (size_t)m * g.ldo32 + n;
-      if (nvalid == 4 && (g.ldo32 & 3) == 0) {
+      if (AL || (nvalid == 4 && (g.ldo32 & 3) == 0)) {
         *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
       } else {
         for (int i = 0; i < nvalid; ++i) o[i] = v[i];
@@ -38,7 +41,7 @@ struct EpiStd {
     }
     if (g.out_f32) {
       float* o = g.out_f32 + (size_t)m * g.ldo32 + n;
-      if (nvalid == 4 && (g.ldo32 & 3) == 0) {
+      if (AL || (nvalid == 4 && (g.ldo32 & 3) == 0)) {
         *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
       } else {
         for (int i = 0; i < nvalid; ++i) o[i] = v[i];
@@ -46,7 +49,7 @@ struct EpiStd {
     }
     if (g.out_t) {
       T* o = (T*)g.out_t + (size_t)m * g.ldot + n;
-      if (nvalid == 4 && (g.ldot & 3) == 0) {
+      if (AL || (nvalid == 4 && (g.ldot & 3) == 0)) {
         *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
       } else {
         for (int i = 0; i < nvalid; ++i) o[i] = (T)v[i];
@@ -61,6 +64,7 @@ struct EpiQkvHeads {
   __device__ __forceinline__ void apply(const GemmArgs& g, f32x4& v, const float4& bv, const float4&) const {
     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
   }
+  template <bool AL>
   __device__ __forceinline__ void store(const GemmArgs& g, int m, int n, const f32x4& v, int nvalid, int z) const {
     // N == 3 * dmodel and dmodel % 64 == 0, so nvalid is always 4 here.
     const int part = n / g.dmodel;
@@ -94,6 +98,7 @@ struct EpiQkvDecode {
   __device__ __forceinline__ void apply(const GemmArgs& g, f32x4& v, const float4& bv, const float4&) const {
     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
   }
+  template <bool AL>
   __device__ __forceinline__ void store(const GemmArgs& g, int m, int n, const f32x4& v, int nvalid, int z) const {
     const int part = n / g.dmodel;
     const int c = n - part * g.dmodel;
@@ -113,7 +118,7 @@ struct EpiQkvDecode {
   }
 };
 
-// Epilogue shared by both GEMM kernels.  With g.gn_part set (EPI_STD, f32 output feeding a GroupNorm32) every
+// Epilogue.  With g.gn_part set (EPI_STD, f32 output feeding a GroupNorm32) every
 // wave also emits (sum, sum of squares) of the values it just produced, per 16-column strip of its TM-row
 // tile: gn_part[row_tile][slot][n / 16][2], slot 1 = rows that belong to the NEXT sequence when the row tile
 // straddles a sequence boundary.  The GroupNorm apply kernel adds these up in a fixed order (deterministic),
@@ -127,50 +132,59 @@ __device__ __forceinline__ float4 load_upto4(const float* p, int nvalid) {  // r
   return r;
 }
 
-template <typename Epi, int FM, int FN, int TM, int TN>
-__device__ __forceinline__ void run_epilogue(const GemmArgs& g, f32x4 (&acc)[FN][FM], int m0w, int n0w, int lane, int z) {
+// Bias and residual operands of a wave tile, requested as whole quads BEFORE the k-loop (epi_fetch) so that their memory
+// round trip (the bias vector is HBM-cold every step) overlaps the whole loop instead of sitting between the last MFMA and
+// the first store (measured: 1.2 - 1.7 us per launch at the decode and denoiser shapes).  One round trip per strip, never
+// one per element (a per-element `if (i < nvalid) v += bias[n + i]` compiles to load / s_waitcnt vmcnt(0) / branch
+// chains).  Out-of-range rows / columns are clamped, never stored.
+template <int FM, int FN>
+struct EpiOperands {
+  float4 bv[FN], rv[FN][FM];
+};
+
+template <typename Epi, int FM, int FN, bool AL>
+__device__ __forceinline__ void epi_fetch(const GemmArgs& g, EpiOperands<FM, FN>& o, int m0w, int n0w, int lane) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const bool use_bias = g.bias != nullptr && !(Epi::kId == 0 && g.splitk > 1);
+  const bool use_res = Epi::kId == 0 && g.res != nullptr && g.splitk == 1;
+  const bool quads = AL;
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int n = n0w + i * 16 + fg * 4;
+    const int nvalid = g.N - n >= 4 ? 4 : g.N - n;
+    o.bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < FM; ++j) o.rv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (quads) {
+      const int nc = max(min(n, g.N - 4), 0);
+      if (use_bias) o.bv[i] = *(const float4*)(g.bias + nc);
+      if (use_res) {
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const int mc = min(m0w + j * 16 + fr, g.M - 1);
+          o.rv[i][j] = *(const float4*)(g.res + (size_t)mc * g.ldres + nc);
+        }
+      }
+    } else {
+      if (use_bias) o.bv[i] = load_upto4(g.bias + n, nvalid);
+      if (use_res) {
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const int m = m0w + j * 16 + fr;
+          if (m < g.M) o.rv[i][j] = load_upto4(g.res + (size_t)m * g.ldres + n, nvalid);
+        }
+      }
+    }
+  }
+}
+
+template <typename Epi, int FM, int FN, int TM, int TN, bool AL>
+__device__ __forceinline__ void run_epilogue(const GemmArgs& g, f32x4 (&acc)[FN][FM], const EpiOperands<FM, FN>& o, int m0w, int n0w, int lane, int z) {
   const int fr = lane & 15, fg = lane >> 4;
   Epi epi;
   const bool stats = Epi::kId == 0 && g.gn_part != nullptr && g.splitk == 1;
   const int rt = m0w / TM;                              // row-tile index (m0w is a multiple of TM)
   const int b_first = stats ? m0w / g.gn_seq : 0;
-  // Bias and residual operands are requested as whole quads for a full column strip BEFORE any arithmetic or store:
-  // one memory round trip per strip instead of one per element (a per-element `if (i < nvalid) v += bias[n + i]`
-  // compiles to load / s_waitcnt vmcnt(0) / branch chains).  Out-of-range rows / columns are clamped, never stored.
-  const bool use_bias = g.bias != nullptr && !(Epi::kId == 0 && g.splitk > 1);
-  const bool use_res = Epi::kId == 0 && g.res != nullptr && g.splitk == 1;
-  const bool quads = (g.N & 3) == 0 && g.N >= 4 && (!use_bias || ((size_t)g.bias & 15) == 0) &&
-                     (!use_res || (((size_t)g.res & 15) == 0 && (g.ldres & 3) == 0));
-  // phase 1: every bias / residual quad of the wave tile is requested up front
-  float4 bv[FN], rv[FN][FM];
-#pragma unroll
-  for (int i = 0; i < FN; ++i) {
-    const int n = n0w + i * 16 + fg * 4;
-    const int nvalid = g.N - n >= 4 ? 4 : g.N - n;
-    bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < FM; ++j) rv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (quads) {
-      const int nc = min(n, g.N - 4);
-      if (use_bias) bv[i] = *(const float4*)(g.bias + nc);
-      if (use_res) {
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-          const int mc = min(m0w + j * 16 + fr, g.M - 1);
-          rv[i][j] = *(const float4*)(g.res + (size_t)mc * g.ldres + nc);
-        }
-      }
-    } else {
-      if (use_bias) bv[i] = load_upto4(g.bias + n, nvalid);
-      if (use_res) {
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-          const int m = m0w + j * 16 + fr;
-          if (m < g.M) rv[i][j] = load_upto4(g.res + (size_t)m * g.ldres + n, nvalid);
-        }
-      }
-    }
-  }
   // phase 2: arithmetic and GroupNorm partial statistics, registers only
   float s0[FN], q0[FN], s1[FN], q1[FN];
 #pragma unroll
@@ -181,7 +195,7 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g, f32x4 (&acc)[FN]
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
       const int m = m0w + j * 16 + fr;
-      epi.apply(g, acc[i][j], bv[i], rv[i][j]);
+      epi.apply(g, acc[i][j], o.bv[i], o.rv[i][j]);
       if (stats) {
         float sv = 0.f, qv = 0.f;
 #pragma unroll
@@ -206,7 +220,7 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g, f32x4 (&acc)[FN]
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
       const int m = m0w + j * 16 + fr;
-      if (m < g.M && n < g.N) epi.store(g, m, n, acc[i][j], nvalid, z);
+      if (m < g.M && n < g.N) epi.template store<AL>(g, m, n, acc[i][j], nvalid, z);
     }
   }
   if (stats) {
@@ -232,179 +246,9 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g, f32x4 (&acc)[FN]
   }
 }
 
-template <typename T, int BM, int BN, int BK, int NW, typename Epi, bool CONV>
-__global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs g) {
-  typedef typename Vec<T>::x8 x8;
-  constexpr int BKP = BK + 8;
-  constexpr int NT = NW * 64;               // threads per workgroup
-  constexpr int WGN = NW / 2;               // wave grid: 2 (rows) x WGN (columns)
-  constexpr int TM = BM / 2, TN = BN / WGN;  // wave tile
-  constexpr int FM = TM / 16, FN = TN / 16;
-  constexpr int TPR = BK / 8;        // threads per tile row (16 B each)
-  constexpr int RPP = NT / TPR;      // rows per workgroup-wide pass
-  constexpr int PA = BM / RPP, PW = BN / RPP;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* As = (T*)smem_raw;                 // [2][BM][BKP]
-  T* Ws = As + 2 * BM * BKP;            // [2][BN][BKP]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
-  // XCD-aware tile order: hardware dispatches workgroup i to XCD i % 8, each with a private 4 MiB L2.
-  // Remap so every XCD owns a contiguous run of tiles (m fastest): its blocks then share W panels and
-  // re-use A rows out of ITS L2 instead of all eight L2s each streaming every panel.
-  int bx = blockIdx.x, by = blockIdx.y;
-  if (g.xcd_mode != 0) {
-    const int gx = gridDim.x, gy = gridDim.y;
-    const int nwg = gx * gy;
-    const int id = blockIdx.x + gx * blockIdx.y;
-    const int xcd = id & 7, loc = id >> 3;
-    if (g.xcd_mode == 3 && (gx & 1) == 0 && (gy & 3) == 0) {
-      // 2-D ownership: XCD (xm, xn) owns half of the row tiles and a quarter of the column tiles
-      const int hx = gx >> 1, qy = gy >> 2;
-      const int xm = xcd & 1, xn = xcd >> 1;
-      bx = xm * hx + loc % hx;
-      by = xn * qy + loc / hx;
-    } else {
-      const int q = nwg >> 3, r = nwg & 7;
-      const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-      if (g.xcd_mode == 2) {  // column tiles fastest: an XCD owns a band of rows and sees every W panel
-        by = nid % gy;
-        bx = nid / gy;
-      } else {                // row tiles fastest: an XCD owns a few W panels and sees every A row
-        bx = nid % gx;
-        by = nid / gx;
-      }
-    }
-  }
-  const int m0 = bx * BM, n0 = by * BN;
-  const int z = blockIdx.z;
-  const int nk_total = g.K / BK;
-  const int kt_begin = (int)((long long)nk_total * z / g.splitk);
-  const int kt_end = (int)((long long)nk_total * (z + 1) / g.splitk);
-
-  const int lrow = tid / TPR;
-  const int lcol = (tid % TPR) * 8;  // element offset inside the k-tile
-  const T* A = (const T*)g.A;
-  const T* W = (const T*)g.W;
-
-  // per-pass source rows (conv taps shift them per k-tile)
-  int a_b[PA], a_s[PA];
-  bool a_ok[PA];
-#pragma unroll
-  for (int p = 0; p < PA; ++p) {
-    const int m = m0 + lrow + RPP * p;
-    a_ok[p] = m < g.M;
-    if (CONV) {
-      a_b[p] = m / g.seq_len;
-      a_s[p] = m - a_b[p] * g.seq_len;
-    } else {
-      a_b[p] = 0;
-      a_s[p] = m;
-    }
-  }
-
-  // Two register tile sets: loads run TWO k-tiles ahead of the MFMAs (one tile being written to LDS,
-  // one still in flight), because at these shapes a block's k-step is shorter than the L2/HBM latency.
-  x8 ra0[PA], rw0[PW], ra1[PA], rw1[PW];
-  unsigned zm0 = 0u, zm1 = 0u;  // CONV only: bit p set = A row p of that set is conv padding (must read as zero)
-  const x8 zero8 = {};
-
-  // Loads are unconditional and their results are NOT touched until store_tile: rows beyond M / N are
-  // clamped to a valid address and simply produce output rows / columns that the epilogue never stores,
-  // so no select is needed (a select right after the load would force an immediate vmcnt wait and
-  // destroy the prefetch distance).  Only conv padding needs real zeros; that select happens at store time.
-  auto load_tile = [&](x8 (&ra)[PA], x8 (&rw)[PW], unsigned& zm, int kt) {
-    const int k0 = kt * BK;
-    int tap = 0, kin = k0;
-    if (CONV) {
-      tap = k0 / g.cin;
-      kin = k0 - tap * g.cin;
-    }
-    const int shift = tap - (g.taps >> 1);
-    unsigned z = 0u;
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-      size_t row;
-      if (CONV) {
-        const int s2 = a_s[p] + shift;
-        const bool ok = a_ok[p] && s2 >= 0 && s2 < g.seq_len;
-        if (!ok) z |= 1u << p;
-        row = ok ? (size_t)a_b[p] * g.seq_len + s2 : 0;
-      } else {
-        row = a_ok[p] ? (size_t)a_s[p] : 0;
-      }
-      ra[p] = *(const x8*)(A + row * g.lda + kin + lcol);
-    }
-    zm = z;
-#pragma unroll
-    for (int p = 0; p < PW; ++p) {
-      const int n = n0 + lrow + RPP * p;
-      rw[p] = *(const x8*)(W + (size_t)(n < g.N ? n : g.N - 1) * g.ldw + k0 + lcol);
-    }
-  };
-  auto store_tile = [&](const x8 (&ra)[PA], const x8 (&rw)[PW], unsigned zm, int buf) {
-    T* as = As + buf * BM * BKP;
-    T* ws = Ws + buf * BN * BKP;
-#pragma unroll
-    for (int p = 0; p < PA; ++p) *(x8*)(as + (lrow + RPP * p) * BKP + lcol) = (CONV && ((zm >> p) & 1u)) ? zero8 : ra[p];
-#pragma unroll
-    for (int p = 0; p < PW; ++p) *(x8*)(ws + (lrow + RPP * p) * BKP + lcol) = rw[p];
-  };
-
-  f32x4 acc[FN][FM];
-#pragma unroll
-  for (int i = 0; i < FN; ++i)
-#pragma unroll
-    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int fr = lane & 15, fg = lane >> 4;
-  auto compute = [&](int buf) {
-    const T* as = As + buf * BM * BKP + (wm * TM + fr) * BKP + fg * 8;
-    const T* ws = Ws + buf * BN * BKP + (wn * TN + fr) * BKP + fg * 8;
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      x8 fa[FM], fw[FN];
-#pragma unroll
-      for (int j = 0; j < FM; ++j) fa[j] = *(const x8*)(as + j * 16 * BKP + ks * 32);
-#pragma unroll
-      for (int i = 0; i < FN; ++i) fw[i] = *(const x8*)(ws + i * 16 * BKP + ks * 32);
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
-    }
-  };
-
-  const int nt = kt_end - kt_begin;  // >= 1 (the launcher guarantees splitk <= k-tiles)
-  const int last = kt_end - 1;
-  // Every iteration issues its prefetch unconditionally (clamped to the last tile; a redundant reload of
-  // the final tile is harmless) so the body stays straight-line and the waits stay counted.
-  load_tile(ra0, rw0, zm0, kt_begin);
-  load_tile(ra1, rw1, zm1, min(kt_begin + 1, last));
-  store_tile(ra0, rw0, zm0, 0);
-  __syncthreads();
-  for (int i = 0; i < nt; i += 2) {
-    // tile i is in LDS buffer 0, tile i+1 in flight in set 1, set 0 is free
-    load_tile(ra0, rw0, zm0, min(kt_begin + i + 2, last));
-    compute(0);
-    store_tile(ra1, rw1, zm1, 1);
-    __syncthreads();
-    if (i + 1 >= nt) break;
-    // tile i+1 is in LDS buffer 1, tile i+2 in flight in set 0, set 1 is free
-    load_tile(ra1, rw1, zm1, min(kt_begin + i + 3, last));
-    compute(1);
-    store_tile(ra0, rw0, zm0, 0);
-    __syncthreads();
-  }
-
-  run_epilogue<Epi, FM, FN, TM, TN>(g, acc, m0 + wm * TM, n0 + wn * TN, lane, z);
-}
-
 // ------------------------------------------------------------------------------------------------------
-// Direct-to-LDS variant (global_load_lds_dwordx4): tiles go HBM/L2 -> LDS without passing through VGPRs or
-// ds_write instructions (the register-staged kernel spends about as many LDS-issue cycles writing a stage as
-// the MFMAs take to consume it).  A wave instruction fills 1 KiB = 8 rows x 128 B, lane-linear, so rows are
+// Direct-to-LDS staging (global_load_lds_dwordx4): tiles go HBM/L2 -> LDS without passing through VGPRs or
+// ds_write instructions.  A wave instruction fills 1 KiB = 8 rows x 128 B, lane-linear, so rows are
 // unpadded; bank conflicts are removed by an XOR swizzle applied on the SOURCE side: LDS chunk c of row r
 // holds global 16-byte chunk c ^ ((r >> 1) & 7), and fragment reads apply the same involution.
 // Conv padding / out-of-range rows cannot be zero-filled by a select any more: those lanes read a 16-byte
@@ -414,7 +258,7 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_page[16] = {0, 0, 0,
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <typename T, int BM, int BN, int NW, int ST, typename Epi, bool CONV, bool QUART = false>
+template <typename T, int BM, int BN, int NW, int ST, typename Epi, bool CONV, bool AL>
 __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(GemmArgs g) {
   typedef typename Vec<T>::x8 x8;
   constexpr int BK = 64;
@@ -430,22 +274,33 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  int bx = blockIdx.x, by = blockIdx.y;
+  // XCD-aware tile order.  Hardware deals workgroup i to XCD i % 8, each with a private 4 MiB L2, and everything that is
+  // not in the LOCAL L2 arrives over the fabric at HBM-like bandwidth (~6.5 TB/s for the whole chip, Infinity-Cache hits
+  // included: scripts/kbench.py bw).  So the tile grid is cut into `xcd_rows` row bands and every XCD owns a contiguous
+  // run of (band, column, row-in-band)-ordered tiles, i.e. a rectangle of about (gx / xcd_rows) x (8 gy / ... ) tiles:
+  // it pulls A / xcd_rows + W * xcd_rows / 8 over the fabric instead of all of A (xcd_rows = 1, the decode shapes where
+  // A is tiny) or all of W (xcd_rows = 8).  gemm_launch picks xcd_rows to minimise that sum.
+  int bx, by;
   {
-    const int gx = gridDim.x;
-    const int nwg = gx * gridDim.y;
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int nwg = gx * gy;
     const int id = blockIdx.x + gx * blockIdx.y;
     const int xcd = id & 7, loc = id >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    bx = nid % gx;
-    by = nid / gx;
+    const int hb = g.xcd_band;                 // row tiles per band (the last band may be shorter)
+    const int band = nid / (hb * gy);
+    const int rem = nid - band * hb * gy;
+    const int h = min(hb, gx - band * hb);
+    by = rem / h;
+    bx = band * hb + rem - by * h;
   }
   const int m0 = bx * BM, n0 = by * BN;
   const int z = blockIdx.z;
-  const int nk_total = g.K / BK;
-  const int kt_begin = (int)((long long)nk_total * z / g.splitk);
-  const int kt_end = (int)((long long)nk_total * (z + 1) / g.splitk);
+  // split-K slab z covers k-tiles [kt_begin, kt_end): nk_total / splitk each, the first nk_total % splitk slabs one more.
+  // (host-computed quotient / remainder: a 64-bit division here costs ~1 us of scalar prologue per launch)
+  const int kt_begin = z * g.sk_quot + min(z, g.sk_rem);
+  const int kt_end = kt_begin + g.sk_quot + (z < g.sk_rem ? 1 : 0);
   const T* A = (const T*)g.A;
   const T* W = (const T*)g.W;
   const T* zero = (const T*)g_zero_page;
@@ -518,6 +373,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(GemmArgs g) {
   for (int i = 0; i < FN; ++i)
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  EpiOperands<FM, FN> eo;
+#if TT_EPI_FETCH == 0
+  epi_fetch<Epi, FM, FN, AL>(g, eo, m0 + wm * TM, n0 + wn * TN, lane);  // requested now, consumed after the k-loop
+#endif
 
   const int fr = lane & 15, fg = lane >> 4;
   auto compute = [&](int buf) {
@@ -544,6 +403,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(GemmArgs g) {
   };
 
   if constexpr (ST == 2) {
+#if TT_EPI_FETCH == 1
+    // two-stage variant: every barrier drains the queue anyway, so the epilogue operands go out with the first tile
+    // (inside the loop, even on the last iteration only, the request de-pipelines the loop: CLVP 0.033 -> 0.037 s)
+    epi_fetch<Epi, FM, FN, AL>(g, eo, m0 + wm * TM, n0 + wn * TN, lane);
+#endif
     issue(kt_begin, 0);
     __syncthreads();  // (drains the LDS-DMA: hipcc emits vmcnt(0) before the barrier while a global_load_lds is pending)
     int cur = 0;
@@ -559,80 +423,32 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(GemmArgs g) {
     // Every iteration issues exactly G loads (tile index clamped; a redundant reload targets the ring slot
     // that was consumed last iteration and is never read again), which keeps the count uniform in the tail.
     constexpr int G = PA + PW;
-    const int nt = kt_end - kt_begin;
-    if constexpr (!QUART) {
-      const int last = kt_end - 1;
+    const int last = kt_end - 1;
 #pragma unroll
-      for (int s = 0; s < ST - 1; ++s) issue(min(kt_begin + s, last), s);
-      int slot = 0;
-      for (int kt = kt_begin; kt < kt_end; ++kt) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * G) : "memory");
-        __builtin_amdgcn_s_barrier();
-        int nslot = slot + ST - 1;
-        if (nslot >= ST) nslot -= ST;
-        issue(min(kt + ST - 1, last), nslot);
-        compute(slot);
-        slot = slot + 1 == ST ? 0 : slot + 1;
-      }
-    } else {
-      // Decode shapes: a CU streams from HBM at only ~24 GB/s, so the four row-tile blocks that share a W panel
-      // must not all pull it in the same order.  The k-range is cut into four quarters; block bx starts at quarter
-      // bx & 3 and wraps, so at any moment the siblings fetch DIFFERENT quarters from HBM and find the others in L2.
-      // Each quarter is summed into its own accumulator in natural k order and the four are combined in a fixed
-      // order, so the result is bit-identical for every rotation (and for every batch size / sharding).
-      const bool quart = (nt & 3) == 0;
-      const int qlen = quart ? nt >> 2 : nt;
-      const int rot = quart ? (bx & 3) : 0;
-      auto tile_of = [&](int i) {  // i-th tile in this block's visiting order (clamped in the tail)
-        const int ii = i < nt ? i : nt - 1;
-        int t = ii + rot * qlen;
-        if (t >= nt) t -= nt;
-        return kt_begin + t;
-      };
-      f32x4 accq[4][FN][FM];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < FN; ++i)
-#pragma unroll
-          for (int j = 0; j < FM; ++j) accq[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < ST - 1; ++s) issue(tile_of(s), s);
-      int slot = 0, in_q = 0, seg = 0;
-      for (int i = 0; i < nt; ++i) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * G) : "memory");
-        __builtin_amdgcn_s_barrier();
-        int nslot = slot + ST - 1;
-        if (nslot >= ST) nslot -= ST;
-        issue(tile_of(i + ST - 1), nslot);
-        compute(slot);
-        slot = slot + 1 == ST ? 0 : slot + 1;
-        if (++in_q == qlen) {  // quarter finished: bank it (block-uniform branch, 4 times per kernel)
-          in_q = 0;
-          const int q = quart ? ((seg + rot) & 3) : 0;
-          ++seg;
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq)
-            if (qq == q) {
-#pragma unroll
-              for (int a = 0; a < FN; ++a)
-#pragma unroll
-                for (int b = 0; b < FM; ++b) {
-                  accq[qq][a][b] += acc[a][b];
-                  acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-        }
-      }
-#pragma unroll
-      for (int a = 0; a < FN; ++a)
-#pragma unroll
-        for (int b = 0; b < FM; ++b) acc[a][b] = ((accq[0][a][b] + accq[1][a][b]) + accq[2][a][b]) + accq[3][a][b];
+    for (int s = 0; s < ST - 1; ++s) issue(min(kt_begin + s, last), s);
+#if TT_EPI_FETCH == 1
+    // Bias / residual operands are requested AFTER the ring fill: memory operations retire in order, so a residual quad
+    // requested first would have to land before the first k-step may start; here it only has to land before stage ST - 1
+    // is consumed (the counted waits below over-wait by these few loads during the first two k-steps, nothing more).
+    epi_fetch<Epi, FM, FN, AL>(g, eo, m0 + wm * TM, n0 + wn * TN, lane);
+#endif
+    int slot = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * G) : "memory");
+      __builtin_amdgcn_s_barrier();
+      int nslot = slot + ST - 1;
+      if (nslot >= ST) nslot -= ST;
+      issue(min(kt + ST - 1, last), nslot);
+      compute(slot);
+      slot = slot + 1 == ST ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+#if TT_EPI_FETCH == 2
+  epi_fetch<Epi, FM, FN, AL>(g, eo, m0 + wm * TM, n0 + wn * TN, lane);
+#endif
 
-  run_epilogue<Epi, FM, FN, TM, TN>(g, acc, m0 + wm * TM, n0 + wn * TN, lane, z);
+  run_epilogue<Epi, FM, FN, TM, TN, AL>(g, acc, eo, m0 + wm * TM, n0 + wn * TN, lane, z);
 }
 
 template <int BM, int BN, int ST>
@@ -640,105 +456,90 @@ constexpr int smem_bytes_glds() {
   return ST * (BM + BN) * 64 * 2;
 }
 
-template <typename T, int BM, int BN, int NW, int ST, typename Epi, bool QUART = false>
-static int launch_glds(const GemmArgs& a, hipStream_t stream, int prof_tile) {
+template <typename T, int BM, int BN, int NW, int ST, typename Epi>
+static int launch_glds(const GemmArgs& a, hipStream_t stream, int prof_id) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), a.splitk);
   constexpr int smem = smem_bytes_glds<BM, BN, ST>();
-  const double out_bytes = (double)a.M * a.N * ((a.out_f32 || Epi::kId != 0 ? 4.0 : 0.0) * (Epi::kId == 0 ? 1.0 : 0.0) + (a.out_t || Epi::kId != 0 ? 2.0 : 0.0));
-  ProfScope ps(prof_tile * 3 + Epi::kId, stream, 2.0 * a.M * a.N * a.K,
-               ((double)a.N * a.K + (double)a.M * a.cin) * 2.0 + out_bytes * (a.splitk > 1 ? a.splitk : 1) + (a.res ? 4.0 * a.M * a.N : 0.0));
-  if constexpr (Epi::kId == 0) {
-    if (a.taps > 1) gemm_glds_kernel<T, BM, BN, NW, ST, Epi, true, QUART><<<grid, dim3(NW * 64), smem, stream>>>(a);
-    else gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false, QUART><<<grid, dim3(NW * 64), smem, stream>>>(a);
-  } else {
-    gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false, QUART><<<grid, dim3(NW * 64), smem, stream>>>(a);
-  }
-  TT_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-template <int BM, int BN, int BK>
-constexpr int smem_bytes() {
-  return 2 * (BM + BN) * (BK + 8) * 2;
-}
-
-// tile configurations: id -> (BM, BN, BK)
-//   0: 64x64x64   1: 128x64x64   2: 128x128x64   3: 64x64x256 (decode: few fat k-stages)
-//   4: 128x128x64 with 8 waves   5: 128x64x64 with 8 waves   (two waves per SIMD overlap LDS and MFMA phases)
-//   6: 128x128 / 7: 128x64 (8 waves), 8: 64x64 (4 waves): direct-to-LDS (global_load_lds) staging
-template <typename T, int BM, int BN, int BK, int NW, typename Epi>
-static int launch_one(const GemmArgs& a, hipStream_t stream, int tile_id) {
-  dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), a.splitk);
-  constexpr int smem = smem_bytes<BM, BN, BK>();
   // algorithmic work of this launch: 2*M*N*K flops; operands read once + result written once
   const double out_bytes = (double)a.M * a.N * ((a.out_f32 || Epi::kId != 0 ? 4.0 : 0.0) * (Epi::kId == 0 ? 1.0 : 0.0) + (a.out_t || Epi::kId != 0 ? 2.0 : 0.0));
-  const int prof_tile = tile_id == 3 ? 0 : (tile_id == 4 ? 2 : (tile_id == 5 ? 1 : tile_id));
-  ProfScope ps(prof_tile * 3 + Epi::kId, stream, 2.0 * a.M * a.N * a.K,
+  ProfScope ps(prof_id, stream, 2.0 * a.M * a.N * a.K,
                ((double)a.N * a.K + (double)a.M * a.cin) * 2.0 + out_bytes * (a.splitk > 1 ? a.splitk : 1) + (a.res ? 4.0 * a.M * a.N : 0.0));
+  // aligned fast path: whole-quad operand fetches and stores with no per-element fallback code in the kernel
+  const bool al = (a.N & 3) == 0 && a.N >= 4 && (!a.bias || ((size_t)a.bias & 15) == 0) &&
+                  (!a.res || (((size_t)a.res & 15) == 0 && (a.ldres & 3) == 0)) &&
+                  (!a.out_f32 || (((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0)) && (!a.out_t || (((size_t)a.out_t & 7) == 0 && (a.ldot & 3) == 0));
   if constexpr (Epi::kId == 0) {
-    if (a.taps > 1) gemm_kernel<T, BM, BN, BK, NW, Epi, true><<<grid, dim3(NW * 64), smem, stream>>>(a);
-    else gemm_kernel<T, BM, BN, BK, NW, Epi, false><<<grid, dim3(NW * 64), smem, stream>>>(a);
+    if (a.taps > 1) {
+      if (al) gemm_glds_kernel<T, BM, BN, NW, ST, Epi, true, true><<<grid, dim3(NW * 64), smem, stream>>>(a);
+      else gemm_glds_kernel<T, BM, BN, NW, ST, Epi, true, false><<<grid, dim3(NW * 64), smem, stream>>>(a);
+    } else {
+      if (al) gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false, true><<<grid, dim3(NW * 64), smem, stream>>>(a);
+      else gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false, false><<<grid, dim3(NW * 64), smem, stream>>>(a);
+    }
   } else {
-    gemm_kernel<T, BM, BN, BK, NW, Epi, false><<<grid, dim3(NW * 64), smem, stream>>>(a);
+    gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false, true><<<grid, dim3(NW * 64), smem, stream>>>(a);
   }
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-static int forced_tile() {
-  static int v = -2;
-  if (v == -2) {
-    const char* e = getenv("TT_GEMM_TILE");  // experiments only (scripts/kbench.py)
-    v = e ? atoi(e) : -1;
-  }
-  return v;
-}
+enum Tile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2 };
 
+// Tile choice from the problem shape only (measured on MI355X, scripts/kbench.py):
+//   >= 256 tiles of 128x128 : 128x128, 8 waves, 2 stages (highest flop per L2 byte; 2 blocks per CU)
+//   fewer, M > 1024         : 128x64, 8 waves, 4-stage ring (more blocks, 3 tiles in flight)
+//   decode / M <= 1024      : 64x64, 4 waves, 4-stage ring (weights stream from HBM: depth hides latency)
+// A GEMM that emits GroupNorm statistics keeps the 128x64 tile for every M > 256: the statistics are grouped per wave tile,
+// so the same tile at one and at two batch rows keeps the denoiser's conditioned row bit-identical whether it is evaluated
+// alone (split tail) or batched with the conditioning-free row.
 static int pick_tile(const GemmArgs& a) {
-  int tile = forced_tile();
-  if (tile < 0) {
-    // Direct-to-LDS kernels by default (measured on MI355X, scripts/kbench.py):
-    //   >= 256 tiles of 128x128 : 128x128, 8 waves, 2 stages (highest flop per L2 byte; 2 blocks per CU)
-    //   fewer, M > 1024         : 128x64, 8 waves, 4-stage ring (more blocks, 3 tiles in flight)
-    //   decode / M <= 1024      : 64x64, 4 waves, 4-stage ring (weights stream from HBM: depth hides latency)
-    const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk;
-    // A GEMM that emits GroupNorm statistics keeps the 128x64 tile for every M > 256: the statistics are grouped per
-    // wave tile, so the same tile at one and at two batch rows keeps the denoiser's conditioned row bit-identical
-    // whether it is evaluated alone (split tail) or batched with the conditioning-free row.
-    if (a.M > 256 && b128 >= 256) tile = 6;
-    else if (a.M > 1024 || (a.M > 256 && a.gn_part != nullptr)) tile = 10;
-    else tile = 11;  // also one denoiser row (M = S <= 1024, the split diffusion tail): 2x the workgroups of 128x64
-  }
-  if (tile == 3 && (a.cin % 256 != 0 || (a.K / 256) < a.splitk)) tile = 0;
-  if (a.w_packed && tile < 6) tile = a.M > 256 ? 10 : 11;  // only the direct-to-LDS kernels read tile-packed weights
-  return tile;
+  const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk;
+  if (a.M > 256 && b128 >= 256) return TILE_128x128;
+  if (a.M > 1024 || (a.M > 256 && a.gn_part != nullptr)) return TILE_128x64;
+  return TILE_64x64;  // also one denoiser row (M = S <= 1024, the split diffusion tail): 2x the workgroups of 128x64
 }
 
 // rows per statistics tile (= the wave tile height TM of the kernel that pick_tile selects)
-static int tile_stat_rows(int tile) {
-  switch (tile) {
-    case 0: case 3: case 8: case 11: case 14: return 32;
-    default: return 64;
+static int tile_stat_rows(int tile) { return tile == TILE_64x64 ? 32 : 64; }
+
+// ProfScope classes: (tile, epilogue, conv?) -> one class per kernel that actually runs
+static int prof_class(int tile, int epi, bool conv) {
+  if (epi == EPI_STD) return (tile == TILE_64x64 ? PROF_GEMM_64x64_STD : tile == TILE_128x64 ? PROF_GEMM_128x64_STD : PROF_GEMM_128x128_STD) + (conv ? 1 : 0);
+  if (epi == EPI_QKV_HEADS) return tile == TILE_64x64 ? PROF_GEMM_64x64_QKV : tile == TILE_128x64 ? PROF_GEMM_128x64_QKV : PROF_GEMM_128x128_QKV;
+  return tile == TILE_64x64 ? PROF_GEMM_64x64_QKVDEC : tile == TILE_128x64 ? PROF_GEMM_128x64_QKVDEC : PROF_GEMM_128x128_QKVDEC;
+}
+
+// Row bands for XCD ownership: minimise the bytes one XCD pulls over the fabric, A / bands + W * bands / 8.
+static void pick_xcd_bands(GemmArgs& a, int bm) {
+  const int gx = cdiv(a.M, bm);
+  int xr = a.xcd_rows;
+  if (xr != 1 && xr != 2 && xr != 4 && xr != 8) {
+    const double A = (double)a.M * a.cin, W = (double)a.N * a.K;
+    double best = 0;
+    xr = 1;
+    for (int c = 1; c <= 8; c *= 2) {
+      const double cost = A / c + W * c / 8.0;
+      if (c == 1 || cost < best) { best = cost; xr = c; }
+    }
   }
+  if (xr > gx) xr = gx > 0 ? gx : 1;
+  a.xcd_rows = xr;
+  a.xcd_band = cdiv(gx, xr);
+  const int nk_total = a.K / 64;
+  a.sk_quot = nk_total / a.splitk;
+  a.sk_rem = nk_total % a.splitk;
 }
 
 template <typename T, typename Epi>
-static int launch_tiles(const GemmArgs& a, hipStream_t stream) {
+static int launch_tiles(const GemmArgs& a0, hipStream_t stream) {
+  GemmArgs a = a0;
   const int tile = pick_tile(a);
+  pick_xcd_bands(a, tile == TILE_64x64 ? 64 : 128);
+  const int pc = prof_class(tile, Epi::kId, a.taps > 1);
   switch (tile) {
-    case 14: return launch_glds<T, 64, 64, 4, 4, Epi, true>(a, stream, 0);
-    case 11: return launch_glds<T, 64, 64, 4, 4, Epi>(a, stream, 0);
-    case 10: return launch_glds<T, 128, 64, 8, 4, Epi>(a, stream, 1);
-    case 9: return launch_glds<T, 128, 128, 8, 3, Epi>(a, stream, 2);
-    case 8: return launch_glds<T, 64, 64, 4, 2, Epi>(a, stream, 0);
-    case 7: return launch_glds<T, 128, 64, 8, 2, Epi>(a, stream, 1);
-    case 6: return launch_glds<T, 128, 128, 8, 2, Epi>(a, stream, 2);
-    case 5: return launch_one<T, 128, 64, 64, 8, Epi>(a, stream, 5);
-    case 4: return launch_one<T, 128, 128, 64, 8, Epi>(a, stream, 4);
-    case 3: return launch_one<T, 64, 64, 256, 4, Epi>(a, stream, 3);
-    case 2: return launch_one<T, 128, 128, 64, 4, Epi>(a, stream, 2);
-    case 1: return launch_one<T, 128, 64, 64, 4, Epi>(a, stream, 1);
-    default: return launch_one<T, 64, 64, 64, 4, Epi>(a, stream, 0);
+    case TILE_128x128: return launch_glds<T, 128, 128, 8, 2, Epi>(a, stream, pc);
+    case TILE_128x64: return launch_glds<T, 128, 64, 8, 4, Epi>(a, stream, pc);
+    default: return launch_glds<T, 64, 64, 4, 4, Epi>(a, stream, pc);
   }
 }
 
@@ -757,12 +558,6 @@ static void normalise(GemmArgs& a) {
   if (a.taps < 1) a.taps = 1;
   if (a.splitk < 1) a.splitk = 1;
   a.cin = a.K / a.taps;
-  static int xm = -2;
-  if (xm == -2) {
-    const char* e = getenv("TT_GEMM_XCD");
-    xm = e ? atoi(e) : -1;
-  }
-  a.xcd_mode = xm >= 0 ? xm : 1;
 }
 
 int gemm_stat_rows(const GemmArgs& a0) {
@@ -798,41 +593,22 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   return -1;
 }
 
-template <typename T, int BM, int BN, int BK, int NW, typename Epi>
-static int set_attr_one() {
-  const void* fn = (const void*)gemm_kernel<T, BM, BN, BK, NW, Epi, false>;
-  TT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN, BK>()));
-  if constexpr (Epi::kId == 0) {
-    const void* fc = (const void*)gemm_kernel<T, BM, BN, BK, NW, Epi, true>;
-    TT_CHECK_HIP(hipFuncSetAttribute(fc, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN, BK>()));
-  }
-  return 0;
-}
-template <typename T, int BM, int BN, int NW, int ST, typename Epi, bool QUART = false>
+template <typename T, int BM, int BN, int NW, int ST, typename Epi>
 static int set_attr_glds() {
-  const void* fn = (const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false, QUART>;
-  TT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes_glds<BM, BN, ST>()));
+  constexpr int smem = smem_bytes_glds<BM, BN, ST>();
+  TT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   if constexpr (Epi::kId == 0) {
-    const void* fc = (const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, true, QUART>;
-    TT_CHECK_HIP(hipFuncSetAttribute(fc, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes_glds<BM, BN, ST>()));
+    TT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   }
   return 0;
 }
 template <typename T, typename Epi>
 static int set_attr() {
   TT_TRY((set_attr_glds<T, 128, 128, 8, 2, Epi>()));
-  TT_TRY((set_attr_glds<T, 128, 64, 8, 2, Epi>()));
-  TT_TRY((set_attr_glds<T, 64, 64, 4, 2, Epi>()));
-  TT_TRY((set_attr_glds<T, 128, 128, 8, 3, Epi>()));
   TT_TRY((set_attr_glds<T, 128, 64, 8, 4, Epi>()));
   TT_TRY((set_attr_glds<T, 64, 64, 4, 4, Epi>()));
-  TT_TRY((set_attr_glds<T, 64, 64, 4, 4, Epi, true>()));
-  TT_TRY((set_attr_one<T, 128, 128, 64, 4, Epi>()));
-  TT_TRY((set_attr_one<T, 128, 64, 64, 4, Epi>()));
-  TT_TRY((set_attr_one<T, 64, 64, 64, 4, Epi>()));
-  TT_TRY((set_attr_one<T, 64, 64, 256, 4, Epi>()));
-  TT_TRY((set_attr_one<T, 128, 128, 64, 8, Epi>()));
-  TT_TRY((set_attr_one<T, 128, 64, 64, 8, Epi>()));
   return 0;
 }
 

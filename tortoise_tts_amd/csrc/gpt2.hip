@@ -128,9 +128,10 @@ static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, 
 }
 
 // One KV-cached decode step for e->B sequences; the fed tokens are in e->next_tok.
-static int decode_step_enqueue(tt_ar* e, hipStream_t s) {
+static int decode_step_enqueue(tt_ar* e, hipStream_t s, bool embedded = false) {
   const int D = e->D, H = e->H, B = e->B, dt = e->cfg.dtype;
-  TT_TRY(ar_embed_launch(e->next_tok, e->state, e->w.mel_emb, e->w.mel_pos, e->x, B, D, e->cfg.mel_pos_offset, s));
+  // `embedded`: the sampler already wrote this step's input rows into e->x (tt_ar_generate)
+  if (!embedded) TT_TRY(ar_embed_launch(e->next_tok, e->state, e->w.mel_emb, e->w.mel_pos, e->x, B, D, e->cfg.mel_pos_offset, s));
   const float* pend_bias = nullptr;
   int pend_slabs = 0;
   for (int l = 0; l < e->cfg.layers; ++l) {
@@ -313,6 +314,7 @@ int tt_ar_generate(tt_ar* e, int B, int max_new, const tt_sampling* sp, int* cod
   sa.exp_noise = sp->exp_noise; sa.seed = sp->seed; sa.row_offset = sp->row_offset;
   sa.state = e->state; sa.unfinished = e->unfinished; sa.stop_token = e->cfg.stop_mel_token;
   sa.codes = codes; sa.ldcodes = max_new; sa.next_tok = e->next_tok; sa.unfinished_count = e->unfinished_count;
+  sa.embed_x = e->x; sa.tok_emb = e->w.mel_emb; sa.pos_emb = e->w.mel_pos; sa.D = e->D; sa.pos_offset = e->cfg.mel_pos_offset;
   // token 0: every row samples from the shared prefill logits
   sa.logits = e->logits; sa.ldl = 0;
   TT_REQUIRE(e->logits_from_prefill, "tt_ar_generate: the logits buffer does not hold prefill logits; call tt_ar_prefill first");
@@ -327,7 +329,7 @@ int tt_ar_generate(tt_ar* e, int B, int max_new, const tt_sampling* sp, int* cod
   int rc = 0;
   if (use_graph) {
     TT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    rc = decode_step_enqueue(e, s);
+    rc = decode_step_enqueue(e, s, true);
     if (!rc) rc = sample_launch(sa, s);
     if (!rc) rc = ar_state_advance_launch(e->state, s);
     hipError_t ce = hipStreamEndCapture(s, &graph);
@@ -351,7 +353,7 @@ int tt_ar_generate(tt_ar* e, int B, int max_new, const tt_sampling* sp, int* cod
       if (le != hipSuccess) { set_error("hipGraphLaunch: %s", hipGetErrorString(le)); rc = -2; break; }
     } else {
       e->host_slot = step - 1;
-      rc = decode_step_enqueue(e, s);
+      rc = decode_step_enqueue(e, s, true);
       if (!rc) rc = sample_launch(sa, s);
       if (!rc) rc = ar_state_advance_launch(e->state, s);
       if (rc) break;

@@ -91,7 +91,6 @@ typedef __attribute__((address_space(1))) const void gbl_void_k;
 
 struct ExpArgs {
   const bf16* A; const bf16* W; bf16* out; int M, N, K, lda, ldw, ldo, taps, seq_len, cin;
-  const char* pf; size_t pf_bytes;  // optional: region the NEXT kernel will stream (prefetched into this XCD's L2)
 };
 
 template <int BM, int BN, int WM, int WN, int ST, int MODE, int MINW, bool CONV>
@@ -190,17 +189,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_exp_kernel(ExpArgs g)
   const int last = nk - 1;
 #pragma unroll
   for (int s = 0; s < ST - 1; ++s) issue(min(s, last), s);
-  if (g.pf_bytes) {  // cross-kernel weight prefetch: touch one 128-B line per load, result never used, never waited for
-    const int gx = gridDim.x, id = blockIdx.x + gx * blockIdx.y, nwg = gx * gridDim.y;
-    const int xcd = id & 7, loc = id >> 3, per_xcd = (nwg + 7) >> 3;
-    const size_t share = (g.pf_bytes / 8 + 127) & ~(size_t)127;
-    const char* base = g.pf + (size_t)xcd * share;
-    const size_t lim = min(share, g.pf_bytes > (size_t)xcd * share ? g.pf_bytes - (size_t)xcd * share : 0);
-    for (size_t off = ((size_t)loc * (NW * 64) + tid) * 128; off < lim; off += (size_t)per_xcd * (NW * 64) * 128) {
-      unsigned tmp;
-      asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(base + off) : "memory");
-    }
-  }
   int slot = 0;
   if (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int kt = 0; kt < nk; ++kt) {
@@ -262,6 +250,11 @@ static int launch_variant(int variant, const ExpArgs& a, hipStream_t s) {
     V3(9, 128, 64, 2, 4, 6)
     case 200: return launch_exp<128, 64, 2, 2, 3, 0, 2>(a, s);
     case 500: return launch_exp<64, 64, 2, 2, 3, 0, 2>(a, s);
+    case 501: return launch_exp<64, 64, 2, 2, 2, 0, 4>(a, s);   // 4 blocks / CU (16 KB LDS each x 2 stages)
+    case 502: return launch_exp<64, 64, 2, 2, 3, 0, 3>(a, s);   // 3 blocks / CU
+    case 1300: return launch_exp<128, 64, 2, 4, 3, 0, 2>(a, s);  // 8 waves, 2 blocks / CU (72 KB LDS each)
+    case 1301: return launch_exp<128, 64, 4, 2, 3, 0, 2>(a, s);
+    case 1600: return launch_exp<128, 128, 2, 4, 2, 0, 2>(a, s); // the product's large-M tile: 2 stages, 2 blocks / CU
 #undef V3
   }
   set_error("kbench: unknown gemm variant %d", variant);
@@ -271,24 +264,24 @@ static int launch_variant(int variant, const ExpArgs& a, hipStream_t s) {
 extern "C" {
 
 // One GEMM shape, `nw` distinct weight matrices visited round-robin (nw large => HBM-cold weights), `chain` launches per
-// graph.  prefetch: every launch also touches the NEXT launch's weights.  us_out = microseconds per launch.
-int tt_kb_gemm_exp(int variant, int M, int N, int K, int taps, int seq_len, int nw, int chain, int prefetch, int reps, double* us_out) {
+// graph.  pad: extra elements per A / W row (row strides K + pad: spreads rows over L2 channels).  us_out = microseconds per launch.
+int tt_kb_gemm_exp(int variant, int M, int N, int K, int taps, int seq_len, int nw, int chain, int pad, int reps, double* us_out) {
   Arena ar;
   GraphTimer gt;
   TT_TRY(gt.init());
   void* A = nullptr; void* out = nullptr;
   std::vector<void*> W(nw);
-  int rc = dev_bf16(ar, &A, (size_t)(M + 8) * (K / taps), 1u);
+  const int lda = K / taps + pad, ldw = K + pad;
+  int rc = dev_bf16(ar, &A, (size_t)(M + 8) * lda, 1u);
   if (!rc) rc = ar.alloc(&out, (size_t)M * N * 2);
-  for (int i = 0; i < nw && !rc; ++i) rc = dev_bf16(ar, &W[i], (size_t)N * K, 77u + i);
+  for (int i = 0; i < nw && !rc; ++i) rc = dev_bf16(ar, &W[i], (size_t)N * ldw, 77u + i);
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
   if (!rc) rc = gt.run([&](hipStream_t s) -> int {
     for (int i = 0; i < chain; ++i) {
       ExpArgs a;
       memset(&a, 0, sizeof(a));
-      a.A = (const bf16*)A; a.W = (const bf16*)W[i % nw]; a.out = (bf16*)out; a.M = M; a.N = N; a.K = K; a.lda = K / taps; a.ldw = K; a.ldo = N;
+      a.A = (const bf16*)A; a.W = (const bf16*)W[i % nw]; a.out = (bf16*)out; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = N;
       a.taps = taps; a.seq_len = seq_len > 0 ? seq_len : M; a.cin = K / taps;
-      if (prefetch) { a.pf = (const char*)W[(i + 1) % nw]; a.pf_bytes = (size_t)N * K * 2; }
       TT_TRY(launch_variant(variant, a, s));
     }
     return 0;
@@ -300,14 +293,15 @@ int tt_kb_gemm_exp(int variant, int M, int N, int K, int taps, int seq_len, int 
 }
 
 // The product GEMM (gemm_launch) on the same harness: one shape, nw weight copies, optional split-K, f32 or T output.
-int tt_kb_gemm_prod(int M, int N, int K, int taps, int seq_len, int splitk, int packed, int nw, int chain, int reps, double* us_out) {
+int tt_kb_gemm_prod(int M, int N, int K, int taps, int seq_len, int splitk, int packed, int nw, int na, int xcd_rows, int chain, int reps, double* us_out) {
   Arena ar;
   GraphTimer gt;
   TT_TRY(gt.init());
-  void* A = nullptr; void* out_t = nullptr; float* out32 = nullptr; float* bias = nullptr;
-  std::vector<void*> W(nw);
+  void* out_t = nullptr; float* out32 = nullptr; float* bias = nullptr;
+  std::vector<void*> W(nw), Av(na);  // na > 1: the activation operand is never L2-resident from the previous launch (in-situ behaviour)
   const int npad = (N + 63) / 64 * 64;
-  int rc = dev_bf16(ar, &A, (size_t)(M + 8) * (K / taps), 1u);
+  int rc = 0;
+  for (int i = 0; i < na && !rc; ++i) rc = dev_bf16(ar, &Av[i], (size_t)(M + 8) * (K / taps), 1u + i);
   if (!rc) rc = ar.alloc(&out_t, (size_t)M * N * 2);
   if (!rc) rc = ar.alloc_t(&out32, (size_t)std::max(splitk, 1) * M * N);
   if (!rc) rc = dev_f32(ar, &bias, N, 5u);
@@ -315,8 +309,8 @@ int tt_kb_gemm_prod(int M, int N, int K, int taps, int seq_len, int splitk, int 
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
   if (!rc) rc = gt.run([&](hipStream_t s) -> int {
     for (int i = 0; i < chain; ++i) {
-      GemmArgs g = gemm_args(A, K / taps, W[i % nw], K, M, N, K);
-      g.taps = taps; g.seq_len = seq_len > 0 ? seq_len : M; g.splitk = splitk; g.w_packed = packed;
+      GemmArgs g = gemm_args(Av[i % na], K / taps, W[i % nw], K, M, N, K);
+      g.taps = taps; g.seq_len = seq_len > 0 ? seq_len : M; g.splitk = splitk; g.w_packed = packed; g.xcd_rows = xcd_rows;
       if (splitk > 1) { g.out_f32 = out32; g.ldo32 = N; }
       else { g.bias = bias; g.out_t = out_t; g.ldot = N; }
       TT_TRY(gemm_launch(DT_BF16, EPI_STD, g, s));
@@ -530,3 +524,65 @@ int tt_kb_decode_attn(int variant, int B, int heads, int P1, int tgen, int tmax,
   return rc;
 }
 }  // extern "C"
+
+
+// --------------------------------------------------------------------------------------------------------------------
+// Per-CU load-path probe: every workgroup streams `bytes_per_wg` from a `footprint`-byte buffer (small footprint => L2 /
+// Infinity-Cache resident) through one of the load paths a GEMM operand can take.
+//   mode 0: global_load_lds_dwordx4 (direct to LDS, 1 KiB per wave instruction)
+//   mode 1: global_load_dwordx4 to VGPRs, full 128-B lines (8 lanes per line)
+//   mode 2: global_load_dwordx4 to VGPRs, MFMA-fragment shaped (16 rows x 64 B per instruction, row stride 2 KiB)
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void bw_probe_kernel(const char* buf, size_t footprint, size_t bytes_per_wg, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t wg_base = ((size_t)blockIdx.x * 1315423911ull * 4096) % footprint;  // scattered start, 4 KiB aligned
+  constexpr int UNR = 8;
+  const size_t per_iter = (size_t)NW * UNR * 1024;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (size_t done = 0; done < bytes_per_wg; done += per_iter) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        size_t off = (wg_base + done + ((size_t)(u * NW + wave)) * 1024 + lane * 16) % footprint;
+        __builtin_amdgcn_global_load_lds((gbl_void_k*)(buf + off), (lds_void_k*)(smem_raw + ((u * NW + wave) % 32) * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      f32x4 v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        size_t off;
+        if (MODE == 1) off = (wg_base + done + ((size_t)(u * NW + wave)) * 1024 + lane * 16) % footprint;
+        else off = (wg_base + done + ((size_t)(u * NW + wave)) * 64 + (size_t)(lane & 15) * 2048 + (lane >> 4) * 16) % footprint;
+        v[u] = *(const f32x4*)(buf + off);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc += v[u];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = acc[0];
+}
+
+extern "C" int tt_kb_bw_probe(int mode, int nw_waves, int nblocks, size_t footprint, size_t bytes_per_wg, int reps, double* us_out) {
+  Arena ar;
+  GraphTimer gt;
+  TT_TRY(gt.init());
+  void* buf = nullptr; float* sink = nullptr;
+  int rc = dev_bf16(ar, &buf, footprint / 2 + 4096, 9u);
+  if (!rc) rc = ar.alloc_t(&sink, 64);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
+  if (!rc) rc = gt.run([&](hipStream_t s) -> int {
+#define BWP(MODE, NW) bw_probe_kernel<MODE, NW><<<nblocks, NW * 64, 32 * 1024, s>>>((const char*)buf, footprint, bytes_per_wg, sink)
+    if (mode == 0 && nw_waves == 4) BWP(0, 4); else if (mode == 0) BWP(0, 8);
+    else if (mode == 1 && nw_waves == 4) BWP(1, 4); else if (mode == 1) BWP(1, 8);
+    else if (nw_waves == 4) BWP(2, 4); else BWP(2, 8);
+#undef BWP
+    TT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }, reps, us_out);
+  gt.destroy();
+  ar.release();
+  return rc;
+}

@@ -223,11 +223,23 @@ __global__ void psample_kernel(PSampleArgs a) {
     }
   }
 }
-__global__ void slot_advance_kernel(int* slot) {
+// End of a sampler step: advance the device-side step counter and stage the NEXT step's scale / shift rows at a fixed
+// address (ss_cur), so that every GroupNorm of the next step reads them with plain up-front loads instead of a dependent
+// "load the counter, then the row it selects" chain (two extra memory round trips per GroupNorm launch).  One block: the
+// counter is read by every thread before it is bumped.
+__global__ __launch_bounds__(1024) void slot_advance_kernel(int* slot, const float* ss_all, float* ss_cur, int row_floats, int last_slot) {
+  const int nxt = min(*slot + 1, last_slot);
+  if (ss_all) {
+    const float4* src = (const float4*)(ss_all + (size_t)nxt * row_floats);
+    float4* dst = (float4*)ss_cur;
+    for (int i = threadIdx.x; i < row_floats / 4; i += 1024) dst[i] = src[i];
+  }
+  __syncthreads();
   if (threadIdx.x == 0) *slot += 1;
 }
-int slot_advance_launch(int* slot, hipStream_t stream) {
-  slot_advance_kernel<<<1, 64, 0, stream>>>(slot);
+int slot_advance_launch(int* slot, const float* ss_all, float* ss_cur, int row_floats, int last_slot, hipStream_t stream) {
+  TT_REQUIRE(row_floats % 4 == 0, "slot_advance: row size must be a multiple of 4 floats");
+  slot_advance_kernel<<<1, 1024, 0, stream>>>(slot, ss_all, ss_cur, row_floats, last_slot);
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchu
     float y[4] = {(t.x - mu) * rs * gm.x + bt.x, (t.y - mu) * rs * gm.y + bt.y, (t.z - mu) * rs * gm.z + bt.z,
                   (t.w - mu) * rs * gm.w + bt.w};
     if (a.scale_shift) {
-      const float* ss = a.scale_shift + (size_t)b * a.ss_batch_stride + (a.ss_slot ? (size_t)(*a.ss_slot) * a.ss_slot_stride : 0);
+      const float* ss = a.scale_shift + (size_t)b * a.ss_batch_stride;
       const float4 sc = *(const float4*)(ss + c);
       const float4 sh = *(const float4*)(ss + C + c);
       y[0] = y[0] * (1.f + sc.x) + sh.x;
@@ -490,8 +490,7 @@ __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, in
   constexpr int C = 1024;
   const int r0 = blockIdx.x * GN_APPLY_ROWS;
   const int c = tid * 4;
-  // request order = need order: step slot (scalar), statistics partials, then the rows and the affine parameters
-  const size_t ss_off = SS && a.ss_slot ? (size_t)(*a.ss_slot) * a.ss_slot_stride : 0;
+  // request order = need order: statistics partials, then the rows and the affine parameters
   float2 head[GN_HEAD];
   if constexpr (FUSED) gn_partial_head(a, b, tid, head);  // FUSED <=> a.gemm_part != nullptr (compile time: no branch to sink consumers into)
   float4 xr[GN_APPLY_ROWS];
@@ -504,7 +503,7 @@ __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, in
   const float4 bt = *(const float4*)(a.beta + c);
   float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
   if constexpr (SS) {  // SS <=> a.scale_shift != nullptr
-    const float* ss = a.scale_shift + (size_t)b * a.ss_batch_stride + ss_off;
+    const float* ss = a.scale_shift + (size_t)b * a.ss_batch_stride;
     sc = *(const float4*)(ss + c);
     sh = *(const float4*)(ss + C + c);
   }

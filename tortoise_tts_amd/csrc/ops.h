@@ -43,8 +43,6 @@ struct GroupNormArgs {
   float eps;
   const float* scale_shift;  // optional [B?][2C]: y = y * (1 + scale) + shift
   size_t ss_batch_stride;    // 0 when every batch row shares one timestep embedding
-  const int* ss_slot;        // optional device int: scale_shift += *ss_slot * ss_slot_stride (hipGraph replay)
-  size_t ss_slot_stride;
   int act;
   void* out_t;
   int ldot;
@@ -104,6 +102,11 @@ struct SampleArgs {
   int ldcodes;
   int* next_tok;           // [B]
   int* unfinished_count;   // [max_steps]: number of unfinished rows after each sampling step
+  // optional fusion of the next decode step's embedding: embed_x[b][:] = tok_emb[tok][:] + pos_emb[step + pos_offset][:]
+  float* embed_x;          // [B][D] or null
+  const float* tok_emb;
+  const float* pos_emb;
+  int D, pos_offset;
 };
 int sample_launch(const SampleArgs& a, hipStream_t stream);
 int ar_state_advance_launch(int* state, hipStream_t stream);
@@ -143,7 +146,7 @@ struct PSampleStep {    // same layout as tt_diff_step (include/tortoise_mi355x.
 };
 struct PSampleArgs {
   const PSampleStep* steps;  // device array; entry *slot is used
-  const int* slot;           // device int (advanced by diff_slot_advance_launch)
+  const int* slot;           // device int (advanced by slot_advance_launch)
   float* x;             // [S][C] f32 state, updated in place
   void* x_t;            // [2][S][cpad] operand copy for the next step's inp_block (both batch rows)
   int cpad;
@@ -155,7 +158,7 @@ struct PSampleArgs {
   float mel_scale, mel_shift;
 };
 int psample_launch(int dtype, const PSampleArgs& a, hipStream_t stream);
-int slot_advance_launch(int* slot, hipStream_t stream);
+int slot_advance_launch(int* slot, const float* ss_all, float* ss_cur, int row_floats, int last_slot, hipStream_t stream);
 
 // ------------------------------------------------------------------------------ UnivNet (fp32 VALU)
 struct Conv1dArgs {

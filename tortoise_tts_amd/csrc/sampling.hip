@@ -40,6 +40,7 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __shared__ unsigned hist[256];
   __shared__ unsigned sel_prefix, sel_remaining;
+  __shared__ unsigned wtot[4];
   __shared__ int nsurv;
   __shared__ float sv[SURV_CAP];
   __shared__ int si[SURV_CAP];
@@ -76,11 +77,12 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     sel_remaining = (unsigned)k;
     nsurv = 0;
   }
+  __syncthreads();
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
     hist[tid] = 0u;
     __syncthreads();
-    const unsigned prefix = sel_prefix;
+    const unsigned prefix = sel_prefix, rem = sel_remaining;
     const unsigned mask_hi = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -91,16 +93,23 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       }
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned rem = sel_remaining;
-      int d = 255;
-      for (; d > 0; --d) {
-        const unsigned c = hist[d];
-        if (c >= rem) break;
-        rem -= c;
-      }
-      sel_prefix = prefix | ((unsigned)d << shift);
-      sel_remaining = rem;
+    // digit d of the k-th largest key: the one with  count(digits > d) < rem <= count(digits >= d).  Suffix sums of the
+    // 256 bins by wave shuffles (bin = thread), not a serial scan by one thread (256 dependent LDS reads per pass).
+    const unsigned c = hist[tid];
+    unsigned sfx = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_down(sfx, o, 64);
+      if ((tid & 63) + o < 64) sfx += t;
+    }
+    if ((tid & 63) == 0) wtot[tid >> 6] = sfx;
+    __syncthreads();
+    unsigned above = 0u;
+    for (int w = (tid >> 6) + 1; w < 4; ++w) above += wtot[w];
+    const unsigned ge = sfx + above, gt = ge - c;
+    if (ge >= rem && gt < rem) {  // exactly one bin
+      sel_prefix = prefix | ((unsigned)tid << shift);
+      sel_remaining = rem - gt;
     }
     __syncthreads();
   }
@@ -131,11 +140,14 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     sorted_i[rank] = id;
   }
   __syncthreads();
-  // ---- top-p on the survivors (everything else already has probability 0)
+  // ---- top-p on the survivors (everything else already has probability 0).  The exponentials are evaluated by all
+  // threads; the three sums stay sequential in index order (one thread, n <= a few dozen adds) so the kept set is decided
+  // with exactly the arithmetic the oracle's cumulative sum uses.
+  for (int i = tid; i < n; i += 256) sv[i] = __expf(sorted_v[i] - sorted_v[0]);  // sv is free after the rank sort
+  __syncthreads();
   if (tid == 0) {
-    const float m = sorted_v[0];
     float total = 0.f;
-    for (int i = 0; i < n; ++i) total += __expf(sorted_v[i] - m);
+    for (int i = 0; i < n; ++i) total += sv[i];
     int keep = n;
     if (a.top_p < 1.0f) {
       float tail = 0.f;
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       const float thr = 1.0f - a.top_p;
       // ascending cumulative probability of element r == sum of probabilities of elements r..n-1
       for (int r = n - 1; r >= 1; --r) {
-        tail += __expf(sorted_v[r] - m) / total;
+        tail += sv[r] / total;
         if (tail > thr) {
           keep = r + 1;
           break;
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       }
     }
     float kt = 0.f;
-    for (int i = 0; i < keep; ++i) kt += __expf(sorted_v[i] - m);
+    for (int i = 0; i < keep; ++i) kt += sv[i];
     kept = keep;
     kept_total = kt;
   }
@@ -208,6 +220,17 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     a.next_tok[b] = tok;
     atomicOr(&seen[tok >> 5], 1u << (tok & 31));
     if (still) atomicAdd(&a.unfinished_count[step], 1);
+    red_i[0] = tok;
+  }
+  if (a.embed_x) {  // next decode step's input row: mel_embedding[tok] + mel_pos_embedding[index of this token + offset]
+    __syncthreads();
+    const int tok = red_i[0];
+    const int pos = step + a.pos_offset;
+    for (int c = tid * 4; c < a.D; c += 1024) {
+      const float4 e = *(const float4*)(a.tok_emb + (size_t)tok * a.D + c);
+      const float4 p = *(const float4*)(a.pos_emb + (size_t)pos * a.D + c);
+      *(float4*)(a.embed_x + (size_t)b * a.D + c) = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+    }
   }
 }
 

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libtortoise_mi355x.so")
+LIB_PATH = os.environ.get("TORTOISE_MI355X_LIB") or os.path.join(HERE, "lib", "libtortoise_mi355x.so")  # env: an alternative build of the same ABI
 
 TT_BF16, TT_F16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3, 4, 5
