@@ -6,7 +6,11 @@
 // step run as batch rows 0/1 of ONE pass, so each weight matrix streams once per step instead of
 // twice (diffusion.py:341-342 calls the model twice).  Everything that depends only on the
 // timestep (time_embed MLP and all 16 ResBlock emb_layers) is evaluated for the whole schedule
-// in three GEMMs before the loop.  The sampler maths (CFG blend, learned-range variance, x0 clamp,
+// in three GEMMs before the loop.  The conditioning_timestep_integrator (3 DiffusionLayers over code_emb,
+// diffusion_decoder.py:292-293) depends on (code_emb, t) but NOT on x_t, so it too leaves the sequential
+// loop: all N timesteps x both guidance rows are evaluated as ONE batch of 2N samples before the loop
+// (GEMMs with M = 2N*S rows instead of 2S: 128x128 tiles on a full grid), stored in the operand type, and
+// each step's integrating conv reads its slice as the second half of K (no concat buffer, no copy).  The sampler maths (CFG blend, learned-range variance, x0 clamp,
 // posterior mean, noise) is one fused kernel with no host round trip (the reference does a
 // .item() per step, diffusion.py:380).  Per-step scalars, the scale/shift rows and the noise slice
 // are all indexed by a device-side step counter, so one captured hipGraph replays every step.
@@ -32,7 +36,11 @@ struct tt_diff {
   float* tmp_b = nullptr;
   float* tmp_c = nullptr;
   void* act = nullptr;         // [rows][C] T   GN/SiLU output (GEMM operand)
-  void* cat = nullptr;         // [rows][2C] T  [inp_block(x) | integrated code_emb]
+  void* cat = nullptr;         // [2S][C] T     inp_block(x) of the current step (left half of the integrating conv's K)
+  void* integ_all = nullptr;   // [steps][B][S][C] T  conditioning_timestep_integrator output of every step (right half of K)
+  float* rep_in = nullptr;     // [chunk samples][S][C] f32: code_emb rows repeated per timestep (batched integrator input)
+  int chunk_rows = 0;          // row capacity of one batched-integrator chunk
+  int integ_B = 0, integ_n = 0; // rows per step / steps currently held by integ_all
   void* q = nullptr; void* k = nullptr; void* vt = nullptr; void* att = nullptr;
   float* gn_partial = nullptr;
   float* gn_gemm_part = nullptr;   // statistics emitted by GEMM epilogues: [row_tile][2][C/16][2]
@@ -59,12 +67,13 @@ struct tt_diff {
   int split_row = -1, split_steps = 0, split_done = 0;
 };
 
-static int run_gn(tt_diff* e, const float* x, int B, int S, const float* g, const float* b, const float* ss, bool /*per_step*/,
+// ss: scale / shift rows [2C]; batch row b reads ss + (b / ss_div) * ss_stride (ss_stride 0: one row for the whole batch)
+static int run_gn(tt_diff* e, const float* x, int B, int S, const float* g, const float* b, const float* ss, size_t ss_stride, int ss_div,
                   int act, void* out_t, int ldot, float* out_f32, hipStream_t s) {
   GroupNormArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.B = B; a.S = S; a.C = e->C; a.gamma = g; a.beta = b; a.eps = 1e-5f;
-  a.scale_shift = ss; a.ss_batch_stride = 0; a.act = act;
+  a.scale_shift = ss; a.ss_batch_stride = ss_stride; a.ss_batch_div = ss_div; a.act = act;
   // per-step scale / shift rows are staged at a fixed address (e->ss_cur): no step-dependent addressing in the kernel
   a.out_t = out_t; a.ldot = ldot; a.out_f32 = out_f32; a.ldo32 = e->C;
   a.partial = e->gn_partial;
@@ -97,7 +106,7 @@ static int gemm_with_stats(tt_diff* e, GemmArgs& g, int S, hipStream_t s) {
 static int run_attn_block(tt_diff* e, const tt_attn_block& w, const float* in, int B, int S, float* out_f32, void* out_t, int ldot,
                           hipStream_t s) {
   const int C = e->C, H = e->H, dt = e->cfg.dtype, M = B * S, n_pad = round_up(S, 32);
-  TT_TRY(run_gn(e, in, B, S, w.norm_g, w.norm_b, nullptr, false, ACT_NONE, e->act, C, nullptr, s));
+  TT_TRY(run_gn(e, in, B, S, w.norm_g, w.norm_b, nullptr, 0, 1, ACT_NONE, e->act, C, nullptr, s));
   GemmArgs g = gemm_args(e->act, C, w.w_qkv, C, M, 3 * C, C);
   g.bias = w.b_qkv; g.seq_len = S; g.dmodel = C; g.heads = H; g.q = e->q; g.k = e->k; g.vt = e->vt; g.seq_pad = n_pad;
   g.q_scale = 0.125f;  // (q * 64^-1/4) . (k * 64^-1/4)  ==  (q/8) . k   (arch_util.py:64-67)
@@ -113,55 +122,75 @@ static int run_attn_block(tt_diff* e, const tt_attn_block& w, const float* in, i
 }
 
 // ResBlock (diffusion_decoder.py:60-120, use_scale_shift_norm, efficient_config, kernel 3).
-static int run_res_block(tt_diff* e, const tt_res_block& w, const float* ss, const float* in, int B, int S, float* out_f32,
-                         hipStream_t s) {
+static int run_res_block(tt_diff* e, const tt_res_block& w, const float* ss, size_t ss_stride, int ss_div, const float* in, int B, int S,
+                         float* out_f32, hipStream_t s) {
   const int C = e->C, dt = e->cfg.dtype, M = B * S;
-  TT_TRY(run_gn(e, in, B, S, w.gn1_g, w.gn1_b, nullptr, false, ACT_SILU, e->act, C, nullptr, s));
+  TT_TRY(run_gn(e, in, B, S, w.gn1_g, w.gn1_b, nullptr, 0, 1, ACT_SILU, e->act, C, nullptr, s));
   GemmArgs g = gemm_args(e->act, C, w.w_in, C, M, C, C);
   g.bias = w.b_in; g.out_f32 = e->tmp_c; g.ldo32 = C;
   TT_TRY(gemm_with_stats(e, g, S, s));
-  TT_TRY(run_gn(e, e->tmp_c, B, S, w.gn2_g, w.gn2_b, ss, true, ACT_SILU, e->act, C, nullptr, s));
+  TT_TRY(run_gn(e, e->tmp_c, B, S, w.gn2_g, w.gn2_b, ss, ss_stride, ss_div, ACT_SILU, e->act, C, nullptr, s));
   g = gemm_args(e->act, C, w.w_out, 3 * C, M, C, 3 * C);
   g.taps = 3; g.seq_len = S; g.bias = w.b_out; g.res = in; g.ldres = C; g.out_f32 = out_f32; g.ldo32 = C;
   return gemm_with_stats(e, g, S, s);
 }
 
-// One denoiser evaluation on B batch rows (B = 2: conditioned + unconditioned); the schedule slot is *e->slot.
-// B batch rows starting at conditioning row `row0` (0 = conditioned embedding, 1 = unconditioned embedding)
-static int diff_forward(tt_diff* e, int B, hipStream_t s, int row0 = 0) {
-  const int C = e->C, S = e->S, dt = e->cfg.dtype, M = B * S, L = e->cfg.num_layers;
-  const float* ss = e->ss_cur;  // the current step's [NR][2C] rows (staged by slot_advance_launch / diff_prepare_timesteps)
-  e->stats_ptr = nullptr;       // no epilogue statistics are valid at the start of a pass
-  // conditioning_timestep_integrator: 3 DiffusionLayers over the [cond | uncond] code embeddings
-  const float* cur = e->code_emb + (size_t)row0 * S * C;
-  for (int i = 0; i < 3; ++i) {
-    TT_TRY(run_res_block(e, e->res[i], ss + (size_t)i * 2 * C, cur, B, S, e->tmp_a, s));
-    if (i < 2) {
-      TT_TRY(run_attn_block(e, e->attn[i], e->tmp_a, B, S, e->tmp_b, nullptr, 0, s));
-      cur = e->tmp_b;
-    } else {
-      // the last integrator layer writes straight into the right half of the concat operand
-      TT_TRY(run_attn_block(e, e->attn[i], e->tmp_a, B, S, nullptr, offset_t(e->cat, C), 2 * C, s));
+// conditioning_timestep_integrator for steps [0, n) x B guidance rows starting at conditioning row `row0`, batched over the
+// timesteps: sample (j, r) = (step j, row r) is one batch row of the three DiffusionLayers, with its own scale / shift rows
+// ss_all[j] (GroupNorm and attention are per sample, so this is exactly the per-step evaluation, reordered).  Result ->
+// integ_all[j][r] in the operand type.  Chunked so the f32 work buffers stay within e->chunk_rows rows.
+static int diff_integrator_all(tt_diff* e, int n, int B, int row0, hipStream_t s) {
+  const int C = e->C, S = e->S;
+  const size_t ss_row = (size_t)e->NR * 2 * C;
+  const int per = std::max(1, e->chunk_rows / (B * S));  // steps per chunk
+  for (int c0 = 0; c0 < n; c0 += per) {
+    const int ns = std::min(per, n - c0), nb = ns * B;
+    e->stats_ptr = nullptr;
+    TT_TRY(repeat_rows_launch(e->code_emb + (size_t)row0 * S * C, e->rep_in, B * S, ns, C, s));
+    const float* cur = e->rep_in;
+    for (int i = 0; i < 3; ++i) {
+      TT_TRY(run_res_block(e, e->res[i], e->ss_all + (size_t)c0 * ss_row + (size_t)i * 2 * C, ss_row, B, cur, nb, S, e->tmp_a, s));
+      if (i < 2) {
+        TT_TRY(run_attn_block(e, e->attn[i], e->tmp_a, nb, S, e->tmp_b, nullptr, 0, s));
+        cur = e->tmp_b;
+      } else {  // the last layer's output is only ever a GEMM operand: store it in the operand type, per step
+        TT_TRY(run_attn_block(e, e->attn[i], e->tmp_a, nb, S, nullptr, offset_t(e->integ_all, (size_t)c0 * B * S * C), C, s));
+      }
     }
   }
-  // inp_block (k3, in_pad -> C) into the left half of the concat operand
+  e->integ_B = B;
+  e->integ_n = n;
+  e->stats_ptr = nullptr;
+  return 0;
+}
+
+// One denoiser evaluation on B batch rows (B = 2: conditioned + unconditioned) for the schedule slot *e->slot; the
+// integrator output of that slot must already be in integ_all (diff_integrator_all with the same B / row0).
+static int diff_forward(tt_diff* e, int B, hipStream_t s) {
+  const int C = e->C, S = e->S, dt = e->cfg.dtype, M = B * S, L = e->cfg.num_layers;
+  TT_REQUIRE(e->integ_B == B, "diffusion: the integrator pre-pass holds %d rows per step, this step evaluates %d", e->integ_B, B);
+  const float* ss = e->ss_cur;  // the current step's [NR][2C] rows (staged by slot_advance_launch / diff_prepare_timesteps)
+  e->stats_ptr = nullptr;       // no epilogue statistics are valid at the start of a pass
+  // inp_block (k3, in_pad -> C): left half of the integrating conv's K
   GemmArgs g = gemm_args(e->x_t, e->cfg.in_pad, e->w.w_inp, 3 * e->cfg.in_pad, M, C, 3 * e->cfg.in_pad);
-  g.taps = 3; g.seq_len = S; g.bias = e->w.b_inp; g.out_t = e->cat; g.ldot = 2 * C;
+  g.taps = 3; g.seq_len = S; g.bias = e->w.b_inp; g.out_t = e->cat; g.ldot = C;
   TT_TRY(gemm_launch(dt, EPI_STD, g, s));
-  g = gemm_args(e->cat, 2 * C, e->w.w_integ, 2 * C, M, C, 2 * C);
+  // integrating_conv over [inp_block(x) | integrator(code_emb, t)]: the right half comes straight from this slot's slice
+  g = gemm_args(e->cat, C, e->w.w_integ, 2 * C, M, C, 2 * C);
+  g.A2 = e->integ_all; g.lda2 = C; g.k_split = C; g.a2_slot = e->slot; g.a2_slot_stride = (size_t)B * S * C;
   g.bias = e->w.b_integ; g.out_f32 = e->tmp_a; g.ldo32 = C;
   TT_TRY(gemm_with_stats(e, g, S, s));
   float* hcur = e->tmp_a;
   float* hoth = e->tmp_b;
   for (int i = 0; i < L; ++i) {
-    TT_TRY(run_res_block(e, e->res[3 + i], ss + (size_t)(3 + i) * 2 * C, hcur, B, S, hoth, s));
+    TT_TRY(run_res_block(e, e->res[3 + i], ss + (size_t)(3 + i) * 2 * C, 0, 1, hcur, B, S, hoth, s));
     TT_TRY(run_attn_block(e, e->attn[3 + i], hoth, B, S, hcur, nullptr, 0, s));
   }
   for (int i = 0; i < 3; ++i) {
-    TT_TRY(run_res_block(e, e->res[3 + L + i], ss + (size_t)(3 + L + i) * 2 * C, hcur, B, S, hoth, s));
+    TT_TRY(run_res_block(e, e->res[3 + L + i], ss + (size_t)(3 + L + i) * 2 * C, 0, 1, hcur, B, S, hoth, s));
     float* t = hcur; hcur = hoth; hoth = t;
   }
-  TT_TRY(run_gn(e, hcur, B, S, e->w.out_gn_g, e->w.out_gn_b, nullptr, false, ACT_SILU, e->act, C, nullptr, s));
+  TT_TRY(run_gn(e, hcur, B, S, e->w.out_gn_g, e->w.out_gn_b, nullptr, 0, 1, ACT_SILU, e->act, C, nullptr, s));
   g = gemm_args(e->act, C, e->w.w_final, 3 * C, M, e->cfg.out_channels, 3 * C);
   g.taps = 3; g.seq_len = S; g.bias = e->w.b_final; g.out_f32 = e->out; g.ldo32 = e->cfg.out_channels;
   return gemm_launch(dt, EPI_STD, g, s);
@@ -225,20 +254,24 @@ int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff*
   e->attn.assign(w->attn_host, w->attn_host + 3 + cfg->num_layers);
   e->res.assign(w->res_host, w->res_host + e->NR);
   const int C = e->C;
-  e->rows_max = std::max(2 * cfg->max_seq, cfg->max_codes);
+  // batched integrator chunk: as many (step, row) samples as fit ~32k rows, at least one step's two rows
+  e->chunk_rows = std::max(2 * cfg->max_seq, std::min(32768, cfg->max_steps * 2 * cfg->max_seq));
+  e->rows_max = std::max(e->chunk_rows, cfg->max_codes);
   const size_t rows = (size_t)e->rows_max + 64;
   int rc = e->sb.init();
   if (!rc) rc = e->arena.alloc_t(&e->code_emb, (size_t)2 * cfg->max_seq * C);
   if (!rc) rc = e->arena.alloc_t(&e->tmp_a, rows * C);
   if (!rc) rc = e->arena.alloc_t(&e->tmp_b, rows * C);
   if (!rc) rc = e->arena.alloc_t(&e->tmp_c, rows * C);
+  if (!rc) rc = e->arena.alloc_t(&e->rep_in, rows * C);
   if (!rc) rc = e->arena.alloc(&e->act, rows * C * 2);
-  if (!rc) rc = e->arena.alloc(&e->cat, rows * 2 * C * 2);
+  if (!rc) rc = e->arena.alloc(&e->cat, ((size_t)2 * cfg->max_seq + 64) * C * 2);
+  if (!rc) rc = e->arena.alloc(&e->integ_all, ((size_t)cfg->max_steps * 2 * cfg->max_seq + 64) * C * 2, false);
   if (!rc) rc = e->arena.alloc(&e->q, rows * C * 2);
   if (!rc) rc = e->arena.alloc(&e->k, rows * C * 2);
-  if (!rc) rc = e->arena.alloc(&e->vt, (size_t)C * (rows + 64) * 2);
+  if (!rc) rc = e->arena.alloc(&e->vt, (size_t)C * (2 * rows + 64) * 2);  // per sample C x round_up(S, 32) keys: <= 2x the rows for short sequences
   if (!rc) rc = e->arena.alloc(&e->att, rows * C * 2);
-  if (!rc) rc = e->arena.alloc_t(&e->gn_partial, groupnorm_partial_floats(2, e->rows_max) + 64);
+  if (!rc) rc = e->arena.alloc_t(&e->gn_partial, ((size_t)e->rows_max / 16 + e->rows_max + 64) * 64);  // [samples][row chunks >= 16 rows][32][2], worst case one-row samples
   if (!rc) rc = e->arena.alloc_t(&e->gn_gemm_part, ((size_t)e->rows_max / 32 + 2) * 2 * (C / 16) * 2 + 64);
   if (!rc) rc = e->arena.alloc(&e->lat_t, ((size_t)cfg->max_codes + 8) * cfg->latent_channels * 2);
   if (!rc) rc = e->arena.alloc_t(&e->ts_dev, cfg->max_steps);
@@ -289,7 +322,7 @@ int tt_diff_condition(tt_diff* e, const float* latents, int M, const float* cond
     float* t = cur; cur = oth; oth = t;
   }
   // code_norm(h) * (1 + cond_scale) + cond_shift   (diffusion_decoder.py:249-250)
-  TT_TRY(run_gn(e, cur, 1, M, e->w.code_norm_g, e->w.code_norm_b, cond, false, ACT_NONE, nullptr, 0, oth, s));
+  TT_TRY(run_gn(e, cur, 1, M, e->w.code_norm_g, e->w.code_norm_b, cond, 0, 1, ACT_NONE, nullptr, 0, oth, s));
   TT_TRY(gather_rows_launch(oth, interp_idx, e->code_emb, S, C, s));                 // F.interpolate(nearest)
   TT_TRY(broadcast_rows_launch(e->w.uncond_emb, e->code_emb + (size_t)S * C, S, C, s));  // unconditioned_embedding.repeat
   return e->sb.leave(us);
@@ -315,6 +348,7 @@ int tt_diff_forward(tt_diff* e, const float* x, int timestep, int cond_free, flo
   TT_TRY(cast_pad_launch(e->cfg.dtype, x, IC, e->x_t, IP, S, IC, IP, s));
   TT_TRY(cast_pad_launch(e->cfg.dtype, x, IC, offset_t(e->x_t, (size_t)S * IP), IP, S, IC, IP, s));
   const int B = cond_free ? 2 : 1;
+  TT_TRY(diff_integrator_all(e, 1, B, 0, s));
   TT_TRY(diff_forward(e, B, s));
   TT_CHECK_HIP(hipMemcpyAsync(out, e->out, (size_t)B * S * e->cfg.out_channels * sizeof(float), hipMemcpyDeviceToDevice, s));
   return e->sb.leave(us);
@@ -338,6 +372,7 @@ int tt_diff_sample(tt_diff* e, const float* x_T, const float* step_noise, const 
   TT_TRY(cast_pad_launch(dt, e->x, IC, e->x_t, IP, S, IC, IP, s));
   TT_TRY(cast_pad_launch(dt, e->x, IC, offset_t(e->x_t, (size_t)S * IP), IP, S, IC, IP, s));
   const int B = cond_free ? 2 : 1;
+  TT_TRY(diff_integrator_all(e, n_steps, B, 0, s));  // every step's conditioning integrator, batched over the schedule
   PSampleArgs pa;
   memset(&pa, 0, sizeof(pa));
   pa.steps = e->steps_dev; pa.slot = e->slot; pa.x = e->x; pa.x_t = e->x_t; pa.cpad = IP; pa.out = e->out;
@@ -394,10 +429,11 @@ int tt_diff_split_begin(tt_diff* e, const float* x_T, const tt_diff_step* steps_
   TT_TRY(transpose_launch(x_T, e->x, IC, S, s));  // [C][S] -> [S][C]
   TT_TRY(cast_pad_launch(dt, e->x, IC, e->x_t, IP, S, IC, IP, s));
   TT_TRY(cast_pad_launch(dt, e->x, IC, offset_t(e->x_t, (size_t)S * IP), IP, S, IC, IP, s));
+  TT_TRY(diff_integrator_all(e, n_steps, 1, row, s));
   int rc = 0;
   if (graphs_enabled()) {
     TT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    rc = diff_forward(e, 1, s, row);
+    rc = diff_forward(e, 1, s);
     hipError_t ce = hipStreamEndCapture(s, &e->split_graph);
     if (!rc && ce != hipSuccess) { set_error("tt_diff_split_begin: capture failed: %s", hipGetErrorString(ce)); rc = -2; }
     if (!rc) {
@@ -422,7 +458,7 @@ int tt_diff_split_forward(tt_diff* e, float* out_row, void* stream) {
     hipError_t ce = hipGraphLaunch(e->split_exec, s);
     if (ce != hipSuccess) { set_error("tt_diff_split_forward: hipGraphLaunch: %s", hipGetErrorString(ce)); return -2; }
   } else {
-    TT_TRY(diff_forward(e, 1, s, e->split_row));
+    TT_TRY(diff_forward(e, 1, s));
   }
   TT_CHECK_HIP(hipMemcpyAsync(out_row, e->out, (size_t)e->S * e->cfg.out_channels * sizeof(float), hipMemcpyDeviceToDevice, s));
   return e->sb.leave(us);

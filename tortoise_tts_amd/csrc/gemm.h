@@ -18,6 +18,13 @@ struct GemmArgs {
   int lda;  // elements between consecutive A rows
   const void* W;
   int ldw;  // elements between consecutive W rows (>= K)
+  // optional second activation source (plain GEMMs only): k >= k_split reads A2[m][k - k_split] instead of A[m][k], i.e.
+  // out = [A | A2] @ W^T without materialising the concatenation.  a2_slot (device int) selects a2_slot_stride-element
+  // blocks of A2 at kernel start (hipGraph replay: the sampler step counter).
+  const void* A2;
+  int lda2, k_split;
+  const int* a2_slot;
+  size_t a2_slot_stride;
   int w_packed;  // 1: W is tile-packed [ceil(N/64)][K/64][64][64] (rows beyond N are zero); ldw ignored
   int n_pad;     // set by gemm_launch
   int M, N, K;

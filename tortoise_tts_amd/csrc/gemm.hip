@@ -304,6 +304,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(GemmArgs g) {
   const T* A = (const T*)g.A;
   const T* W = (const T*)g.W;
   const T* zero = (const T*)g_zero_page;
+  const T* A2 = nullptr;
+  if (!CONV && g.A2) A2 = (const T*)g.A2 + (g.a2_slot ? (size_t)(*g.a2_slot) * g.a2_slot_stride : 0);
 
   // per-piece lane geometry: this lane fills LDS chunk lc of row (piece * 8 + lr) with global chunk lc ^ swz(row)
   const int lr = lane >> 3, lc = lane & 7;
@@ -359,7 +361,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(GemmArgs g) {
         const bool ok = a_ok[p] && s2 >= 0 && s2 < g.seq_len;
         src = ok ? A + ((size_t)a_b[p] * g.seq_len + s2) * g.lda + kin + a_src[p] : zero;
       } else {
-        src = A + (size_t)a_s[p] * g.lda + kin + a_src[p];
+        const bool second = A2 != nullptr && kin >= g.k_split;  // block-uniform: k-tiles never straddle k_split (multiple of 64)
+        src = second ? A2 + (size_t)a_s[p] * g.lda2 + (kin - g.k_split) + a_src[p] : A + (size_t)a_s[p] * g.lda + kin + a_src[p];
       }
       __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(as + (wave + NW * p) * 8 * BK), 16, 0, 0);
     }
@@ -574,6 +577,7 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   TT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda=%d / ldw=%d must be multiples of 8 elements", a.lda, a.ldw);
   TT_REQUIRE(a.splitk == 1 || (epi == EPI_STD && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
   TT_REQUIRE(a.splitk <= a.K / 64, "gemm: splitk=%d exceeds the %d k-tiles", a.splitk, a.K / 64);
+  if (a.A2) TT_REQUIRE(a.taps == 1 && a.k_split > 0 && a.k_split < a.K && a.k_split % 64 == 0 && a.lda2 % 8 == 0, "gemm: bad second activation source (k_split=%d lda2=%d)", a.k_split, a.lda2);
   if (a.w_packed) {
     TT_REQUIRE(a.taps == 1, "gemm: tile-packed weights are not supported for conv taps");
     a.n_pad = (a.N + 63) / 64 * 64;

@@ -147,6 +147,21 @@ __global__ void broadcast_rows_kernel(const float* vec, float* dst, int rows, in
   const long total = (long)rows * C;
   for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) dst[f] = vec[f % C];
 }
+__global__ void repeat_rows_kernel(const float4* src, float4* dst, size_t n4, int reps) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = src[i];
+    for (int j = 0; j < reps; ++j) dst[(size_t)j * n4 + i] = v;
+  }
+}
+int repeat_rows_launch(const float* src, float* dst, int rows, int reps, int C, hipStream_t stream) {
+  TT_REQUIRE(C % 4 == 0, "repeat_rows: C must be a multiple of 4");
+  const size_t n4 = (size_t)rows * C / 4;
+  const int blocks = (int)std::min<long>(cdiv64((long)n4, 256), 4096);
+  repeat_rows_kernel<<<blocks, 256, 0, stream>>>((const float4*)src, (float4*)dst, n4, reps);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int broadcast_rows_launch(const float* vec, float* dst, int rows, int C, hipStream_t stream) {
   const int blocks = (int)std::min<long>(cdiv64((long)rows * C, 256), 4096);
   broadcast_rows_kernel<<<blocks, 256, 0, stream>>>(vec, dst, rows, C);

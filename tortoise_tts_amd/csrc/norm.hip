@@ -363,30 +363,39 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 // statistics round trip overlaps the row loads; gn_finalize then sums head + remainder in the same fixed order.
 constexpr int GN_HEAD = 8;
 
-__device__ __forceinline__ float2 gn_partial_item(const GroupNormArgs& a, int b, int g, int e, int t0, int nitems, int spg, int nc16) {
+// All index arithmetic here is shifts and compares: part_rows (the producing GEMM's wave-tile height) is a power of two
+// and the strips per group (C / 32 / 16) are a compile-time power of two on the C == 1024 path (SPG_SHIFT = 1), 
+// because this code sits in front of every activation load of the kernel (integer divisions by run-time values cost
+// ~30 instructions each, 3 per partial item).
+template <int SPG_SHIFT>
+__device__ __forceinline__ float2 gn_partial_item(const GroupNormArgs& a, int b, int g, int e, int t0, int nitems, int nc16, int r_shift) {
   const int ec = min(e, nitems - 1);  // clamped, unconditional load; out-of-range items are zeroed by the caller
-  const int t = t0 + ec / spg, strip = g * spg + ec % spg;
-  const int slot = (t * a.part_rows) / a.S == b ? 0 : 1;
+  const int t = t0 + (ec >> SPG_SHIFT), strip = (g << SPG_SHIFT) + (ec & ((1 << SPG_SHIFT) - 1));
+  // a row tile's slot 0 holds the rows of the sequence its FIRST row belongs to, slot 1 those of the next sequence: tile t of
+  // sample b starts inside sample b unless it is the first tile and straddles in from sample b - 1
+  const int slot = ((t << r_shift) < b * a.S) ? 1 : 0;
   return *(const float2*)(a.gemm_part + (((size_t)t * 2 + slot) * nc16 + strip) * 2);
 }
 
+template <int SPG_SHIFT>
 __device__ __forceinline__ void gn_partial_head(const GroupNormArgs& a, int b, int tid, float2 (&head)[GN_HEAD]) {
   const int g = tid & 31, part = tid >> 5;
-  const int S = a.S, R = a.part_rows, nc16 = a.C >> 4, spg = (a.C / 32) >> 4;
-  const int t0 = (b * S) / R, t1 = ((b + 1) * S - 1) / R;
-  const int nitems = (t1 - t0 + 1) * spg;
+  const int S = a.S, r_shift = 31 - __builtin_clz(a.part_rows), nc16 = a.C >> 4;
+  const int t0 = (b * S) >> r_shift, t1 = ((b + 1) * S - 1) >> r_shift;
+  const int nitems = (t1 - t0 + 1) << SPG_SHIFT;
 #pragma unroll
-  for (int k = 0; k < GN_HEAD; ++k) head[k] = gn_partial_item(a, b, g, part + 8 * k, t0, nitems, spg, nc16);
+  for (int k = 0; k < GN_HEAD; ++k) head[k] = gn_partial_item<SPG_SHIFT>(a, b, g, part + 8 * k, t0, nitems, nc16, r_shift);
 }
 
+template <int SPG_SHIFT>
 __device__ __forceinline__ void gn_finalize(const GroupNormArgs& a, int b, int tid, int nchunk, float* mean_s, float* rstd_s,
                                             double (*part_s)[32], double (*part_q)[32], const float2* head = nullptr) {
   const int g = tid & 31, part = tid >> 5;
   double s = 0.0, q = 0.0;
   if (a.gemm_part) {
-    const int S = a.S, R = a.part_rows, nc16 = a.C >> 4, spg = (a.C / 32) >> 4;  // 16-column strips per group
-    const int t0 = (b * S) / R, t1 = ((b + 1) * S - 1) / R;
-    const int nitems = (t1 - t0 + 1) * spg;
+    const int S = a.S, r_shift = 31 - __builtin_clz(a.part_rows), nc16 = a.C >> 4;
+    const int t0 = (b * S) >> r_shift, t1 = ((b + 1) * S - 1) >> r_shift;
+    const int nitems = (t1 - t0 + 1) << SPG_SHIFT;  // 16-column strips per group x row tiles
     int e = part;
     if (head) {
 #pragma unroll
@@ -399,7 +408,7 @@ __device__ __forceinline__ void gn_finalize(const GroupNormArgs& a, int b, int t
     }
 #pragma unroll 4
     for (; e < nitems; e += 8) {
-      const float2 v = gn_partial_item(a, b, g, e, t0, nitems, spg, nc16);
+      const float2 v = gn_partial_item<SPG_SHIFT>(a, b, g, e, t0, nitems, nc16, r_shift);
       s += (double)v.x;
       q += (double)v.y;
     }
@@ -443,7 +452,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchu
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x;
   const int C = a.C, S = a.S;
-  gn_finalize(a, b, tid, nchunk, mean_s, rstd_s, part_s, part_q);
+  {
+    const int spg = (a.C / 32) >> 4;  // strips per group: 1, 2 or 4 (C = 512, 1024, 2048)
+    if (spg == 4) gn_finalize<2>(a, b, tid, nchunk, mean_s, rstd_s, part_s, part_q);
+    else if (spg == 2) gn_finalize<1>(a, b, tid, nchunk, mean_s, rstd_s, part_s, part_q);
+    else gn_finalize<0>(a, b, tid, nchunk, mean_s, rstd_s, part_s, part_q);
+  }
   const int c4n = C >> 2;
   const int cpg = C / 32;
   const int r0 = chunk * rows_per_block;
@@ -461,7 +475,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchu
     float y[4] = {(t.x - mu) * rs * gm.x + bt.x, (t.y - mu) * rs * gm.y + bt.y, (t.z - mu) * rs * gm.z + bt.z,
                   (t.w - mu) * rs * gm.w + bt.w};
     if (a.scale_shift) {
-      const float* ss = a.scale_shift + (size_t)b * a.ss_batch_stride;
+      const float* ss = a.scale_shift + (size_t)(b / (a.ss_batch_div > 0 ? a.ss_batch_div : 1)) * a.ss_batch_stride;
       const float4 sc = *(const float4*)(ss + c);
       const float4 sh = *(const float4*)(ss + C + c);
       y[0] = y[0] * (1.f + sc.x) + sh.x;
@@ -492,7 +506,7 @@ __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, in
   const int c = tid * 4;
   // request order = need order: statistics partials, then the rows and the affine parameters
   float2 head[GN_HEAD];
-  if constexpr (FUSED) gn_partial_head(a, b, tid, head);  // FUSED <=> a.gemm_part != nullptr (compile time: no branch to sink consumers into)
+  if constexpr (FUSED) gn_partial_head<1>(a, b, tid, head);  // FUSED <=> a.gemm_part != nullptr (compile time: no branch to sink consumers into)
   float4 xr[GN_APPLY_ROWS];
 #pragma unroll
   for (int i = 0; i < GN_APPLY_ROWS; ++i) {
@@ -503,12 +517,12 @@ __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, in
   const float4 bt = *(const float4*)(a.beta + c);
   float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
   if constexpr (SS) {  // SS <=> a.scale_shift != nullptr
-    const float* ss = a.scale_shift + (size_t)b * a.ss_batch_stride;
+    const float* ss = a.scale_shift + (size_t)(b / (a.ss_batch_div > 0 ? a.ss_batch_div : 1)) * a.ss_batch_stride;
     sc = *(const float4*)(ss + c);
     sh = *(const float4*)(ss + C + c);
   }
   __builtin_amdgcn_sched_barrier(0);  // keep every request above in flight before the first consumer waits
-  gn_finalize(a, b, tid, nchunk, mean_s, rstd_s, part_s, part_q, FUSED ? head : nullptr);
+  gn_finalize<1>(a, b, tid, nchunk, mean_s, rstd_s, part_s, part_q, FUSED ? head : nullptr);
   const float mu = mean_s[tid >> 3], rs = rstd_s[tid >> 3];
 #pragma unroll
   for (int i = 0; i < GN_APPLY_ROWS; ++i) {
@@ -542,7 +556,9 @@ int groupnorm_launch(int dtype, const GroupNormArgs& a, hipStream_t stream) {
   dim3 grid(nchunk, a.B);
   ProfScope ps(PROF_GROUPNORM, stream, 0.0, (double)a.B * a.S * a.C * ((a.gemm_part ? 4.0 : 8.0) + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)));
   if (a.gemm_part) {
-    TT_REQUIRE((a.C / 32) % 16 == 0 && a.part_rows > 0 && a.S >= a.part_rows, "groupnorm: fused statistics need >= 16 channels per group and S >= the row tile");
+    const int spg = (a.C / 32) / 16;
+    TT_REQUIRE((a.C / 32) % 16 == 0 && (spg == 1 || spg == 2 || spg == 4) && a.part_rows > 0 && (a.part_rows & (a.part_rows - 1)) == 0 && a.S >= a.part_rows,
+               "groupnorm: fused statistics need 16 / 32 / 64 channels per group, a power-of-two row tile and S >= the row tile");
   } else {
     gn_stats_kernel<<<grid, 256, 0, stream>>>(a.x, a.S, a.C, a.partial, rpc);
     TT_CHECK_HIP(hipGetLastError());

@@ -43,6 +43,7 @@ struct GroupNormArgs {
   float eps;
   const float* scale_shift;  // optional [B?][2C]: y = y * (1 + scale) + shift
   size_t ss_batch_stride;    // 0 when every batch row shares one timestep embedding
+  int ss_batch_div;          // batch row b reads block b / ss_batch_div (>= 1; 0 is treated as 1): rows of one timestep share it
   int act;
   void* out_t;
   int ldot;
@@ -132,6 +133,8 @@ int clvp_score_launch(const float* t, int t_rows, const float* s, const float* t
                       hipStream_t stream);
 // f32 -> T with optional column zero-padding: dst[r][0..cpad) = src[r][0..c) | 0
 int cast_pad_launch(int dtype, const float* src, int lds, void* dst, int ldd, int rows, int c, int cpad, hipStream_t stream);
+// dst[j][r][:] = src[r][:] for j < reps (f32 rows of C floats; r < rows)
+int repeat_rows_launch(const float* src, float* dst, int rows, int reps, int C, hipStream_t stream);
 // broadcast a [C] vector over rows
 int broadcast_rows_launch(const float* vec, float* dst, int rows, int C, hipStream_t stream);
 // f32 transpose: dst[c][r] = src[r][c]
