@@ -262,6 +262,236 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(FlashArgs a) {  // 2 wave
   }
 }
 
+// ------------------------------------------------------------------------------- LDS-staged flash attention
+// Same arithmetic as flash_kernel (swapped QK^T / PV MFMAs, online softmax per 32 keys), different data movement: the four
+// waves of a block own DIFFERENT queries (16 * NQ each) and SHARE every 64-key K / V^T tile, which goes global -> LDS
+// directly (global_load_lds_dwordx4, 16 KiB per tile, XOR-swizzled on the source side like the GEMM tiles) through a 3-stage
+// ring with counted vmcnt, one raw barrier per tile.  Against the register-prefetch kernel this divides the L2 -> CU traffic
+// by 4 (a K / V byte is fetched once per block, not once per wave), puts two more tiles in flight per wave without spending
+// VGPRs on them, and removes the 4-way partial-state merge.
+typedef __attribute__((address_space(3))) void lds_void_a;
+typedef __attribute__((address_space(1))) const void gbl_void_a;
+
+template <typename T, int NQ>
+__global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
+  typedef typename Vec<T>::x8 x8;
+  typedef typename Vec<T>::x4 x4;
+  constexpr int ST = 3, KT = 64;                 // ring stages, keys per tile
+  constexpr int STAGE = 2 * KT * 64;             // elements per stage: K tile [64 keys][64] + V^T tile [64 dims][64 keys]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* ring = (T*)smem_raw;                        // [ST][STAGE]
+  float* rp = (float*)(ring + ST * STAGE);       // [132] relative-position table (ONE shared object: a second one de-pipelines the ring)
+  int bx = blockIdx.x, bh = blockIdx.y;
+  {
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    const int lin = bh * gx + bx, xcd = lin & 7, slot = lin >> 3;
+    const int per = total >> 3, rem = total & 7;
+    const int lin2 = xcd * per + min(xcd, rem) + slot;
+    bh = lin2 / gx;
+    bx = lin2 - bh * gx;
+  }
+  const int h = bh % a.heads, b = bh / a.heads;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n = a.n;
+  if (a.relpos) {
+    if (threadIdx.x < 129) rp[threadIdx.x] = a.relpos[h * 129 + threadIdx.x];
+    __syncthreads();
+  }
+  const int qblock = bx * 64 * NQ;               // first query of the block
+  const int qbase = qblock + wave * 16 * NQ;     // first query of this wave (may be >= n: the wave then only helps loading)
+  const T* Q = (const T*)a.q + (size_t)bh * n * 64;
+  const T* K = (const T*)a.k + (size_t)bh * n * 64;
+  const T* VT = (const T*)a.vt + (size_t)bh * 64 * a.n_pad;
+
+  x8 qf[NQ][2];
+#pragma unroll
+  for (int iq = 0; iq < NQ; ++iq) {
+    const int qr = min(qbase + iq * 16 + fr, n - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[iq][ks] = *(const x8*)(Q + (size_t)qr * 64 + ks * 32 + fg * 8);
+  }
+  float m_run[NQ], l_run[NQ];
+  f32x4 acc[NQ][4];
+#pragma unroll
+  for (int iq = 0; iq < NQ; ++iq) {
+    m_run[iq] = -1e30f;
+    l_run[iq] = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) acc[iq][blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int q_last_blk = min(qblock + 64 * NQ, n) - 1;
+  const int q_last = min(qbase + 16 * NQ, n) - 1;            // < qbase when the wave has no query
+  const int kend_blk = a.causal ? q_last_blk + 1 : n;        // block-uniform: every wave walks the same tiles
+  const int kend = qbase >= n ? 0 : (a.causal ? q_last + 1 : n);  // keys this wave's queries can see (none: the wave only helps loading)
+  const int ntile = (kend_blk + KT - 1) / KT;
+
+  // stage fill: 16 one-KiB pieces per tile (8 rows x 128 B each): pieces 0-7 = K rows, 8-15 = V^T rows; 4 per wave
+  const int lr = lane >> 3, lc = lane & 7;
+  auto issue = [&](int t, int stage) {
+    const int key0 = t * KT;
+    T* base = ring + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = wave + 4 * i;
+      const int row = (piece & 7) * 8 + lr;
+      const int chunk = lc ^ ((row >> 1) & 7);
+      const T* src;
+      if (piece < 8) src = K + (size_t)min(key0 + row, n - 1) * 64 + chunk * 8;                      // key row, 8 dims
+      else src = VT + (size_t)row * a.n_pad + min(key0 + chunk * 8, a.n_pad - 8);                    // dim row, 8 keys
+      __builtin_amdgcn_global_load_lds((gbl_void_a*)src, (lds_void_a*)(base + piece * 512), 16, 0, 0);
+    }
+  };
+
+  constexpr float LOG2E = 1.4426950408889634f;
+  // one 32-key half tile (kp = 0 / 1) of the staged tile against this wave's queries
+  auto process = [&](const T* kt, const T* vt, int kp, int key0) {
+    x8 kf[2][2], vf[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int r = kp * 32 + kb * 16 + fr;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) kf[kb][ks] = *(const x8*)(kt + r * 64 + (((ks * 4 + fg) ^ ((r >> 1) & 7)) * 8));
+    }
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      const int d = blk * 16 + fr;
+      const int sw = (d >> 1) & 7;
+      // keys kp*32 + fg*4 .. +3 (lo) and +16 .. +19 (hi): chunk = key / 8, 8-byte half (fg & 1)
+      const int c_lo = kp * 4 + (fg >> 1), c_hi = c_lo + 2;
+      const x4 lo = *(const x4*)(vt + d * 64 + ((c_lo ^ sw) * 8) + (fg & 1) * 4);
+      const x4 hi = *(const x4*)(vt + d * 64 + ((c_hi ^ sw) * 8) + (fg & 1) * 4);
+      x8 v;
+      v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+      v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+      vf[blk] = v;
+    }
+    const bool tail = key0 + 32 > n;
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) {
+      const int q0 = qbase + iq * 16;
+      const int qi = q0 + fr;
+      float sv[2][4];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f};
+        st = mfma16(kf[kb][0], qf[iq][0], st);
+        st = mfma16(kf[kb][1], qf[iq][1], st);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[kb][r] = st[r];
+      }
+      if (a.relpos) {
+        if (key0 - (q0 + 15) >= 64) {          // every key is >= 64 after every query: bucket saturated
+          const float bconst = rp[128];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sv[kb][r] += bconst;
+        } else if (q0 - (key0 + 31) >= 64) {   // every key is >= 64 before every query
+          const float bconst = rp[0];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sv[kb][r] += bconst;
+        } else {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              int d = key0 + kb * 16 + fg * 4 + r - qi;
+              d = d < -64 ? -64 : (d > 64 ? 64 : d);
+              sv[kb][r] += rp[d + 64];
+            }
+        }
+      }
+      if (tail || (a.causal && key0 + 31 > q0)) {  // masks only on the last key tile / the causal diagonal
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = key0 + kb * 16 + fg * 4 + r;
+            if (key >= n || (a.causal && key > qi)) sv[kb][r] = -INFINITY;
+          }
+      }
+      float mx = fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
+                       fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[iq], mx);
+      if (__any(m_new > m_run[iq])) {  // some row maximum moved: rescale the running state (exact when skipped)
+        const float alpha = __builtin_amdgcn_exp2f((m_run[iq] - m_new) * LOG2E);
+        l_run[iq] *= alpha;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+          acc[iq][blk][0] *= alpha; acc[iq][blk][1] *= alpha; acc[iq][blk][2] *= alpha; acc[iq][blk][3] *= alpha;
+        }
+        m_run[iq] = m_new;
+      }
+      const float mc = m_new * LOG2E;
+      float psum = 0.f;
+      x8 pf;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sv[kb][r], LOG2E, -mc));
+          psum += pv;
+          pf[kb * 4 + r] = (T)pv;
+        }
+      l_run[iq] += psum;  // lane-partial: reduced over the four key groups once, after the loop
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) acc[iq][blk] = mfma16(vf[blk], pf, acc[iq][blk]);
+    }
+  };
+
+  constexpr int G = 4;  // LDS-DMA instructions per wave per tile
+  const int last = ntile - 1;
+#pragma unroll
+  for (int s_ = 0; s_ < ST - 1; ++s_) issue(min(s_, last), s_);
+  int slot = 0;
+  for (int t = 0; t < ntile; ++t) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * G) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int nslot = slot + ST - 1;
+    if (nslot >= ST) nslot -= ST;
+    issue(min(t + ST - 1, last), nslot);
+    const int key0 = t * KT;
+    const T* kt = ring + slot * STAGE;
+    const T* vt = kt + KT * 64;
+    if (key0 < kend) process(kt, vt, 0, key0);            // wave-uniform: tiles beyond this wave's causal horizon are skipped
+    if (key0 + 32 < kend) process(kt, vt, 1, key0 + 32);
+    slot = slot + 1 == ST ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int iq = 0; iq < NQ; ++iq) {
+    l_run[iq] += __shfl_xor(l_run[iq], 16, 64);
+    l_run[iq] += __shfl_xor(l_run[iq], 32, 64);
+    const int qi = qbase + iq * 16 + fr;
+    if (qi < n) {
+      const float inv = 1.0f / l_run[iq];
+      T* o = (T*)a.out + ((size_t)b * n + qi) * a.ldo + h * 64 + fg * 4;
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+        *(x4*)(o + blk * 16) = pack4<T>(acc[iq][blk][0] * inv, acc[iq][blk][1] * inv, acc[iq][blk][2] * inv, acc[iq][blk][3] * inv);
+    }
+  }
+}
+
+template <typename T, int NQ>
+static int launch_flash_lds(const FlashArgs& a, hipStream_t stream) {
+  constexpr int smem = 3 * 2 * 64 * 64 * 2 + 132 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TT_CHECK_HIP(hipFuncSetAttribute((const void*)flash_lds_kernel<T, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.n, 64 * NQ), a.BH);
+  flash_lds_kernel<T, NQ><<<grid, 256, smem, stream>>>(a);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.BH > 0 && a.n > 0 && a.heads > 0 && a.BH % a.heads == 0, "flash: bad shape BH=%d n=%d heads=%d", a.BH, a.n, a.heads);
   TT_REQUIRE(a.n_pad % 32 == 0 && a.n_pad >= ((a.n + 31) / 32) * 32, "flash: n_pad=%d must be a multiple of 32 covering n=%d", a.n_pad, a.n);
@@ -272,6 +502,14 @@ int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
   // Every K / V^T tile a wave loads is used by NQ*16 of its queries, so L2->CU traffic per flop falls as 1/NQ
   // (with NQ = 1 the kernel sits on the L2 bandwidth, ~80 TFLOP/s).  Few (batch, head) pairs: 64 queries per
   // wave and the keys split over the block's 4 waves; many pairs: 32 queries per wave, no split.
+  if (a.n > 128 && a.n_pad >= 8) {
+    // LDS-staged kernel: 64 queries per block while that keeps >= 2 blocks per CU busy, 128 otherwise (half the K / V traffic)
+    const long blocks64 = (long)cdiv(a.n, 64) * a.BH;
+    static const int variant = [] { const char* e = getenv("TT_FLASH_NQ"); return e ? atoi(e) : 0; }();  // kbench A/B only
+    const bool nq2 = variant ? variant == 2 : blocks64 >= 2048;
+    if (nq2) return dtype == DT_BF16 ? launch_flash_lds<bf16, 2>(a, stream) : launch_flash_lds<f16, 2>(a, stream);
+    if (variant != 9) return dtype == DT_BF16 ? launch_flash_lds<bf16, 1>(a, stream) : launch_flash_lds<f16, 1>(a, stream);
+  }
   const long waves_own = (long)cdiv(a.n, 32) * a.BH;
   if (waves_own >= 8192) {
     dim3 grid(cdiv(a.n, 128), a.BH);

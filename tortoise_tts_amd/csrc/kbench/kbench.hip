@@ -586,3 +586,32 @@ extern "C" int tt_kb_bw_probe(int mode, int nw_waves, int nblocks, size_t footpr
   ar.release();
   return rc;
 }
+
+
+extern "C" int tt_kb_flash(int B, int H, int n, int causal, int relpos, int chain, int reps, double* us_out) {
+  Arena ar;
+  GraphTimer gt;
+  TT_TRY(gt.init());
+  const int n_pad = (n + 31) / 32 * 32;
+  void* q = nullptr; void* k = nullptr; void* vt = nullptr; void* out = nullptr; float* rp = nullptr;
+  int rc = dev_bf16(ar, &q, (size_t)B * H * n * 64 + 64, 1u);
+  if (!rc) rc = dev_bf16(ar, &k, (size_t)B * H * n * 64 + 64, 2u);
+  if (!rc) rc = dev_bf16(ar, &vt, (size_t)B * H * 64 * n_pad + 64, 3u);
+  if (!rc) rc = ar.alloc(&out, (size_t)B * n * H * 64 * 2);
+  if (!rc) rc = dev_f32(ar, &rp, (size_t)H * 129, 4u);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
+  if (!rc) rc = gt.run([&](hipStream_t s) -> int {
+    for (int i = 0; i < chain; ++i) {
+      FlashArgs f;
+      memset(&f, 0, sizeof(f));
+      f.q = q; f.k = k; f.vt = vt; f.out = out; f.ldo = H * 64; f.BH = B * H; f.heads = H; f.n = n; f.n_pad = n_pad; f.causal = causal;
+      f.relpos = relpos ? rp : nullptr;
+      TT_TRY(flash_attention_launch(DT_BF16, f, s));
+    }
+    return 0;
+  }, reps, us_out);
+  if (!rc) *us_out /= chain;
+  gt.destroy();
+  ar.release();
+  return rc;
+}
