@@ -52,28 +52,38 @@ def synthetic_prompt(seed=0, text_tokens=54):
 
 
 def cpu_baseline(sds, text, latents, preset_kw, M, cores):
-    """Reference algorithm (oracle/, fp32) on the host cores, bounded sample, linear extrapolation."""
+    """Reference algorithm (oracle/, fp32) on the host cores, bounded sample, linear extrapolation.  The thread count is
+    swept on the dominant stage (the KV-cached AR step: GEMV-sized work that oversubscribed threads slow down ~4x) and the
+    best one is used for every stage; `cores` in the result is the thread count actually used."""
     from oracle import tortoise_oracle as O
     from tortoise_tts_amd.config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
     import torch.nn.functional as F
-    torch.set_num_threads(cores)
     ar_cfg, clvp_cfg, d_cfg, v_cfg = ARConfig(), CLVPConfig(), DiffusionConfig(), VocoderConfig()
     auto, diffc = latents
     tt = F.pad(text.int()[None], (0, 1))
     N, iters = preset_kw["num_autoregressive_samples"], preset_kw["diffusion_iterations"]
-    Bc, nsteps = 16, 6  # reference default AR batch on a >=14 GB device (api.py:156-157)
+    Bc = 16  # reference default AR batch on a >=14 GB device (api.py:156-157)
     with torch.no_grad():
         sd = sds["autoregressive"]
-        t0 = time.perf_counter()
+        torch.set_num_threads(min(cores, 16))
         prefix = O.ar_prefix(sd, ar_cfg, auto, tt)
-        lg, kv = O.ar_prefill(sd, ar_cfg, prefix, Bc)
-        t_pf = time.perf_counter() - t0
+        lg0, kv0 = O.ar_prefill(sd, ar_cfg, prefix, Bc)
         tok = torch.zeros(Bc, dtype=torch.long)
+        sweep = {}
+        for th in sorted({t for t in (8, 16, 32, 64) if t <= cores} | {min(cores, 8)}):
+            torch.set_num_threads(th)
+            lg, kv = O.ar_step(sd, ar_cfg, tok, 1, kv0)  # warm the thread pool
+            t0 = time.perf_counter()
+            for s_ in range(3):
+                lg, kv = O.ar_step(sd, ar_cfg, tok, s_ + 2, kv)
+                O.warp_logits(lg, torch.zeros(Bc, 60, dtype=torch.long))
+            sweep[th] = (time.perf_counter() - t0) / 3
+        best = min(sweep, key=sweep.get)
+        t_step = sweep[best]
+        torch.set_num_threads(best)
         t0 = time.perf_counter()
-        for s in range(nsteps):
-            lg, kv = O.ar_step(sd, ar_cfg, tok, s + 1, kv)
-            O.warp_logits(lg, torch.zeros(Bc, 60, dtype=torch.long))
-        t_step = (time.perf_counter() - t0) / nsteps
+        O.ar_prefill(sd, ar_cfg, prefix, Bc)
+        t_pf = time.perf_counter() - t0
         ar_total = (N / Bc) * (t_pf + (M - 1) * t_step)
         codes = torch.randint(0, 8192, (1, M))
         t0 = time.perf_counter()
@@ -99,12 +109,26 @@ def cpu_baseline(sds, text, latents, preset_kw, M, cores):
         voc_total = time.perf_counter() - t0
     total = ar_total + clvp_total + lat_total + diff_total + voc_total
     audio_s = S * 256 / 24000.0
-    return {"value": audio_s / total, "unit": "audio-s/wall-s", "cores": cores, "kind": "port",
+    return {"value": audio_s / total, "unit": "audio-s/wall-s", "cores": best, "host_cores": cores, "kind": "port",
             "latency_s_extrapolated": total,
-            "sample": (f"oracle fp32: AR prefill + {nsteps} cached steps at B={Bc} ({t_pf:.2f}s + {t_step:.3f}s/step), CLVP 1 of {N} "
-                       f"candidates, 1 latent pass, timestep_independent + 1 cond/uncond denoiser pair of {iters} ({t_pair:.2f}s), "
-                       f"full UnivNet ({voc_total:.2f}s); stages extrapolated linearly to the full utterance"),
+            "ar_step_s_by_threads": {str(k): round(v, 4) for k, v in sweep.items()},
+            "sample": (f"oracle fp32 on {best} threads (best of {sorted(sweep)} on the AR step): AR prefill + 3 cached steps at B={Bc} "
+                       f"({t_pf:.2f}s + {t_step:.3f}s/step), CLVP 1 of {N} candidates, 1 latent pass, timestep_independent + 1 cond/uncond "
+                       f"denoiser pair of {iters} ({t_pair:.2f}s), full UnivNet ({voc_total:.2f}s); stages extrapolated linearly to the full utterance"),
             "stages_s": {"ar": ar_total, "clvp": clvp_total, "latents": lat_total, "diffusion": diff_total, "vocoder": voc_total}}
+
+
+def source_digest():
+    """sha256 over the engine sources: ties a committed PMC summary to the build it was collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.join(ROOT, "tortoise_tts_amd", "csrc")
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(root, f), "rb") as fh:
+                h.update(f.encode())
+                h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def roofline_leg(tts, run_step):
@@ -140,31 +164,31 @@ def roofline_leg(tts, run_step):
     else:
         ach = d["bytes"] / sec / 1e9
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-    traffic, traffic_src = pmc_traffic(d["kernel"])
-    roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": d["kernel"], "launches": d["launches"], "avg_launch_us": d["avg_us"],
+    traffic, traffic_src, stale = pmc_traffic(d["kernel"])
+    roof.update({"traffic": traffic, "traffic_source": traffic_src, "traffic_stale": stale, "kernel": d["kernel"], "launches": d["launches"], "avg_launch_us": d["avg_us"],
                  "algorithmic_flops_per_launch": d["flops"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                  "arithmetic_intensity": intensity, "share_of_kernel_time": d["total_ms"] / sum(r["total_ms"] for r in rows)})
     return roof, rows
 
 
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_bench.json")
+
+
 def pmc_traffic(kernel_class):
-    """HBM-side bytes per launch of one kernel class from the committed PMC summary (profiles/r01_pmc_bench.json,
-    written by scripts/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes over this same
-    workload, aggregated per kernel).  Counters cannot be read from inside a timed run, so the bench line carries the
-    figure of the last committed PMC pass, corrected as MI355X_MICROARCH.md prescribes for gfx950: both counters are
-    in KiB and FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) reads at 64 bytes, so it is doubled."""
-    import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_bench.json")
-    m = re.match(r"gemm_kernel<(\d+),(\d+),(\w+)>", kernel_class)
-    alias = {"gn_stats_kernel+gn_apply_kernel": "gn_apply_c1024_kernel", "rownorm_kernel": "rownorm_narrow_kernelIDF16bLi4ELb1ELb0EEEvNS_11RowNormArgsE"}
-    key = "gemm<%s,%s,%s>" % m.groups() if m else alias.get(kernel_class, kernel_class)
+    """HBM-side bytes per launch of one kernel class from the committed PMC summary (profiles/r02_pmc_bench.json, written by
+    scripts/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes over this same workload, aggregated
+    per kernel class under the names the engine's profiler uses).  Counters cannot be read from inside a timed run, so the
+    bench line carries the figure of the last committed PMC pass, corrected as MI355X_MICROARCH.md prescribes for gfx950:
+    both counters are in KiB and FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) reads at 64 bytes, so it is
+    doubled.  The summary records the source digest of the build it was collected on; a different digest now => stale."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             pmc = json.load(f)
-        row = pmc[key]
-        return (2.0 * row["FETCH_SIZE"]["avg"] + row["WRITE_SIZE"]["avg"]) * 1024.0, "profiles/r01_pmc_bench.json[%s]" % key
+        row = pmc[kernel_class]
+        stale = pmc.get("_meta", {}).get("source_digest") != source_digest()
+        return (2.0 * row["FETCH_SIZE"]["avg"] + row["WRITE_SIZE"]["avg"]) * 1024.0, "%s[%s]" % (PMC_SUMMARY, kernel_class), stale
     except (OSError, KeyError, ValueError):
-        return None, None
+        return None, None, None
 
 
 def main():
@@ -175,6 +199,9 @@ def main():
     ap.add_argument("--preset", default="standard")
     ap.add_argument("--mel-tokens", type=int, default=200, help="fixed decode length M (SURVEY.md §8d: 200 and 500)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--workload", default="utterance", choices=["utterance", "read"],
+                    help="utterance: one tts_with_preset call per step (BASELINE metric); read: one long-form paragraph per step = 15 chunks "
+                         "spread over the GPUs as replicas (BASELINE config #4, tortoise/read.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -193,12 +220,28 @@ def main():
     t_build = time.perf_counter()
     sds = synthetic_weights()
     text, latents = synthetic_prompt()
-    tts = TextToSpeech(state_dicts=sds, dtype=args.dtype, max_candidates=N // world, max_mel_tokens=max(M, 32))
+    read_mode = args.workload == "read"
+    # read: every rank holds a complete engine with the full candidate batch and renders whole chunks (no candidate sharding)
+    tts = TextToSpeech(state_dicts=sds, dtype=args.dtype, max_candidates=N if read_mode else N // world, max_mel_tokens=max(M, 32),
+                       candidate_sharding=not read_mode)
     t_build = time.perf_counter() - t_build
+    S_audio = M * 4 * 24000 // 22050 * 256 / 24000.0  # seconds of audio per fixed-length utterance (api.py:122, hop 256 @ 24 kHz)
+    if read_mode:
+        from tortoise_tts_amd.longform import read_long_form
+        g = torch.Generator().manual_seed(4)
+        # tortoise/data/riding_hood.txt -> 15 chunks of 60-110 text tokens; synthetic ids of those lengths
+        chunks = [torch.randint(1, 255, (int(torch.randint(60, 111, (1,), generator=g)),), generator=g) for _ in range(15)]
 
-    def run_step(i=0):
-        return tts.tts_with_preset(text, preset=args.preset, conditioning_latents=latents, max_mel_tokens=M,
-                                   use_deterministic_seed=1000 + i, k=1, verbose=False)
+        def run_step(i=0):
+            full, _ = read_long_form(tts, chunks, preset=args.preset, conditioning_latents=latents, seed=1000 + i, texts_are_chunks=True,
+                                     max_mel_tokens=M, verbose=False)
+            return full
+        audio_per_step = len(chunks) * S_audio
+    else:
+        def run_step(i=0):
+            return tts.tts_with_preset(text, preset=args.preset, conditioning_latents=latents, max_mel_tokens=M,
+                                       use_deterministic_seed=1000 + i, k=1, verbose=False)
+        audio_per_step = S_audio
 
     wav = None
     for i in range(args.warmup):
@@ -215,29 +258,33 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = tdist.max_over_ranks(dt)
-    audio_s = float(wav.shape[-1]) / 24000.0
-    assert torch.isfinite(wav).all() and wav.abs().max() <= 1.0
+    audio_s = audio_per_step
+    if rank == 0:  # rendered audio lives on rank 0 only
+        assert abs(float(wav.shape[-1]) / 24000.0 - audio_s) < 1e-6, (wav.shape, audio_s)
+        assert torch.isfinite(wav).all() and wav.abs().max() <= 1.0
 
     roof, breakdown, cpu = None, [], None
-    if not args.no_roofline:
+    if not args.no_roofline and not read_mode:
         roof, breakdown = roofline_leg(tts, lambda: run_step(999))  # every rank runs it (the step contains a collective)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not read_mode:
         cores = min(os.cpu_count() or 1, 64)
         cpu = cpu_baseline(sds, text, latents, preset_kw, M, cores)
 
     if rank == 0:
         out = {
-            "metric": "rtf_standard_preset", "value": audio_s * args.steps / dt, "unit": "audio-s/wall-s",
+            "metric": "rtf_standard_preset" if not read_mode else "rtf_longform_read", "value": audio_s * args.steps / dt, "unit": "audio-s/wall-s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "latency_s": dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"tts_with_preset('{args.preset}'): {N} AR candidates x {M} mel tokens (EOS suppressed, fixed length), "
+            "config": {"workload": ("read.py long-form: 15 chunks per step, each = " if read_mode else "") +
+                                   f"tts_with_preset('{args.preset}'): {N} AR candidates x {M} mel tokens (EOS suppressed, fixed length), "
                                    f"CLVP top-1, {preset_kw['diffusion_iterations']} diffusion iterations cond_free={preset_kw.get('cond_free', True)}, "
                                    f"UnivNet; 55 text tokens; {audio_s:.2f} s of 24 kHz audio per step",
                        "weights": "seeded synthetic at the reference hyper-parameters (no checkpoints offline)",
-                       "parallelism": f"candidates sharded {N // world}/GPU, 1 all_gather of scores+codes, "
-                                      + ("winner's diffusion tail split over ranks 0/1 (one denoiser row each, 1 exchange per step), vocoder on rank 0"
-                                         if tts.split_diffusion else "winner rendered on rank 0")},
+                       "parallelism": (f"chunk j on rank j % {world} (replicas, complete pipeline per rank), clips sent to rank 0" if read_mode else
+                                       f"candidates sharded {N // world}/GPU, 1 all_gather of scores+codes, "
+                                       + ("winner's diffusion tail split over ranks 0/1 (one denoiser row each, 1 exchange per step), vocoder on rank 0"
+                                          if tts.split_diffusion else "winner rendered on rank 0"))},
             "stages_s_per_step": {k_: v / args.steps for k_, v in stage_acc.items()},
             "audio_seconds_per_step": audio_s, "engine_build_s": t_build,
             "roofline": roof, "cpu_baseline": cpu,

@@ -17,28 +17,49 @@ for set in "${SETS[@]}"; do
   echo "pmc [$set] rc=$?" | tee -a $OUT/summary.txt
 done
 OUT=$OUT PMC_JSON=${PMC_JSON:-pmc_bench.json} python - <<'PY'
-import csv, glob, collections, json, os, re
+import csv, glob, collections, json, os, re, sys
+sys.path.insert(0, os.getcwd())
 out = os.environ["OUT"]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+
+
+def klass(k):
+    """rocprofv3 kernel name -> the engine profiler's class name (tortoise_tts_amd/csrc/common.hip g_prof_names)."""
+    m = re.search(r"gemm_glds_kernelI\w+?Li(\d+)ELi(\d+)ELi\d+ELi\d+ENS_\d+(EpiStd|EpiQkvHeads|EpiQkvDecode)\w*?EELb([01])ELb[01]E", k)
+    if m:
+        bm, bn, epi, conv = m.groups()
+        return "gemm_glds<%s,%s,%s%s>" % (bm, bn, epi, (",conv" if conv == "1" else ",1x1") if epi == "EpiStd" else "")
+    if "gemm_glds_kernel" in k:
+        m = re.search(r"gemm_glds_kernel<[^,]+, (\d+), (\d+), \d+, \d+, tt::(\w+)<[^>]+>, (true|false)", k)
+        if m:
+            bm, bn, epi, conv = m.groups()
+            return "gemm_glds<%s,%s,%s%s>" % (bm, bn, epi, (",conv" if conv == "true" else ",1x1") if epi == "EpiStd" else "")
+        return "gemm_glds<?>"
+    for pat, name in (("flash_lds_kernel", "flash_kernel"), ("flash_kernel", "flash_kernel"), ("decode_attn_kernel", "decode_attn_kernel"),
+                      ("gn_apply", "gn_apply_kernel(+gn_stats)"), ("gn_stats", "gn_apply_kernel(+gn_stats)"), ("rownorm", "rownorm_kernel"),
+                      ("sample_kernel", "sample_kernel"), ("lvc_kernel", "lvc_kernel"), ("conv1d_direct", "conv1d_direct_kernel"), ("convt1d", "convt1d_kernel")):
+        if pat in k:
+            return name
+    return None
+
+
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"]
-        m = re.search(r"(gemm_glds_kernel|gemm_kernel|flash_kernel|decode_attn_kernel|gn_apply\w*|gn_stats\w*|rownorm\w*|sample_kernel|lvc_kernel)", k)
-        if not m:
+        name = klass(r["Kernel_Name"])
+        if not name:
             continue
-        name = m.group(1)
-        if name.startswith("gemm"):
-            t = re.search(r"Li(\d+)ELi(\d+)E", k)
-            e = re.search(r"(EpiStd|EpiQkvHeads|EpiQkvDecode)", k)
-            name = "gemm<%s,%s,%s>" % (t.group(1) if t else "?", t.group(2) if t else "?", e.group(1) if e else "?")
         a = agg[name][r["Counter_Name"]]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
 res = {}
 for k, cs in agg.items():
     res[k] = {c: {"dispatches": v[0], "sum": v[1], "avg": v[1] / max(v[0], 1)} for c, v in cs.items()}
+import bench
+res["_meta"] = {"source_digest": bench.source_digest(), "command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline (TT_NO_GRAPH=1)",
+                "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch as rocprofv3 reports them (FETCH_SIZE is doubled by bench.py)"}
 json.dump(res, open(out + "/../" + os.environ["PMC_JSON"], "w"), indent=1, sort_keys=True)
 for k in sorted(res):
-    print(k, {c: round(v["avg"], 1) for c, v in res[k].items()}, {c: v["dispatches"] for c, v in res[k].items()})
+    if k != "_meta":
+        print(k, {c: round(v["avg"], 1) for c, v in res[k].items()}, {c: v["dispatches"] for c, v in res[k].items()})
 PY
 find $OUT -name "*.csv" -size +1M -delete

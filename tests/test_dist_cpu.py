@@ -124,3 +124,55 @@ def _collect_worker(rank, world, port, out_dir):
 
 def test_rendered_winners_are_collected_on_rank0_only():
     mp.spawn(_collect_worker, args=(2, _free_port(), ""), nprocs=2, join=True)
+
+
+def _riding_hood_chunks():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "text_split.json")) as f:
+        chunks = json.load(f)[2]["chunks"]  # the reference's own 15 chunks of tortoise/data/riding_hood.txt
+    # pre-tokenised stand-ins (the BPE vocabulary is a reference data file that is not on every box): one id per character
+    return [[1 + (ord(c) % 250) for c in ch][:24] for ch in chunks]
+
+
+def _longform_worker(rank, world, port, out_dir):
+    """BASELINE config #4 on CPU stand-ins: chunk j is rendered by rank j % world with the complete (unsharded) pipeline."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    if world > 1:
+        tdist.init_from_env()
+    import pytest
+    from tests import fake_stages
+    from tests.test_api_flow_cpu import small_setup, voice_latents
+    mp_ = pytest.MonkeyPatch()
+    fake_stages.install(mp_)
+    try:
+        from tortoise_tts_amd.api import TextToSpeech
+        from tortoise_tts_amd.longform import read_long_form
+        sds, cfgs = small_setup()
+        tts = TextToSpeech(state_dicts=sds, configs=cfgs, max_candidates=8, max_mel_tokens=16, kv_cache=True, candidate_sharding=False)
+        calls = []
+        orig = tts.tts_with_preset
+        tts.tts_with_preset = lambda *a, **k: (calls.append(k.get("use_deterministic_seed")), orig(*a, **k))[1]
+        full, clips = read_long_form(tts, _riding_hood_chunks(), preset="ultra_fast", conditioning_latents=voice_latents(cfgs), seed=5,
+                                     texts_are_chunks=True, num_autoregressive_samples=2, diffusion_iterations=2, max_mel_tokens=10)
+        assert calls and all(c == 5 for c in calls)  # the same seed for every chunk (read.py:54, 70-71)
+        assert len(calls) == len([j for j in range(15) if j % world == rank])
+        if rank == 0:
+            assert len(clips) == 15 and full.shape[-1] == sum(c.shape[-1] for c in clips)
+            torch.save((full, clips), os.path.join(out_dir, f"longform_w{world}.pt"))
+        else:
+            assert full is None and clips is None
+    finally:
+        mp_.undo()
+    if world > 1:
+        tdist.barrier()
+        dist.destroy_process_group()
+
+
+def test_longform_chunks_spread_over_ranks_match_sequential(tmp_path):
+    _longform_worker(0, 1, 0, str(tmp_path))                                            # sequential, like read.py
+    mp.spawn(_longform_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)  # chunk j -> rank j % 2
+    f1, c1 = torch.load(tmp_path / "longform_w1.pt")
+    f2, c2 = torch.load(tmp_path / "longform_w2.pt")
+    assert torch.equal(f1, f2), "spreading the chunks over two ranks changed the audio"
+    assert all(torch.equal(a, b) for a, b in zip(c1, c2))  # chunk order preserved
+    assert len({tuple(c.flatten()[:64].tolist()) for c in c1}) > 1  # different chunks give different audio

@@ -102,7 +102,8 @@ class TextToSpeech:
 
     def __init__(self, autoregressive_batch_size=None, models_dir=MODELS_DIR, enable_redaction=True, kv_cache=False,
                  use_deepspeed=False, half=False, device=None, tokenizer_vocab_file=None, tokenizer_basic=False, *,
-                 state_dicts=None, dtype=None, max_candidates=256, configs=None, max_mel_tokens=500, max_text_tokens=402):
+                 state_dicts=None, dtype=None, max_candidates=256, configs=None, max_mel_tokens=500, max_text_tokens=402,
+                 candidate_sharding=True):
         self.models_dir = models_dir
         if use_deepspeed:
             raise NotImplementedError("use_deepspeed: DeepSpeed kernel injection is a CUDA-only reference option; the MI355X engine "
@@ -112,7 +113,9 @@ class TextToSpeech:
         self.enable_redaction = bool(enable_redaction)
         self.kv_cache = bool(kv_cache)
         self.half = bool(half)
-        self.rank, self.world = tdist.world()
+        # candidate_sharding=False: this instance renders whole utterances on its own GPU even inside a multi-rank job (the
+        # long-form driver spreads CHUNKS over the ranks instead: tortoise_tts_amd/longform.py, BASELINE config #4)
+        self.rank, self.world = tdist.world() if candidate_sharding else (0, 1)
         # With >= 2 ranks a single winner's diffusion tail is split over ranks 0 and 1 (conditioned / conditioning-free
         # row each, one exchange per step).  TT_SPLIT_DIFFUSION=0 keeps the whole tail on rank 0.
         self.split_diffusion = self.world >= 2 and os.environ.get("TT_SPLIT_DIFFUSION", "1") != "0"
@@ -204,7 +207,8 @@ class TextToSpeech:
     def deterministic_state(self, seed=None):
         """api.py:598-609."""
         seed = int(torch.seed() % (2 ** 31)) if seed is None else int(seed)
-        seed = tdist.broadcast_int(seed)  # every rank must draw the same noise and key the same Philox streams
+        if self.world > 1:
+            seed = tdist.broadcast_int(seed)  # every rank must draw the same noise and key the same Philox streams
         torch.manual_seed(seed)
         random.seed(seed)
         return seed
@@ -282,7 +286,7 @@ class TextToSpeech:
         # ---- CLVP ranking (api.py:447-477) + the one collective of the path
         fixed = fix_autoregressive_output(samples, stop)
         scores = self.clvp.score(text_tokens, fixed)
-        scores_all, codes_all = tdist.gather_candidates(scores, fixed.to(torch.int32))
+        scores_all, codes_all = tdist.gather_candidates(scores, fixed.to(torch.int32)) if self.world > 1 else (scores, fixed.to(torch.int32))
         best = tdist.topk_lowest_index(scores_all, k)
         best_results = codes_all[best].long()
         self.last_best_codes = best_results  # the k ranked winners' codes (tests, sharding checks)
@@ -331,7 +335,8 @@ class TextToSpeech:
         self.timings = {"ar_s": ev.seconds(0, 1), "clvp_s": ev.seconds(1, 2), "latents_s": ev.seconds(2, 3),
                         "diffusion_s": ev.seconds(3, 4), "vocoder_s": ev.seconds(4, 5), "total_s": ev.seconds(0, 5)}
         # Rendered winners go to rank 0 only (the reference returns the audio to ONE caller); other ranks get None entries.
-        wavs = tdist.collect_on_rank0(wavs, k)
+        if self.world > 1:
+            wavs = tdist.collect_on_rank0(wavs, k)
         if wavs is None:
             res = None
             return (res, (seed, text, voice_samples, conditioning_latents)) if return_deterministic_state else res
