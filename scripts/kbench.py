@@ -123,6 +123,15 @@ def main():
                             print(f"decode {name:8s} M={M:3d} N={N} K={K} exp {label:38s} row pad {pad:3d} cold W: {us:7.2f} us {N * K * 2 / us / 1e3:7.1f} GB/s weights", flush=True)
                     us = gemm_exp(400, M, N, K, nw=1)
                     print(f"decode {name:8s} M={M:3d} N={N} K={K} exp {CFG[4]:38s} hot W: {us:7.2f} us", flush=True)
+    if "gemm_ablate" in which:
+        for name, N, K, sk in (("qkv", 3072, 1024, 1), ("fc", 4096, 1024, 1)):
+            nw = max(8, int(700e6 // (N * K * 2)))
+            for rep in range(2):
+                us = gemm_prod(256, N, K, splitk=sk, nw=nw)
+                print(f"ablate {name} M=256 PRODUCT cold W: {us:7.2f} us", flush=True)
+                for v, label in ((400, "exp 64x64"), (403, "exp 64x64 + bias quads behind the ring fill")):
+                    us = gemm_exp(v, 256, N, K, nw=nw)
+                    print(f"ablate {name} M=256 {label:46s} cold W: {us:7.2f} us", flush=True)
     if "attn" in which:
         for B in (256, 32):
             for tgen in (50, 100, 200):

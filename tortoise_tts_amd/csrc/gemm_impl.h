@@ -1,0 +1,740 @@
+// MFMA GEMM kernels for gfx950 (see gemm.h; instantiated per operand type by gemm_bf16.hip / gemm_f16.hip).
+//
+// One kernel family, gemm_glds_kernel: NW waves in a 2 x NW/2 grid, each wave owns a (BM/2) x (BN / (NW/2)) sub-tile built
+// from v_mfma_f32_16x16x32 fragments.  The MFMA is issued "swapped" (W fragment as the A operand, activation fragment as B)
+// so that a lane ends up holding four consecutive output columns n..n+3 of one row m: epilogue stores are 16 B (f32) /
+// 8 B (bf16).  Tiles move global -> LDS directly (global_load_lds_dwordx4, no register stage, no ds_write), XOR-swizzled on
+// the source side; conv taps shift the source rows per k-tile and read a zero page for the sequence-edge padding.
+//
+// What the kernel is paid for at this engine's shapes (M = 256 decode rows, M = 1740 denoiser rows) is latency, not
+// bandwidth: a launch lasts 5 - 30 us and ~80 000 of them make one utterance, so everything between the first instruction
+// and the first tile request is on the critical path of every launch.  Hence:
+//   * the device-side argument block (GemmDev) is compact, hot fields first, so the prologue is ONE scalar-memory round
+//     trip instead of a chain of dependent kernarg loads;
+//   * every integer division in the prologue / k-loop / epilogue is a multiply-high by a host-computed reciprocal;
+//   * the features that a launch does not use (activation switch, GroupNorm statistics, second activation source) are
+//     compiled out in the "fast" instantiations (template value 0 / 1); the value -1 keeps the run-time test (generic
+//     kernel: odd alignments, rare activations, tile-packed weights).
+#pragma once
+#include "gemm.h"
+
+namespace tt {
+
+// ---------------------------------------------------------------------------------------------- reciprocal division
+struct FastDiv {
+  unsigned d, m;  // m = floor(2^32 / d) (0xFFFFFFFF for d == 1): q = mulhi(n, m) is floor(n / d) or one less
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d ? d : 1u;
+  f.m = f.d == 1u ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / f.d);
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f, unsigned& rem) {
+  unsigned q = __umulhi(n, f.m);
+  unsigned r = n - q * f.d;
+  const bool up = r >= f.d;
+  q += up ? 1u : 0u;
+  rem = up ? r - f.d : r;
+  return q;
+}
+
+// ---------------------------------------------------------------------------------------------- device argument block
+struct GemmCore {
+  const void* A;           // 0
+  const void* W;           // 8
+  int lda, ldw;            // 16
+  int M, N;                // 24
+  int cin_tiles;           // 32  k-tiles per conv tap (= all k-tiles for a plain GEMM)
+  int taps_half;           // 36  taps / 2
+  int seq_len;             // 40
+  int w_tile_stride;       // 44  elements between consecutive k-tiles of a W row (64, or 4096 when tile-packed)
+  FastDiv seq;             // 48  / seq_len
+  unsigned xq, xr;         // 56  workgroups / 8, workgroups % 8
+  unsigned gx, gy;         // 64  row tiles, column tiles
+  unsigned hb, last_band;  // 72  row tiles per XCD band, index of the last band
+  FastDiv band;            // 80  / (hb * gy)
+  FastDiv hfull;           // 88  / hb
+  FastDiv hlast;           // 96  / (row tiles of the last band)
+  int sk_quot, sk_rem;     // 104 k-tiles per split-K slab (quotient, remainder)
+  int w_packed, n_pad;     // 112
+  // second activation source (HA2): k-tiles >= a2_tile read A2
+  const void* A2;          // 120
+  const int* a2_slot;      // 128
+  size_t a2_slot_stride;   // 136
+  int lda2, a2_tile;       // 144
+};
+
+struct EpiStdArgs {
+  const float* bias;
+  const float* res;
+  float* out_f32;
+  void* out_t;
+  float* gn_part;
+  int ldres, ldo32, ldot, act;
+  float slope;
+  int splitk;
+  int gn_ncol16;
+  FastDiv gn_seq;
+};
+struct EpiQkvHeadsArgs {
+  const float* bias;
+  void* q; void* k; void* v; void* vt;
+  int heads, seq_pad;
+  float q_scale;
+  FastDiv dmodel;
+};
+struct EpiQkvDecodeArgs {
+  const float* bias;
+  const int* step;
+  void* qbuf; void* kc; void* vc;
+  int heads, tmax, dmodel_i;
+  float q_scale;
+  FastDiv dmodel;
+};
+template <typename EA>
+struct GemmDev {
+  GemmCore c;
+  EA e;
+};
+
+__device__ __forceinline__ float4 load_upto4(const float* p, int nvalid) {  // ragged / unaligned edge: element loads
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nvalid > 0) r.x = p[0];
+  if (nvalid > 1) r.y = p[1];
+  if (nvalid > 2) r.z = p[2];
+  if (nvalid > 3) r.w = p[3];
+  return r;
+}
+
+// Every epilogue is split in three so that the kernel can request the operands early (fetch: right behind the ring fill),
+// do ALL arithmetic in registers (apply) and issue ALL stores back to back (store).
+//   ACT   : -1 run-time switch on e.act, otherwise the compile-time activation
+//   STATS : -1 run-time test of e.gn_part, 0 never, 1 always (GroupNorm partial statistics, see run_epilogue)
+template <typename T, int ACT, int STATS>
+struct EpiStd {
+  typedef EpiStdArgs Args;
+  static constexpr int kId = 0;
+  static constexpr int kStats = STATS;
+  template <int FM, int FN> struct Ops { float4 bv[FN], rv[FN][FM]; __device__ __forceinline__ int step() const { return 0; } };
+
+  template <int FM, int FN, bool AL>
+  static __device__ __forceinline__ void fetch(const GemmCore& c, const Args& e, Ops<FM, FN>& o, int m0w, int n0w, int lane) {
+    const int fr = lane & 15, fg = lane >> 4;
+    const bool use_bias = e.bias != nullptr && e.splitk <= 1;
+    const bool use_res = e.res != nullptr && e.splitk <= 1;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int n = n0w + i * 16 + fg * 4;
+      const int nvalid = c.N - n >= 4 ? 4 : c.N - n;
+      o.bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < FM; ++j) o.rv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (AL) {
+        const int nc = max(min(n, c.N - 4), 0);
+        if (use_bias) o.bv[i] = *(const float4*)(e.bias + nc);
+        if (use_res) {
+#pragma unroll
+          for (int j = 0; j < FM; ++j) {
+            const int mc = min(m0w + j * 16 + fr, c.M - 1);
+            o.rv[i][j] = *(const float4*)(e.res + (size_t)mc * e.ldres + nc);
+          }
+        }
+      } else {
+        if (use_bias) o.bv[i] = load_upto4(e.bias + n, nvalid);
+        if (use_res) {
+#pragma unroll
+          for (int j = 0; j < FM; ++j) {
+            const int m = m0w + j * 16 + fr;
+            if (m < c.M) o.rv[i][j] = load_upto4(e.res + (size_t)m * e.ldres + n, nvalid);
+          }
+        }
+      }
+    }
+  }
+  static __device__ __forceinline__ void apply(const Args& e, f32x4& v, const float4& bv, const float4& rv) {
+    if (e.splitk > 1) return;  // raw partial sums; bias / activation / residual belong to the slab consumer
+    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    if (ACT < 0) {
+      if (e.act != ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], e.act, e.slope);
+      }
+    } else if (ACT != ACT_NONE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], ACT, e.slope);
+    }
+    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+  }
+  // AL (compile time): N % 4 == 0 and every operand / output row is 16-byte aligned, so every access is a whole quad
+  template <bool AL>
+  static __device__ __forceinline__ void store(const GemmCore& c, const Args& e, int, int m, int n, const f32x4& v, int nvalid, int z) {
+    if (e.splitk > 1) {
+      float* o = e.out_f32 + (size_t)z * c.M * e.ldo32 + (size_t)m * e.ldo32 + n;
+      if (AL || (nvalid == 4 && (e.ldo32 & 3) == 0)) {
+        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        for (int i = 0; i < nvalid; ++i) o[i] = v[i];
+      }
+      return;
+    }
+    if (e.out_f32) {
+      float* o = e.out_f32 + (size_t)m * e.ldo32 + n;
+      if (AL || (nvalid == 4 && (e.ldo32 & 3) == 0)) {
+        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        for (int i = 0; i < nvalid; ++i) o[i] = v[i];
+      }
+    }
+    if (e.out_t) {
+      T* o = (T*)e.out_t + (size_t)m * e.ldot + n;
+      if (AL || (nvalid == 4 && (e.ldot & 3) == 0)) {
+        *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
+      } else {
+        for (int i = 0; i < nvalid; ++i) o[i] = (T)v[i];
+      }
+    }
+  }
+};
+
+// N == 3 * dmodel, dmodel % 64 == 0: a wave's columns [n0w, n0w + TN), TN <= 64, never straddle a part or a head, so
+// (part, head) are wave-uniform per 16-column strip and only the row -> (batch, position) split is per lane.
+template <typename T>
+struct EpiQkvHeads {
+  typedef EpiQkvHeadsArgs Args;
+  static constexpr int kId = 1;
+  static constexpr int kStats = 0;
+  template <int FM, int FN> struct Ops { float4 bv[FN]; __device__ __forceinline__ int step() const { return 0; } };
+  template <int FM, int FN, bool AL>
+  static __device__ __forceinline__ void fetch(const GemmCore& c, const Args& e, Ops<FM, FN>& o, int, int n0w, int lane) {
+    const int fg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int nc = max(min(n0w + i * 16 + fg * 4, c.N - 4), 0);
+      o.bv[i] = e.bias ? *(const float4*)(e.bias + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  static __device__ __forceinline__ void apply(const Args&, f32x4& v, const float4& bv, const float4&) {
+    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+  }
+  template <bool AL>
+  static __device__ __forceinline__ void store(const GemmCore& c, const Args& e, int, int m, int n, const f32x4& v, int, int) {
+    unsigned cc, s;
+    const unsigned part = fdiv((unsigned)n, e.dmodel, cc);
+    const int h = cc >> 6, d = cc & 63;
+    const unsigned b = fdiv((unsigned)m, c.seq, s);
+    const size_t bh = (size_t)b * e.heads + h;
+    if (part == 0) {
+      T* o = (T*)e.q + (bh * c.seq_len + s) * 64 + d;
+      *(typename Vec<T>::x4*)o = pack4<T>(v[0] * e.q_scale, v[1] * e.q_scale, v[2] * e.q_scale, v[3] * e.q_scale);
+    } else if (part == 1) {
+      T* o = (T*)e.k + (bh * c.seq_len + s) * 64 + d;
+      *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
+    } else {
+      if (e.v) {
+        T* o = (T*)e.v + (bh * c.seq_len + s) * 64 + d;
+        *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
+      }
+      if (e.vt) {
+        T* o = (T*)e.vt + (bh * 64 + d) * e.seq_pad + s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[(size_t)i * e.seq_pad] = (T)v[i];
+      }
+    }
+  }
+};
+
+template <typename T>
+struct EpiQkvDecode {
+  typedef EpiQkvDecodeArgs Args;
+  static constexpr int kId = 2;
+  static constexpr int kStats = 0;
+  template <int FM, int FN> struct Ops { float4 bv[FN]; int t; __device__ __forceinline__ int step() const { return t; } };
+  template <int FM, int FN, bool AL>
+  static __device__ __forceinline__ void fetch(const GemmCore& c, const Args& e, Ops<FM, FN>& o, int, int n0w, int lane) {
+    const int fg = lane >> 4;
+    o.t = *e.step;  // KV slot of this step (device-side counter: the captured graph is step-invariant)
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int nc = max(min(n0w + i * 16 + fg * 4, c.N - 4), 0);
+      o.bv[i] = e.bias ? *(const float4*)(e.bias + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  static __device__ __forceinline__ void apply(const Args&, f32x4& v, const float4& bv, const float4&) {
+    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+  }
+  template <bool AL>
+  static __device__ __forceinline__ void store(const GemmCore&, const Args& e, int t, int m, int n, const f32x4& v, int, int) {
+    unsigned cc;
+    const unsigned part = fdiv((unsigned)n, e.dmodel, cc);
+    const int h = cc >> 6, d = cc & 63;
+    const size_t bh = (size_t)m * e.heads + h;
+    if (part == 0) {
+      T* o = (T*)e.qbuf + (size_t)m * e.dmodel_i + cc;
+      *(typename Vec<T>::x4*)o = pack4<T>(v[0] * e.q_scale, v[1] * e.q_scale, v[2] * e.q_scale, v[3] * e.q_scale);
+    } else if (part == 1) {
+      T* o = (T*)e.kc + ((bh * 8 + (d >> 3)) * e.tmax + t) * 8 + (d & 7);
+      *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
+    } else {
+      T* o = (T*)e.vc + (bh * e.tmax + t) * 64 + d;
+      *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+  }
+};
+
+// Epilogue.  With GroupNorm statistics on (EPI_STD, f32 output feeding a GroupNorm32) every wave also emits (sum, sum of
+// squares) of the values it just produced, per 16-column strip of its TM-row tile:
+// gn_part[row_tile][slot][n / 16][2], slot 1 = rows that belong to the NEXT sequence when the row tile straddles a
+// sequence boundary.  The GroupNorm apply kernel adds these up in a fixed order (deterministic), which removes the separate
+// statistics pass over the tensor.
+template <typename Epi, int FM, int FN, int TM, int TN, bool AL, typename Ops>
+__device__ __forceinline__ void run_epilogue(const GemmCore& c, const typename Epi::Args& e, f32x4 (&acc)[FN][FM], const Ops& o, int step_t,
+                                             int m0w, int n0w, int lane, int z) {
+  const int fr = lane & 15, fg = lane >> 4;
+  bool stats = false;
+  if constexpr (Epi::kId == 0) {
+    if constexpr (Epi::kStats < 0) stats = e.gn_part != nullptr && e.splitk <= 1;
+    else stats = Epi::kStats > 0;
+  }
+  const int rt = m0w / TM;  // row-tile index (m0w is a multiple of TM, a power of two)
+  int next_start = 0x7fffffff, b_first = 0;
+  if constexpr (Epi::kId == 0) {
+    if (stats) {
+      unsigned r_;
+      b_first = (int)fdiv((unsigned)m0w, e.gn_seq, r_);
+      next_start = (b_first + 1) * (int)e.gn_seq.d;  // first row of the next sequence
+    }
+  }
+  // phase 2: arithmetic and GroupNorm partial statistics, registers only
+  float s0[FN], q0[FN], s1[FN], q1[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int n = n0w + i * 16 + fg * 4;
+    const int nvalid = c.N - n >= 4 ? 4 : c.N - n;
+    s0[i] = q0[i] = s1[i] = q1[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = m0w + j * 16 + fr;
+      if constexpr (Epi::kId == 0) Epi::apply(e, acc[i][j], o.bv[i], o.rv[i][j]);
+      else Epi::apply(e, acc[i][j], o.bv[i], make_float4(0.f, 0.f, 0.f, 0.f));
+      if (stats) {
+        float sv = 0.f, qv = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ev = (r < nvalid && m < c.M) ? acc[i][j][r] : 0.f;
+          sv += ev;
+          qv += ev * ev;
+        }
+        const bool first = m < next_start;
+        s0[i] += first ? sv : 0.f;
+        q0[i] += first ? qv : 0.f;
+        s1[i] += first ? 0.f : sv;
+        q1[i] += first ? 0.f : qv;
+      }
+    }
+  }
+  // phase 3: stores, back to back
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int n = n0w + i * 16 + fg * 4;
+    const int nvalid = c.N - n >= 4 ? 4 : c.N - n;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = m0w + j * 16 + fr;
+      if (m < c.M && n < c.N) Epi::template store<AL>(c, e, step_t, m, n, acc[i][j], nvalid, z);
+    }
+  }
+  if constexpr (Epi::kId == 0) {
+    if (stats) {
+      const bool straddle = m0w + TM - 1 >= next_start;  // wave-uniform
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int n16 = (n0w + i * 16) >> 4;
+        if (n0w + i * 16 < c.N) {
+          const float a0 = wave_sum(s0[i]), b0 = wave_sum(q0[i]);
+          float a1 = 0.f, b1 = 0.f;
+          if (straddle) {
+            a1 = wave_sum(s1[i]);
+            b1 = wave_sum(q1[i]);
+          }
+          if (lane == 0) {
+            float* p = e.gn_part + (((size_t)rt * 2 + 0) * e.gn_ncol16 + n16) * 2;
+            *(float2*)p = make_float2(a0, b0);
+            float* p1 = e.gn_part + (((size_t)rt * 2 + 1) * e.gn_ncol16 + n16) * 2;
+            *(float2*)p1 = make_float2(a1, b1);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Direct-to-LDS staging (global_load_lds_dwordx4): tiles go HBM/L2 -> LDS without passing through VGPRs or
+// ds_write instructions.  A wave instruction fills 1 KiB = 8 rows x 128 B, lane-linear, so rows are
+// unpadded; bank conflicts are removed by an XOR swizzle applied on the SOURCE side: LDS chunk c of row r
+// holds global 16-byte chunk c ^ ((r >> 1) & 7), and fragment reads apply the same involution.
+// Conv padding / out-of-range rows cannot be zero-filled by a select any more: those lanes read a 16-byte
+// zero page instead.
+static __device__ __attribute__((aligned(16))) unsigned int g_zero_page[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+// HA2: second activation source: -1 run-time test of c.A2, 0 never, 1 always
+template <typename T, int BM, int BN, int NW, int ST, typename Epi, bool CONV, bool AL, int HA2>
+__global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typename Epi::Args> g) {
+  typedef typename Vec<T>::x8 x8;
+  constexpr int BK = 64;
+  constexpr int WGN = NW / 2;
+  constexpr int TM = BM / 2, TN = BN / WGN;
+  constexpr int FM = TM / 16, FN = TN / 16;
+  constexpr int PA = BM / 8 / NW, PW = BN / 8 / NW;  // 1-KiB pieces (8 rows) per wave per stage
+  static_assert(PA >= 1 && PW >= 1, "tile too small for this many waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* As = (T*)smem_raw;             // [ST][BM][64]
+  T* Ws = As + ST * BM * BK;        // [ST][BN][64]
+  const GemmCore& c = g.c;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  // XCD-aware tile order.  Hardware deals workgroup i to XCD i % 8, each with a private 4 MiB L2, and everything that is
+  // not in the LOCAL L2 arrives over the fabric at HBM-like bandwidth (~6.5 TB/s for the whole chip, Infinity-Cache hits
+  // included: scripts/kbench.py bw).  So the tile grid is cut into row bands and every XCD owns a contiguous run of
+  // (band, column, row-in-band)-ordered tiles, i.e. a rectangle of about (gx / bands) x (8 gy / ...) tiles: it pulls
+  // A / bands + W * bands / 8 over the fabric instead of all of A (one band, the decode shapes where A is tiny) or all
+  // of W (8 bands).  gemm_launch picks the band count to minimise that sum.  The grid is one-dimensional
+  // (gx * gy workgroups, z = split-K slab) and every division is a multiply-high by a host-computed reciprocal.
+  unsigned bx, by;
+  {
+    const unsigned id = blockIdx.x;
+    const unsigned xcd = id & 7, loc = id >> 3;
+    const unsigned nid = xcd * c.xq + min(xcd, c.xr) + loc;
+    unsigned rem, rr;
+    const unsigned band = fdiv(nid, c.band, rem);
+    const bool lastb = band == c.last_band;
+    FastDiv hd;
+    hd.d = lastb ? c.hlast.d : c.hfull.d;
+    hd.m = lastb ? c.hlast.m : c.hfull.m;
+    by = fdiv(rem, hd, rr);
+    bx = band * c.hb + rr;
+  }
+  const int m0 = bx * BM, n0 = by * BN;
+  const int z = blockIdx.z;
+  // split-K slab z covers k-tiles [kt_begin, kt_end): nk_total / splitk each, the first nk_total % splitk slabs one more.
+  const int kt_begin = z * c.sk_quot + min(z, c.sk_rem);
+  const int kt_end = kt_begin + c.sk_quot + (z < c.sk_rem ? 1 : 0);
+  const T* A = (const T*)c.A;
+  const T* W = (const T*)c.W;
+  const T* zero = (const T*)g_zero_page;
+  const T* A2 = nullptr;
+  if constexpr (!CONV && HA2 != 0) {
+    if (HA2 > 0 || c.A2) A2 = (const T*)c.A2 + (c.a2_slot ? (size_t)(*c.a2_slot) * c.a2_slot_stride : 0);
+  }
+
+  // per-piece lane geometry: this lane fills LDS chunk lc of row (piece * 8 + lr) with global chunk lc ^ swz(row)
+  const int lr = lane >> 3, lc = lane & 7;
+  int a_b[PA], a_s[PA], a_src[PA];
+  bool a_ok[PA];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int row = (wave + NW * p) * 8 + lr;
+    a_src[p] = (lc ^ ((row >> 1) & 7)) * 8;
+    const int m = m0 + row;
+    a_ok[p] = m < c.M;
+    if (CONV) {
+      unsigned s_;
+      a_b[p] = (int)fdiv((unsigned)m, c.seq, s_);
+      a_s[p] = (int)s_;
+    } else {
+      a_b[p] = 0;
+      a_s[p] = a_ok[p] ? m : 0;  // rows beyond M re-read row 0: their outputs are never stored
+    }
+  }
+  const T* w_ptr[PW];
+#pragma unroll
+  for (int p = 0; p < PW; ++p) {
+    const int row = (wave + NW * p) * 8 + lr;
+    const int n = n0 + row;
+    if (HA2 < 0 && c.w_packed) {  // (generic kernel only)
+      // tile-packed weights [N/64][K/64][64][64]: every 64x64 k-tile of a column panel is one contiguous 8 KiB block
+      const int nc = n < c.n_pad ? n : c.n_pad - 1;
+      w_ptr[p] = W + ((size_t)(nc >> 6) * c.cin_tiles * 64 + (nc & 63)) * 64 + (lc ^ ((row >> 1) & 7)) * 8;
+    } else {
+      w_ptr[p] = W + (size_t)(n < c.N ? n : c.N - 1) * c.ldw + (lc ^ ((row >> 1) & 7)) * 8;
+    }
+  }
+  const int w_tile_stride = HA2 < 0 ? c.w_tile_stride : BK;
+
+  // k-tile cursor of the NEXT tile to request: (it, tap, k-tile within the tap).  Advanced incrementally (no division
+  // in the loop); it stops at the last tile, which is then re-requested into a ring slot that is never read again.
+  const int last = kt_end - 1;
+  int it = min(kt_begin, last), it_tap = 0, it_kin = it;
+  if (CONV && it > 0) {  // conv + split-K only: one real division, off the common path
+    it_tap = it / c.cin_tiles;
+    it_kin = it - it_tap * c.cin_tiles;
+  }
+  auto issue = [&](int buf) {
+    const int kin = it_kin * BK;
+    const int shift = it_tap - c.taps_half;
+    T* as = As + buf * BM * BK;
+    T* ws = Ws + buf * BN * BK;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const T* src;
+      if (CONV) {
+        const int s2 = a_s[p] + shift;
+        const bool ok = a_ok[p] && s2 >= 0 && s2 < c.seq_len;
+        src = ok ? A + ((size_t)a_b[p] * c.seq_len + s2) * c.lda + kin + a_src[p] : zero;
+      } else if (HA2 != 0) {
+        const bool second = A2 != nullptr && it >= c.a2_tile;  // block-uniform: k-tiles never straddle k_split (multiple of 64)
+        src = second ? A2 + (size_t)a_s[p] * c.lda2 + (kin - c.a2_tile * BK) + a_src[p] : A + (size_t)a_s[p] * c.lda + kin + a_src[p];
+      } else {
+        src = A + (size_t)a_s[p] * c.lda + kin + a_src[p];
+      }
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(as + (wave + NW * p) * 8 * BK), 16, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < PW; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_ptr[p] + (size_t)it * w_tile_stride), (lds_void_t*)(ws + (wave + NW * p) * 8 * BK), 16, 0, 0);
+    if (it < last) {
+      ++it;
+      ++it_kin;
+      if (CONV && it_kin == c.cin_tiles) {
+        it_kin = 0;
+        ++it_tap;
+      }
+    }
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typename Epi::template Ops<FM, FN> eo;
+
+  const int fr = lane & 15, fg = lane >> 4;
+  auto compute = [&](int buf) {
+    const T* as = As + buf * BM * BK;
+    const T* ws = Ws + buf * BN * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      x8 fa[FM], fw[FN];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int r = wm * TM + j * 16 + fr;
+        fa[j] = *(const x8*)(as + r * BK + (((ks * 4 + fg) ^ ((r >> 1) & 7)) * 8));
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int r = wn * TN + i * 16 + fr;
+        fw[i] = *(const x8*)(ws + r * BK + (((ks * 4 + fg) ^ ((r >> 1) & 7)) * 8));
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
+    }
+  };
+
+  if constexpr (ST == 2) {
+    // two-stage variant: every barrier drains the queue anyway, so the epilogue operands go out with the first tile
+    // (inside the loop, even on the last iteration only, the request de-pipelines the loop: CLVP 0.033 -> 0.037 s)
+    issue(0);
+    Epi::template fetch<FM, FN, AL>(c, g.e, eo, m0 + wm * TM, n0 + wn * TN, lane);
+    __syncthreads();  // (drains the LDS-DMA: hipcc emits vmcnt(0) before the barrier while a global_load_lds is pending)
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      if (kt + 1 < kt_end) issue(cur ^ 1);
+      compute(cur);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    // ST-stage ring, ST-1 tiles in flight.  One raw barrier per k-step; the wait is a COUNTED vmcnt so the
+    // newer stages stay in flight across the barrier (a __syncthreads() here would drain them: vmcnt(0)).
+    // Every iteration issues exactly G loads (tile index clamped; a redundant reload targets the ring slot
+    // that was consumed last iteration and is never read again), which keeps the count uniform in the tail.
+    constexpr int G = PA + PW;
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s) issue(s);
+    // Bias / residual operands are requested AFTER the ring fill: memory operations retire in order, so a residual quad
+    // requested first would have to land before the first k-step may start; here it only has to land before stage ST - 1
+    // is consumed (the counted waits below over-wait by these few loads during the first two k-steps, nothing more).
+    Epi::template fetch<FM, FN, AL>(c, g.e, eo, m0 + wm * TM, n0 + wn * TN, lane);
+    int slot = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * G) : "memory");
+      __builtin_amdgcn_s_barrier();
+      int nslot = slot + ST - 1;
+      if (nslot >= ST) nslot -= ST;
+      issue(nslot);
+      compute(slot);
+      slot = slot + 1 == ST ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+
+  run_epilogue<Epi, FM, FN, TM, TN, AL>(c, g.e, acc, eo, eo.step(), m0 + wm * TM, n0 + wn * TN, lane, z);
+}
+
+
+// ---------------------------------------------------------------------------------------------- host side (per operand type)
+enum Tile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2 };
+// EPI_STD kernel variants: the generic one tests everything at run time, the others compile the unused features out
+enum StdVariant { V_GEN = 0, V_NONE = 1, V_GELU = 2, V_STATS = 3, V_STATS_A2 = 4, V_COUNT = 5 };
+constexpr int kNoKernel = -100;  // visit_*: this combination is not instantiated
+
+struct GemmPlan {   // what gemm_launch (gemm.hip) decided: tile, grid, the device argument core
+  GemmCore core;
+  int tile;
+  int splitk;
+  int prof_id;
+  double flops, bytes;
+};
+
+template <int BM, int BN, int ST>
+constexpr int smem_bytes_glds() {
+  return ST * (BM + BN) * 64 * 2;
+}
+
+template <typename T, int BM, int BN, int NW, int ST, typename Epi, bool CONV, bool AL, int HA2>
+struct KernelRef {
+  typedef typename Epi::Args EA;
+  static constexpr int smem = smem_bytes_glds<BM, BN, ST>();
+  static constexpr int threads = NW * 64;
+  static const void* fn() { return (const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, CONV, AL, HA2>; }
+  static void launch(dim3 grid, hipStream_t s, const GemmDev<EA>& d) {
+    gemm_glds_kernel<T, BM, BN, NW, ST, Epi, CONV, AL, HA2><<<grid, dim3(NW * 64), smem, s>>>(d);
+  }
+};
+
+// v(KernelRef) is called for the EPI_STD instantiation (tile, variant, conv, al); kNoKernel when that one does not exist
+template <typename T, int BM, int BN, int NW, int ST, typename V>
+static int visit_std_tile(int variant, bool conv, bool al, V&& v) {
+  switch (variant) {
+    case V_GEN:
+      if (conv) return al ? v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, -1, -1>, true, true, -1>{}) : v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, -1, -1>, true, false, -1>{});
+      return al ? v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, -1, -1>, false, true, -1>{}) : v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, -1, -1>, false, false, -1>{});
+    case V_NONE:
+      if (!al) return kNoKernel;
+      return conv ? v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, ACT_NONE, 0>, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, ACT_NONE, 0>, false, true, 0>{});
+    case V_GELU:
+      if (!al || conv) return kNoKernel;
+      return v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, ACT_GELU_TANH, 0>, false, true, 0>{});
+    case V_STATS:
+      if (!al) return kNoKernel;
+      return conv ? v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, ACT_NONE, 1>, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, ACT_NONE, 1>, false, true, 0>{});
+    case V_STATS_A2:
+      if (!al || conv) return kNoKernel;
+      return v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, ACT_NONE, 1>, false, true, 1>{});
+  }
+  return kNoKernel;
+}
+template <typename T, typename V>
+static int visit_std(int tile, int variant, bool conv, bool al, V&& v) {
+  switch (tile) {
+    case TILE_128x128: return visit_std_tile<T, 128, 128, 8, 2>(variant, conv, al, v);
+    case TILE_128x64: return visit_std_tile<T, 128, 64, 8, 4>(variant, conv, al, v);
+    default: return visit_std_tile<T, 64, 64, 4, 4>(variant, conv, al, v);
+  }
+}
+template <typename T, typename Epi, typename V>
+static int visit_qkv(int tile, V&& v) {
+  switch (tile) {
+    case TILE_128x128: return v(KernelRef<T, 128, 128, 8, 2, Epi, false, true, 0>{});
+    case TILE_128x64: return v(KernelRef<T, 128, 64, 8, 4, Epi, false, true, 0>{});
+    default: return v(KernelRef<T, 64, 64, 4, 4, Epi, false, true, 0>{});
+  }
+}
+
+static inline EpiStdArgs make_epi_std(const GemmArgs& a) {
+  EpiStdArgs e;
+  memset(&e, 0, sizeof(e));
+  e.bias = a.bias; e.res = a.res; e.out_f32 = a.out_f32; e.out_t = a.out_t; e.gn_part = a.gn_part;
+  e.ldres = a.ldres; e.ldo32 = a.ldo32; e.ldot = a.ldot; e.act = a.act; e.slope = a.slope; e.splitk = a.splitk;
+  e.gn_ncol16 = a.gn_ncol16;
+  e.gn_seq = make_fastdiv(a.gn_seq > 0 ? a.gn_seq : 1);
+  return e;
+}
+
+template <typename T>
+int gemm_launch_typed(int epi, const GemmArgs& a, const GemmPlan& plan, hipStream_t stream) {
+  const dim3 grid(plan.core.gx * plan.core.gy, 1, plan.splitk);
+  ProfScope ps(plan.prof_id, stream, plan.flops, plan.bytes);
+  int rc = kNoKernel;
+  if (epi == EPI_STD) {
+    GemmDev<EpiStdArgs> d;
+    d.c = plan.core;
+    d.e = make_epi_std(a);
+    // aligned fast path: whole-quad operand fetches and stores with no per-element fallback code in the kernel
+    const bool al = (a.N & 3) == 0 && a.N >= 4 && (!a.bias || ((size_t)a.bias & 15) == 0) &&
+                    (!a.res || (((size_t)a.res & 15) == 0 && (a.ldres & 3) == 0)) &&
+                    (!a.out_f32 || (((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0)) && (!a.out_t || (((size_t)a.out_t & 7) == 0 && (a.ldot & 3) == 0));
+    const bool conv = a.taps > 1, stats = a.gn_part != nullptr, a2 = a.A2 != nullptr;
+    int variant = V_GEN;
+    if (al && !a.w_packed) {
+      if (a.act == ACT_NONE) variant = a2 ? (stats ? V_STATS_A2 : V_GEN) : (stats ? V_STATS : V_NONE);
+      else if (a.act == ACT_GELU_TANH && !a2 && !stats) variant = V_GELU;
+    }
+    auto go = [&](auto kr) -> int {
+      decltype(kr)::launch(grid, stream, d);
+      return 0;
+    };
+    rc = visit_std<T>(plan.tile, variant, conv, al, go);
+    if (rc == kNoKernel) rc = visit_std<T>(plan.tile, V_GEN, conv, al, go);
+  } else if (epi == EPI_QKV_HEADS) {
+    GemmDev<EpiQkvHeadsArgs> d;
+    d.c = plan.core;
+    memset(&d.e, 0, sizeof(d.e));
+    d.e.bias = a.bias; d.e.q = a.q; d.e.k = a.k; d.e.v = a.v; d.e.vt = a.vt; d.e.heads = a.heads; d.e.seq_pad = a.seq_pad; d.e.q_scale = a.q_scale;
+    d.e.dmodel = make_fastdiv(a.dmodel);
+    rc = visit_qkv<T, EpiQkvHeads<T>>(plan.tile, [&](auto kr) -> int {
+      decltype(kr)::launch(grid, stream, d);
+      return 0;
+    });
+  } else if (epi == EPI_QKV_DECODE) {
+    GemmDev<EpiQkvDecodeArgs> d;
+    d.c = plan.core;
+    memset(&d.e, 0, sizeof(d.e));
+    d.e.bias = a.bias; d.e.step = a.step; d.e.qbuf = a.qbuf; d.e.kc = a.kc; d.e.vc = a.vc; d.e.heads = a.heads; d.e.tmax = a.tmax; d.e.dmodel_i = a.dmodel;
+    d.e.q_scale = a.q_scale;
+    d.e.dmodel = make_fastdiv(a.dmodel);
+    rc = visit_qkv<T, EpiQkvDecode<T>>(plan.tile, [&](auto kr) -> int {
+      decltype(kr)::launch(grid, stream, d);
+      return 0;
+    });
+  }
+  if (rc == kNoKernel) {
+    set_error("gemm: no kernel for epilogue %d tile %d", epi, plan.tile);
+    return -1;
+  }
+  TT_CHECK_HIP(hipGetLastError());
+  return rc;
+}
+
+// dynamic-LDS attribute of every instantiation this type can launch
+template <typename T>
+int gemm_init_typed() {
+  int bad = 0;
+  auto setattr = [&](auto kr) -> int {
+    if (hipFuncSetAttribute(decltype(kr)::fn(), hipFuncAttributeMaxDynamicSharedMemorySize, decltype(kr)::smem) != hipSuccess) ++bad;
+    return 0;
+  };
+  for (int tile = 0; tile < 3; ++tile) {
+    for (int variant = 0; variant < V_COUNT; ++variant)
+      for (int conv = 0; conv < 2; ++conv)
+        for (int al = 0; al < 2; ++al) (void)visit_std<T>(tile, variant, conv != 0, al != 0, setattr);
+    (void)visit_qkv<T, EpiQkvHeads<T>>(tile, setattr);
+    (void)visit_qkv<T, EpiQkvDecode<T>>(tile, setattr);
+  }
+  if (bad) {
+    set_error("gemm: hipFuncSetAttribute failed for %d kernel(s): %s", bad, hipGetErrorString(hipGetLastError()));
+    return -2;
+  }
+  return 0;
+}
+
+}  // namespace tt

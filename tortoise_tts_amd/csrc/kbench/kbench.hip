@@ -91,6 +91,7 @@ typedef __attribute__((address_space(1))) const void gbl_void_k;
 
 struct ExpArgs {
   const bf16* A; const bf16* W; bf16* out; int M, N, K, lda, ldw, ldo, taps, seq_len, cin;
+  const float* bias;  // MODE 3: f32 bias quads requested behind the ring fill, added in the epilogue
 };
 
 template <int BM, int BN, int WM, int WN, int ST, int MODE, int MINW, bool CONV>
@@ -189,6 +190,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_exp_kernel(ExpArgs g)
   const int last = nk - 1;
 #pragma unroll
   for (int s = 0; s < ST - 1; ++s) issue(min(s, last), s);
+  float4 bq[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) bq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == 3) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i) bq[i] = *(const float4*)(g.bias + min(n0 + wn * TN + i * 16 + fg * 4, g.N - 4));
+  }
   int slot = 0;
   if (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int kt = 0; kt < nk; ++kt) {
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_exp_kernel(ExpArgs g)
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
       const int m = m0 + wm * TM + j * 16 + fr, n = n0 + wn * TN + i * 16 + fg * 4;
-      if (m < g.M && n < g.N) *(Vec<bf16>::x4*)(g.out + (size_t)m * g.ldo + n) = pack4<bf16>(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (m < g.M && n < g.N) *(Vec<bf16>::x4*)(g.out + (size_t)m * g.ldo + n) = pack4<bf16>(acc[i][j][0] + bq[i].x, acc[i][j][1] + bq[i].y, acc[i][j][2] + bq[i].z, acc[i][j][3] + bq[i].w);
     }
 }
 
@@ -239,7 +247,8 @@ static int launch_variant(int variant, const ExpArgs& a, hipStream_t s) {
 #define V3(cfg, ...) \
     case cfg * 100 + 0: return launch_exp<__VA_ARGS__, 0, 1>(a, s); \
     case cfg * 100 + 1: return launch_exp<__VA_ARGS__, 1, 1>(a, s); \
-    case cfg * 100 + 2: return launch_exp<__VA_ARGS__, 2, 1>(a, s);
+    case cfg * 100 + 2: return launch_exp<__VA_ARGS__, 2, 1>(a, s); \
+    case cfg * 100 + 3: return launch_exp<__VA_ARGS__, 3, 1>(a, s);
     V3(0, 128, 64, 2, 4, 4)
     V3(1, 128, 64, 2, 2, 4)
     V3(3, 128, 64, 4, 2, 4)
@@ -272,8 +281,10 @@ int tt_kb_gemm_exp(int variant, int M, int N, int K, int taps, int seq_len, int 
   void* A = nullptr; void* out = nullptr;
   std::vector<void*> W(nw);
   const int lda = K / taps + pad, ldw = K + pad;
+  float* bias = nullptr;
   int rc = dev_bf16(ar, &A, (size_t)(M + 8) * lda, 1u);
   if (!rc) rc = ar.alloc(&out, (size_t)M * N * 2);
+  if (!rc) rc = dev_f32(ar, &bias, N + 64, 5u);
   for (int i = 0; i < nw && !rc; ++i) rc = dev_bf16(ar, &W[i], (size_t)N * ldw, 77u + i);
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
   if (!rc) rc = gt.run([&](hipStream_t s) -> int {
@@ -281,7 +292,7 @@ int tt_kb_gemm_exp(int variant, int M, int N, int K, int taps, int seq_len, int 
       ExpArgs a;
       memset(&a, 0, sizeof(a));
       a.A = (const bf16*)A; a.W = (const bf16*)W[i % nw]; a.out = (bf16*)out; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = N;
-      a.taps = taps; a.seq_len = seq_len > 0 ? seq_len : M; a.cin = K / taps;
+      a.taps = taps; a.seq_len = seq_len > 0 ? seq_len : M; a.cin = K / taps; a.bias = bias;
       TT_TRY(launch_variant(variant, a, s));
     }
     return 0;
