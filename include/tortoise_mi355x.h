@@ -58,7 +58,6 @@ typedef struct tt_ar_config {
   int max_prefix;        /* max P+1 (conditioning + text + start token) */
   int max_new_tokens;    /* per-sequence KV slots */
   int max_full_rows;     /* rows of the largest teacher-forced pass (k * (1 + T+2 + M+2)) */
-  int weights_tile_packed; /* 1: the five GEMM weight matrices are [ceil(N/64)][K/64][64][64] tile-packed (pack.py) */
   int mel_pos_offset;    /* mel position row of generated token i (i >= 0; the start token uses row 0) = i + mel_pos_offset:
                           * 2 = TextToSpeech(kv_cache=True): rows 0,2,3,... (autoregressive.py:145-149, attention_mask.shape[1] - mel_len)
                           * 1 = TextToSpeech(kv_cache=False), the reference DEFAULT: rows 0,1,2,... (autoregressive.py:134-144) */
@@ -274,9 +273,6 @@ int tt_prof_read(int id, double* out);
  * ============================================================================================ */
 int tt_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int taps, int seq_len,
                int splitk, const float* bias, int act, const float* res, float* out_f32, void* out_t, void* stream);
-/* same with W tile-packed as [ceil(N/64)][K/64][64][64] */
-int tt_op_gemm_packed(int dtype, const void* A, int lda, const void* W, int M, int N, int K, int splitk, const float* bias, int act,
-                      const float* res, float* out_f32, void* out_t, void* stream);
 int tt_op_layernorm(int dtype, const float* x, int M, int D, const float* g, const float* b, float eps, int rms,
                     void* out_t, float* out_f32, void* stream);
 int tt_op_groupnorm(int dtype, const float* x, int B, int S, int C, const float* g, const float* b, const float* scale_shift,

@@ -27,9 +27,9 @@ def gemm_exp(variant, M, N, K, taps=1, seq=0, nw=1, chain=32, pad=0, reps=10):
     return us.value
 
 
-def gemm_prod(M, N, K, taps=1, seq=0, splitk=1, packed=0, nw=1, na=1, xcd_rows=0, chain=32, reps=10):
+def gemm_prod(M, N, K, taps=1, seq=0, splitk=1, packed=0, nw=1, na=1, xcd_rows=0, chain=32, reps=10, act=0):
     us = D(0)
-    chk(lib.tt_kb_gemm_prod(M, N, K, taps, seq, splitk, packed, nw, na, xcd_rows, chain, reps, C.byref(us)))
+    chk(lib.tt_kb_gemm_prod(M, N, K, taps, seq, splitk, packed, nw, na, xcd_rows, chain, reps, C.byref(us), act))
     return us.value
 
 
@@ -128,7 +128,11 @@ def main():
             nw = max(8, int(700e6 // (N * K * 2)))
             for rep in range(2):
                 us = gemm_prod(256, N, K, splitk=sk, nw=nw)
-                print(f"ablate {name} M=256 PRODUCT cold W: {us:7.2f} us", flush=True)
+                print(f"ablate {name} M=256 PRODUCT (run-time outputs) cold W: {us:7.2f} us", flush=True)
+                us = gemm_prod(256, N, K, splitk=sk, nw=nw, act=1)
+                print(f"ablate {name} M=256 PRODUCT gelu -> T (compile-time outputs) cold W: {us:7.2f} us", flush=True)
+                us = gemm_prod(256, N, K, splitk=4, nw=nw)
+                print(f"ablate {name} M=256 PRODUCT split-K 4 slabs cold W: {us:7.2f} us", flush=True)
                 for v, label in ((400, "exp 64x64"), (403, "exp 64x64 + bias quads behind the ring fill")):
                     us = gemm_exp(v, 256, N, K, nw=nw)
                     print(f"ablate {name} M=256 {label:46s} cold W: {us:7.2f} us", flush=True)

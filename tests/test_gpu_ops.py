@@ -242,21 +242,3 @@ def test_univnet_kernels(lib):
         o = O.location_variable_convolution(xin[None].cpu(), kk, bb, hop)
         ref = xres.cpu() + (torch.sigmoid(o[:, :32]) * torch.tanh(o[:, 32:]))[0]
         report(f"lvc hop={hop}", xr, ref, 1e-5)
-
-
-@pytest.mark.parametrize("M,N,K,sk", [(256, 1024, 1024, 1), (33, 8194, 128, 1), (256, 1024, 4096, 4), (600, 3072, 1024, 1)])
-def test_gemm_tile_packed_weights(lib, M, N, K, sk):
-    """W re-laid as [ceil(N/64)][K/64][64][64] (pack.Holder.op_packed) must give the same product."""
-    from tortoise_tts_amd.pack import Holder
-    g = torch.Generator().manual_seed(N + K)
-    tdt = torch.bfloat16
-    A = dev(torch.randn(M, K, generator=g).to(tdt))
-    Wf = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt)
-    Wp = Holder(torch.device("cuda"), E.TT_BF16).op_packed(Wf.float())
-    bias = dev(torch.randn(N, generator=g))
-    out = torch.zeros(max(sk, 1), M, N, device="cuda")
-    E.check(lib.tt_op_gemm_packed(E.TT_BF16, E.ptr(A), K, E.ptr(Wp), M, N, K, sk, E.ptr(bias) if sk == 1 else None, E.ACT_NONE, None,
-                                  E.ptr(out), None, None))
-    torch.cuda.synchronize()
-    ref = A.float() @ dev(Wf).float().t() + (bias if sk == 1 else 0)
-    report(f"gemm tile-packed {M}x{N}x{K} sk={sk}", out.sum(0), ref, 2e-5)

@@ -26,14 +26,6 @@ int tt_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, int M,
   return gemm_launch(dtype, EPI_STD, g, (hipStream_t)stream);
 }
 
-int tt_op_gemm_packed(int dtype, const void* A, int lda, const void* W, int M, int N, int K, int splitk, const float* bias, int act,
-                      const float* res, float* out_f32, void* out_t, void* stream) {
-  GemmArgs g = gemm_args(A, lda, W, K, M, N, K);
-  g.w_packed = 1; g.splitk = splitk;
-  g.bias = bias; g.act = act; g.slope = 0.2f; g.res = res; g.ldres = N; g.out_f32 = out_f32; g.ldo32 = N; g.out_t = out_t; g.ldot = N;
-  return gemm_launch(dtype, EPI_STD, g, (hipStream_t)stream);
-}
-
 int tt_op_layernorm(int dtype, const float* x, int M, int D, const float* g, const float* b, float eps, int rms, void* out_t,
                     float* out_f32, void* stream) {
   RowNormArgs a;

@@ -71,9 +71,10 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-__device__ __forceinline__ float gelu_tanh(float x) {  // HF "gelu_new"
-  const float k = 0.7978845608028654f;
-  return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+__device__ __forceinline__ float gelu_tanh(float x) {  // HF "gelu_new": 0.5 x (1 + tanh(u)) == x * sigmoid(2u), one v_exp + one v_rcp
+  const float k2 = 2.0f * 0.7978845608028654f;
+  const float u2 = k2 * (x + 0.044715f * x * x * x);
+  return x * __frcp_rn(1.0f + __expf(-u2));
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }

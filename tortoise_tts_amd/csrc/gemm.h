@@ -25,8 +25,6 @@ struct GemmArgs {
   int lda2, k_split;
   const int* a2_slot;
   size_t a2_slot_stride;
-  int w_packed;  // 1: W is tile-packed [ceil(N/64)][K/64][64][64] (rows beyond N are zero); ldw ignored
-  int n_pad;     // set by gemm_launch
   int M, N, K;
   int taps;     // 1 = plain GEMM
   int seq_len;  // rows per sequence (conv boundary / head-layout epilogues)

@@ -47,8 +47,6 @@ static void plan_core(const GemmArgs& a, int epi, GemmPlan& p) {
   c.taps_half = a.taps >> 1;
   c.seq_len = a.seq_len;
   c.seq = make_fastdiv(a.seq_len > 0 ? a.seq_len : 1);
-  c.w_packed = a.w_packed; c.n_pad = a.n_pad;
-  c.w_tile_stride = a.w_packed ? 64 * 64 : 64;
   const int gx = cdiv(a.M, bm), gy = cdiv(a.N, bn);
   c.gx = gx; c.gy = gy;
   const unsigned nwg = (unsigned)gx * gy;
@@ -105,10 +103,6 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   TT_REQUIRE(a.splitk == 1 || (epi == EPI_STD && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
   TT_REQUIRE(a.splitk <= a.K / 64, "gemm: splitk=%d exceeds the %d k-tiles", a.splitk, a.K / 64);
   if (a.A2) TT_REQUIRE(a.taps == 1 && a.k_split > 0 && a.k_split < a.K && a.k_split % 64 == 0 && a.lda2 % 8 == 0, "gemm: bad second activation source (k_split=%d lda2=%d)", a.k_split, a.lda2);
-  if (a.w_packed) {
-    TT_REQUIRE(a.taps == 1, "gemm: tile-packed weights are not supported for conv taps");
-    a.n_pad = (a.N + 63) / 64 * 64;
-  }
   if (a.gn_part) {
     TT_REQUIRE(epi == EPI_STD && a.splitk == 1 && a.out_f32 && a.gn_seq > 0 && a.N % 16 == 0, "gemm: GroupNorm statistics need the standard epilogue, an f32 output, no split-K and N %% 16 == 0");
     a.gn_ncol16 = a.N / 16;

@@ -14,7 +14,7 @@
 //   * every integer division in the prologue / k-loop / epilogue is a multiply-high by a host-computed reciprocal;
 //   * the features that a launch does not use (activation switch, GroupNorm statistics, second activation source) are
 //     compiled out in the "fast" instantiations (template value 0 / 1); the value -1 keeps the run-time test (generic
-//     kernel: odd alignments, rare activations, tile-packed weights).
+//     kernel: odd alignments, rare activations and output combinations).
 #pragma once
 #include "gemm.h"
 
@@ -48,7 +48,7 @@ struct GemmCore {
   int cin_tiles;           // 32  k-tiles per conv tap (= all k-tiles for a plain GEMM)
   int taps_half;           // 36  taps / 2
   int seq_len;             // 40
-  int w_tile_stride;       // 44  elements between consecutive k-tiles of a W row (64, or 4096 when tile-packed)
+  int pad0;                // 44
   FastDiv seq;             // 48  / seq_len
   unsigned xq, xr;         // 56  workgroups / 8, workgroups % 8
   unsigned gx, gy;         // 64  row tiles, column tiles
@@ -57,7 +57,7 @@ struct GemmCore {
   FastDiv hfull;           // 88  / hb
   FastDiv hlast;           // 96  / (row tiles of the last band)
   int sk_quot, sk_rem;     // 104 k-tiles per split-K slab (quotient, remainder)
-  int w_packed, n_pad;     // 112
+  int pad1, pad2;          // 112
   // second activation source (HA2): k-tiles >= a2_tile read A2
   const void* A2;          // 120
   const int* a2_slot;      // 128
@@ -111,18 +111,26 @@ __device__ __forceinline__ float4 load_upto4(const float* p, int nvalid) {  // r
 // do ALL arithmetic in registers (apply) and issue ALL stores back to back (store).
 //   ACT   : -1 run-time switch on e.act, otherwise the compile-time activation
 //   STATS : -1 run-time test of e.gn_part, 0 never, 1 always (GroupNorm partial statistics, see run_epilogue)
-template <typename T, int ACT, int STATS>
+//   MODE  : -1 run-time tests of bias / res / out_f32 / out_t / splitk, otherwise the compile-time set of EB_* bits.  At
+//           one wave per SIMD every instruction of the epilogue is serial latency (~3 ns each): the run-time form costs
+//           ~150 instructions of flag tests, exec masking and repeated 64-bit address arithmetic per wave.
+enum EpiBits { EB_BIAS = 1, EB_RES = 2, EB_F32 = 4, EB_T = 8, EB_SLAB = 16 };
+template <typename T, int ACT, int STATS, int MODE>
 struct EpiStd {
   typedef EpiStdArgs Args;
   static constexpr int kId = 0;
   static constexpr int kStats = STATS;
   template <int FM, int FN> struct Ops { float4 bv[FN], rv[FN][FM]; __device__ __forceinline__ int step() const { return 0; } };
+  static __device__ __forceinline__ bool slab(const Args& e) { return MODE < 0 ? e.splitk > 1 : (MODE & EB_SLAB) != 0; }
+  static __device__ __forceinline__ bool has_bias(const Args& e) { return MODE < 0 ? (e.bias != nullptr && e.splitk <= 1) : (MODE & EB_BIAS) != 0; }
+  static __device__ __forceinline__ bool has_res(const Args& e) { return MODE < 0 ? (e.res != nullptr && e.splitk <= 1) : (MODE & EB_RES) != 0; }
+  static __device__ __forceinline__ bool has_f32(const Args& e) { return MODE < 0 ? e.out_f32 != nullptr : (MODE & EB_F32) != 0; }
+  static __device__ __forceinline__ bool has_t(const Args& e) { return MODE < 0 ? e.out_t != nullptr : (MODE & EB_T) != 0; }
 
   template <int FM, int FN, bool AL>
   static __device__ __forceinline__ void fetch(const GemmCore& c, const Args& e, Ops<FM, FN>& o, int m0w, int n0w, int lane) {
     const int fr = lane & 15, fg = lane >> 4;
-    const bool use_bias = e.bias != nullptr && e.splitk <= 1;
-    const bool use_res = e.res != nullptr && e.splitk <= 1;
+    const bool use_bias = has_bias(e), use_res = has_res(e);
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
       const int n = n0w + i * 16 + fg * 4;
@@ -153,8 +161,8 @@ struct EpiStd {
     }
   }
   static __device__ __forceinline__ void apply(const Args& e, f32x4& v, const float4& bv, const float4& rv) {
-    if (e.splitk > 1) return;  // raw partial sums; bias / activation / residual belong to the slab consumer
-    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    if (slab(e)) return;  // raw partial sums; bias / activation / residual belong to the slab consumer
+    if (MODE < 0 || (MODE & EB_BIAS)) { v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
     if (ACT < 0) {
       if (e.act != ACT_NONE) {
 #pragma unroll
@@ -164,12 +172,12 @@ struct EpiStd {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], ACT, e.slope);
     }
-    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+    if (MODE < 0 || (MODE & EB_RES)) { v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
   }
   // AL (compile time): N % 4 == 0 and every operand / output row is 16-byte aligned, so every access is a whole quad
   template <bool AL>
   static __device__ __forceinline__ void store(const GemmCore& c, const Args& e, int, int m, int n, const f32x4& v, int nvalid, int z) {
-    if (e.splitk > 1) {
+    if (slab(e)) {
       float* o = e.out_f32 + (size_t)z * c.M * e.ldo32 + (size_t)m * e.ldo32 + n;
       if (AL || (nvalid == 4 && (e.ldo32 & 3) == 0)) {
         *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
@@ -178,7 +186,7 @@ struct EpiStd {
       }
       return;
     }
-    if (e.out_f32) {
+    if (has_f32(e)) {
       float* o = e.out_f32 + (size_t)m * e.ldo32 + n;
       if (AL || (nvalid == 4 && (e.ldo32 & 3) == 0)) {
         *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
@@ -186,7 +194,7 @@ struct EpiStd {
         for (int i = 0; i < nvalid; ++i) o[i] = v[i];
       }
     }
-    if (e.out_t) {
+    if (has_t(e)) {
       T* o = (T*)e.out_t + (size_t)m * e.ldot + n;
       if (AL || (nvalid == 4 && (e.ldot & 3) == 0)) {
         *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
@@ -293,7 +301,7 @@ __device__ __forceinline__ void run_epilogue(const GemmCore& c, const typename E
   const int fr = lane & 15, fg = lane >> 4;
   bool stats = false;
   if constexpr (Epi::kId == 0) {
-    if constexpr (Epi::kStats < 0) stats = e.gn_part != nullptr && e.splitk <= 1;
+    if constexpr (Epi::kStats < 0) stats = e.gn_part != nullptr && !Epi::slab(e);
     else stats = Epi::kStats > 0;
   }
   const int rt = m0w / TM;  // row-tile index (m0w is a multiple of TM, a power of two)
@@ -457,15 +465,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
   for (int p = 0; p < PW; ++p) {
     const int row = (wave + NW * p) * 8 + lr;
     const int n = n0 + row;
-    if (HA2 < 0 && c.w_packed) {  // (generic kernel only)
-      // tile-packed weights [N/64][K/64][64][64]: every 64x64 k-tile of a column panel is one contiguous 8 KiB block
-      const int nc = n < c.n_pad ? n : c.n_pad - 1;
-      w_ptr[p] = W + ((size_t)(nc >> 6) * c.cin_tiles * 64 + (nc & 63)) * 64 + (lc ^ ((row >> 1) & 7)) * 8;
-    } else {
-      w_ptr[p] = W + (size_t)(n < c.N ? n : c.N - 1) * c.ldw + (lc ^ ((row >> 1) & 7)) * 8;
-    }
+    w_ptr[p] = W + (size_t)(n < c.N ? n : c.N - 1) * c.ldw + (lc ^ ((row >> 1) & 7)) * 8;
   }
-  const int w_tile_stride = HA2 < 0 ? c.w_tile_stride : BK;
 
   // k-tile cursor of the NEXT tile to request: (it, tap, k-tile within the tap).  Advanced incrementally (no division
   // in the loop); it stops at the last tile, which is then re-requested into a ring slot that is never read again.
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
     }
 #pragma unroll
     for (int p = 0; p < PW; ++p)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_ptr[p] + (size_t)it * w_tile_stride), (lds_void_t*)(ws + (wave + NW * p) * 8 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_ptr[p] + (size_t)it * BK), (lds_void_t*)(ws + (wave + NW * p) * 8 * BK), 16, 0, 0);
     if (it < last) {
       ++it;
       ++it_kin;
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
 // ---------------------------------------------------------------------------------------------- host side (per operand type)
 enum Tile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2 };
 // EPI_STD kernel variants: the generic one tests everything at run time, the others compile the unused features out
-enum StdVariant { V_GEN = 0, V_NONE = 1, V_GELU = 2, V_STATS = 3, V_STATS_A2 = 4, V_COUNT = 5 };
+enum StdVariant { V_GEN = 0, V_NONE = 1, V_SLAB = 2, V_GELU_T = 3, V_ST_F32 = 4, V_ST_RES = 5, V_ST_A2 = 6, V_BIAS_T = 7, V_COUNT = 8 };
 constexpr int kNoKernel = -100;  // visit_*: this combination is not instantiated
 
 struct GemmPlan {   // what gemm_launch (gemm.hip) decided: tile, grid, the device argument core
@@ -614,22 +615,38 @@ struct KernelRef {
 // v(KernelRef) is called for the EPI_STD instantiation (tile, variant, conv, al); kNoKernel when that one does not exist
 template <typename T, int BM, int BN, int NW, int ST, typename V>
 static int visit_std_tile(int variant, bool conv, bool al, V&& v) {
+  typedef EpiStd<T, -1, -1, -1> EGen;                                     // everything tested at run time
+  typedef EpiStd<T, ACT_NONE, 0, -1> ENone;                               // no activation / statistics, run-time outputs
+  typedef EpiStd<T, ACT_NONE, 0, EB_SLAB> ESlab;                          // split-K partial sums (decode projections)
+  typedef EpiStd<T, ACT_GELU_TANH, 0, EB_BIAS | EB_T> EGeluT;             // GPT-2 c_fc
+  typedef EpiStd<T, ACT_NONE, 0, EB_BIAS | EB_T> EBiasT;                  // plain Linear / conv feeding the next GEMM
+  typedef EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_F32> EStF32;                // denoiser 1x1 in front of a GroupNorm
+  typedef EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_RES | EB_F32> EStRes;       // denoiser conv / attention projection + skip
   switch (variant) {
     case V_GEN:
-      if (conv) return al ? v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, -1, -1>, true, true, -1>{}) : v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, -1, -1>, true, false, -1>{});
-      return al ? v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, -1, -1>, false, true, -1>{}) : v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, -1, -1>, false, false, -1>{});
+      if (conv) return al ? v(KernelRef<T, BM, BN, NW, ST, EGen, true, true, -1>{}) : v(KernelRef<T, BM, BN, NW, ST, EGen, true, false, -1>{});
+      return al ? v(KernelRef<T, BM, BN, NW, ST, EGen, false, true, -1>{}) : v(KernelRef<T, BM, BN, NW, ST, EGen, false, false, -1>{});
     case V_NONE:
       if (!al) return kNoKernel;
-      return conv ? v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, ACT_NONE, 0>, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, ACT_NONE, 0>, false, true, 0>{});
-    case V_GELU:
+      return conv ? v(KernelRef<T, BM, BN, NW, ST, ENone, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, ST, ENone, false, true, 0>{});
+    case V_SLAB:
       if (!al || conv) return kNoKernel;
-      return v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, ACT_GELU_TANH, 0>, false, true, 0>{});
-    case V_STATS:
+      return v(KernelRef<T, BM, BN, NW, ST, ESlab, false, true, 0>{});
+    case V_GELU_T:
+      if (!al || conv) return kNoKernel;
+      return v(KernelRef<T, BM, BN, NW, ST, EGeluT, false, true, 0>{});
+    case V_ST_F32:
       if (!al) return kNoKernel;
-      return conv ? v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, ACT_NONE, 1>, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, ACT_NONE, 1>, false, true, 0>{});
-    case V_STATS_A2:
+      return conv ? v(KernelRef<T, BM, BN, NW, ST, EStF32, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, ST, EStF32, false, true, 0>{});
+    case V_ST_RES:
+      if (!al) return kNoKernel;
+      return conv ? v(KernelRef<T, BM, BN, NW, ST, EStRes, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, ST, EStRes, false, true, 0>{});
+    case V_ST_A2:
       if (!al || conv) return kNoKernel;
-      return v(KernelRef<T, BM, BN, NW, ST, EpiStd<T, ACT_NONE, 1>, false, true, 1>{});
+      return v(KernelRef<T, BM, BN, NW, ST, EStF32, false, true, 1>{});
+    case V_BIAS_T:
+      if (!al) return kNoKernel;
+      return conv ? v(KernelRef<T, BM, BN, NW, ST, EBiasT, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, ST, EBiasT, false, true, 0>{});
   }
   return kNoKernel;
 }
@@ -675,9 +692,19 @@ int gemm_launch_typed(int epi, const GemmArgs& a, const GemmPlan& plan, hipStrea
                     (!a.out_f32 || (((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0)) && (!a.out_t || (((size_t)a.out_t & 7) == 0 && (a.ldot & 3) == 0));
     const bool conv = a.taps > 1, stats = a.gn_part != nullptr, a2 = a.A2 != nullptr;
     int variant = V_GEN;
-    if (al && !a.w_packed) {
-      if (a.act == ACT_NONE) variant = a2 ? (stats ? V_STATS_A2 : V_GEN) : (stats ? V_STATS : V_NONE);
-      else if (a.act == ACT_GELU_TANH && !a2 && !stats) variant = V_GELU;
+    if (al) {
+      const int mode = a.splitk > 1 ? EB_SLAB : ((a.bias ? EB_BIAS : 0) | (a.res ? EB_RES : 0) | (a.out_f32 ? EB_F32 : 0) | (a.out_t ? EB_T : 0));
+      if (a.act == ACT_NONE) {
+        if (stats) {
+          if (!a2 && mode == (EB_BIAS | EB_F32)) variant = V_ST_F32;
+          else if (!a2 && mode == (EB_BIAS | EB_RES | EB_F32)) variant = V_ST_RES;
+          else if (a2 && !conv && mode == (EB_BIAS | EB_F32)) variant = V_ST_A2;
+        } else if (!a2) {
+          variant = (mode == EB_SLAB && !conv) ? V_SLAB : mode == (EB_BIAS | EB_T) ? V_BIAS_T : V_NONE;
+        }
+      } else if (a.act == ACT_GELU_TANH && !a2 && !stats && !conv && mode == (EB_BIAS | EB_T)) {
+        variant = V_GELU_T;
+      }
     }
     auto go = [&](auto kr) -> int {
       decltype(kr)::launch(grid, stream, d);

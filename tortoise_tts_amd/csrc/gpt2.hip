@@ -47,9 +47,7 @@ struct tt_ar {
 static const int MAX_SPLIT = 8;
 
 static inline GemmArgs ar_gemm(const tt_ar* e, const void* A, int lda, const void* W, int ldw, int M, int N, int K) {
-  GemmArgs g = gemm_args(A, lda, W, ldw, M, N, K);
-  g.w_packed = e->cfg.weights_tile_packed;
-  return g;
+  return gemm_args(A, lda, W, ldw, M, N, K);
 }
 
 static int ar_rownorm(tt_ar* e, float* x, int M, const float* g1, const float* b1, const float* g2, const float* b2,

@@ -304,7 +304,7 @@ int tt_kb_gemm_exp(int variant, int M, int N, int K, int taps, int seq_len, int 
 }
 
 // The product GEMM (gemm_launch) on the same harness: one shape, nw weight copies, optional split-K, f32 or T output.
-int tt_kb_gemm_prod(int M, int N, int K, int taps, int seq_len, int splitk, int packed, int nw, int na, int xcd_rows, int chain, int reps, double* us_out) {
+int tt_kb_gemm_prod(int M, int N, int K, int taps, int seq_len, int splitk, int packed, int nw, int na, int xcd_rows, int chain, int reps, double* us_out, int act) {
   Arena ar;
   GraphTimer gt;
   TT_TRY(gt.init());
@@ -321,9 +321,9 @@ int tt_kb_gemm_prod(int M, int N, int K, int taps, int seq_len, int splitk, int 
   if (!rc) rc = gt.run([&](hipStream_t s) -> int {
     for (int i = 0; i < chain; ++i) {
       GemmArgs g = gemm_args(Av[i % na], K / taps, W[i % nw], K, M, N, K);
-      g.taps = taps; g.seq_len = seq_len > 0 ? seq_len : M; g.splitk = splitk; g.w_packed = packed; g.xcd_rows = xcd_rows;
+      g.taps = taps; g.seq_len = seq_len > 0 ? seq_len : M; g.splitk = splitk; (void)packed; g.xcd_rows = xcd_rows;
       if (splitk > 1) { g.out_f32 = out32; g.ldo32 = N; }
-      else { g.bias = bias; g.out_t = out_t; g.ldot = N; }
+      else { g.bias = bias; g.out_t = out_t; g.ldot = N; g.act = act; }
       TT_TRY(gemm_launch(DT_BF16, EPI_STD, g, s));
     }
     return 0;

@@ -26,7 +26,7 @@ class GptLayer(C.Structure):
 
 class ArConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("dtype", "layers", "model_dim", "heads", "vocab", "start_mel_token", "stop_mel_token",
-                                       "mel_pos_len", "max_batch", "max_prefix", "max_new_tokens", "max_full_rows", "weights_tile_packed",
+                                       "mel_pos_len", "max_batch", "max_prefix", "max_new_tokens", "max_full_rows",
                                        "mel_pos_offset")]
 
 
@@ -132,7 +132,6 @@ _PROTOS = {
     "tt_prof_class_name": (C.c_char_p, [_i]),
     "tt_prof_read": (_i, [_i, C.POINTER(C.c_double)]),
     "tt_op_gemm": (_i, [_i, vp, _i, vp, _i, _i, _i, _i, _i, _i, _i, vp, _i, vp, vp, vp, vp]),
-    "tt_op_gemm_packed": (_i, [_i, vp, _i, vp, _i, _i, _i, _i, vp, _i, vp, vp, vp, vp]),
     "tt_op_layernorm": (_i, [_i, vp, _i, _i, vp, vp, _f, _i, vp, vp, vp]),
     "tt_op_groupnorm": (_i, [_i, vp, _i, _i, _i, vp, vp, vp, _i, vp, vp, vp, vp]),
     "tt_op_groupnorm_workspace": (_sz, [_i, _i]),

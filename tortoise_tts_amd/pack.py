@@ -40,20 +40,6 @@ class Holder:
         self.keep.append(t)
         return t
 
-    def op_packed(self, t):
-        """GEMM operand [out][in] re-laid as [ceil(out/64)][in/64][64][64]: every 64x64 k-tile of a 64-row panel is one
-        contiguous 8 KiB block (sequential DRAM pages for the weight-streaming decode GEMMs).  Pad rows are zero."""
-        t = t.detach().to(device=self.device, dtype=torch.float32)
-        t = t.reshape(t.shape[0], -1)
-        n, k = t.shape
-        assert k % 64 == 0, k
-        npad = (n + 63) // 64 * 64
-        p = torch.zeros(npad, k, device=self.device, dtype=torch.float32)
-        p[:n] = t
-        p = p.reshape(npad // 64, 64, k // 64, 64).permute(0, 2, 1, 3).to(self.tdtype).contiguous()
-        self.keep.append(p)
-        return p
-
     def conv(self, w, in_pad=None):
         """Conv1d weight [out][in][k] -> [out][k][in_pad] operand."""
         w = w.detach().to(device=self.device, dtype=torch.float32)
@@ -69,10 +55,9 @@ def _p(t):
 
 
 # ----------------------------------------------------------------------------------------- AR
-def pack_ar(sd, cfg: ARConfig, device, dtype, tile_packed=True):
+def pack_ar(sd, cfg: ARConfig, device, dtype):
     h = Holder(device, dtype)
-    h.tile_packed = bool(tile_packed)
-    wop = h.op_packed if tile_packed else h.op
+    wop = h.op
     layers = (E.GptLayer * cfg.layers)()
     for i in range(cfg.layers):
         p = f"gpt.h.{i}"

@@ -40,7 +40,6 @@ class ArStage:
         c.max_prefix = 1 + max_text + 2 + 1
         c.max_new_tokens = max_new_tokens + 2
         c.max_full_rows = max_latent_candidates * (1 + max_text + 2 + max_new_tokens + 2)
-        c.weights_tile_packed = int(getattr(self.w, "tile_packed", False))
         # TextToSpeech(kv_cache=...) only changes WHICH mel position row a generated token gets (autoregressive.py:134-149):
         # the engine always keeps a KV cache; kv_cache=False (the reference default) selects rows 0,1,2,... instead of 0,2,3,...
         c.mel_pos_offset = 2 if kv_cache else 1
