@@ -139,10 +139,10 @@ def main():
     if "attn" in which:
         for B in (256, 32):
             for tgen in (50, 100, 200):
-                for v, label in ((0, "product (8-byte V loads)"), (1, "v2 16-byte V loads, 32 keys/iter"), (2, "v2 16-byte V loads, 48 keys/iter")):
+                for v, label in ((10, "per-wave prefix kernel"), (11, "shared prefix in LDS, 16 seq / workgroup"), (12, "shared prefix in LDS, 4 seq / workgroup"), (0, "product (auto)")):
                     us, md = attn(v, B, 16, 59, tgen, 202, 8)
                     by = (B * tgen + 59) * 16 * 64 * 2 * 2
-                    print(f"decode_attn B={B} tgen={tgen} {label:36s}: {us:7.2f} us {by / us / 1e3:7.1f} GB/s  max|diff| vs product {md:.3e}", flush=True)
+                    print(f"decode_attn B={B} tgen={tgen} {label:36s}: {us:7.2f} us {by / us / 1e3:7.1f} GB/s  max|diff| vs per-wave kernel {md:.3e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -688,15 +688,231 @@ __global__ __launch_bounds__(256, 4) void decode_attn_kernel(DecodeAttnArgs a, i
   }
 }
 
+// Shared-prefix variant.  Every candidate of an utterance attends to the SAME [cond | text | start] prefix keys; the kernel
+// above reads them once per (sequence, head) wave - 15 KB per wave, 61 MB of L2 -> CU traffic per launch at 256 candidates,
+// which is on the critical path of every wave (per-CU L2 bandwidth is ~50 GB/s) although it never touches HBM.  Here a
+// workgroup is NSEQ waves = NSEQ sequences of ONE head: the head's prefix K / V are staged into LDS once per workgroup
+// (global_load_lds; K re-laid chunk-major on the fly through the per-lane source address so the lane-per-key reads are
+// conflict-free ds_read_b128), and only the per-sequence cache is streamed from HBM.  The first own-key slots are requested
+// before the workgroup waits for the staged prefix (counted vmcnt: the direct-to-LDS loads are older in the queue), so the
+// HBM stream starts at once.  Arithmetic and summation order per (sequence, head) are exactly those of decode_attn_kernel.
+template <typename T, int NSEQ>
+__global__ __launch_bounds__(NSEQ * 64, 4) void decode_attn_lds_kernel(DecodeAttnArgs a, int ctx_cap, int kl_bytes, int vl_bytes) {
+  typedef typename Vec<T>::x8 x8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dec[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tgen = *a.step + 1;       // generated keys 0..*step (read first: a scalar load, nothing in front of it to drain)
+  const int h = (int)blockIdx.x;      // grid = (heads, sequence groups)
+  const int b_raw = (int)blockIdx.y * NSEQ + wave;
+  const int b = min(b_raw, a.B - 1);  // surplus waves of the last group repeat its last sequence (never stored)
+  const int P1 = a.P1;
+  const T* kp = (const T*)a.kp + (size_t)h * P1 * 64;
+  const T* vp = (const T*)a.vp + (size_t)h * P1 * 64;
+  unsigned char* Kl = smem_dec;                 // [slot][8 chunks][64 keys][8]  (chunk-major like the per-sequence cache)
+  unsigned char* Vl = smem_dec + kl_bytes;      // [key][64]
+  float* sc = (float*)(smem_dec + kl_bytes + vl_bytes) + (size_t)wave * ctx_cap;
+  const int nsp = (P1 + 63) >> 6;
+
+  // stage the prefix: K instruction (slot s, chunk c): lane k <- kp[s*64 + k][c*8 .. c*8+7]; V instruction i: rows 8i .. 8i+7
+  {
+    const int nk_ins = nsp * 8, nv_ins = (P1 + 7) >> 3;
+    for (int i = wave; i < nk_ins; i += NSEQ) {
+      const int sidx = i >> 3, c = i & 7;
+      const int key = min(sidx * 64 + lane, P1 - 1);
+      __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)((const char*)kp + ((size_t)key * 64 + c * 8) * sizeof(T)),
+                                       (__attribute__((address_space(3))) void*)(Kl + (size_t)i * 1024), 16, 0, 0);
+    }
+    for (int i = wave; i < nv_ins; i += NSEQ) {
+      const int row = min(i * 8 + (lane >> 3), P1 - 1);
+      __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)((const char*)vp + ((size_t)row * 64 + (lane & 7) * 8) * sizeof(T)),
+                                       (__attribute__((address_space(3))) void*)(Vl + (size_t)i * 1024), 16, 0, 0);
+    }
+  }
+  const int ctx = P1 + tgen;
+  const size_t bh = (size_t)b * a.heads + h;
+  const T* kc = (const T*)a.kc + bh * 8 * a.tmax * 8;
+  const T* vc = (const T*)a.vc + bh * a.tmax * 64;
+
+  float mx = -1e30f;
+  // The query is wave-uniform: it lives in 32 SGPRs (two s_load_dwordx16), not in 32 VGPRs per lane, and its load is not on
+  // the vector-memory counter, so nothing the compiler places between the staged prefix and the first use of q can force a
+  // vmcnt(0) that would also drain the own-key requests below.  (Inline asm: hipcc only emits scalar loads for memory it can
+  // prove read-only, and q was written by the previous kernel.)
+  typedef int int16v __attribute__((ext_vector_type(16)));
+  typedef int int4v __attribute__((ext_vector_type(4)));
+  int16v qlo, qhi;
+  {
+    const T* qp = (const T*)a.q + (size_t)b * a.heads * 64 + h * 64;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=s"(qlo), "=s"(qhi) : "s"(qp) : "memory");
+  }
+  const int nso = (tgen + 63) >> 6;
+  auto load_own = [&](x8 (&kk)[8], int slot) {  // own keys of slot (clamped: an odd slot count repeats the last slot, result dropped)
+    const int k = min(slot, nso - 1) * 64 + lane;
+    const unsigned off = (unsigned)min(k, tgen - 1) * 8u * (unsigned)sizeof(T);
+    const unsigned cs = (unsigned)a.tmax * 8u * (unsigned)sizeof(T);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) kk[c] = *(const x8*)((const char*)kc + (off + c * cs));
+  };
+  x8 k0[8], k1[8];
+  load_own(k0, 0);
+  load_own(k1, 1);
+  // the staged prefix must have landed (this wave's direct-to-LDS loads are older than the 16 register loads above)
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(qlo), "+s"(qhi)::"memory");  // q has landed (every later use depends on this statement)
+  x8 qk[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int16v& src = c < 4 ? qlo : qhi;
+    int4v w;
+    w[0] = src[(c & 3) * 4 + 0]; w[1] = src[(c & 3) * 4 + 1]; w[2] = src[(c & 3) * 4 + 2]; w[3] = src[(c & 3) * 4 + 3];
+    qk[c] = __builtin_bit_cast(x8, w);
+  }
+  // prefix scores from LDS
+#pragma unroll 1
+  for (int sidx = 0; sidx < nsp; ++sidx) {
+    float sv = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sv = dot8(qk[c], *(const x8*)(Kl + ((size_t)(sidx * 8 + c) * 64 + lane) * 16), sv);
+    const int k = sidx * 64 + lane;
+    if (k < P1) {
+      sc[k] = sv;
+      mx = fmaxf(mx, sv);
+    }
+  }
+  // own scores, two slots per iteration
+#pragma unroll 1
+  for (int sl0 = 0; sl0 < nso; sl0 += 2) {
+    if (sl0 > 0) {
+      load_own(k0, sl0);
+      load_own(k1, sl0 + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s0 = dot8(qk[c], k0[c], s0);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s1 = dot8(qk[c], k1[c], s1);
+    const int ka = sl0 * 64 + lane, kb = ka + 64;
+    if (ka < tgen) {
+      sc[P1 + ka] = s0;
+      mx = fmaxf(mx, s0);
+    }
+    if (kb < tgen && sl0 + 1 < nso) {
+      sc[P1 + kb] = s1;
+      mx = fmaxf(mx, s1);
+    }
+  }
+
+  const int kk8 = lane >> 3, cg = lane & 7;
+  const int nvp = (P1 + DEC_VKEYS - 1) / DEC_VKEYS, nvo = (tgen + DEC_VKEYS - 1) / DEC_VKEYS;
+  auto load_v = [&](x8 (&t)[DEC_VROWS], int it) {  // own rows of iteration `it` (past the end: the last rows again, weighted 0)
+    const int k0r = min(it, nvo - 1) * DEC_VKEYS + kk8;
+#pragma unroll
+    for (int u = 0; u < DEC_VROWS; ++u) {
+      const unsigned jc = (unsigned)min(k0r + 8 * u, tgen - 1);
+      t[u] = *(const x8*)((const char*)vc + (jc * 64u + (unsigned)cg * 8u) * (unsigned)sizeof(T));
+    }
+  };
+  x8 ta[DEC_VROWS], tb[DEC_VROWS];
+  load_v(ta, 0);  // the first V rows do not depend on the scores: request them before the softmax
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < ctx; j += 64) {
+    const float e = __expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // sc[] is private to this wave: LDS operations of a wave execute in order
+  float o[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) o[c] = 0.f;
+  // prefix rows from LDS
+#pragma unroll 1
+  for (int it = 0; it < nvp; ++it) {
+    const int k0r = it * DEC_VKEYS + kk8;
+#pragma unroll
+    for (int u = 0; u < DEC_VROWS; ++u) {
+      const int j = k0r + 8 * u;
+      const float pj = j < P1 ? sc[j] : 0.f;
+      const x8 t = *(const x8*)(Vl + ((size_t)min(j, P1 - 1) * 64 + cg * 8) * sizeof(T));
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] += pj * (float)t[c];
+    }
+  }
+  auto consume = [&](const x8 (&t)[DEC_VROWS], int it) {
+    const int k0r = it * DEC_VKEYS + kk8, lim = it < nvo ? tgen : 0;
+    const float* scs = sc + P1;
+#pragma unroll
+    for (int u = 0; u < DEC_VROWS; ++u) {
+      const int j = k0r + 8 * u;
+      const float pj = j < lim ? scs[j] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] += pj * (float)t[u][c];
+    }
+  };
+#pragma unroll 1
+  for (int it = 0; it < nvo; it += 2) {  // two register sets: the next rows are in flight while these are summed
+    load_v(tb, it + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(ta, it);
+    __builtin_amdgcn_sched_barrier(0);
+    load_v(ta, it + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(tb, it + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {  // sum the 8 key sub-rows (lanes with equal channel group)
+    o[c] += __shfl_xor(o[c], 8, 64);
+    o[c] += __shfl_xor(o[c], 16, 64);
+    o[c] += __shfl_xor(o[c], 32, 64);
+  }
+  if (b_raw < a.B && kk8 == 0) {
+    const float inv = 1.0f / sum;
+    x8 r;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) r[c] = (T)(o[c] * inv);
+    *(x8*)((T*)a.out + (size_t)b * a.heads * 64 + h * 64 + cg * 8) = r;
+  }
+}
+
 int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.B > 0 && a.heads > 0 && a.P1 >= 0 && a.tmax > 0, "decode_attention: bad shape");
   const int ctx_cap = a.P1 + a.tmax;
-  const size_t smem = (size_t)4 * ctx_cap * sizeof(float);
-  TT_REQUIRE(smem <= 64 * 1024, "decode_attention: context %d too long for the score buffer", ctx_cap);
-  const int blocks = cdiv(a.B * a.heads, 4);
   // algorithmic bytes: every sequence reads its own generated K and V rows once (host_tgen keys) + the shared prefix once
   ProfScope ps(PROF_DECODE_ATTN, stream, 4.0 * a.B * a.heads * 64.0 * (a.P1 + a.host_tgen),
                ((double)a.B * a.host_tgen + a.P1) * a.heads * 64 * 2 * 2.0 + 2.0 * a.B * a.heads * 64 * 2.0);
+  // shared-prefix kernel with 4 sequences per workgroup (measured 2 % ahead of 16 at 256 candidates and 40 % ahead at 32:
+  // more, smaller workgroups); the per-wave kernel only when the staged prefix + score rows do not fit the LDS (very long prompts)
+  int nseq = a.variant == 1 ? 0 : a.variant == 2 ? 16 : 4;
+  const int kl_bytes = ((a.P1 + 63) >> 6) * 8 * 1024, vl_bytes = ((a.P1 + 7) >> 3) * 1024;
+  if (a.P1 < 1) nseq = 0;
+  if (nseq && (size_t)kl_bytes + vl_bytes + (size_t)nseq * ctx_cap * sizeof(float) > 160 * 1024) nseq = nseq == 16 ? 4 : 0;
+  if (nseq && (size_t)kl_bytes + vl_bytes + (size_t)nseq * ctx_cap * sizeof(float) > 160 * 1024) nseq = 0;
+  if (nseq) {
+    const size_t smem = (size_t)kl_bytes + vl_bytes + (size_t)nseq * ctx_cap * sizeof(float);
+    const dim3 blocks(a.heads, cdiv(a.B, nseq));
+#define TT_DEC(T, NS)                                                                                                              \
+    do {                                                                                                                             \
+      static bool attr_done = false;                                                                                                 \
+      if (!attr_done) {                                                                                                              \
+        TT_CHECK_HIP(hipFuncSetAttribute((const void*)decode_attn_lds_kernel<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        attr_done = true;                                                                                                            \
+      }                                                                                                                              \
+      decode_attn_lds_kernel<T, NS><<<blocks, NS * 64, smem, stream>>>(a, ctx_cap, kl_bytes, vl_bytes);                              \
+    } while (0)
+    if (dtype == DT_BF16) { if (nseq == 16) TT_DEC(bf16, 16); else TT_DEC(bf16, 4); }
+    else { if (nseq == 16) TT_DEC(f16, 16); else TT_DEC(f16, 4); }
+#undef TT_DEC
+    TT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  const size_t smem = (size_t)4 * ctx_cap * sizeof(float);
+  TT_REQUIRE(smem <= 64 * 1024, "decode_attention: context %d too long for the score buffer", ctx_cap);
+  const int blocks = cdiv(a.B * a.heads, 4);
   if (dtype == DT_BF16) decode_attn_kernel<bf16><<<blocks, 256, smem, stream>>>(a, ctx_cap);
   else decode_attn_kernel<f16><<<blocks, 256, smem, stream>>>(a, ctx_cap);
   TT_CHECK_HIP(hipGetLastError());

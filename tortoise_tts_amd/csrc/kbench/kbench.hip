@@ -498,7 +498,10 @@ int tt_kb_decode_attn(int variant, int B, int heads, int P1, int tgen, int tmax,
     memset(&a, 0, sizeof(a));
     a.q = q; a.kp = kp; a.vp = vp; a.P1 = P1; a.kc = kc[layer]; a.vc = vc[layer]; a.tmax = tmax; a.step = step; a.host_tgen = tgen;
     a.out = o; a.B = B; a.heads = heads;
-    if (var == 0) return decode_attention_launch(DT_BF16, a, s);
+    if (var == 0 || var >= 10) {
+      a.variant = var >= 10 ? var - 9 : 0;  // 10: per-wave prefix kernel, 11 / 12: shared-prefix kernel with 16 / 4 sequences per workgroup
+      return decode_attention_launch(DT_BF16, a, s);
+    }
     const int ctx_cap = P1 + tmax;
     const size_t smem = (size_t)4 * ctx_cap * sizeof(float);
     const int blocks = cdiv(B * heads, 4);
@@ -513,7 +516,7 @@ int tt_kb_decode_attn(int variant, int B, int heads, int P1, int tgen, int tmax,
   }, reps, us_out);
   if (!rc) *us_out /= chain;
   if (!rc && maxdiff) {  // agreement with the product kernel on layer 0
-    rc = launch(0, 0, out_ref, gt.s);
+    rc = launch(10, 0, out_ref, gt.s);
     if (!rc) rc = launch(variant, 0, out, gt.s);
     if (!rc && hipStreamSynchronize(gt.s) != hipSuccess) rc = -2;
     if (!rc) {

@@ -82,6 +82,7 @@ struct DecodeAttnArgs {
   int host_tgen;    // host-side copy of *step + 1 for profiling estimates only (0 when unknown)
   void* out;        // [B][heads*64]
   int B, heads;
+  int variant;      // 0: chosen from the shape; 1: per-wave prefix kernel; 2 / 3: shared-prefix kernel with 16 / 4 sequences per workgroup
 };
 int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stream);
 
