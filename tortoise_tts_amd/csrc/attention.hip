@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(FlashArgs a) {  // 2 wave
       }
       float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
                        fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = max_xor16(mx);
+      mx = max_xor32(mx);
       const float m_new = fmaxf(m_run[iq], mx);
       if (__any(m_new > m_run[iq])) {  // some row maximum moved: rescale the running state (exact when skipped)
         const float alpha = __builtin_amdgcn_exp2f((m_run[iq] - m_new) * LOG2E);
@@ -203,8 +203,8 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(FlashArgs a) {  // 2 wave
   }
 #pragma unroll
   for (int iq = 0; iq < NQ; ++iq) {
-    l_run[iq] += __shfl_xor(l_run[iq], 16, 64);
-    l_run[iq] += __shfl_xor(l_run[iq], 32, 64);
+    l_run[iq] = add_xor16(l_run[iq]);
+    l_run[iq] = add_xor32(l_run[iq]);
   }
   if (SPLIT) {
     // merge the four waves' partial (max, sum, O) states, one query block at a time, into wave 0
@@ -415,8 +415,8 @@ __global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
       }
       float mx = fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
                        fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = max_xor16(mx);
+      mx = max_xor32(mx);
       const float m_new = fmaxf(m_run[iq], mx);
       if (__any(m_new > m_run[iq])) {  // some row maximum moved: rescale the running state (exact when skipped)
         const float alpha = __builtin_amdgcn_exp2f((m_run[iq] - m_new) * LOG2E);
@@ -465,8 +465,8 @@ __global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int iq = 0; iq < NQ; ++iq) {
-    l_run[iq] += __shfl_xor(l_run[iq], 16, 64);
-    l_run[iq] += __shfl_xor(l_run[iq], 32, 64);
+    l_run[iq] = add_xor16(l_run[iq]);
+    l_run[iq] = add_xor32(l_run[iq]);
     const int qi = qbase + iq * 16 + fr;
     if (qi < n) {
       const float inv = 1.0f / l_run[iq];
@@ -675,9 +675,9 @@ __global__ __launch_bounds__(256, 4) void decode_attn_kernel(DecodeAttnArgs a, i
   }
 #pragma unroll
   for (int c = 0; c < 8; ++c) {  // sum the 8 key sub-rows (lanes with equal channel group)
-    o[c] += __shfl_xor(o[c], 8, 64);
-    o[c] += __shfl_xor(o[c], 16, 64);
-    o[c] += __shfl_xor(o[c], 32, 64);
+    o[c] = add_xor8(o[c]);
+    o[c] = add_xor16(o[c]);
+    o[c] = add_xor32(o[c]);
   }
   if ((int)blockIdx.x * 4 + wave < a.B * a.heads && kk8 == 0) {
     const float inv = 1.0f / sum;
@@ -866,9 +866,9 @@ __global__ __launch_bounds__(NSEQ * 64, 4) void decode_attn_lds_kernel(DecodeAtt
   }
 #pragma unroll
   for (int c = 0; c < 8; ++c) {  // sum the 8 key sub-rows (lanes with equal channel group)
-    o[c] += __shfl_xor(o[c], 8, 64);
-    o[c] += __shfl_xor(o[c], 16, 64);
-    o[c] += __shfl_xor(o[c], 32, 64);
+    o[c] = add_xor8(o[c]);
+    o[c] = add_xor16(o[c]);
+    o[c] = add_xor32(o[c]);
   }
   if (b_raw < a.B && kk8 == 0) {
     const float inv = 1.0f / sum;

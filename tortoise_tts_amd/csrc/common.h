@@ -42,15 +42,47 @@ template <typename T> __device__ __forceinline__ typename Vec<T>::x4 pack4(float
   return r;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Cross-lane exchanges without the LDS: __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt (a ~100-cycle LDS round trip per
+// step, 6 of them in a wave reduction, and at one or two waves per SIMD nothing hides them).  Within a row of 16 lanes the
+// DPP modifier does the exchange inside the VALU instruction; across rows gfx950 has v_permlane16_swap / v_permlane32_swap.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {  // CTRL: quad_perm 0x00-0xFF, row_ror:n 0x120+n, row_mirror 0x140, row_half_mirror 0x141
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// (value of lane l, value of lane l ^ 16) / (l, l ^ 32) as a pair, in lane-symmetric order.  Inline asm: with ROCm 7.2's
+// __builtin_amdgcn_permlane16_swap / permlane32_swap both elements of the returned pair come out as the FIRST register
+// (`v_add_f32 v1, v1, v1` after the swap), i.e. the builtin silently drops the second result.
+__device__ __forceinline__ void pair_xor16(float v, float& a, float& b) {
+  a = v;
+  b = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void pair_xor32(float v, float& a, float& b) {
+  a = v;
+  b = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float add_xor8(float v) { return v + dpp_mov<0x128>(v); }   // row_ror:8 == lane ^ 8 inside a 16-lane row
+__device__ __forceinline__ float add_xor16(float v) { float a, b; pair_xor16(v, a, b); return a + b; }
+__device__ __forceinline__ float add_xor32(float v) { float a, b; pair_xor32(v, a, b); return a + b; }
+__device__ __forceinline__ float max_xor16(float v) { float a, b; pair_xor16(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float max_xor32(float v) { float a, b; pair_xor32(v, a, b); return fmaxf(a, b); }
+
+__device__ __forceinline__ float wave_sum(float v) {  // every lane gets the sum of all 64
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror: the other quad of the 8
+  v += dpp_mov<0x140>(v);  // row_mirror: the other half of the row
+  v = add_xor16(v);
+  return add_xor32(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  v = max_xor16(v);
+  return max_xor32(v);
 }
 
 // block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 4 floats of LDS.
@@ -58,6 +90,14 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   v = wave_sum(v);
   const int w = threadIdx.x >> 6;
   __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+// same without the leading barrier: `red` must not have been read since the last barrier (give every reduction of a kernel its own array)
+__device__ __forceinline__ float block_sum_256_fresh(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) red[w] = v;
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
 // generic kernel: bias, slabs in order, two-pass variance.
 template <typename T, int NSLAB, bool BIAS, bool RMS>
 __global__ __launch_bounds__(256) void rownorm_narrow_kernel(RowNormArgs a) {
-  __shared__ float red[4];
+  __shared__ float red[8];  // one 4-float array per reduction: no barrier is needed to recycle it
   const int row = blockIdx.x, tid = threadIdx.x;
   const bool live = tid * 4 < a.D;
   const int c = min(tid * 4, a.D - 4);  // idle lanes re-read the last quad (no branch), masked below
@@ -153,14 +153,14 @@ __global__ __launch_bounds__(256) void rownorm_narrow_kernel(RowNormArgs a) {
 
   float4 y;
   if constexpr (RMS) {
-    const float sq = block_sum_256(t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w, red);
+    const float sq = block_sum_256_fresh(t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w, red);
     const float nrm = sqrtf(sq) * rsqrtf((float)a.D);
     const float inv = 1.0f / fmaxf(nrm, a.eps1);
     y = make_float4(t.x * inv * g.x, t.y * inv * g.y, t.z * inv * g.z, t.w * inv * g.w);
   } else {
-    const float mean = block_sum_256(t.x + t.y + t.z + t.w, red) / (float)a.D;
+    const float mean = block_sum_256_fresh(t.x + t.y + t.z + t.w, red) / (float)a.D;
     const float dx = t.x - mean, dy = t.y - mean, dz = t.z - mean, dw = t.w - mean;
-    const float var = block_sum_256(live ? dx * dx + dy * dy + dz * dz + dw * dw : 0.f, red) / (float)a.D;
+    const float var = block_sum_256_fresh(live ? dx * dx + dy * dy + dz * dz + dw * dw : 0.f, red + 4) / (float)a.D;
     const float rstd = rsqrtf(var + a.eps1);
     y = make_float4(dx * rstd * g.x + b.x, dy * rstd * g.y + b.y, dz * rstd * g.z + b.z, dw * rstd * g.w + b.w);
   }
