@@ -269,6 +269,36 @@ const char* tt_prof_class_name(int id);
 int tt_prof_read(int id, double* out);
 
 /* ============================================================================================
+ * Conditioning front-end of the voice_samples path (replaces autoregressive.get_conditioning and
+ * diffusion.get_conditioning, called from api.py:276 and api.py:289 get_conditioning_latents)
+ * ============================================================================================ */
+typedef struct tt_cond_config {
+  int dtype;
+  int ar_dim, ar_heads, ar_blocks;          /* 1024, 16, 6: ConditioningEncoder (autoregressive.py:204-228) */
+  int ar_mel, ar_mel_pad;                   /* 80, 128 */
+  int diff_channels, diff_heads, diff_blocks; /* 1024 (the embedder is 2x that wide), 16, 5: contextual_embedder (diffusion_decoder.py:186-192) */
+  int diff_mel, diff_mel_pad;               /* 100, 128 */
+  int max_frames;                           /* longest clip in mel frames */
+} tt_cond_config;
+typedef struct tt_cond_weights {
+  const void* ar_w_init; const float* ar_b_init;   /* T [D][ar_mel_pad] conditioning_encoder.init (1x1) */
+  const tt_attn_block* ar_attn_host;               /* ar_blocks blocks, 64-wide heads: QKV rows [q|k|v][head][64], relpos NULL */
+  const void* diff_w_c0; const float* diff_b_c0;   /* T [C][3][diff_mel_pad]  contextual_embedder.0 (k3, stride 2) */
+  const void* diff_w_c1; const float* diff_b_c1;   /* T [2C][3][C]            contextual_embedder.1 (k3, stride 2) */
+  const tt_attn_block* diff_attn_host;             /* diff_blocks blocks over 2C channels; heads wider than 64 keep the reference's
+                                                    * QKV row order [head][q|k|v][ch]; relpos f32 [heads][129] scaled by sqrt(ch) */
+} tt_cond_weights;
+typedef struct tt_cond tt_cond;
+int tt_cond_create(const tt_cond_config* cfg, const tt_cond_weights* w, tt_cond** out);
+void tt_cond_destroy(tt_cond* h);
+/* ConditioningEncoder on ONE clip: mel f32 [ar_mel][T] (channels first, as api.py:271-276 builds it) -> out f32 [ar_dim] = h[:, :, 0];
+ * UnifiedVoice.get_conditioning is the mean of these vectors over the clips. */
+int tt_cond_ar_clip(tt_cond* h, const float* mel, int T, float* out, void* stream);
+/* contextual_embedder on ONE clip: mel f32 [diff_mel][T] -> out_sum f32 [2C] = sum over the clip's *frames output frames
+ * (DiffusionTts.get_conditioning = sum over all clips / total frames: the clips are concatenated along time and averaged). */
+int tt_cond_diff_clip(tt_cond* h, const float* mel, int T, float* out_sum, int* frames, void* stream);
+
+/* ============================================================================================
  * Operator-level entry points (used by tests/ to check single kernels against torch references)
  * ============================================================================================ */
 int tt_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int taps, int seq_len,

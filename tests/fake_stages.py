@@ -92,6 +92,17 @@ class FakeRandomLatentStage:
         return O.random_latent_converter(self.sds[0], r_auto), O.random_latent_converter(self.sds[1], r_diffuser)
 
 
+class FakeConditioningStage:
+    def __init__(self, sd_ar, sd_diff, ar_cfg, diff_cfg, device="cpu", dtype=0, max_frames=1024):
+        self.sd_ar, self.sd_diff, self.ar_cfg, self.diff_cfg = sd_ar, sd_diff, ar_cfg, diff_cfg
+
+    def auto_latent(self, mels):
+        return O.ar_get_conditioning(self.sd_ar, self.ar_cfg, torch.stack([m.float().cpu() for m in mels], dim=1))
+
+    def diffusion_latent(self, mels):
+        return O.diffusion_get_conditioning(self.sd_diff, self.diff_cfg, torch.stack([m.float().cpu() for m in mels], dim=1))
+
+
 def install(monkeypatch):
     """Route tortoise_tts_amd.api onto the CPU stand-ins (and a CPU 'device')."""
     from tortoise_tts_amd import api
@@ -100,5 +111,6 @@ def install(monkeypatch):
     monkeypatch.setattr(api.stages, "DiffusionStage", FakeDiffusionStage)
     monkeypatch.setattr(api.stages, "VocoderStage", FakeVocoderStage)
     monkeypatch.setattr(api.stages, "RandomLatentStage", FakeRandomLatentStage)
+    monkeypatch.setattr(api.stages, "ConditioningStage", FakeConditioningStage)
     monkeypatch.setattr(api.E, "require_gpu", lambda device=None: torch.device("cpu"))
     monkeypatch.setattr(api, "_StageTimer", FakeTimer)

@@ -98,6 +98,25 @@ def test_random_voice_and_error_behaviour(tts):
         tts.tts("hello", conditioning_latents=(a, d), max_mel_tokens=500)
 
 
+@torch.no_grad()
+def test_voice_samples_path(tts):
+    """do_tts.py with a wav voice: load_voices returns (clips, None) and tts() calls get_conditioning_latents(voice_samples)
+    (api.py:396-397, 258-299).  Raw 22.05 kHz clips go through the torch mel front-end (audio.py), ready mel pairs are taken as is."""
+    from tortoise_tts_amd.audio import MelFrontEnd
+    g = torch.Generator().manual_seed(5)
+    clips = [torch.randn(1, 30000, generator=g).clamp(-1, 1) * 0.2, torch.randn(1, 45000, generator=g).clamp(-1, 1) * 0.2]
+    tts.mel_front_end = MelFrontEnd(mel_norms=torch.ones(80))  # data/mel_norms.pth may be absent on the test box
+    a, d, am, dm = tts.get_conditioning_latents(clips, return_mels=True)
+    assert a.shape == (1, tts._cfgs["ar"].model_dim) and d.shape == (1, 2 * tts._cfgs["diffusion"].model_channels)
+    assert am.shape[:3] == (1, 2, 80) and dm.shape[:3] == (1, 2, 100)  # api.py:275, 288: clips stacked on dim 1
+    pairs = [(am[:, 0], dm[:, 0]), (am[:, 1], dm[:, 1])]
+    a2, d2 = tts.get_conditioning_latents(pairs)
+    assert torch.equal(a, a2) and torch.equal(d, d2)
+    wav = tts.tts("hello there", voice_samples=clips, num_autoregressive_samples=4, diffusion_iterations=4, max_mel_tokens=24,
+                  use_deterministic_seed=2)
+    assert torch.is_tensor(wav) and wav.shape[:2] == (1, 1) and torch.isfinite(wav).all()
+
+
 def test_constructor_flags(monkeypatch):
     fake_stages.install(monkeypatch)
     from tortoise_tts_amd.api import TextToSpeech

@@ -354,3 +354,59 @@ def test_ar_position_rule_and_hf_generate_codes(kv_cache):
         assert n == want.shape[1], "the engine ran a different number of steps than HF generate()"
         assert agree >= 0.95  # fp16 operands vs fp32 reference: a near-tie in argmax(p/q) may flip a token (measured: see profiles/)
         st.close()
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@torch.no_grad()
+def test_conditioning_encoders(name, dt, tdt, tol):
+    """SURVEY.md 8f-3 on the device: ConditioningEncoder (64-wide heads -> the flash path) and contextual_embedder (stride-2
+    convolutions, 128-wide heads with relative positions -> the wave-per-query kernel) vs the oracle on rounded weights and
+    vs the reference modules' own get_conditioning outputs (tests/golden/conditioning.npz)."""
+    a_cfg, d_cfg = ARConfig(**G.AR_CFG), DiffusionConfig(**G.DIFF_CFG)
+    a_sd = W.synthetic_state_dict(W.ar_manifest(a_cfg), seed=G.COND_SEED)
+    d_sd = W.synthetic_state_dict(W.diffusion_manifest(d_cfg), seed=G.COND_SEED + 1)
+    mel_ar, mel_diff = G.cond_inputs()
+    st = stages.ConditioningStage(a_sd, d_sd, a_cfg, d_cfg, dtype=dt, max_frames=256)
+    got_a = st.auto_latent(mel_ar).cpu()
+    got_d = st.diffusion_latent(mel_diff).cpu()
+    g = gold("conditioning.npz")
+    report(f"conditioning auto latent {name} vs reference golden", got_a, torch.from_numpy(g["auto_latent"]), tol * 1.6)
+    report(f"conditioning diffusion latent {name} vs reference golden", got_d, torch.from_numpy(g["diffusion_latent"]), tol * 1.6)
+    report(f"conditioning auto latent {name} vs oracle", got_a, O.ar_get_conditioning(quantize_sd(a_sd, tdt), a_cfg, mel_ar), tol)
+    report(f"conditioning diffusion latent {name} vs oracle", got_d, O.diffusion_get_conditioning(quantize_sd(d_sd, tdt), d_cfg, mel_diff), tol)
+    # clips of different lengths, passed as a list (api.py:271-289 stacks equal-length clips; the engine takes them one by one)
+    clips = [mel_diff[:, 0], mel_diff[:, 1, :, :37]]
+    got = st.diffusion_latent(clips).cpu()
+    sdq = quantize_sd(d_sd, tdt)
+    outs = []
+    for c in clips:
+        import torch.nn.functional as F_
+        h = F_.conv1d(c.float(), sdq["contextual_embedder.0.weight"], sdq["contextual_embedder.0.bias"], stride=2, padding=1)
+        h = F_.conv1d(h, sdq["contextual_embedder.1.weight"], sdq["contextual_embedder.1.bias"], stride=2, padding=1)
+        i = 2
+        while f"contextual_embedder.{i}.norm.weight" in sdq:
+            h = O.attention_block(sdq, f"contextual_embedder.{i}", h, d_cfg.num_heads)
+            i += 1
+        outs.append(h)
+    report(f"conditioning diffusion latent {name}, ragged clips", got, torch.cat(outs, dim=-1).mean(dim=-1), tol)
+    st.close()
+
+
+@torch.no_grad()
+def test_conditioning_encoders_full_width():
+    """The api.py:217-236 widths (1024 x 16 heads x 6 blocks at 517 frames; 2048-wide embedder, 128-wide heads, 100 frames) vs the oracle."""
+    a_cfg, d_cfg = ARConfig(), DiffusionConfig()
+    keep_a = lambda k: k.startswith("conditioning_encoder.")
+    keep_d = lambda k: k.startswith("contextual_embedder.")
+    a_sd = {k: v for k, v in W.synthetic_state_dict(W.ar_manifest(a_cfg), seed=5).items() if keep_a(k)}
+    d_sd = {k: v for k, v in W.synthetic_state_dict(W.diffusion_manifest(d_cfg), seed=6).items() if keep_d(k)}
+    gen = torch.Generator().manual_seed(8)
+    mel_ar = torch.randn(1, 2, 80, 517, generator=gen)
+    mel_diff = torch.randn(1, 2, 100, 400, generator=gen)
+    st = stages.ConditioningStage(a_sd, d_sd, a_cfg, d_cfg, dtype=E.TT_BF16, max_frames=640)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    report("FULL conditioning auto latent bf16 vs oracle", st.auto_latent(mel_ar).cpu(),
+           O.ar_get_conditioning(quantize_sd(a_sd, torch.bfloat16), a_cfg, mel_ar), 2.5e-2)
+    report("FULL conditioning diffusion latent bf16 vs oracle", st.diffusion_latent(mel_diff).cpu(),
+           O.diffusion_get_conditioning(quantize_sd(d_sd, torch.bfloat16), d_cfg, mel_diff), 2.5e-2)
+    st.close()

@@ -17,7 +17,7 @@ Constructor flags of the reference and what they mean here:
                the engine-only `dtype=` says otherwise;
   * enable_redaction  bracketed text needs the wav2vec2 aligner (out of scope): such text raises, other text is unaffected.
 Out of scope (raise, never silently fall back): CVVP (cvvp_amount != 0, removed upstream), wav2vec redaction of
-bracketed text, DeepSpeed flag, wav -> mel front-end of voice_samples (pass mel spectrograms or conditioning_latents).
+bracketed text, DeepSpeed flag.
 """
 import os
 import random
@@ -157,6 +157,7 @@ class TextToSpeech:
         self._state_dicts = sds
         self.rlg = None         # random-voice latent MLPs, built lazily like the reference (api.py:301-309)
         self.conditioning = None  # conditioning encoders (voice_samples path), built lazily
+        self.mel_front_end = None
         # attributes the reference exposes and callers touch (api.py:408, 523)
         self.stop_mel_token = self.ar_cfg.stop_mel_token
         self.mel_length_compression = self.ar_cfg.mel_length_compression
@@ -172,20 +173,28 @@ class TextToSpeech:
 
     def get_conditioning_latents(self, voice_samples, return_mels=False):
         """api.py:258-299 on the engine: ConditioningEncoder (autoregressive.py:204-228) and contextual_embedder
-        (diffusion_decoder.py:186-192, 222-230) run on the device.  The wav -> mel front-end (TacotronSTFT /
-        torchaudio resample + TorchMelSpectrogram) stays with the caller: voice_samples is a list of (auto_mel f32 [1, 80, T_a],
-        diffusion_mel f32 [1, 100, T_d]) pairs, one per clip, i.e. what api.py:271-289 computes from the raw clips."""
+        (diffusion_decoder.py:186-192, 222-230) run on the device (csrc/cond.hip).  voice_samples is, as in
+        the reference, a list of 22.05 kHz waveform tensors (the mel front-end of api.py:271-287 then runs in torch,
+        tortoise_tts_amd/audio.py: restated without torchaudio / librosa, parity unpinned), or a list of ready
+        (auto_mel f32 [1, 80, T_a], diffusion_mel f32 [1, 100, T_d]) pairs, one per clip."""
+        if torch.is_tensor(voice_samples):
+            voice_samples = [voice_samples]  # api.py:269-270
         if self.conditioning is None:
             self.conditioning = stages.ConditioningStage(self._sd("autoregressive"), self._sd("diffusion"), self.ar_cfg, self.diff_cfg,
                                                          self.device, self.dtype)
         auto_mels, diff_mels = [], []
         for vs in voice_samples:
-            if not (isinstance(vs, (tuple, list)) and len(vs) == 2):
-                raise NotImplementedError("voice_samples must be (auto_mel [1, 80, T], diffusion_mel [1, 100, T]) pairs: the STFT / mel "
-                                          "front-end of raw clips (torchaudio, librosa) is outside the accelerated path; or pass "
-                                          "conditioning_latents= (the .pth files the reference caches per voice)")
-            auto_mels.append(vs[0])
-            diff_mels.append(vs[1])
+            if isinstance(vs, (tuple, list)) and len(vs) == 2:
+                am, dm = vs
+            elif torch.is_tensor(vs):
+                if self.mel_front_end is None:
+                    from .audio import MelFrontEnd
+                    self.mel_front_end = MelFrontEnd(self.models_dir)
+                am, dm = self.mel_front_end(vs.to(self.device))
+            else:
+                raise TypeError("voice_samples entries must be waveform tensors or (auto_mel, diffusion_mel) pairs")
+            auto_mels.append(am.to(self.device).float().reshape(1, am.shape[-2], am.shape[-1]))
+            diff_mels.append(dm.to(self.device).float().reshape(1, dm.shape[-2], dm.shape[-1]))
         auto_latent = self.conditioning.auto_latent(auto_mels)
         diffusion_latent = self.conditioning.diffusion_latent(diff_mels)
         if return_mels:

@@ -128,6 +128,8 @@ extern "C" size_t tt_struct_size(int which) {
     case 12: return sizeof(tt_voc_block);
     case 13: return sizeof(tt_voc_config);
     case 14: return sizeof(tt_voc_weights);
+    case 15: return sizeof(tt_cond_config);
+    case 16: return sizeof(tt_cond_weights);
   }
   return 0;
 }

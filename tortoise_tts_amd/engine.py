@@ -93,9 +93,19 @@ class VocWeights(C.Structure):
     _fields_ = [("w_pre", vp), ("b_pre", vp), ("blocks_host", C.POINTER(VocBlock)), ("w_post", vp), ("b_post", vp)]
 
 
+class CondConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("dtype", "ar_dim", "ar_heads", "ar_blocks", "ar_mel", "ar_mel_pad", "diff_channels", "diff_heads",
+                                       "diff_blocks", "diff_mel", "diff_mel_pad", "max_frames")]
+
+
+class CondWeights(C.Structure):
+    _fields_ = [("ar_w_init", vp), ("ar_b_init", vp), ("ar_attn_host", C.POINTER(AttnBlock)),
+                ("diff_w_c0", vp), ("diff_b_c0", vp), ("diff_w_c1", vp), ("diff_b_c1", vp), ("diff_attn_host", C.POINTER(AttnBlock))]
+
+
 # order == tt_struct_size(which)
 BOUNDARY_STRUCTS = [GptLayer, ArConfig, ArWeights, Sampling, ClvpLayer, ClvpTower, ClvpConfig, AttnBlock, ResBlock, DiffConfig,
-                    DiffWeights, DiffStep, VocBlock, VocConfig, VocWeights]
+                    DiffWeights, DiffStep, VocBlock, VocConfig, VocWeights, CondConfig, CondWeights]
 
 _i, _f, _sz = C.c_int, C.c_float, C.c_size_t
 _PROTOS = {
@@ -124,6 +134,10 @@ _PROTOS = {
     "tt_diff_split_forward": (_i, [vp, vp, vp]),
     "tt_diff_split_update": (_i, [vp, vp, vp, vp, vp]),
     "tt_diff_split_end": (_i, [vp]),
+    "tt_cond_create": (_i, [C.POINTER(CondConfig), C.POINTER(CondWeights), C.POINTER(vp)]),
+    "tt_cond_destroy": (None, [vp]),
+    "tt_cond_ar_clip": (_i, [vp, vp, _i, vp, vp]),
+    "tt_cond_diff_clip": (_i, [vp, vp, _i, vp, C.POINTER(_i), vp]),
     "tt_voc_create": (_i, [C.POINTER(VocConfig), C.POINTER(VocWeights), C.POINTER(vp)]),
     "tt_voc_destroy": (None, [vp]),
     "tt_voc_run": (_i, [vp, vp, _i, vp, vp, vp]),

@@ -237,6 +237,62 @@ def pack_diffusion(sd, cfg: DiffusionConfig, device, dtype, in_pad=128):
     return h
 
 
+# ----------------------------------------------------------------------------------------- conditioning front-end
+def _pack_attn_natural(h, sd, prefix, C, heads):
+    """AttentionBlock whose heads are not 64 wide: QKV rows stay in the reference's [head][q|k|v][ch] order (cond.hip's
+    wave-per-query attention reads that layout); the relative-position table is scaled by sqrt(ch) (arch_util.py:106)."""
+    a = E.AttnBlock()
+    a.norm_g = _p(h.f32(sd[f"{prefix}.norm.weight"]))
+    a.norm_b = _p(h.f32(sd[f"{prefix}.norm.bias"]))
+    a.w_qkv = _p(h.op(sd[f"{prefix}.qkv.weight"]))
+    a.b_qkv = _p(h.f32(sd[f"{prefix}.qkv.bias"]))
+    a.w_proj = _p(h.op(sd[f"{prefix}.proj_out.weight"]))
+    a.b_proj = _p(h.f32(sd[f"{prefix}.proj_out.bias"]))
+    key = f"{prefix}.relative_pos_embeddings.relative_attention_bias.weight"
+    a.relpos = _p(h.f32(relpos_table(sd[key], (C // heads) ** 0.5))) if key in sd else None
+    return a
+
+
+def pack_conditioning(sd_ar, sd_diff, ar_cfg: ARConfig, diff_cfg: DiffusionConfig, device, dtype, mel_pad=128):
+    """Weights of UnifiedVoice.conditioning_encoder (autoregressive.py:204-228) and DiffusionTts.contextual_embedder
+    (diffusion_decoder.py:186-192) for tt_cond_create."""
+    h = Holder(device, dtype)
+    D, Hh = ar_cfg.model_dim, ar_cfg.heads
+    n_ar = 0
+    while f"conditioning_encoder.attn.{n_ar}.norm.weight" in sd_ar:
+        n_ar += 1
+    ar_attn = (E.AttnBlock * n_ar)()
+    for i in range(n_ar):
+        p = f"conditioning_encoder.attn.{i}"
+        ar_attn[i] = _pack_attn(h, sd_ar, p, D, Hh) if D // Hh == 64 else _pack_attn_natural(h, sd_ar, p, D, Hh)
+    C_, Hd = diff_cfg.model_channels, diff_cfg.num_heads
+    n_d = 0
+    while f"contextual_embedder.{2 + n_d}.norm.weight" in sd_diff:
+        n_d += 1
+    d_attn = (E.AttnBlock * n_d)()
+    for i in range(n_d):
+        p = f"contextual_embedder.{2 + i}"
+        d_attn[i] = _pack_attn(h, sd_diff, p, 2 * C_, Hd) if (2 * C_) // Hd == 64 else _pack_attn_natural(h, sd_diff, p, 2 * C_, Hd)
+    w = E.CondWeights()
+    wi = sd_ar["conditioning_encoder.init.weight"]
+    n_mel_ar = wi.shape[1]
+    wpad = torch.zeros(D, mel_pad)
+    wpad[:, :n_mel_ar] = wi.detach().float().cpu().reshape(D, n_mel_ar)
+    w.ar_w_init = _p(h.op(wpad))
+    w.ar_b_init = _p(h.f32(sd_ar["conditioning_encoder.init.bias"]))
+    w.ar_attn_host = ar_attn
+    n_mel_d = sd_diff["contextual_embedder.0.weight"].shape[1]
+    w.diff_w_c0 = _p(h.conv(sd_diff["contextual_embedder.0.weight"], mel_pad))
+    w.diff_b_c0 = _p(h.f32(sd_diff["contextual_embedder.0.bias"]))
+    w.diff_w_c1 = _p(h.conv(sd_diff["contextual_embedder.1.weight"]))
+    w.diff_b_c1 = _p(h.f32(sd_diff["contextual_embedder.1.bias"]))
+    w.diff_attn_host = d_attn
+    h.keep += [ar_attn, d_attn]
+    h.weights = w
+    h.shape = dict(ar_blocks=n_ar, diff_blocks=n_d, ar_mel=n_mel_ar, diff_mel=n_mel_d, mel_pad=mel_pad)
+    return h
+
+
 # ----------------------------------------------------------------------------------------- vocoder
 def pack_vocoder(sd_folded, cfg: VocoderConfig, device, dtype, mel_pad=128):
     """sd_folded: UnivNet state_dict with weight-norm already folded (weights.fold_weight_norm)."""

@@ -297,16 +297,78 @@ class DiffusionStage:
 
 
 class ConditioningStage:
-    """Conditioning encoders of the voice_samples path: UnifiedVoice.get_conditioning
-    (ConditioningEncoder, autoregressive.py:204-228) and DiffusionTts.get_conditioning (contextual_embedder,
-    diffusion_decoder.py:186-192, 222-230).  Not on the device yet: the oracle side exists and is pinned
-    (oracle.ar_get_conditioning / diffusion_get_conditioning, tests/golden/conditioning.npz); constructing this stage
-    refuses loudly so voice_samples= never silently runs somewhere else."""
+    """Conditioning encoders of the voice_samples path on the device (csrc/cond.hip):
+    UnifiedVoice.get_conditioning (ConditioningEncoder, autoregressive.py:204-228, 444-452) and
+    DiffusionTts.get_conditioning (contextual_embedder, diffusion_decoder.py:186-192, 222-230).  Inputs are the mel
+    spectrograms api.py:271-289 builds from the clips; the per-clip results are combined exactly as the reference does."""
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("voice_samples -> conditioning latents (ConditioningEncoder / contextual_embedder, api.py:258-299) "
-                                  "is not on the accelerated path yet (SURVEY.md §8f-3); pass conditioning_latents= (e.g. the .pth "
-                                  "latent files the reference caches per voice) or use the random voice")
+    def __init__(self, sd_ar, sd_diff, ar_cfg, diff_cfg, device="cuda", dtype=E.TT_BF16, max_frames=1024):
+        self.lib = E.init()
+        self.device = torch.device(device)
+        self.ar_cfg, self.diff_cfg = ar_cfg, diff_cfg
+        self.w = pack.pack_conditioning(sd_ar, sd_diff, ar_cfg, diff_cfg, self.device, dtype)
+        sh = self.w.shape
+        c = E.CondConfig()
+        c.dtype = dtype
+        c.ar_dim, c.ar_heads, c.ar_blocks = ar_cfg.model_dim, ar_cfg.heads, sh["ar_blocks"]
+        c.ar_mel, c.ar_mel_pad = sh["ar_mel"], sh["mel_pad"]
+        c.diff_channels, c.diff_heads, c.diff_blocks = diff_cfg.model_channels, diff_cfg.num_heads, sh["diff_blocks"]
+        c.diff_mel, c.diff_mel_pad = sh["diff_mel"], sh["mel_pad"]
+        c.max_frames = max_frames
+        self.cfg = c
+        self.handle = C.c_void_p()
+        E.check(self.lib.tt_cond_create(C.byref(c), C.byref(self.w.weights), C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            self.lib.tt_cond_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _clips(self, mels, n_mel):
+        """Accepts [1, n_clips, n_mel, T] (the reference's stacked tensor) or a list of [1, n_mel, T] / [n_mel, T] clips."""
+        if torch.is_tensor(mels):
+            mels = [mels[0, j] for j in range(mels.shape[1])] if mels.dim() == 4 else [mels]
+        out = []
+        for m in mels:
+            m = m.to(self.device).float()
+            m = m.reshape(-1, m.shape[-1]) if m.dim() == 3 else m
+            if m.shape[0] != n_mel:
+                raise ValueError(f"conditioning clip has {m.shape[0]} mel channels, the encoder takes {n_mel}")
+            out.append(m.contiguous())
+        if not out:
+            raise ValueError("no conditioning clips")
+        return out
+
+    def auto_latent(self, mels):
+        """mels f32 [1, n_clips, 80, T] (or a list of clips) -> f32 [1, model_dim]: mean over the clips of h[:, :, 0]."""
+        clips = self._clips(mels, self.cfg.ar_mel)
+        acc = torch.zeros(self.cfg.ar_dim, device=self.device, dtype=torch.float32)
+        out = torch.empty(self.cfg.ar_dim, device=self.device, dtype=torch.float32)
+        for m in clips:
+            E.check(self.lib.tt_cond_ar_clip(self.handle, E.ptr(m), m.shape[1], E.ptr(out), E.stream_ptr()))
+            acc += out
+        return (acc / len(clips))[None]
+
+    def diffusion_latent(self, mels):
+        """mels f32 [1, n_clips, 100, T] (or a list of clips) -> f32 [1, 2 * model_channels]: the clips' embedder outputs
+        concatenated along time and averaged."""
+        clips = self._clips(mels, self.cfg.diff_mel)
+        C2 = 2 * self.cfg.diff_channels
+        acc = torch.zeros(C2, device=self.device, dtype=torch.float32)
+        out = torch.empty(C2, device=self.device, dtype=torch.float32)
+        total = 0
+        for m in clips:
+            frames = C.c_int(0)
+            E.check(self.lib.tt_cond_diff_clip(self.handle, E.ptr(m), m.shape[1], E.ptr(out), C.byref(frames), E.stream_ptr()))
+            acc += out
+            total += frames.value
+        return (acc / total)[None]
 
 
 class RandomLatentStage:
