@@ -744,7 +744,8 @@ __global__ __launch_bounds__(NSEQ * 64, 4) void decode_attn_lds_kernel(DecodeAtt
   int16v qlo, qhi;
   {
     const T* qp = (const T*)a.q + (size_t)b * a.heads * 64 + h * 64;
-    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=s"(qlo), "=s"(qhi) : "s"(qp) : "memory");
+    // early-clobber outputs: the second load still reads the address pair after the first one has been issued (and may have landed)
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(qlo), "=&s"(qhi) : "s"(qp) : "memory");
   }
   const int nso = (tgen + 63) >> 6;
   auto load_own = [&](x8 (&kk)[8], int slot) {  // own keys of slot (clamped: an odd slot count repeats the last slot, result dropped)

@@ -435,12 +435,14 @@ __device__ __forceinline__ void gn_finalize(const GroupNormArgs& a, int b, int t
       ss += part_s[p][tid];
       qq += part_q[p][tid];
     }
-    const double n = (double)a.S * (double)(a.C / 32);
-    const double m = ss / n;
-    double var = qq / n - m * m;
+    // the sums are combined in fp64 (E[x^2] - E[x]^2 cancels in fp32); the reciprocal square root of the O(1) result is an
+    // fp32 instruction, not an fp64 divide + square root (hundreds of cycles on the one wave every block waits for)
+    const double inv_n = a.inv_count;  // 1 / (S * C / 32), set by groupnorm_launch
+    const double m = ss * inv_n;
+    double var = qq * inv_n - m * m;
     if (var < 0.0) var = 0.0;
     mean_s[tid] = (float)m;
-    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+    rstd_s[tid] = rsqrtf((float)var + a.eps);
   }
   __syncthreads();
 }
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchu
 
 // C == 1024 fast path: thread t owns channels 4t..4t+3 (group t/8) of GN_APPLY_ROWS consecutive rows.  The x rows
 // are requested BEFORE the statistics are finalised, so the streaming loads overlap the (latency-bound) prologue.
-constexpr int GN_APPLY_ROWS = 8;
+constexpr int GN_APPLY_ROWS = 4;  // 4 rows per block: 2 blocks per CU at the denoiser's 1740 rows, so one block's statistics prologue overlaps the other's stream
 template <typename T, bool FUSED, bool SS>
 __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, int nchunk) {
   __shared__ float mean_s[32], rstd_s[32];
@@ -547,7 +549,9 @@ __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, in
   }
 }
 
-int groupnorm_launch(int dtype, const GroupNormArgs& a, hipStream_t stream) {
+int groupnorm_launch(int dtype, const GroupNormArgs& a0, hipStream_t stream) {
+  GroupNormArgs a = a0;
+  a.inv_count = 1.0 / ((double)a.S * (double)(a.C / 32));
   const int c4n = a.C / 4;
   TT_REQUIRE(a.C % 128 == 0 && ((c4n <= 256 && (c4n & (c4n - 1)) == 0) || c4n % 256 == 0), "groupnorm: unsupported C=%d", a.C);
   TT_REQUIRE(a.B > 0 && a.S > 0 && a.partial != nullptr, "groupnorm: bad arguments");

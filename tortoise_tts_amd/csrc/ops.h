@@ -53,6 +53,7 @@ struct GroupNormArgs {
   const float* gemm_part;  // optional: statistics already emitted by the producing GEMM's epilogue (gemm.hip
                            // run_epilogue) as [row_tile][2][C/16][2]; the separate statistics pass is skipped
   int part_rows;           // rows per row tile of gemm_part
+  double inv_count;        // set by groupnorm_launch: 1 / (S * C / 32)
 };
 int groupnorm_launch(int dtype, const GroupNormArgs& a, hipStream_t stream);
 size_t groupnorm_partial_floats(int B, int S);
