@@ -299,6 +299,41 @@ int tt_cond_ar_clip(tt_cond* h, const float* mel, int T, float* out, void* strea
 int tt_cond_diff_clip(tt_cond* h, const float* mel, int T, float* out_sum, int* frames, void* stream);
 
 /* ============================================================================================
+ * HiFi-GAN decoder of the streaming path (replaces hifi_decoder.inference(gpt_latents, auto_conditioning),
+ * api_fast.py:420 tts_stream and api_fast.py:517 tts; hifigan_decoder.py:159-294)
+ * ============================================================================================ */
+#define TT_HIFI_MAX_STAGES 6
+typedef struct tt_hifi_resblock {           /* hifigan_decoder.ResBlock1: convs1[d] (dilated) / convs2[d] per dilation d */
+  const void* w1[3]; const float* b1[3];    /* T [Cp][k][Cp]  (Cp = channels padded to a multiple of 64, pad rows / columns zero) */
+  const void* w2[3]; const float* b2[3];
+} tt_hifi_resblock;
+typedef struct tt_hifi_config {
+  int dtype;
+  int in_channels, cond_channels, initial_channel;   /* 1024, 1024, 512 */
+  int num_stages; int up_factor[TT_HIFI_MAX_STAGES]; /* 4: 8, 8, 2, 2 (transposed-conv kernel = 2 * factor) */
+  int num_kernels; int kernel_size[3];               /* 3: 3, 7, 11 */
+  int num_dilations; int dilation[3];                /* 3: 1, 3, 5 */
+  float lrelu_slope;                                 /* 0.1 */
+  int max_latents;                                   /* longest latent sequence (mel codes) */
+} tt_hifi_config;
+typedef struct tt_hifi_weights {
+  const void* w_pre; const float* b_pre;             /* T [C0][7][in]  conv_pre */
+  const void* w_cond; const float* b_cond;           /* T [C0][cond]   cond_layer (1x1) */
+  const void* w_up[TT_HIFI_MAX_STAGES];              /* T [u * Cp_out][2][Cp_in]: row r * Cp_out + co = (w[:, co, r + u] | w[:, co, r]) */
+  const float* b_up[TT_HIFI_MAX_STAGES];             /* f32 [u * Cp_out] */
+  const tt_hifi_resblock* res_host;                  /* num_stages * num_kernels blocks */
+  const void* w_post; const float* b_post;           /* T [1][7][Cp_last], f32 [1]  conv_post */
+} tt_hifi_weights;
+typedef struct tt_hifi tt_hifi;
+int tt_hifi_create(const tt_hifi_config* cfg, const tt_hifi_weights* w, tt_hifi** out);
+void tt_hifi_destroy(tt_hifi* h);
+/* frames after the two linear interpolations of HifiganGenerator.inference (x4, x24000/22050); samples = frames * prod(up_factor) */
+int tt_hifi_output_frames(int n_latents);
+/* latents f32 [T][in_channels] (GPT latents of ONE sequence), g f32 [cond_channels] (AR conditioning latent)
+ * -> wav f32 [*n_samples] in [-1, 1] (tanh), *n_samples = tt_hifi_output_frames(T) * prod(up_factor) */
+int tt_hifi_run(tt_hifi* h, const float* latents, int T, const float* g, float* wav, int* n_samples, void* stream);
+
+/* ============================================================================================
  * Operator-level entry points (used by tests/ to check single kernels against torch references)
  * ============================================================================================ */
 int tt_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int taps, int seq_len,

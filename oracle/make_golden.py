@@ -272,6 +272,35 @@ def golden_rlg():
     np.savez_compressed(os.path.join(OUT, "rlg.npz"), **out)
 
 
+HIFI_CFG = dict(in_channels=128, cond_channels=128, upsample_initial_channel=256)
+HIFI_SEED, HIFI_T = 21, 12
+
+
+def hifi_inputs(cfg):
+    g = torch.Generator().manual_seed(HIFI_SEED + 1)
+    return torch.randn(1, HIFI_T, cfg.in_channels, generator=g), torch.randn(1, cfg.cond_channels, generator=g) * 0.5
+
+
+@torch.no_grad()
+def golden_hifigan():
+    """HifiganGenerator.inference of the streaming path (hifigan_decoder.py:259-289, api_fast.py:222-225 structure) at a
+    reduced width: channels 256 -> 128 -> 64 -> 32 -> 16, factors [8, 8, 2, 2], three ResBlock1 per stage."""
+    ref_shims.install()
+    from tortoise.models.hifigan_decoder import HifiganGenerator
+    from tortoise_tts_amd.config import HifiganConfig
+    cfg = HifiganConfig(**HIFI_CFG)
+    sd = W.synthetic_state_dict(W.hifigan_manifest(cfg), seed=HIFI_SEED)
+    m = HifiganGenerator(in_channels=cfg.in_channels, out_channels=1, resblock_type="1",
+                         resblock_dilation_sizes=[list(cfg.resblock_dilation_sizes)] * len(cfg.resblock_kernel_sizes),
+                         resblock_kernel_sizes=list(cfg.resblock_kernel_sizes), upsample_kernel_sizes=list(cfg.upsample_kernel_sizes),
+                         upsample_initial_channel=cfg.upsample_initial_channel, upsample_factors=list(cfg.upsample_factors),
+                         cond_channels=cfg.cond_channels).eval()
+    m.load_state_dict(sd, strict=True)
+    m.device = torch.device("cpu")
+    lat, g = hifi_inputs(cfg)
+    np.savez_compressed(os.path.join(OUT, "hifigan.npz"), wav=m.inference(lat, g).numpy())
+
+
 def golden_text():
     """Long-form chunking (tortoise/utils/text.py:4-72).  The three cases are the reference's OWN expectations
     (text.py:82-130, which pass here: `python tortoise/utils/text.py`); inputs and outputs are stored so the GPU box,
@@ -333,6 +362,7 @@ def main():
     golden_vocoder(ref)
     golden_conditioning(ref)
     golden_rlg()
+    golden_hifigan()
     golden_text()
     golden_integer()
     for f in sorted(os.listdir(OUT)):

@@ -640,3 +640,34 @@ def univnet_inference(sd, cfg: VocoderConfig, mel, z):
     pad = torch.full((mel.shape[0], cfg.n_mel_channels, 10), -11.5129)
     audio = univnet_forward(sd, cfg, torch.cat((mel, pad), dim=2), z)
     return audio[:, :, :-(cfg.hop_length * 10)].clamp(-1, 1)
+
+
+def hifigan_inference(sd, cfg, latents, g):
+    """HifiganGenerator.inference + forward (hifigan_decoder.py:229-289) on weight-norm-folded weights:
+    latents [B, T, in_channels] -> linear x4 -> linear x24000/22050 -> conv_pre + cond_layer(g) -> per stage
+    [lrelu(0.1) -> ConvTranspose1d -> mean of the ResBlock1 stack] -> lrelu(0.01) -> conv_post -> tanh.
+    g [B, cond_channels] (the AR conditioning latent); returns [B, 1, T2 * hop]."""
+    up1 = F.interpolate(latents.float().transpose(1, 2), scale_factor=[1024 / 256], mode="linear")
+    x = F.interpolate(up1, scale_factor=[24000 / 22050], mode="linear")
+    o = F.conv1d(x, sd["conv_pre.weight"], sd["conv_pre.bias"], padding=3)
+    o = o + F.conv1d(g.float().unsqueeze(0).transpose(1, 2), sd["cond_layer.weight"], sd["cond_layer.bias"])
+    nk = len(cfg.resblock_kernel_sizes)
+    for i, (u, k) in enumerate(zip(cfg.upsample_factors, cfg.upsample_kernel_sizes)):
+        o = F.leaky_relu(o, cfg.lrelu_slope)
+        o = F.conv_transpose1d(o, sd[f"ups.{i}.weight"], sd[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
+        z_sum = None
+        for j, ks in enumerate(cfg.resblock_kernel_sizes):
+            xr = o
+            p = f"resblocks.{i * nk + j}"
+            for dd, dil in enumerate(cfg.resblock_dilation_sizes):  # ResBlock1.forward (hifigan_decoder.py:90-107)
+                xt = F.leaky_relu(xr, cfg.lrelu_slope)
+                xt = F.conv1d(xt, sd[f"{p}.convs1.{dd}.weight"], sd[f"{p}.convs1.{dd}.bias"], dilation=dil, padding=(ks * dil - dil) // 2)
+                xt = F.leaky_relu(xt, cfg.lrelu_slope)
+                xt = F.conv1d(xt, sd[f"{p}.convs2.{dd}.weight"], sd[f"{p}.convs2.{dd}.bias"], padding=(ks - 1) // 2)
+                xr = xt + xr
+            z_sum = xr if z_sum is None else z_sum + xr
+        o = z_sum / nk
+    o = F.leaky_relu(o)  # default slope 0.01 (hifigan_decoder.py:257)
+    o = F.conv1d(o, sd["conv_post.weight"], sd["conv_post.bias"], padding=3)
+    return torch.tanh(o)
+

@@ -14,7 +14,7 @@ from oracle import tortoise_oracle as O
 from tortoise_tts_amd import engine as E
 from tortoise_tts_amd import weights as W
 from tortoise_tts_amd import stages
-from tortoise_tts_amd.config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
+from tortoise_tts_amd.config import ARConfig, CLVPConfig, DiffusionConfig, HifiganConfig, VocoderConfig
 from tortoise_tts_amd.schedule import Schedule
 from tests.gpu_util import DTYPES, quantize_sd, report, rel_err
 
@@ -409,4 +409,37 @@ def test_conditioning_encoders_full_width():
            O.ar_get_conditioning(quantize_sd(a_sd, torch.bfloat16), a_cfg, mel_ar), 2.5e-2)
     report("FULL conditioning diffusion latent bf16 vs oracle", st.diffusion_latent(mel_diff).cpu(),
            O.diffusion_get_conditioning(quantize_sd(d_sd, torch.bfloat16), d_cfg, mel_diff), 2.5e-2)
+    st.close()
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@torch.no_grad()
+def test_hifigan_decoder(name, dt, tdt, tol):
+    """HifiganGenerator.inference on the MFMA conv-GEMM path (dilated taps, transposed conv as a 2-tap GEMM,
+    channel widths 32 / 16 padded to 64) vs the oracle on rounded weights and vs the reference module's own output."""
+    cfg = HifiganConfig(**G.HIFI_CFG)
+    sd = W.fold_weight_norm(W.synthetic_state_dict(W.hifigan_manifest(cfg), seed=G.HIFI_SEED))
+    lat, g = G.hifi_inputs(cfg)
+    st = stages.HifiganStage(sd, cfg, dtype=dt, max_latents=32)
+    got = st.inference(lat, g).cpu()
+    want = torch.from_numpy(gold("hifigan.npz")["wav"])
+    assert got.shape == want.shape == (1, 1, E.load_library().tt_hifi_output_frames(G.HIFI_T) * cfg.hop)
+    report(f"hifigan wav {name} vs reference golden", got, want, tol * 1.6)
+    report(f"hifigan wav {name} vs oracle", got, O.hifigan_inference(quantize_sd(sd, tdt), cfg, lat, g), tol)
+    # a shorter latent sequence on the same handle (streaming chunks grow from call to call)
+    got5 = st.inference(lat[:, :5], g).cpu()
+    report(f"hifigan wav {name}, 5 latents", got5, O.hifigan_inference(quantize_sd(sd, tdt), cfg, lat[:, :5], g), tol)
+    st.close()
+
+
+@torch.no_grad()
+def test_hifigan_decoder_full_width():
+    """api_fast.py:222-225 widths (1024 -> 512 -> 256 -> 128 -> 64 -> 32 channels, factors 8, 8, 2, 2) on 40 latents vs the oracle."""
+    cfg = HifiganConfig()
+    sd = W.fold_weight_norm(W.synthetic_state_dict(W.hifigan_manifest(cfg), seed=31))
+    gen = torch.Generator().manual_seed(32)
+    lat, g = torch.randn(1, 40, cfg.in_channels, generator=gen), torch.randn(1, cfg.cond_channels, generator=gen) * 0.5
+    st = stages.HifiganStage(sd, cfg, dtype=E.TT_BF16, max_latents=64)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    report("FULL hifigan wav bf16 vs oracle", st.inference(lat, g).cpu(), O.hifigan_inference(quantize_sd(sd, torch.bfloat16), cfg, lat, g), 2.5e-2)
     st.close()

@@ -124,3 +124,13 @@ def test_random_latent_converter():
         got = O.random_latent_converter(sd, G.rlg_inputs(ch))
         assert got.shape == (1, ch) and float(got.abs().mean()) > 1e-3
         close(got, g[f"latent_{ch}"], 1e-5)
+
+
+@torch.no_grad()
+def test_hifigan_decoder():
+    """oracle.hifigan_inference vs the reference HifiganGenerator.inference output (hifigan_decoder.py:259-289)."""
+    from tortoise_tts_amd.config import HifiganConfig
+    cfg = HifiganConfig(**G.HIFI_CFG)
+    sd = W.fold_weight_norm(W.synthetic_state_dict(W.hifigan_manifest(cfg), seed=G.HIFI_SEED))
+    lat, g = G.hifi_inputs(cfg)
+    close(O.hifigan_inference(sd, cfg, lat, g), gold("hifigan.npz")["wav"], 1e-6)

@@ -79,6 +79,26 @@ class VocoderConfig:
     n_mel_channels: int = 100
 
 
+@dataclass
+class HifiganConfig:
+    """HifiganGenerator of the streaming path (reference: tortoise/models/hifigan_decoder.py:159-294, api_fast.py:222-225)."""
+    in_channels: int = 1024
+    cond_channels: int = 1024
+    upsample_initial_channel: int = 512
+    upsample_factors: List[int] = field(default_factory=lambda: [8, 8, 2, 2])
+    upsample_kernel_sizes: List[int] = field(default_factory=lambda: [16, 16, 4, 4])
+    resblock_kernel_sizes: List[int] = field(default_factory=lambda: [3, 7, 11])
+    resblock_dilation_sizes: List[int] = field(default_factory=lambda: [1, 3, 5])
+    lrelu_slope: float = 0.1
+
+    @property
+    def hop(self):
+        h = 1
+        for u in self.upsample_factors:
+            h *= u
+        return h
+
+
 PRESETS = {  # reference: tortoise/api.py:320-329
     "ultra_fast": {"num_autoregressive_samples": 16, "diffusion_iterations": 30, "cond_free": False},
     "fast": {"num_autoregressive_samples": 96, "diffusion_iterations": 80},

@@ -130,6 +130,9 @@ extern "C" size_t tt_struct_size(int which) {
     case 14: return sizeof(tt_voc_weights);
     case 15: return sizeof(tt_cond_config);
     case 16: return sizeof(tt_cond_weights);
+    case 17: return sizeof(tt_hifi_resblock);
+    case 18: return sizeof(tt_hifi_config);
+    case 19: return sizeof(tt_hifi_weights);
   }
   return 0;
 }

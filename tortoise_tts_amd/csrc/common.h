@@ -119,13 +119,14 @@ __device__ __forceinline__ float gelu_tanh(float x) {  // HF "gelu_new": 0.5 x (
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
-enum Act { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_LRELU = 4 };
+enum Act { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_LRELU = 4, ACT_TANH = 5 };
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {
     case ACT_GELU_TANH: return gelu_tanh(v);
     case ACT_GELU_ERF: return gelu_erf(v);
     case ACT_SILU: return silu(v);
     case ACT_LRELU: return v > 0.f ? v : v * slope;
+    case ACT_TANH: return tanhf(v);
     default: return v;
   }
 }

@@ -27,6 +27,7 @@ struct GemmArgs {
   size_t a2_slot_stride;
   int M, N, K;
   int taps;     // 1 = plain GEMM
+  int dilation; // rows between conv taps (0 / 1: adjacent rows); tap t reads row s + (t - taps/2) * dilation
   int seq_len;  // rows per sequence (conv boundary / head-layout epilogues)
   int cin;      // K / taps
   int splitk;   // >1: raw partial sums go to out_f32 + z * M * ldo32 (EPI_STD only)
@@ -43,6 +44,8 @@ struct GemmArgs {
   int ldo32;
   void* out_t;  // T-typed copy of the result (operand of the next GEMM)
   int ldot;
+  int act_t;    // ACT_LRELU: the T-typed copy alone gets LeakyReLU(slope_t) AFTER the residual add (input activation of the next conv)
+  float slope_t;
   float* gn_part;  // optional: per-(row tile, 16-column strip) sum / sum-of-squares of the f32 output (see gemm.hip)
   int gn_seq;      // rows per sequence for those statistics
   int gn_ncol16;   // set by gemm_launch

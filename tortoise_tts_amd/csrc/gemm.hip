@@ -20,7 +20,7 @@ extern template int gemm_init_typed<f16>();
 // alone (split tail) or batched with the conditioning-free row.
 static int pick_tile(const GemmArgs& a) {
   const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk;
-  if (a.M > 256 && b128 >= 256) return TILE_128x128;
+  if (a.M > 256 && b128 >= 256 && a.N > 64) return TILE_128x128;  // (N <= 64: half of a 128-wide tile would be padding)
   if (a.M > 1024 || (a.M > 256 && a.gn_part != nullptr)) return TILE_128x64;
   return TILE_64x64;  // also one denoiser row (M = S <= 1024, the split diffusion tail): 2x the workgroups of 128x64
 }
@@ -45,6 +45,7 @@ static void plan_core(const GemmArgs& a, int epi, GemmPlan& p) {
   c.A = a.A; c.W = a.W; c.lda = a.lda; c.ldw = a.ldw; c.M = a.M; c.N = a.N;
   c.cin_tiles = a.cin / 64;
   c.taps_half = a.taps >> 1;
+  c.dil = a.dilation > 0 ? a.dilation : 1;
   c.seq_len = a.seq_len;
   c.seq = make_fastdiv(a.seq_len > 0 ? a.seq_len : 1);
   const int gx = cdiv(a.M, bm), gy = cdiv(a.N, bn);
@@ -103,6 +104,7 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   TT_REQUIRE(a.splitk == 1 || (epi == EPI_STD && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
   TT_REQUIRE(a.splitk <= a.K / 64, "gemm: splitk=%d exceeds the %d k-tiles", a.splitk, a.K / 64);
   if (a.A2) TT_REQUIRE(a.taps == 1 && a.k_split > 0 && a.k_split < a.K && a.k_split % 64 == 0 && a.lda2 % 8 == 0, "gemm: bad second activation source (k_split=%d lda2=%d)", a.k_split, a.lda2);
+  TT_REQUIRE(a.act_t == ACT_NONE || (a.act_t == ACT_LRELU && epi == EPI_STD && a.out_t && a.splitk == 1), "gemm: act_t supports LeakyReLU on the T-typed output of the standard epilogue only");
   if (a.gn_part) {
     TT_REQUIRE(epi == EPI_STD && a.splitk == 1 && a.out_f32 && a.gn_seq > 0 && a.N % 16 == 0, "gemm: GroupNorm statistics need the standard epilogue, an f32 output, no split-K and N %% 16 == 0");
     a.gn_ncol16 = a.N / 16;

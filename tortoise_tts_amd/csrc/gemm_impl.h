@@ -48,7 +48,7 @@ struct GemmCore {
   int cin_tiles;           // 32  k-tiles per conv tap (= all k-tiles for a plain GEMM)
   int taps_half;           // 36  taps / 2
   int seq_len;             // 40
-  int pad0;                // 44
+  int dil;                 // 44  rows between conv taps
   FastDiv seq;             // 48  / seq_len
   unsigned xq, xr;         // 56  workgroups / 8, workgroups % 8
   unsigned gx, gy;         // 64  row tiles, column tiles
@@ -74,6 +74,8 @@ struct EpiStdArgs {
   int ldres, ldo32, ldot, act;
   float slope;
   int splitk;
+  int act_t;
+  float slope_t;
   int gn_ncol16;
   FastDiv gn_seq;
 };
@@ -196,10 +198,15 @@ struct EpiStd {
     }
     if (has_t(e)) {
       T* o = (T*)e.out_t + (size_t)m * e.ldot + n;
+      f32x4 w = v;
+      if (MODE < 0 && e.act_t == ACT_LRELU) {  // (run-time-output variants only)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = w[i] > 0.f ? w[i] : w[i] * e.slope_t;
+      }
       if (AL || (nvalid == 4 && (e.ldot & 3) == 0)) {
-        *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
+        *(typename Vec<T>::x4*)o = pack4<T>(w[0], w[1], w[2], w[3]);
       } else {
-        for (int i = 0; i < nvalid; ++i) o[i] = (T)v[i];
+        for (int i = 0; i < nvalid; ++i) o[i] = (T)w[i];
       }
     }
   }
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
   }
   auto issue = [&](int buf) {
     const int kin = it_kin * BK;
-    const int shift = it_tap - c.taps_half;
+    const int shift = (it_tap - c.taps_half) * c.dil;
     T* as = As + buf * BM * BK;
     T* ws = Ws + buf * BN * BK;
 #pragma unroll
@@ -673,6 +680,7 @@ static inline EpiStdArgs make_epi_std(const GemmArgs& a) {
   e.bias = a.bias; e.res = a.res; e.out_f32 = a.out_f32; e.out_t = a.out_t; e.gn_part = a.gn_part;
   e.ldres = a.ldres; e.ldo32 = a.ldo32; e.ldot = a.ldot; e.act = a.act; e.slope = a.slope; e.splitk = a.splitk;
   e.gn_ncol16 = a.gn_ncol16;
+  e.act_t = a.act_t; e.slope_t = a.slope_t;
   e.gn_seq = make_fastdiv(a.gn_seq > 0 ? a.gn_seq : 1);
   return e;
 }
@@ -700,9 +708,9 @@ int gemm_launch_typed(int epi, const GemmArgs& a, const GemmPlan& plan, hipStrea
           else if (!a2 && mode == (EB_BIAS | EB_RES | EB_F32)) variant = V_ST_RES;
           else if (a2 && !conv && mode == (EB_BIAS | EB_F32)) variant = V_ST_A2;
         } else if (!a2) {
-          variant = (mode == EB_SLAB && !conv) ? V_SLAB : mode == (EB_BIAS | EB_T) ? V_BIAS_T : V_NONE;
+          variant = (mode == EB_SLAB && !conv) ? V_SLAB : (mode == (EB_BIAS | EB_T) && !a.act_t) ? V_BIAS_T : V_NONE;
         }
-      } else if (a.act == ACT_GELU_TANH && !a2 && !stats && !conv && mode == (EB_BIAS | EB_T)) {
+      } else if (a.act == ACT_GELU_TANH && !a2 && !stats && !conv && mode == (EB_BIAS | EB_T) && !a.act_t) {
         variant = V_GELU_T;
       }
     }

@@ -103,9 +103,27 @@ class CondWeights(C.Structure):
                 ("diff_w_c0", vp), ("diff_b_c0", vp), ("diff_w_c1", vp), ("diff_b_c1", vp), ("diff_attn_host", C.POINTER(AttnBlock))]
 
 
+HIFI_MAX_STAGES = 6
+
+
+class HifiResBlock(C.Structure):
+    _fields_ = [("w1", vp * 3), ("b1", vp * 3), ("w2", vp * 3), ("b2", vp * 3)]
+
+
+class HifiConfig(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("in_channels", C.c_int), ("cond_channels", C.c_int), ("initial_channel", C.c_int),
+                ("num_stages", C.c_int), ("up_factor", C.c_int * HIFI_MAX_STAGES), ("num_kernels", C.c_int), ("kernel_size", C.c_int * 3),
+                ("num_dilations", C.c_int), ("dilation", C.c_int * 3), ("lrelu_slope", C.c_float), ("max_latents", C.c_int)]
+
+
+class HifiWeights(C.Structure):
+    _fields_ = [("w_pre", vp), ("b_pre", vp), ("w_cond", vp), ("b_cond", vp), ("w_up", vp * HIFI_MAX_STAGES), ("b_up", vp * HIFI_MAX_STAGES),
+                ("res_host", C.POINTER(HifiResBlock)), ("w_post", vp), ("b_post", vp)]
+
+
 # order == tt_struct_size(which)
 BOUNDARY_STRUCTS = [GptLayer, ArConfig, ArWeights, Sampling, ClvpLayer, ClvpTower, ClvpConfig, AttnBlock, ResBlock, DiffConfig,
-                    DiffWeights, DiffStep, VocBlock, VocConfig, VocWeights, CondConfig, CondWeights]
+                    DiffWeights, DiffStep, VocBlock, VocConfig, VocWeights, CondConfig, CondWeights, HifiResBlock, HifiConfig, HifiWeights]
 
 _i, _f, _sz = C.c_int, C.c_float, C.c_size_t
 _PROTOS = {
@@ -138,6 +156,10 @@ _PROTOS = {
     "tt_cond_destroy": (None, [vp]),
     "tt_cond_ar_clip": (_i, [vp, vp, _i, vp, vp]),
     "tt_cond_diff_clip": (_i, [vp, vp, _i, vp, C.POINTER(_i), vp]),
+    "tt_hifi_create": (_i, [C.POINTER(HifiConfig), C.POINTER(HifiWeights), C.POINTER(vp)]),
+    "tt_hifi_destroy": (None, [vp]),
+    "tt_hifi_output_frames": (_i, [_i]),
+    "tt_hifi_run": (_i, [vp, vp, _i, vp, vp, C.POINTER(_i), vp]),
     "tt_voc_create": (_i, [C.POINTER(VocConfig), C.POINTER(VocWeights), C.POINTER(vp)]),
     "tt_voc_destroy": (None, [vp]),
     "tt_voc_run": (_i, [vp, vp, _i, vp, vp, vp]),

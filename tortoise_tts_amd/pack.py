@@ -293,6 +293,67 @@ def pack_conditioning(sd_ar, sd_diff, ar_cfg: ARConfig, diff_cfg: DiffusionConfi
     return h
 
 
+# ----------------------------------------------------------------------------------------- HiFi-GAN decoder
+def _cpad(c):
+    return max(64, (c + 63) // 64 * 64)
+
+
+def pack_hifigan(sd, cfg, device, dtype):
+    """HifiganGenerator weights (weight norm already folded) for tt_hifi_create: token-major conv-GEMM operands with the
+    channel widths padded to multiples of 64 by zero rows / columns; ConvTranspose1d(k = 2u, stride u) as the 2-tap GEMM
+    with N = u * C_out described in csrc/hifigan.hip."""
+    h = Holder(device, dtype)
+    c0 = cfg.upsample_initial_channel
+    ns, nk, nd = len(cfg.upsample_factors), len(cfg.resblock_kernel_sizes), len(cfg.resblock_dilation_sizes)
+    assert ns <= E.HIFI_MAX_STAGES and nk <= 3 and nd <= 3
+
+    def conv_padded(wt, cout_pad, cin_pad):
+        wt = wt.detach().float().cpu()
+        co, ci, k = wt.shape
+        p = torch.zeros(cout_pad, k, cin_pad)
+        p[:co, :, :ci] = wt.permute(0, 2, 1)
+        return h.op(p)
+
+    def bias_padded(b, n):
+        p = torch.zeros(n)
+        p[:b.numel()] = b.detach().float().cpu()
+        return h.f32(p)
+
+    w = E.HifiWeights()
+    w.w_pre = _p(conv_padded(sd["conv_pre.weight"], _cpad(c0), cfg.in_channels))
+    w.b_pre = _p(bias_padded(sd["conv_pre.bias"], _cpad(c0)))
+    w.w_cond = _p(h.op(sd["cond_layer.weight"]))
+    w.b_cond = _p(h.f32(sd["cond_layer.bias"]))
+    res = (E.HifiResBlock * (ns * nk))()
+    for i, (u, k) in enumerate(zip(cfg.upsample_factors, cfg.upsample_kernel_sizes)):
+        assert k == 2 * u and u % 2 == 0, "transposed convs must have kernel = 2 * stride (api_fast.py:224)"
+        cin, cout = c0 // (2 ** i), c0 // (2 ** (i + 1))
+        cin_p, cout_p = _cpad(cin), _cpad(cout)
+        wt = sd[f"ups.{i}.weight"].detach().float().cpu()       # [cin][cout][2u]
+        p = torch.zeros(u, cout_p, 2, cin_p)
+        p[:, :cout, 0, :cin] = wt[:, :, u:].permute(2, 1, 0)      # tap 0 reads x[j - 1]: kernel index r + u
+        p[:, :cout, 1, :cin] = wt[:, :, :u].permute(2, 1, 0)      # tap 1 reads x[j]:     kernel index r
+        w.w_up[i] = _p(h.op(p.reshape(u * cout_p, 2 * cin_p)))
+        b = torch.zeros(u, cout_p)
+        b[:, :cout] = sd[f"ups.{i}.bias"].detach().float().cpu()[None]
+        w.b_up[i] = _p(h.f32(b.reshape(-1)))
+        for j in range(nk):
+            rb = res[i * nk + j]
+            for dd in range(nd):
+                pre = f"resblocks.{i * nk + j}"
+                rb.w1[dd] = _p(conv_padded(sd[f"{pre}.convs1.{dd}.weight"], cout_p, cout_p))
+                rb.b1[dd] = _p(bias_padded(sd[f"{pre}.convs1.{dd}.bias"], cout_p))
+                rb.w2[dd] = _p(conv_padded(sd[f"{pre}.convs2.{dd}.weight"], cout_p, cout_p))
+                rb.b2[dd] = _p(bias_padded(sd[f"{pre}.convs2.{dd}.bias"], cout_p))
+    c_last = _cpad(c0 // (2 ** ns))
+    w.res_host = res
+    w.w_post = _p(conv_padded(sd["conv_post.weight"], 1, c_last))
+    w.b_post = _p(h.f32(sd["conv_post.bias"]))
+    h.keep.append(res)
+    h.weights = w
+    return h
+
+
 # ----------------------------------------------------------------------------------------- vocoder
 def pack_vocoder(sd_folded, cfg: VocoderConfig, device, dtype, mel_pad=128):
     """sd_folded: UnivNet state_dict with weight-norm already folded (weights.fold_weight_norm)."""

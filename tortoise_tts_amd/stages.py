@@ -409,6 +409,57 @@ class RandomLatentStage:
         return self._run(self.nets[0], r_auto), self._run(self.nets[1], r_diffuser)
 
 
+class HifiganStage:
+    """HiFi-GAN decoder of the streaming path (csrc/hifigan.hip): hifi_decoder.inference(gpt_latents,
+    auto_conditioning) of api_fast.py:420 / 517 (hifigan_decoder.py:259-289)."""
+
+    def __init__(self, sd_folded, cfg, device="cuda", dtype=E.TT_BF16, max_latents=512):
+        self.lib = E.init()
+        self.device = torch.device(device)
+        self.cfg = cfg
+        self.w = pack.pack_hifigan(sd_folded, cfg, self.device, dtype)
+        c = E.HifiConfig()
+        c.dtype = dtype
+        c.in_channels, c.cond_channels, c.initial_channel = cfg.in_channels, cfg.cond_channels, cfg.upsample_initial_channel
+        c.num_stages = len(cfg.upsample_factors)
+        for i, u in enumerate(cfg.upsample_factors):
+            c.up_factor[i] = u
+        c.num_kernels = len(cfg.resblock_kernel_sizes)
+        for i, k in enumerate(cfg.resblock_kernel_sizes):
+            c.kernel_size[i] = k
+        c.num_dilations = len(cfg.resblock_dilation_sizes)
+        for i, d in enumerate(cfg.resblock_dilation_sizes):
+            c.dilation[i] = d
+        c.lrelu_slope = cfg.lrelu_slope
+        c.max_latents = max_latents
+        self.c = c
+        self.handle = C.c_void_p()
+        E.check(self.lib.tt_hifi_create(C.byref(c), C.byref(self.w.weights), C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            self.lib.tt_hifi_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def inference(self, latents, g):
+        """latents f32 [1, T, in_channels], g f32 [1, cond_channels] -> wav f32 [1, 1, frames * hop] (on the device)."""
+        lat = latents.to(self.device).float().reshape(-1, self.cfg.in_channels).contiguous()
+        gv = g.to(self.device).float().reshape(-1).contiguous()
+        T = lat.shape[0]
+        n = self.lib.tt_hifi_output_frames(T) * self.cfg.hop
+        wav = torch.empty(n, device=self.device, dtype=torch.float32)
+        ns = C.c_int(0)
+        E.check(self.lib.tt_hifi_run(self.handle, E.ptr(lat), T, E.ptr(gv), E.ptr(wav), C.byref(ns), E.stream_ptr()))
+        assert ns.value == n, (ns.value, n)
+        return wav[None, None]
+
+
 class VocoderStage:
     """UnivNetGenerator.inference (vocoder.py:300-312)."""
 

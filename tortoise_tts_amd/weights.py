@@ -192,6 +192,27 @@ def vocoder_manifest(cfg: VocoderConfig = VocoderConfig()):
     return d
 
 
+def hifigan_manifest(cfg):
+    """HifiganGenerator.state_dict() with weight_norm parameters (hifigan_decoder.py:191-228): conv_pre, ups.i
+    (ConvTranspose1d: [in, out, k]), resblocks.(i * n_kernels + j).convs1/convs2.d, conv_post, cond_layer (plain Conv1d)."""
+    d = OrderedDict()
+    c0 = cfg.upsample_initial_channel
+    _wn(d, "conv_pre", (c0, cfg.in_channels, 7))
+    nk = len(cfg.resblock_kernel_sizes)
+    ch = c0
+    for i, (u, k) in enumerate(zip(cfg.upsample_factors, cfg.upsample_kernel_sizes)):
+        cin, ch = c0 // (2 ** i), c0 // (2 ** (i + 1))
+        _wn(d, f"ups.{i}", (cin, ch, k), g_dim0=ch)
+        for j, ks in enumerate(cfg.resblock_kernel_sizes):
+            for dd in range(len(cfg.resblock_dilation_sizes)):
+                _wn(d, f"resblocks.{i * nk + j}.convs1.{dd}", (ch, ch, ks))
+                _wn(d, f"resblocks.{i * nk + j}.convs2.{dd}", (ch, ch, ks))
+    _wn(d, "conv_post", (1, ch, 7))
+    d["cond_layer.weight"] = (c0, cfg.cond_channels, 1)
+    d["cond_layer.bias"] = (c0,)
+    return d
+
+
 def rlg_manifest(channels):
     """RandomLatentConverter(channels) (random_latent_generator.py:42-55): 5 EqualLinear + 1 Linear; rlg_auto.pth is
     channels = 1024, rlg_diffuser.pth 2048 (api.py:301-309)."""
