@@ -100,6 +100,12 @@ typedef struct tt_sampling {
  * stop_mel_token past each row's end (api.py:425-426 padding).  The per-token step is replayed
  * from a hipGraph.  Synchronises `stream` before returning; *n_steps_host = tokens per row. */
 int tt_ar_generate(tt_ar* h, int B, int max_new, const tt_sampling* s, int* codes, int* n_steps_host, void* stream);
+/* The same loop in resumable pieces (the streaming path, api_fast.py:389-420 pulls tokens from
+ * get_generator() chunk by chunk): first != 0 starts a generation (token 0 from the prefill logits), first == 0 resumes it;
+ * n_more further tokens are sampled into codes int32 [B][ldcodes] (the SAME buffer on every call).
+ * *n_total_host = tokens per row so far, *finished_host = 1 once every row has emitted stop_mel_token. */
+int tt_ar_generate_chunk(tt_ar* h, int B, int first, int n_more, int ldcodes, const tt_sampling* s, int* codes, int* n_total_host,
+                         int* finished_host, void* stream);
 
 /* Teacher-forced single steps for parity tests: tt_ar_begin resets per-sequence state for B rows
  * after a prefill; tt_ar_decode_step feeds tokens int32 [B] (KV-cached position rule of

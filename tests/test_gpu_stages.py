@@ -443,3 +443,55 @@ def test_hifigan_decoder_full_width():
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
     report("FULL hifigan wav bf16 vs oracle", st.inference(lat, g).cpu(), O.hifigan_inference(quantize_sd(sd, torch.bfloat16), cfg, lat, g), 2.5e-2)
     st.close()
+
+
+@torch.no_grad()
+def test_ar_generate_chunks_equal_one_shot_loop():
+    """tt_ar_generate_chunk (the streaming path resumes the hipGraph decode loop chunk by chunk) must reproduce tt_ar_generate
+    bit for bit: same Philox streams, same device-side state, ragged stop tokens included."""
+    cfg = ARConfig(**G.AR_CFG)
+    sd = G.sampling_state_dict(cfg, 2.0)
+    cond, text = G.ar_inputs(cfg)
+    st = stages.ArStage(sd, cfg, max_batch=8, max_text=40, max_new_tokens=40, max_latent_candidates=1)
+    st.prefill(cond, text)
+    full, n = st.generate(6, 36, seed=5)
+    st.prefill(cond, text)
+    last, pieces = None, 0
+    for codes, done in st.generate_stream(6, 36, 5, first_chunk=7, seed=5):
+        last, pieces = codes, pieces + 1
+        assert torch.equal(codes, full[:, :codes.shape[1]])
+    assert pieces >= 2 and last.shape[1] == n and torch.equal(last, full)
+    st.close()
+
+
+@torch.no_grad()
+def test_api_fast_tts_and_stream():
+    """tortoise.api_fast.TextToSpeech surface: tts() = generate -> latents -> HiFi-GAN; tts_stream() resumes the
+    decode loop per chunk, re-decodes the latents so far and cross-fades (handle_chunks, api_fast.py:275-309)."""
+    from tortoise_tts_amd.api_fast import TextToSpeech
+    a_cfg = ARConfig(**G.AR_CFG)
+    h_cfg = HifiganConfig(in_channels=a_cfg.model_dim, cond_channels=a_cfg.model_dim, upsample_initial_channel=128)
+    sds = {"autoregressive": W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(a_cfg), seed=G.AR_SEED), a_cfg),
+           "hifidecoder": W.synthetic_state_dict(W.hifigan_manifest(h_cfg), seed=41)}
+    tts = TextToSpeech(state_dicts=sds, configs={"ar": a_cfg, "hifigan": h_cfg}, max_mel_tokens=104, max_text_tokens=40, kv_cache=True)
+    gen = torch.Generator().manual_seed(3)
+    lat = (torch.randn(1, a_cfg.model_dim, generator=gen) * 0.5,)
+    text = list(range(5, 25))
+    wav = tts.tts(text, conditioning_latents=lat, max_mel_tokens=100, use_deterministic_seed=9)
+    frames = E.load_library().tt_hifi_output_frames(100)
+    assert wav.shape == (1, 1, frames * h_cfg.hop) and wav.device.type == "cpu" and torch.isfinite(wav).all() and wav.abs().max() <= 1.0
+    codes_full = tts.last_codes
+    chunks = list(tts.tts_stream(text, conditioning_latents=lat, max_mel_tokens=100, use_deterministic_seed=9, stream_chunk_size=12,
+                                 overlap_wav_len=256))
+    assert len(chunks) == 5  # 60 (first buffer, api_fast.py:401), then 12 tokens per piece: 72, 84, 96, 100
+    total = sum(int(c.shape[0]) for c in chunks)
+    assert total == wav.shape[-1] - 256  # everything but the last overlap window is emitted (api_fast.py:277-281)
+    # the first piece is the decode of the first 60 codes, minus its overlap tail
+    first = tts.hifi_decoder.inference(tts.ar.latents(lat[0].cuda(), F_pad_text(text), codes_full[:, :60]), lat[0]).reshape(-1)
+    assert torch.equal(chunks[0].cpu(), first[:-256].cpu())
+    tts.ar.close(); tts.hifi_decoder.close()
+
+
+def F_pad_text(ids):
+    import torch.nn.functional as F_
+    return F_.pad(torch.tensor(ids, dtype=torch.int32, device="cuda")[None], (0, 1))

@@ -94,6 +94,14 @@ def _load_state_dict(models_dir, name):
     return sd["model_g"] if name == "vocoder" else sd
 
 
+def _load_file(models_dir, filename):
+    path = os.path.join(models_dir, filename)
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} not found. Put the reference checkpoints in models_dir (or $TORTOISE_MODELS_DIR), or pass "
+                                f"state_dicts= to TextToSpeech; there is no network access to download them.")
+    return torch.load(path, map_location="cpu")
+
+
 class TextToSpeech:
     """Main entry point; see the module docstring.  Engine-only keyword arguments (all optional, after
     the reference's): `state_dicts` (dict of reference-layout state_dicts instead of files in

@@ -211,6 +211,7 @@ int tt_cond_ar_clip(tt_cond* e, const float* mel, int T, float* out, void* strea
 
 int tt_cond_diff_clip(tt_cond* e, const float* mel, int T, float* out_sum, int* frames, void* stream) {
   TT_REQUIRE(e && mel && out_sum && frames, "tt_cond_diff_clip: null argument");
+  TT_REQUIRE(e->cfg.diff_blocks > 0 && e->w.diff_w_c0 && e->w.diff_w_c1, "tt_cond_diff_clip: this handle was created without the diffusion embedder");
   TT_REQUIRE(T >= 4 && T <= e->cfg.max_frames, "tt_cond_diff_clip: %d frames outside [4, %d]", T, e->cfg.max_frames);
   hipStream_t us = (hipStream_t)stream, s = e->sb.own;
   TT_TRY(e->sb.enter(us));

@@ -42,6 +42,8 @@ struct tt_ar {
   int logits_rows = 0;
   bool logits_from_prefill = false;
   int host_slot = -1;  // host mirror of state[1]; only feeds the profiler's byte estimates
+  int gen_done = 0;    // tokens sampled by the running generation (tt_ar_generate / tt_ar_generate_chunk)
+  bool gen_finished = false;
 };
 
 static const int MAX_SPLIT = 8;
@@ -294,36 +296,38 @@ int tt_ar_decode_step(tt_ar* e, const int* tokens, void* stream) {
   return e->sb.leave(us);
 }
 
-int tt_ar_generate(tt_ar* e, int B, int max_new, const tt_sampling* sp, int* codes, int* n_steps_host, void* stream) {
-  TT_REQUIRE(e && sp && codes, "tt_ar_generate: null argument");
-  TT_REQUIRE(B >= 1 && B <= e->cfg.max_batch, "tt_ar_generate: batch %d exceeds capacity %d", B, e->cfg.max_batch);
-  TT_REQUIRE(max_new >= 1 && max_new <= e->tmax, "tt_ar_generate: max_new %d exceeds capacity %d", max_new, e->tmax);
-  TT_REQUIRE(max_new - 2 + e->cfg.mel_pos_offset < e->cfg.mel_pos_len, "tt_ar_generate: max_new %d exceeds the mel position table", max_new);
-  TT_REQUIRE(e->P1 > 0, "tt_ar_generate: call tt_ar_prefill first");
-  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
-  TT_TRY(e->sb.enter(us));
-  e->B = B;
-  TT_TRY(ar_begin_launch(e->state, e->seen, e->unfinished, e->unfinished_count, B, e->V, e->tmax + 8, e->cfg.start_mel_token, s));
-  TT_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)codes, e->cfg.stop_mel_token, (size_t)B * max_new, s));
+// Sampling loop shared by tt_ar_generate (fresh = true: the whole utterance) and tt_ar_generate_chunk (streaming: the loop
+// is resumed where the previous chunk stopped; every per-step quantity lives in device-side state, so resuming is just
+// replaying the step graph again).  Tokens [e->gen_done, target) are produced; codes is [B][ldcodes].
+static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes, const tt_sampling* sp, int* codes, int* n_steps_host,
+                           int* finished_host, hipStream_t s) {
   SampleArgs sa;
   memset(&sa, 0, sizeof(sa));
   sa.B = B; sa.V = e->V; sa.seen = e->seen;
   sa.rep_penalty = sp->repetition_penalty; sa.temperature = sp->temperature; sa.top_p = sp->top_p; sa.top_k = sp->top_k;
   sa.exp_noise = sp->exp_noise; sa.seed = sp->seed; sa.row_offset = sp->row_offset;
   sa.state = e->state; sa.unfinished = e->unfinished; sa.stop_token = e->cfg.stop_mel_token;
-  sa.codes = codes; sa.ldcodes = max_new; sa.next_tok = e->next_tok; sa.unfinished_count = e->unfinished_count;
+  sa.codes = codes; sa.ldcodes = ldcodes; sa.next_tok = e->next_tok; sa.unfinished_count = e->unfinished_count;
   sa.embed_x = e->x; sa.tok_emb = e->w.mel_emb; sa.pos_emb = e->w.mel_pos; sa.D = e->D; sa.pos_offset = e->cfg.mel_pos_offset;
-  // token 0: every row samples from the shared prefill logits
-  sa.logits = e->logits; sa.ldl = 0;
-  TT_REQUIRE(e->logits_from_prefill, "tt_ar_generate: the logits buffer does not hold prefill logits; call tt_ar_prefill first");
-  e->logits_from_prefill = false;
-  TT_TRY(sample_launch(sa, s));
-  TT_TRY(ar_state_advance_launch(e->state, s));
-  sa.ldl = e->V;
+  if (fresh) {
+    e->B = B;
+    e->gen_done = 0;
+    e->gen_finished = false;
+    TT_TRY(ar_begin_launch(e->state, e->seen, e->unfinished, e->unfinished_count, B, e->V, e->tmax + 8, e->cfg.start_mel_token, s));
+    TT_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)codes, e->cfg.stop_mel_token, (size_t)B * ldcodes, s));
+    // token 0: every row samples from the shared prefill logits
+    sa.logits = e->logits; sa.ldl = 0;
+    TT_REQUIRE(e->logits_from_prefill, "tt_ar_generate: the logits buffer does not hold prefill logits; call tt_ar_prefill first");
+    e->logits_from_prefill = false;
+    TT_TRY(sample_launch(sa, s));
+    TT_TRY(ar_state_advance_launch(e->state, s));
+    e->gen_done = 1;
+  }
+  sa.logits = e->logits; sa.ldl = e->V;
 
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  const bool use_graph = graphs_enabled() && max_new > 2;
+  const bool use_graph = graphs_enabled() && target - e->gen_done > 1;
   int rc = 0;
   if (use_graph) {
     TT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -342,10 +346,11 @@ int tt_ar_generate(tt_ar* e, int B, int max_new, const tt_sampling* sp, int* cod
       return -2;
     }
   }
-  int steps_done = 1;
-  bool finished = false;
+  const int first_step = e->gen_done;
+  int steps_done = e->gen_done;
+  bool finished = e->gen_finished;
   int first_zero = -1;
-  for (int step = 1; step < max_new && !finished; ++step) {
+  for (int step = first_step; step < target && !finished; ++step) {
     if (use_graph) {
       hipError_t le = hipGraphLaunch(exec, s);
       if (le != hipSuccess) { set_error("hipGraphLaunch: %s", hipGetErrorString(le)); rc = -2; break; }
@@ -357,7 +362,7 @@ int tt_ar_generate(tt_ar* e, int B, int max_new, const tt_sampling* sp, int* cod
       if (rc) break;
     }
     steps_done = step + 1;
-    if ((step & 7) == 7 || step == max_new - 1) {
+    if (((step - first_step) & 7) == 7 || step == target - 1) {
       hipError_t ce = hipMemcpyAsync(e->count_host, e->unfinished_count, (size_t)steps_done * sizeof(int), hipMemcpyDeviceToHost, s);
       if (ce == hipSuccess) ce = hipStreamSynchronize(s);
       if (ce != hipSuccess) { set_error("tt_ar_generate: %s", hipGetErrorString(ce)); rc = -2; break; }
@@ -365,14 +370,54 @@ int tt_ar_generate(tt_ar* e, int B, int max_new, const tt_sampling* sp, int* cod
         if (e->count_host[i] == 0) { first_zero = i; finished = true; break; }
     }
   }
-  if (max_new == 1 && !rc) {
-    hipError_t ce = hipStreamSynchronize(s);
+  if (steps_done == first_step && !rc) {  // nothing to replay (one-token request): still a host-visible completion point
+    hipError_t ce = hipMemcpyAsync(e->count_host, e->unfinished_count, (size_t)steps_done * sizeof(int), hipMemcpyDeviceToHost, s);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(s);
     if (ce != hipSuccess) { set_error("tt_ar_generate: %s", hipGetErrorString(ce)); rc = -2; }
+    for (int i = 0; i < steps_done && !rc; ++i)
+      if (e->count_host[i] == 0) { first_zero = i; finished = true; break; }
   }
   if (exec) (void)hipGraphExecDestroy(exec);
   if (graph) (void)hipGraphDestroy(graph);
   TT_TRY(rc);
-  if (n_steps_host) *n_steps_host = first_zero >= 0 ? first_zero + 1 : steps_done;
+  e->gen_done = first_zero >= 0 ? first_zero + 1 : steps_done;
+  e->gen_finished = finished;
+  e->host_slot = e->gen_done - 1;
+  if (n_steps_host) *n_steps_host = e->gen_done;
+  if (finished_host) *finished_host = finished ? 1 : 0;
+  return 0;
+}
+
+int tt_ar_generate(tt_ar* e, int B, int max_new, const tt_sampling* sp, int* codes, int* n_steps_host, void* stream) {
+  TT_REQUIRE(e && sp && codes, "tt_ar_generate: null argument");
+  TT_REQUIRE(B >= 1 && B <= e->cfg.max_batch, "tt_ar_generate: batch %d exceeds capacity %d", B, e->cfg.max_batch);
+  TT_REQUIRE(max_new >= 1 && max_new <= e->tmax, "tt_ar_generate: max_new %d exceeds capacity %d", max_new, e->tmax);
+  TT_REQUIRE(max_new - 2 + e->cfg.mel_pos_offset < e->cfg.mel_pos_len, "tt_ar_generate: max_new %d exceeds the mel position table", max_new);
+  TT_REQUIRE(e->P1 > 0, "tt_ar_generate: call tt_ar_prefill first");
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  TT_TRY(ar_generate_run(e, B, true, max_new, max_new, sp, codes, n_steps_host, nullptr, s));
+  return e->sb.leave(us);
+}
+
+int tt_ar_generate_chunk(tt_ar* e, int B, int first, int n_more, int ldcodes, const tt_sampling* sp, int* codes, int* n_total_host,
+                         int* finished_host, void* stream) {
+  TT_REQUIRE(e && sp && codes && n_total_host && finished_host, "tt_ar_generate_chunk: null argument");
+  TT_REQUIRE(B >= 1 && B <= e->cfg.max_batch, "tt_ar_generate_chunk: batch %d exceeds capacity %d", B, e->cfg.max_batch);
+  TT_REQUIRE(e->P1 > 0, "tt_ar_generate_chunk: call tt_ar_prefill first");
+  TT_REQUIRE(first || (e->gen_done >= 1 && e->B == B), "tt_ar_generate_chunk: no generation of %d rows to resume", B);
+  const int done = first ? 0 : e->gen_done;
+  const int target = done + n_more;
+  TT_REQUIRE(n_more >= 1 && target <= ldcodes && target <= e->tmax, "tt_ar_generate_chunk: %d + %d tokens exceed capacity (%d code columns, %d KV slots)", done, n_more, ldcodes, e->tmax);
+  TT_REQUIRE(target - 2 + e->cfg.mel_pos_offset < e->cfg.mel_pos_len, "tt_ar_generate_chunk: %d tokens exceed the mel position table", target);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  if (!first && e->gen_finished) {  // every row already stopped
+    *n_total_host = e->gen_done;
+    *finished_host = 1;
+    return e->sb.leave(us);
+  }
+  TT_TRY(ar_generate_run(e, B, first != 0, target, ldcodes, sp, codes, n_total_host, finished_host, s));
   return e->sb.leave(us);
 }
 

@@ -136,6 +136,7 @@ _PROTOS = {
     "tt_ar_prefill": (_i, [vp, vp, _i, vp]),
     "tt_ar_get_logits": (_i, [vp, vp, _i, vp]),
     "tt_ar_generate": (_i, [vp, _i, _i, C.POINTER(Sampling), vp, C.POINTER(_i), vp]),
+    "tt_ar_generate_chunk": (_i, [vp, _i, _i, _i, _i, C.POINTER(Sampling), vp, C.POINTER(_i), C.POINTER(_i), vp]),
     "tt_ar_begin": (_i, [vp, _i, vp]),
     "tt_ar_decode_step": (_i, [vp, vp, vp]),
     "tt_ar_latents": (_i, [vp, vp, _i, _i, vp, vp]),

@@ -265,11 +265,12 @@ def pack_conditioning(sd_ar, sd_diff, ar_cfg: ARConfig, diff_cfg: DiffusionConfi
     for i in range(n_ar):
         p = f"conditioning_encoder.attn.{i}"
         ar_attn[i] = _pack_attn(h, sd_ar, p, D, Hh) if D // Hh == 64 else _pack_attn_natural(h, sd_ar, p, D, Hh)
-    C_, Hd = diff_cfg.model_channels, diff_cfg.num_heads
+    have_diff = sd_diff is not None  # the streaming path (api_fast) has no diffusion stage: autoregressive encoder only
+    C_, Hd = (diff_cfg.model_channels, diff_cfg.num_heads) if have_diff else (64, 1)
     n_d = 0
-    while f"contextual_embedder.{2 + n_d}.norm.weight" in sd_diff:
+    while have_diff and f"contextual_embedder.{2 + n_d}.norm.weight" in sd_diff:
         n_d += 1
-    d_attn = (E.AttnBlock * n_d)()
+    d_attn = (E.AttnBlock * max(n_d, 1))()
     for i in range(n_d):
         p = f"contextual_embedder.{2 + i}"
         d_attn[i] = _pack_attn(h, sd_diff, p, 2 * C_, Hd) if (2 * C_) // Hd == 64 else _pack_attn_natural(h, sd_diff, p, 2 * C_, Hd)
@@ -281,15 +282,17 @@ def pack_conditioning(sd_ar, sd_diff, ar_cfg: ARConfig, diff_cfg: DiffusionConfi
     w.ar_w_init = _p(h.op(wpad))
     w.ar_b_init = _p(h.f32(sd_ar["conditioning_encoder.init.bias"]))
     w.ar_attn_host = ar_attn
-    n_mel_d = sd_diff["contextual_embedder.0.weight"].shape[1]
-    w.diff_w_c0 = _p(h.conv(sd_diff["contextual_embedder.0.weight"], mel_pad))
-    w.diff_b_c0 = _p(h.f32(sd_diff["contextual_embedder.0.bias"]))
-    w.diff_w_c1 = _p(h.conv(sd_diff["contextual_embedder.1.weight"]))
-    w.diff_b_c1 = _p(h.f32(sd_diff["contextual_embedder.1.bias"]))
+    n_mel_d = 100
+    if have_diff:
+        n_mel_d = sd_diff["contextual_embedder.0.weight"].shape[1]
+        w.diff_w_c0 = _p(h.conv(sd_diff["contextual_embedder.0.weight"], mel_pad))
+        w.diff_b_c0 = _p(h.f32(sd_diff["contextual_embedder.0.bias"]))
+        w.diff_w_c1 = _p(h.conv(sd_diff["contextual_embedder.1.weight"]))
+        w.diff_b_c1 = _p(h.f32(sd_diff["contextual_embedder.1.bias"]))
     w.diff_attn_host = d_attn
     h.keep += [ar_attn, d_attn]
     h.weights = w
-    h.shape = dict(ar_blocks=n_ar, diff_blocks=n_d, ar_mel=n_mel_ar, diff_mel=n_mel_d, mel_pad=mel_pad)
+    h.shape = dict(ar_blocks=n_ar, diff_blocks=n_d, ar_mel=n_mel_ar, diff_mel=n_mel_d, mel_pad=mel_pad, diff_channels=C_, diff_heads=Hd)
     return h
 
 

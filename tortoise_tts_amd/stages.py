@@ -100,6 +100,29 @@ class ArStage:
         E.check(self.lib.tt_ar_generate(self.h, B, max_new, C.byref(s), E.ptr(codes), C.byref(n), E.stream_ptr()))
         return codes[:, :n.value].long(), n.value
 
+    def generate_stream(self, B, max_new, chunk, first_chunk=None, temperature=0.8, top_p=0.8, repetition_penalty=2.0, top_k=50, seed=0,
+                        row_offset=0):
+        """Generator over the sampling loop in pieces (api_fast.py:389-420 pulls get_generator() token by token and decodes every
+        `stream_chunk_size` tokens): yields (codes int64 [B, n_so_far], finished) after each chunk."""
+        s = E.Sampling()
+        s.temperature, s.top_p, s.repetition_penalty, s.top_k = temperature, top_p, repetition_penalty, top_k
+        s.seed, s.row_offset = seed, row_offset
+        s.exp_noise = None
+        codes = torch.empty(B, max_new, device=self.device, dtype=torch.int32)
+        n, fin = C.c_int(0), C.c_int(0)
+        first = True
+        while True:
+            want = min((first_chunk or chunk) if first else chunk, max_new - n.value)
+            if want <= 0:
+                return
+            E.check(self.lib.tt_ar_generate_chunk(self.h, B, 1 if first else 0, want, max_new, C.byref(s), E.ptr(codes), C.byref(n),
+                                                  C.byref(fin), E.stream_ptr()))
+            first = False
+            done = bool(fin.value) or n.value >= max_new
+            yield codes[:, :n.value].long(), done
+            if done:
+                return
+
     # -- latent re-pass (autoregressive.py:454-506 as api.py:521-524 calls it)
     def latents(self, cond_latent, text_tokens, codes):
         cfg = self.cfg
@@ -312,7 +335,7 @@ class ConditioningStage:
         c.dtype = dtype
         c.ar_dim, c.ar_heads, c.ar_blocks = ar_cfg.model_dim, ar_cfg.heads, sh["ar_blocks"]
         c.ar_mel, c.ar_mel_pad = sh["ar_mel"], sh["mel_pad"]
-        c.diff_channels, c.diff_heads, c.diff_blocks = diff_cfg.model_channels, diff_cfg.num_heads, sh["diff_blocks"]
+        c.diff_channels, c.diff_heads, c.diff_blocks = sh["diff_channels"], sh["diff_heads"], sh["diff_blocks"]
         c.diff_mel, c.diff_mel_pad = sh["diff_mel"], sh["mel_pad"]
         c.max_frames = max_frames
         self.cfg = c
