@@ -202,6 +202,8 @@ def main():
     ap.add_argument("--workload", default="utterance", choices=["utterance", "read"],
                     help="utterance: one tts_with_preset call per step (BASELINE metric); read: one long-form paragraph per step = 15 chunks "
                          "spread over the GPUs as replicas (BASELINE config #4, tortoise/read.py)")
+    ap.add_argument("--diffusion-iterations", type=int, default=None,
+                    help="override the preset's diffusion iterations (profiling passes only: the headline metric uses the preset's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -215,6 +217,10 @@ def main():
 
     preset_kw = dict(BASE_SETTINGS)
     preset_kw.update(PRESETS[args.preset])
+    extra_kw = {}
+    if args.diffusion_iterations is not None:
+        preset_kw["diffusion_iterations"] = args.diffusion_iterations
+        extra_kw["diffusion_iterations"] = args.diffusion_iterations
     N = preset_kw["num_autoregressive_samples"]
     M = args.mel_tokens
     t_build = time.perf_counter()
@@ -240,7 +246,7 @@ def main():
     else:
         def run_step(i=0):
             return tts.tts_with_preset(text, preset=args.preset, conditioning_latents=latents, max_mel_tokens=M,
-                                       use_deterministic_seed=1000 + i, k=1, verbose=False)
+                                       use_deterministic_seed=1000 + i, k=1, verbose=False, **extra_kw)
         audio_per_step = S_audio
 
     wav = None

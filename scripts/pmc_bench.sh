@@ -13,7 +13,7 @@ i=0
 for set in "${SETS[@]}"; do
   i=$((i+1)); c=pass$i
   (cd /tmp && timeout 900 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$c -o p -- \
-     env TT_NO_GRAPH=1 python $OLDPWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/$c.log 2>&1)
+     env TT_NO_GRAPH=1 python $OLDPWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline ${PMC_BENCH_ARGS:---diffusion-iterations 24} > $OUT/$c.log 2>&1)
   echo "pmc [$set] rc=$?" | tee -a $OUT/summary.txt
 done
 OUT=$OUT PMC_JSON=${PMC_JSON:-pmc_bench.json} python - <<'PY'
@@ -35,7 +35,7 @@ def klass(k):
             bm, bn, epi, conv = m.groups()
             return "gemm_glds<%s,%s,%s%s>" % (bm, bn, epi, (",conv" if conv == "true" else ",1x1") if epi == "EpiStd" else "")
         return "gemm_glds<?>"
-    for pat, name in (("flash_lds_kernel", "flash_kernel"), ("flash_kernel", "flash_kernel"), ("decode_attn_kernel", "decode_attn_kernel"),
+    for pat, name in (("flash_lds_kernel", "flash_kernel"), ("flash_kernel", "flash_kernel"), ("decode_attn_lds_kernel", "decode_attn_kernel"), ("decode_attn_kernel", "decode_attn_kernel"),
                       ("gn_apply", "gn_apply_kernel(+gn_stats)"), ("gn_stats", "gn_apply_kernel(+gn_stats)"), ("rownorm", "rownorm_kernel"),
                       ("sample_kernel", "sample_kernel"), ("lvc_kernel", "lvc_kernel"), ("conv1d_direct", "conv1d_direct_kernel"), ("convt1d", "convt1d_kernel")):
         if pat in k:
@@ -55,7 +55,7 @@ res = {}
 for k, cs in agg.items():
     res[k] = {c: {"dispatches": v[0], "sum": v[1], "avg": v[1] / max(v[0], 1)} for c, v in cs.items()}
 import bench
-res["_meta"] = {"source_digest": bench.source_digest(), "command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline (TT_NO_GRAPH=1)",
+res["_meta"] = {"source_digest": bench.source_digest(), "command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline " + os.environ.get("PMC_BENCH_ARGS", "--diffusion-iterations 24") + " (TT_NO_GRAPH=1; every kernel class at its benchmark shape, 24 instead of 200 denoiser steps: this rocprofv3 segfaults in counter collection on the full 80 000-dispatch utterance)",
                 "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch as rocprofv3 reports them (FETCH_SIZE is doubled by bench.py)"}
 json.dump(res, open(out + "/../" + os.environ["PMC_JSON"], "w"), indent=1, sort_keys=True)
 for k in sorted(res):
