@@ -22,7 +22,7 @@ for ph in $PHASES; do
             find $OUT/prof -type f -size +8M -delete; find $OUT/prof -type f | head -20; tail -3 $OUT/prof.log ;;
   esac
 done
-grep -h "\[parity\]" $OUT/*.log 2>/dev/null | tail -150 > $OUT/parity.txt
+grep -h "\[parity\]" $OUT/*.log 2>/dev/null | sed "s/^\.*//" > $OUT/parity.txt
 tail -25 $OUT/summary.txt
 for f in ops stages full smoke; do [ -f $OUT/$f.log ] && { echo "--- $f"; grep -E "passed|failed|error|Error|FAILED|assert" $OUT/$f.log | tail -30; }; done
 exit 0
