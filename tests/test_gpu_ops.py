@@ -187,6 +187,37 @@ def test_sampler_matches_oracle(lib):
         assert allowed[b, int(c1[b, 0])], "sampled token outside the top-k/top-p nucleus"
 
 
+def test_sampler_tie_plateau_is_deterministic(lib):
+    """More scores tie at the k-th value than the survivor buffer holds (quantised / saturated logits): the kept set must not depend
+    on atomic slot order.  Rows: a full plateau, and 20 clear winners above a plateau."""
+    B, V = 2, 8194
+    logits = torch.zeros(B, V)
+    logits[1, 100:120] = 5.0
+    g = torch.Generator().manual_seed(6)
+    q = torch.empty(1, B, V).exponential_(1, generator=g)
+    seen_np = torch.zeros(B, (V + 31) // 32, dtype=torch.int32)
+    s = E.Sampling()
+    s.temperature, s.top_p, s.repetition_penalty, s.top_k, s.seed, s.row_offset = 1.0, 1.0, 1.0, 50, 0, 0
+    qd = dev(q)
+    s.exp_noise = E.ptr(qd)
+    logits_d = dev(logits)
+    outs = []
+    for _ in range(4):
+        codes = torch.zeros(B, 4, device="cuda", dtype=torch.int32)
+        un = dev(torch.ones(B, dtype=torch.int32))
+        sn = dev(seen_np.clone())
+        E.check(lib.tt_op_sample(E.ptr(logits_d), V, B, V, E.ptr(sn), C.byref(s), 0, E.ptr(un), 8193, E.ptr(codes), 4, None))
+        outs.append(codes[:, 0].cpu())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    # the deterministic kept set: everything above the plateau + the lowest-index ties up to 512 entries; uniform p -> argmax(1/q) = argmin q
+    want0 = int(q[0, 0, :512].argmin())
+    kept1 = torch.cat([torch.arange(100, 120), torch.arange(0, 512 - 20)])
+    p1 = torch.softmax(logits[1, kept1], -1)
+    want1 = int(kept1[(p1 / q[0, 1, kept1]).argmax()])
+    print("[parity] sampler plateau tokens", outs[0].tolist(), [want0, want1])
+    assert outs[0].tolist() == [want0, want1]
+
+
 def test_univnet_kernels(lib):
     g = torch.Generator().manual_seed(9)
     # dilated conv with fused LeakyReLUs

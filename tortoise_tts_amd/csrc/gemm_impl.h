@@ -1,6 +1,6 @@
 // MFMA GEMM kernels for gfx950 (see gemm.h; instantiated per operand type by gemm_bf16.hip / gemm_f16.hip).
 //
-// One kernel family, gemm_glds_kernel: NW waves in a 2 x NW/2 grid, each wave owns a (BM/2) x (BN / (NW/2)) sub-tile built
+// One kernel family, gemm_glds_kernel: NW waves in a WM x NW/WM grid, each wave owns a (BM/WM) x (BN / (NW/WM)) sub-tile built
 // from v_mfma_f32_16x16x32 fragments.  The MFMA is issued "swapped" (W fragment as the A operand, activation fragment as B)
 // so that a lane ends up holding four consecutive output columns n..n+3 of one row m: epilogue stores are 16 B (f32) /
 // 8 B (bf16).  Tiles move global -> LDS directly (global_load_lds_dwordx4, no register stage, no ds_write), XOR-swizzled on
@@ -397,12 +397,12 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 // HA2: second activation source: -1 run-time test of c.A2, 0 never, 1 always
-template <typename T, int BM, int BN, int NW, int ST, typename Epi, bool CONV, bool AL, int HA2>
+template <typename T, int BM, int BN, int NW, int WM, int ST, typename Epi, bool CONV, bool AL, int HA2>
 __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typename Epi::Args> g) {
   typedef typename Vec<T>::x8 x8;
   constexpr int BK = 64;
-  constexpr int WGN = NW / 2;
-  constexpr int TM = BM / 2, TN = BN / WGN;
+  constexpr int WGN = NW / WM;        // waves along N; WM waves along M
+  constexpr int TM = BM / WM, TN = BN / WGN;
   constexpr int FM = TM / 16, FN = TN / 16;
   constexpr int PA = BM / 8 / NW, PW = BN / 8 / NW;  // 1-KiB pieces (8 rows) per wave per stage
   static_assert(PA >= 1 && PW >= 1, "tile too small for this many waves");
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WM, wn = wave / WM;
   // XCD-aware tile order.  Hardware deals workgroup i to XCD i % 8, each with a private 4 MiB L2, and everything that is
   // not in the LOCAL L2 arrives over the fabric at HBM-like bandwidth (~6.5 TB/s for the whole chip, Infinity-Cache hits
   // included: scripts/kbench.py bw).  So the tile grid is cut into row bands and every XCD owns a contiguous run of
@@ -608,19 +608,19 @@ constexpr int smem_bytes_glds() {
   return ST * (BM + BN) * 64 * 2;
 }
 
-template <typename T, int BM, int BN, int NW, int ST, typename Epi, bool CONV, bool AL, int HA2>
+template <typename T, int BM, int BN, int NW, int WM, int ST, typename Epi, bool CONV, bool AL, int HA2>
 struct KernelRef {
   typedef typename Epi::Args EA;
   static constexpr int smem = smem_bytes_glds<BM, BN, ST>();
   static constexpr int threads = NW * 64;
-  static const void* fn() { return (const void*)gemm_glds_kernel<T, BM, BN, NW, ST, Epi, CONV, AL, HA2>; }
+  static const void* fn() { return (const void*)gemm_glds_kernel<T, BM, BN, NW, WM, ST, Epi, CONV, AL, HA2>; }
   static void launch(dim3 grid, hipStream_t s, const GemmDev<EA>& d) {
-    gemm_glds_kernel<T, BM, BN, NW, ST, Epi, CONV, AL, HA2><<<grid, dim3(NW * 64), smem, s>>>(d);
+    gemm_glds_kernel<T, BM, BN, NW, WM, ST, Epi, CONV, AL, HA2><<<grid, dim3(NW * 64), smem, s>>>(d);
   }
 };
 
 // v(KernelRef) is called for the EPI_STD instantiation (tile, variant, conv, al); kNoKernel when that one does not exist
-template <typename T, int BM, int BN, int NW, int ST, typename V>
+template <typename T, int BM, int BN, int NW, int WM, int ST, typename V>
 static int visit_std_tile(int variant, bool conv, bool al, V&& v) {
   typedef EpiStd<T, -1, -1, -1> EGen;                                     // everything tested at run time
   typedef EpiStd<T, ACT_NONE, 0, -1> ENone;                               // no activation / statistics, run-time outputs
@@ -631,46 +631,46 @@ static int visit_std_tile(int variant, bool conv, bool al, V&& v) {
   typedef EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_RES | EB_F32> EStRes;       // denoiser conv / attention projection + skip
   switch (variant) {
     case V_GEN:
-      if (conv) return al ? v(KernelRef<T, BM, BN, NW, ST, EGen, true, true, -1>{}) : v(KernelRef<T, BM, BN, NW, ST, EGen, true, false, -1>{});
-      return al ? v(KernelRef<T, BM, BN, NW, ST, EGen, false, true, -1>{}) : v(KernelRef<T, BM, BN, NW, ST, EGen, false, false, -1>{});
+      if (conv) return al ? v(KernelRef<T, BM, BN, NW, WM, ST, EGen, true, true, -1>{}) : v(KernelRef<T, BM, BN, NW, WM, ST, EGen, true, false, -1>{});
+      return al ? v(KernelRef<T, BM, BN, NW, WM, ST, EGen, false, true, -1>{}) : v(KernelRef<T, BM, BN, NW, WM, ST, EGen, false, false, -1>{});
     case V_NONE:
       if (!al) return kNoKernel;
-      return conv ? v(KernelRef<T, BM, BN, NW, ST, ENone, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, ST, ENone, false, true, 0>{});
+      return conv ? v(KernelRef<T, BM, BN, NW, WM, ST, ENone, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, WM, ST, ENone, false, true, 0>{});
     case V_SLAB:
       if (!al || conv) return kNoKernel;
-      return v(KernelRef<T, BM, BN, NW, ST, ESlab, false, true, 0>{});
+      return v(KernelRef<T, BM, BN, NW, WM, ST, ESlab, false, true, 0>{});
     case V_GELU_T:
       if (!al || conv) return kNoKernel;
-      return v(KernelRef<T, BM, BN, NW, ST, EGeluT, false, true, 0>{});
+      return v(KernelRef<T, BM, BN, NW, WM, ST, EGeluT, false, true, 0>{});
     case V_ST_F32:
       if (!al) return kNoKernel;
-      return conv ? v(KernelRef<T, BM, BN, NW, ST, EStF32, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, ST, EStF32, false, true, 0>{});
+      return conv ? v(KernelRef<T, BM, BN, NW, WM, ST, EStF32, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, WM, ST, EStF32, false, true, 0>{});
     case V_ST_RES:
       if (!al) return kNoKernel;
-      return conv ? v(KernelRef<T, BM, BN, NW, ST, EStRes, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, ST, EStRes, false, true, 0>{});
+      return conv ? v(KernelRef<T, BM, BN, NW, WM, ST, EStRes, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, WM, ST, EStRes, false, true, 0>{});
     case V_ST_A2:
       if (!al || conv) return kNoKernel;
-      return v(KernelRef<T, BM, BN, NW, ST, EStF32, false, true, 1>{});
+      return v(KernelRef<T, BM, BN, NW, WM, ST, EStF32, false, true, 1>{});
     case V_BIAS_T:
       if (!al) return kNoKernel;
-      return conv ? v(KernelRef<T, BM, BN, NW, ST, EBiasT, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, ST, EBiasT, false, true, 0>{});
+      return conv ? v(KernelRef<T, BM, BN, NW, WM, ST, EBiasT, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, WM, ST, EBiasT, false, true, 0>{});
   }
   return kNoKernel;
 }
 template <typename T, typename V>
 static int visit_std(int tile, int variant, bool conv, bool al, V&& v) {
   switch (tile) {
-    case TILE_128x128: return visit_std_tile<T, 128, 128, 8, 2>(variant, conv, al, v);
-    case TILE_128x64: return visit_std_tile<T, 128, 64, 8, 4>(variant, conv, al, v);
-    default: return visit_std_tile<T, 64, 64, 4, 4>(variant, conv, al, v);
+    case TILE_128x128: return visit_std_tile<T, 128, 128, 8, 2, 2>(variant, conv, al, v);
+    case TILE_128x64: return visit_std_tile<T, 128, 64, 8, 4, 4>(variant, conv, al, v);   // 4 x 2 waves of 32 x 32: 1 LDS fragment read per MFMA (2 x 4 of 64 x 16: 1.25)
+    default: return visit_std_tile<T, 64, 64, 4, 2, 4>(variant, conv, al, v);
   }
 }
 template <typename T, typename Epi, typename V>
 static int visit_qkv(int tile, V&& v) {
   switch (tile) {
-    case TILE_128x128: return v(KernelRef<T, 128, 128, 8, 2, Epi, false, true, 0>{});
-    case TILE_128x64: return v(KernelRef<T, 128, 64, 8, 4, Epi, false, true, 0>{});
-    default: return v(KernelRef<T, 64, 64, 4, 4, Epi, false, true, 0>{});
+    case TILE_128x128: return v(KernelRef<T, 128, 128, 8, 2, 2, Epi, false, true, 0>{});
+    case TILE_128x64: return v(KernelRef<T, 128, 64, 8, 4, 4, Epi, false, true, 0>{});
+    default: return v(KernelRef<T, 64, 64, 4, 2, 4, Epi, false, true, 0>{});
   }
 }
 

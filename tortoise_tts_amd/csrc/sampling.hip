@@ -126,6 +126,48 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     }
   }
   __syncthreads();
+  if (nsurv > SURV_CAP) {
+    // Degenerate plateau: more than SURV_CAP scores tie at the k-th value (HF keeps them all).  The slots above were handed out in
+    // atomic order, i.e. run-dependent: redo the selection deterministically - everything strictly above the k-th value (< k
+    // entries), then the ties in ascending token order until the buffer is full.  (block-uniform branch: nsurv is shared)
+    __syncthreads();
+    if (tid == 0) nsurv = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int t = tid + 256 * j;
+      if (t < V && f2key(val[j]) > kth) {
+        const int slot = atomicAdd(&nsurv, 1);
+        sv[slot] = val[j];
+        si[slot] = t;
+      }
+    }
+    __syncthreads();
+    int base = nsurv;
+#pragma unroll 1
+    for (int j = 0; j < PER && base < SURV_CAP; ++j) {
+      const int t = tid + 256 * j;
+      const bool tie = t < V && f2key(val[j]) == kth;
+      const unsigned long long m = __ballot(tie);
+      const int before = __popcll(m & ((1ull << (tid & 63)) - 1ull));
+      if ((tid & 63) == 0) wtot[tid >> 6] = (unsigned)__popcll(m);
+      __syncthreads();
+      int off = base, total = 0;
+      for (int w = 0; w < 4; ++w) {
+        if (w < (tid >> 6)) off += (int)wtot[w];
+        total += (int)wtot[w];
+      }
+      const int slot = off + before;
+      if (tie && slot < SURV_CAP) {
+        sv[slot] = val[j];
+        si[slot] = t;
+      }
+      base += total;
+      __syncthreads();
+    }
+    if (tid == 0) nsurv = base;
+    __syncthreads();
+  }
   const int n = nsurv < SURV_CAP ? nsurv : SURV_CAP;
   // ---- rank sort: descending score, ascending index on ties (deterministic irrespective of slot order)
   for (int i = tid; i < n; i += 256) {
