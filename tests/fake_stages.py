@@ -51,6 +51,25 @@ class FakeArStage:
         k = codes.shape[0]
         return O.ar_latents(self.sd, self.cfg, cond_latent.float().cpu().expand(k, -1), text_tokens.cpu().expand(k, -1), codes.cpu())
 
+    def generate_stream(self, B, max_new, chunk, first_chunk=None, **kw):
+        """The resumable loop of the streaming path: the oracle loop is not resumable, so the whole sequence is sampled once and
+        handed out in the same pieces the engine would produce (the engine test checks chunks == one-shot bit for bit)."""
+        codes, n = self.generate(B, max_new, **kw)
+        done_at = n if n < max_new or bool((codes[:, -1] == self.cfg.stop_mel_token).all()) else max_new
+        pos, first = 0, True
+        while pos < done_at:
+            pos = min(pos + ((first_chunk or chunk) if first else chunk), done_at)
+            first = False
+            yield codes[:, :pos], pos >= done_at
+
+
+class FakeHifiganStage:
+    def __init__(self, sd_folded, cfg, device="cpu", dtype=0, max_latents=512):
+        self.sd, self.cfg = sd_folded, cfg
+
+    def inference(self, latents, g):
+        return O.hifigan_inference(self.sd, self.cfg, latents.float().cpu(), g.float().cpu().reshape(1, -1))
+
 
 class FakeClvpStage:
     def __init__(self, sd, cfg, device="cpu", dtype=0, max_rows=0):
@@ -112,5 +131,6 @@ def install(monkeypatch):
     monkeypatch.setattr(api.stages, "VocoderStage", FakeVocoderStage)
     monkeypatch.setattr(api.stages, "RandomLatentStage", FakeRandomLatentStage)
     monkeypatch.setattr(api.stages, "ConditioningStage", FakeConditioningStage)
+    monkeypatch.setattr(api.stages, "HifiganStage", FakeHifiganStage)
     monkeypatch.setattr(api.E, "require_gpu", lambda device=None: torch.device("cpu"))
     monkeypatch.setattr(api, "_StageTimer", FakeTimer)

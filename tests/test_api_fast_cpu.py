@@ -53,3 +53,34 @@ def test_signatures_follow_the_reference():
     ref_args = [a.arg for a in fn.args.args][1:]
     ours = list(inspect.signature(TextToSpeech.__init__).parameters)[1:]
     assert ours[:len(ref_args)] == ref_args
+
+
+@torch.no_grad()
+def test_tts_and_stream_flow_on_oracle_backed_stages(monkeypatch):
+    """api_fast host logic end to end on CPU stand-ins (tests/fake_stages.py): tts() = 1 sampled sequence -> teacher-forced latents ->
+    HiFi-GAN; tts_stream() emits the first piece after 60 tokens, then every stream_chunk_size tokens, cross-faded; the pieces add up
+    to the one-shot waveform minus the last overlap window."""
+    from oracle import make_golden as G
+    from tests import fake_stages
+    from tortoise_tts_amd import weights as W
+    from tortoise_tts_amd.config import ARConfig, HifiganConfig
+    fake_stages.install(monkeypatch)
+    from tortoise_tts_amd import api_fast
+    monkeypatch.setattr(api_fast.E, "require_gpu", lambda device=None: torch.device("cpu"))
+    a_cfg = ARConfig(**G.AR_CFG)
+    h_cfg = HifiganConfig(in_channels=a_cfg.model_dim, cond_channels=a_cfg.model_dim, upsample_initial_channel=64)
+    sds = {"autoregressive": W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(a_cfg), seed=G.AR_SEED), a_cfg),
+           "hifidecoder": W.synthetic_state_dict(W.hifigan_manifest(h_cfg), seed=43),
+           "rlg_auto": W.synthetic_state_dict(W.rlg_manifest(a_cfg.model_dim), seed=G.RLG_SEED, gain=3.0)}
+    tts = api_fast.TextToSpeech(state_dicts=sds, configs={"ar": a_cfg, "hifigan": h_cfg}, max_mel_tokens=80, max_text_tokens=40, kv_cache=True)
+    text = list(range(5, 20))
+    wav = tts.tts(text, max_mel_tokens=70, use_deterministic_seed=4)  # random voice (api_fast.py:375)
+    assert wav.dim() == 3 and wav.shape[:2] == (1, 1) and torch.isfinite(wav).all() and wav.abs().max() <= 1.0
+    torch.manual_seed(0)
+    chunks = list(tts.tts_stream(text, max_mel_tokens=70, use_deterministic_seed=4, stream_chunk_size=5, overlap_wav_len=128))
+    assert len(chunks) == 3  # 60 tokens (first buffer), 65, 70
+    assert sum(int(c.shape[0]) for c in chunks) == wav.shape[-1] - 128
+    with pytest.raises(ValueError, match="Too much text"):
+        tts.tts(list(range(1, 255)) * 2)
+    with pytest.raises(NotImplementedError):
+        tts.tts(text, cvvp_amount=0.5)

@@ -252,3 +252,27 @@ def test_integer_postprocessing_matches_reference_source(ref):
         want = ns["fix_autoregressive_output"](torch.tensor(codes).clone(), 8193, complain=False).numpy()
         got = O.fix_autoregressive_output(codes, 8193)
         assert np.array_equal(want, got)
+
+
+@pytest.mark.parametrize("c0,factors,kernels", [(64, [8, 8, 2, 2], [3, 7, 11]), (128, [4, 2], [3, 5]), (32, [2, 2, 2], [7])])
+@torch.no_grad()
+def test_hifigan_decoder(ref, c0, factors, kernels):
+    """oracle.hifigan_inference vs the live HifiganGenerator.inference (hifigan_decoder.py:259-289) over several generator shapes
+    (the streaming path's decoder)."""
+    from tortoise.models.hifigan_decoder import HifiganGenerator
+    from tortoise_tts_amd.config import HifiganConfig
+    cfg = HifiganConfig(in_channels=48, cond_channels=40, upsample_initial_channel=c0, upsample_factors=factors,
+                        upsample_kernel_sizes=[2 * u for u in factors], resblock_kernel_sizes=kernels)
+    sd = W.synthetic_state_dict(W.hifigan_manifest(cfg), seed=c0)
+    m = HifiganGenerator(in_channels=cfg.in_channels, out_channels=1, resblock_type="1",
+                         resblock_dilation_sizes=[list(cfg.resblock_dilation_sizes)] * len(kernels), resblock_kernel_sizes=list(kernels),
+                         upsample_kernel_sizes=list(cfg.upsample_kernel_sizes), upsample_initial_channel=c0,
+                         upsample_factors=list(factors), cond_channels=cfg.cond_channels).eval()
+    m.load_state_dict(sd, strict=True)
+    m.device = torch.device("cpu")
+    g = torch.Generator().manual_seed(1)
+    lat, cond = torch.randn(1, 9, cfg.in_channels, generator=g), torch.randn(1, cfg.cond_channels, generator=g)
+    want = m.inference(lat, cond)
+    got = O.hifigan_inference(W.fold_weight_norm(sd), cfg, lat, cond)
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, atol=1e-6, rtol=1e-4), float((got - want).abs().max())
