@@ -75,6 +75,12 @@ static void plan_core(const GemmArgs& a, int epi, GemmPlan& p) {
   c.A2 = a.A2; c.a2_slot = a.a2_slot; c.a2_slot_stride = a.a2_slot_stride; c.lda2 = a.lda2; c.a2_tile = a.A2 ? a.k_split / 64 : 0x7fffffff;
   p.tile = tile;
   p.splitk = a.splitk;
+  // shared-halo 3-tap kernel: the denoiser's ResBlock convolutions (statistics epilogue => 128x64 tile at every M > 256, so the
+  // conditioned row keeps one accumulation order whether it is evaluated alone or batched)
+  const bool al16 = (a.N & 3) == 0 && (!a.bias || ((size_t)a.bias & 15) == 0) && (!a.res || (((size_t)a.res & 15) == 0 && (a.ldres & 3) == 0)) &&
+                    a.out_f32 && ((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0;
+  p.conv3s = epi == EPI_STD && tile == TILE_128x64 && a.taps == 3 && a.dilation <= 1 && a.splitk == 1 && a.gn_part != nullptr && a.bias != nullptr &&
+             a.out_t == nullptr && a.act == ACT_NONE && a.A2 == nullptr && al16 && a.cin >= 256;
   p.prof_id = prof_class(tile, epi, a.taps > 1);
   // algorithmic work of this launch: 2*M*N*K flops; operands read once + result written once
   const bool std_epi = epi == EPI_STD;

@@ -16,6 +16,7 @@
 //     compiled out in the "fast" instantiations (template value 0 / 1); the value -1 keeps the run-time test (generic
 //     kernel: odd alignments, rare activations and output combinations).
 #pragma once
+#include <type_traits>
 #include "gemm.h"
 
 namespace tt {
@@ -589,6 +590,170 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
 }
 
 
+// ------------------------------------------------------------------------------------------------------
+// 3-tap convolution with the A tile shared between the taps.  The tap-as-k-tile kernel above requests every activation
+// row three times (once per tap) and, at the denoiser's shapes, sits on the per-CU L2 -> LDS bandwidth: a
+// 128 x 64 tile moves 24 KB per k-step for 1 MFMA-step of work.  Here a ring stage holds, for ONE 64-channel slice, the
+// (BM + 2)-row halo tile of A (rows m0 - 1 .. m0 + BM) and the three taps' W tiles: 42 KB for three k-steps of work (14 KB
+// per step, -42 %), one barrier per three k-steps.  Tap t of output row r reads LDS row r + t of the same tile.  Rows whose
+// neighbour lies in another sequence cannot be zero-filled at load time any more (the same LDS row is a valid neighbour for
+// one output row and padding for another): the fragment registers of those rows are zeroed after the LDS read, in waves that
+// contain a sequence edge (wave-uniform test).  Accumulation order is slice-major (tap inside), not tap-major as above.
+// LDS image of a stage: A pieces 0 .. APIECES-1 (8 rows x 128 B each; body row r at LDS row r + 8, the two halo rows at LDS rows
+// 7 and BM + 8, the rest of those two pieces reads the zero page), then W pieces tap-major.  The PIECES 1-KiB pieces are dealt
+// round-robin to the NW waves: waves < PIECES % NW carry one more, so the counted vmcnt has two (wave-uniform) values.
+template <typename T, int BM, int BN, int NW, int WM, int ST, typename Epi, bool AL>
+__global__ __launch_bounds__(NW * 64) void gemm_conv3s_kernel(const GemmDev<typename Epi::Args> g) {
+  typedef typename Vec<T>::x8 x8;
+  constexpr int BK = 64, TAPS = 3;
+  constexpr int WGN = NW / WM;
+  constexpr int TM = BM / WM, TN = BN / WGN;
+  constexpr int FM = TM / 16, FN = TN / 16;
+  constexpr int AROWS = BM + 16, APIECES = AROWS / 8, WPT = BN / 8, WPIECES = TAPS * WPT;
+  constexpr int PIECES = APIECES + WPIECES;
+  constexpr int PMAX = (PIECES + NW - 1) / NW, PMIN = PIECES / NW, NBIG = PIECES % NW;
+  constexpr int STAGE = PIECES * 512;  // elements per ring stage
+  static_assert(PMAX <= 8 && ST >= 3, "conv3s geometry");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* ring = (T*)smem_raw;
+  const GemmCore& c = g.c;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  unsigned bx, by;
+  {
+    const unsigned id = blockIdx.x;
+    const unsigned xcd = id & 7, loc = id >> 3;
+    const unsigned nid = xcd * c.xq + min(xcd, c.xr) + loc;
+    unsigned rem, rr;
+    const unsigned band = fdiv(nid, c.band, rem);
+    const bool lastb = band == c.last_band;
+    FastDiv hd;
+    hd.d = lastb ? c.hlast.d : c.hfull.d;
+    hd.m = lastb ? c.hlast.m : c.hfull.m;
+    by = fdiv(rem, hd, rr);
+    bx = band * c.hb + rr;
+  }
+  const int m0 = bx * BM, n0 = by * BN;
+  const T* A = (const T*)c.A;
+  const T* W = (const T*)c.W;
+  const T* zero = (const T*)g_zero_page;
+  const int lr = lane >> 3, lc = lane & 7;
+  const int cin = c.cin_tiles * BK;
+
+  // this wave's pieces: source pointer for slice 0 and per-slice advance (0 for zero-page lanes)
+  const T* src[PMAX];
+  int adv[PMAX];
+#pragma unroll
+  for (int k = 0; k < PMAX; ++k) {
+    const int p = wave + NW * k;  // wave-uniform
+    src[k] = zero;
+    adv[k] = 0;
+    if (p < APIECES) {
+      const int R = p * 8 + lr;                     // LDS row of the A image
+      const int m = m0 + R - 8;                     // activation row it mirrors
+      const bool wanted = R >= 7 && R <= BM + 8;    // body + the two halo rows
+      if (wanted && m >= 0 && m < c.M) {
+        src[k] = A + (size_t)m * c.lda + (lc ^ ((R >> 1) & 7)) * 8;
+        adv[k] = BK;
+      }
+    } else if (p < PIECES) {
+      const int q = p - APIECES, t = q / WPT, row = (q - t * WPT) * 8 + lr;
+      const int n = min(n0 + row, c.N - 1);
+      src[k] = W + (size_t)n * c.ldw + (size_t)t * cin + (lc ^ ((row >> 1) & 7)) * 8;
+      adv[k] = BK;
+    }
+  }
+  const int nslice = c.cin_tiles;
+  int issued = 0;
+  auto issue = [&](int buf) {
+    T* st = ring + (size_t)buf * STAGE;
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k) {
+      const int p = wave + NW * k;
+      if (p < PIECES) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src[k], (lds_void_t*)(st + p * 512), 16, 0, 0);
+        if (issued + 1 < nslice) src[k] += adv[k];  // the last slice is re-requested in the tail (uniform request count)
+      }
+    }
+    if (issued + 1 < nslice) ++issued;
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typename Epi::template Ops<FM, FN> eo;
+  const int fr = lane & 15, fg = lane >> 4;
+  // sequence edges inside this wave's rows: tap 0 of a sequence's first row and tap 2 of its last row read padding
+  bool first_row[FM], last_row[FM];
+  bool edge = false;
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    unsigned sp;
+    (void)fdiv((unsigned)(m0 + wm * TM + j * 16 + fr), c.seq, sp);
+    first_row[j] = sp == 0u;
+    last_row[j] = (int)sp == c.seq_len - 1;
+    edge = edge || first_row[j] || last_row[j];
+  }
+  const bool wave_edge = __builtin_amdgcn_ballot_w64(edge) != 0ull;
+
+  auto compute = [&](int buf, auto masked) {
+    constexpr bool MASK = decltype(masked)::value;
+    const T* as = ring + (size_t)buf * STAGE;
+    const T* ws = as + APIECES * 512;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        x8 fa[FM], fw[FN];
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const int R = 8 + wm * TM + j * 16 + fr + (t - 1);
+          fa[j] = *(const x8*)(as + R * BK + (((ks * 4 + fg) ^ ((R >> 1) & 7)) * 8));
+          if (MASK) {
+            const bool pad = (t == 0 && first_row[j]) || (t == 2 && last_row[j]);
+            if (pad) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) fa[j][q] = (T)0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          const int r = wn * TN + i * 16 + fr;
+          fw[i] = *(const x8*)(ws + (t * BN + r) * BK + (((ks * 4 + fg) ^ ((r >> 1) & 7)) * 8));
+        }
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
+      }
+    }
+  };
+
+#pragma unroll
+  for (int s_ = 0; s_ < ST - 1; ++s_) issue(s_);
+  Epi::template fetch<FM, FN, AL>(c, g.e, eo, m0 + wm * TM, n0 + wn * TN, lane);
+  int slot = 0;
+  const bool big = wave < NBIG;  // this wave requests PMAX pieces per stage
+  for (int js = 0; js < nslice; ++js) {
+    if (big) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * PMAX) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * PMIN) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int nslot = slot + ST - 1;
+    if (nslot >= ST) nslot -= ST;
+    issue(nslot);
+    if (wave_edge) compute(slot, std::true_type{});
+    else compute(slot, std::false_type{});
+    slot = slot + 1 == ST ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  run_epilogue<Epi, FM, FN, TM, TN, AL>(c, g.e, acc, eo, eo.step(), m0 + wm * TM, n0 + wn * TN, lane, 0);
+}
+
 // ---------------------------------------------------------------------------------------------- host side (per operand type)
 enum Tile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2 };
 // EPI_STD kernel variants: the generic one tests everything at run time, the others compile the unused features out
@@ -598,6 +763,7 @@ constexpr int kNoKernel = -100;  // visit_*: this combination is not instantiate
 struct GemmPlan {   // what gemm_launch (gemm.hip) decided: tile, grid, the device argument core
   GemmCore core;
   int tile;
+  bool conv3s;     // shared-halo 3-tap convolution kernel
   int splitk;
   int prof_id;
   double flops, bytes;
@@ -685,11 +851,26 @@ static inline EpiStdArgs make_epi_std(const GemmArgs& a) {
   return e;
 }
 
+// shared-halo 3-tap convolution (gemm_conv3s_kernel): 128 x 64 tile, 8 waves as 4 x 2, 3-stage ring of 42 KB stages
+constexpr int kConv3sStages = 3;
+constexpr int kConv3sSmem = kConv3sStages * ((128 + 16) / 8 + 3 * 64 / 8) * 1024;
+template <typename T, typename Epi>
+static const void* conv3s_fn() { return (const void*)gemm_conv3s_kernel<T, 128, 64, 8, 4, kConv3sStages, Epi, true>; }
+
 template <typename T>
 int gemm_launch_typed(int epi, const GemmArgs& a, const GemmPlan& plan, hipStream_t stream) {
   const dim3 grid(plan.core.gx * plan.core.gy, 1, plan.splitk);
   ProfScope ps(plan.prof_id, stream, plan.flops, plan.bytes);
   int rc = kNoKernel;
+  if (epi == EPI_STD && plan.conv3s) {  // (gemm.hip decided: aligned, statistics epilogue, bias + f32 output (+ skip), 128x64 tile)
+    GemmDev<EpiStdArgs> d;
+    d.c = plan.core;
+    d.e = make_epi_std(a);
+    if (a.res) gemm_conv3s_kernel<T, 128, 64, 8, 4, kConv3sStages, EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_RES | EB_F32>, true><<<grid, 512, kConv3sSmem, stream>>>(d);
+    else gemm_conv3s_kernel<T, 128, 64, 8, 4, kConv3sStages, EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_F32>, true><<<grid, 512, kConv3sSmem, stream>>>(d);
+    TT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (epi == EPI_STD) {
     GemmDev<EpiStdArgs> d;
     d.c = plan.core;
@@ -765,6 +946,8 @@ int gemm_init_typed() {
     (void)visit_qkv<T, EpiQkvHeads<T>>(tile, setattr);
     (void)visit_qkv<T, EpiQkvDecode<T>>(tile, setattr);
   }
+  if (hipFuncSetAttribute(conv3s_fn<T, EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_RES | EB_F32>>(), hipFuncAttributeMaxDynamicSharedMemorySize, kConv3sSmem) != hipSuccess) ++bad;
+  if (hipFuncSetAttribute(conv3s_fn<T, EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_F32>>(), hipFuncAttributeMaxDynamicSharedMemorySize, kConv3sSmem) != hipSuccess) ++bad;
   if (bad) {
     set_error("gemm: hipFuncSetAttribute failed for %d kernel(s): %s", bad, hipGetErrorString(hipGetLastError()));
     return -2;
