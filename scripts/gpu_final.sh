@@ -23,8 +23,15 @@ timeout 600 python scripts/kbench.py bw gemm2 gemm_decode attn flash 2>&1 | grep
 for cfg in "--preset fast" "--preset high_quality --dtype fp16" "--mel-tokens 500" "--dtype fp16"; do
   timeout 600 python bench.py $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> $OUT/bench_other.jsonl
 done
+timeout 600 python bench.py --workload read --steps 1 --warmup 0 2>/dev/null | tail -1 > $OUT/bench_read.json
+TT_DIST_SHARE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 1 --warmup 1 --no-roofline 2>$OUT/bench_2rank.err | tail -1 > $OUT/bench_2rank_shared.json
 python - <<'PY'
 import json
+for f in ('gpurun_out/bench_read.json', 'gpurun_out/bench_2rank_shared.json'):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, d['metric'], d['n_gpus'], round(d['ms_per_step'],1), 'ms RTF', round(d['value'],2))
+    except Exception as e:
+        print(f, 'FAILED', e)
 for l in open('gpurun_out/bench_other.jsonl'):
     d=json.loads(l); print(d['config']['workload'][:70], d['dtype'], round(d['ms_per_step'],1), 'ms RTF', round(d['value'],2))
 PY

@@ -75,7 +75,7 @@ def main():
             us = D(0)
             chk(lib.tt_kb_flash(B, H, n, causal, rel, 16, 10, C.byref(us)))
             fl = 4.0 * B * H * n * n * 64 * (0.5 if causal else 1.0)
-            print(f"flash B={B} H={H} n={n} causal={causal} relpos={rel} TT_FLASH_NQ={os.environ.get('TT_FLASH_NQ', 'auto')}: {us.value:8.2f} us {fl / us.value / 1e6:7.1f} TFLOP/s", flush=True)
+            print(f"flash B={B} H={H} n={n} causal={causal} relpos={rel}: {us.value:8.2f} us {fl / us.value / 1e6:7.1f} TFLOP/s", flush=True)
     if "xcd" in which:
         shapes = [("1x1 1024->1024", 1740, 1024, 1024, 1, 0, 40), ("k3 1024->1024", 1740, 1024, 3072, 3, 870, 16), ("qkv 1024->3072", 1740, 3072, 1024, 1, 0, 16),
                   ("integ 2048->1024", 1740, 1024, 2048, 1, 0, 20), ("decode fc M=256", 256, 4096, 1024, 1, 0, 40), ("clvp ff1", 51200, 3072, 768, 1, 0, 2)]

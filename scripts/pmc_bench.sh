@@ -25,12 +25,14 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 
 def klass(k):
     """rocprofv3 kernel name -> the engine profiler's class name (tortoise_tts_amd/csrc/common.hip g_prof_names)."""
-    m = re.search(r"gemm_glds_kernelI\w+?Li(\d+)ELi(\d+)ELi\d+ELi\d+ENS_\d+(EpiStd|EpiQkvHeads|EpiQkvDecode)\w*?EELb([01])ELb[01]E", k)
+    m = re.search(r"gemm_glds_kernelI\w+?Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ENS_\d+(EpiStd|EpiQkvHeads|EpiQkvDecode)\w*?EELb([01])ELb[01]E", k)
     if m:
         bm, bn, epi, conv = m.groups()
         return "gemm_glds<%s,%s,%s%s>" % (bm, bn, epi, (",conv" if conv == "1" else ",1x1") if epi == "EpiStd" else "")
+    if "gemm_conv3s_kernel" in k:
+        return "gemm_glds<128,64,EpiStd,conv>"  # the shared-halo 3-tap kernel reports under the conv class of its tile
     if "gemm_glds_kernel" in k:
-        m = re.search(r"gemm_glds_kernel<[^,]+, (\d+), (\d+), \d+, \d+, tt::(\w+)<[^>]+>, (true|false)", k)
+        m = re.search(r"gemm_glds_kernel<[^,]+, (\d+), (\d+), \d+, \d+, \d+, tt::(\w+)<[^>]+>, (true|false)", k)
         if m:
             bm, bn, epi, conv = m.groups()
             return "gemm_glds<%s,%s,%s%s>" % (bm, bn, epi, (",conv" if conv == "true" else ",1x1") if epi == "EpiStd" else "")

@@ -499,31 +499,18 @@ int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
   // 32 queries per wave once there is enough work to fill the chip; 16 otherwise.
   // QK^T + PV: 4 * n * n * 64 flops per (batch, head) (halved when causal); Q, K, V read + O written once
   ProfScope ps(PROF_FLASH, stream, 4.0 * a.BH * (double)a.n * a.n * 64 * (a.causal ? 0.5 : 1.0), 4.0 * a.BH * (double)a.n * 64 * 2.0);
-  // Every K / V^T tile a wave loads is used by NQ*16 of its queries, so L2->CU traffic per flop falls as 1/NQ
-  // (with NQ = 1 the kernel sits on the L2 bandwidth, ~80 TFLOP/s).  Few (batch, head) pairs: 64 queries per
-  // wave and the keys split over the block's 4 waves; many pairs: 32 queries per wave, no split.
-  if (a.n > 128 && a.n_pad >= 8) {
-    // LDS-staged kernel: 64 queries per block while that keeps >= 2 blocks per CU busy, 128 otherwise (half the K / V traffic)
+  if (a.n > 128) {
+    // LDS-staged kernel: 64 queries per block while that keeps >= 2 blocks per CU busy, 128 otherwise (half the K / V traffic per
+    // flop; measured on the kbench shapes: 32 queries per wave only pays from ~2048 blocks of 64 queries on)
     const long blocks64 = (long)cdiv(a.n, 64) * a.BH;
-    static const int variant = [] { const char* e = getenv("TT_FLASH_NQ"); return e ? atoi(e) : 0; }();  // kbench A/B only
-    const bool nq2 = variant ? variant == 2 : blocks64 >= 2048;
-    if (nq2) return dtype == DT_BF16 ? launch_flash_lds<bf16, 2>(a, stream) : launch_flash_lds<f16, 2>(a, stream);
-    if (variant != 9) return dtype == DT_BF16 ? launch_flash_lds<bf16, 1>(a, stream) : launch_flash_lds<f16, 1>(a, stream);
+    if (blocks64 >= 2048) return dtype == DT_BF16 ? launch_flash_lds<bf16, 2>(a, stream) : launch_flash_lds<f16, 2>(a, stream);
+    return dtype == DT_BF16 ? launch_flash_lds<bf16, 1>(a, stream) : launch_flash_lds<f16, 1>(a, stream);
   }
-  const long waves_own = (long)cdiv(a.n, 32) * a.BH;
-  if (waves_own >= 8192) {
-    dim3 grid(cdiv(a.n, 128), a.BH);
-    if (dtype == DT_BF16) flash_kernel<bf16, 2, false><<<grid, 256, 0, stream>>>(a);
-    else flash_kernel<f16, 2, false><<<grid, 256, 0, stream>>>(a);
-  } else if (a.n > 128) {
-    dim3 grid(cdiv(a.n, 64), a.BH);
-    if (dtype == DT_BF16) flash_kernel<bf16, 4, true><<<grid, 256, 0, stream>>>(a);
-    else flash_kernel<f16, 4, true><<<grid, 256, 0, stream>>>(a);
-  } else {
-    dim3 grid(cdiv(a.n, 16), a.BH);
-    if (dtype == DT_BF16) flash_kernel<bf16, 1, true><<<grid, 256, 0, stream>>>(a);
-    else flash_kernel<f16, 1, true><<<grid, 256, 0, stream>>>(a);
-  }
+  // short sequences (prefill of a few dozen rows, reduced test configurations): the register-prefetch kernel, the 4 waves of a
+  // block share one 16-query block and split the keys
+  dim3 grid(cdiv(a.n, 16), a.BH);
+  if (dtype == DT_BF16) flash_kernel<bf16, 1, true><<<grid, 256, 0, stream>>>(a);
+  else flash_kernel<f16, 1, true><<<grid, 256, 0, stream>>>(a);
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
