@@ -489,7 +489,12 @@ def test_api_fast_tts_and_stream():
     # the first piece is the decode of the first 60 codes, minus its overlap tail
     first = tts.hifi_decoder.inference(tts.ar.latents(lat[0].cuda(), F_pad_text(text), codes_full[:, :60]), lat[0]).reshape(-1)
     assert torch.equal(chunks[0].cpu(), first[:-256].cpu())
-    tts.ar.close(); tts.hifi_decoder.close()
+    # voice_samples on the streaming path: only the autoregressive encoder exists there (api_fast.py:230-247); mel clips in, latent out
+    mel_ar, _ = G.cond_inputs()
+    sd_c = W.synthetic_state_dict(W.ar_manifest(a_cfg), seed=G.AR_SEED)
+    got = tts.get_conditioning_latents([mel_ar[:, 0], mel_ar[:, 1]]).cpu()
+    report("api_fast conditioning latent bf16 vs oracle", got, O.ar_get_conditioning(quantize_sd(sd_c, torch.bfloat16), a_cfg, mel_ar), 2.5e-2)
+    tts.ar.close(); tts.hifi_decoder.close(); tts.conditioning.close()
 
 
 def F_pad_text(ids):
