@@ -51,6 +51,32 @@ def test_ar_prefill_and_teacher_forced_steps(name, dt, tdt, tol):
     st.close()
 
 
+@torch.no_grad()
+def test_ar_long_prompt_multi_slot_prefix():
+    """A long prompt (390 text tokens, the reference's limit is < 400: api.py:392): prefix of 394 rows = 7 prefix slots of 64 keys
+    in the decode attention's LDS staging, ragged last slot, 5 sequences (a partly filled last workgroup of 4); 70 cached steps
+    so that the own keys also span two slots.  Teacher-forced logits vs the oracle."""
+    import torch.nn.functional as F_
+    cfg = ARConfig(**G.AR_CFG)
+    sd = quantize_sd(W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.AR_SEED), torch.bfloat16)
+    g = torch.Generator().manual_seed(2)
+    cond = torch.randn(1, cfg.model_dim, generator=g)
+    text = F_.pad(torch.randint(1, 255, (1, 390), generator=g).int(), (0, 1))
+    B, steps = 5, 70
+    st = stages.ArStage(sd, cfg, dtype=E.TT_BF16, max_batch=8, max_text=400, max_new_tokens=80, max_latent_candidates=1)
+    st.prefill(cond, text)
+    lg, kv = O.ar_prefill(sd, cfg, O.ar_prefix(sd, cfg, cond, text), B)
+    report("AR long-prompt prefill logits bf16 vs oracle", st.logits(1)[0], lg[0], 2.5e-2)
+    st.begin(B)
+    toks = torch.randint(0, 8192, (steps, B), generator=g)
+    for s in range(steps):
+        st.decode_step(toks[s])
+        lg, kv = O.ar_step(sd, cfg, toks[s], s + 1, kv)
+        if s in (0, 1, 62, 63, 64, steps - 1):
+            report(f"AR long-prompt cached step {s + 1} logits bf16 vs oracle", st.logits(B), lg, 2.5e-2)
+    st.close()
+
+
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
 @torch.no_grad()
 def test_ar_latents(name, dt, tdt, tol):
