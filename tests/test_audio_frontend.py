@@ -1,6 +1,7 @@
 """CPU checks of the wav -> mel front-end restatement (tortoise_tts_amd/audio.py).  torchaudio / librosa are absent offline,
-so these are DEFINITIONAL properties (the module header says "parity unpinned"): mel-scale anchors, unit-area triangular
-filters, the polyphase resampler on a band-limited signal, output shapes of api.py:271-287."""
+so the mel basis and the resampler are checked through DEFINITIONAL properties (mel-scale anchors, unit-area triangular filters,
+a band-limited sine through the polyphase resampler, output shapes of api.py:271-287); the STFT, the clip and the log
+compression around the basis ARE pinned against the reference's own TacotronSTFT / STFT classes (last test, reference tree only)."""
 import math
 
 import torch
@@ -52,3 +53,67 @@ def test_front_end_shapes_match_the_reference_call_sites():
     assert float(dm.min()) >= math.log(1e-5) - 1e-6
     short = fe.auto_mel(clip[:, :1000])                                              # zero-padded to the conditioning length
     assert short.shape == am.shape
+
+
+def _reference_audio_module():
+    """tortoise/utils/audio.py + stft.py imported from the reference tree with import-only librosa stubs: pad_center / tiny /
+    normalize are one-liners (the window already has the filter length), and librosa.filters.mel is handed OUR filter bank,
+    so what the comparison pins is everything around the mel basis - the STFT (reflect padding, periodic Hann window,
+    frame count), the clip to [-1, 1], the matmul and the log(clamp(1e-5)) compression - against the reference's own code."""
+    import sys
+    import types
+
+    import numpy as np
+    import pytest
+
+    from oracle import ref_shims
+    if not ref_shims.reference_available():
+        pytest.skip("reference tree not present")
+    ref_shims.install()
+    if "librosa" not in sys.modules:
+        lib, util, filt = types.ModuleType("librosa"), types.ModuleType("librosa.util"), types.ModuleType("librosa.filters")
+
+        def pad_center(data, size=None, **kw):
+            assert len(data) == size
+            return data
+        util.pad_center = pad_center
+        util.tiny = lambda x: np.finfo(np.float32).tiny
+        util.normalize = lambda x, norm=None: x
+        filt.mel = lambda sr, n_fft, n_mels, fmin, fmax: A.mel_filterbank(sr, n_fft, n_mels, fmin, fmax, htk=False).numpy()
+        lib.util, lib.filters = util, filt
+        sys.modules.update({"librosa": lib, "librosa.util": util, "librosa.filters": filt})
+    import importlib
+    return importlib.import_module("tortoise.utils.audio")
+
+
+def test_stft_and_compression_match_the_reference_tacotron_stft():
+    RA = _reference_audio_module()
+    g = torch.Generator().manual_seed(3)
+    wav = (torch.randn(1, 30000, generator=g) * 0.4)                                 # some samples beyond [-1, 1]: exercises the clip
+    for n_fft, hop in ((1024, 256), (800, 200)):
+        ref_stft = RA.STFT(n_fft, hop, n_fft)
+        mag_ref, _ = ref_stft.transform(wav)
+        mag = A.stft_magnitude(wav, n_fft, hop, n_fft)
+        assert mag.shape == mag_ref.shape
+        assert (mag - mag_ref).abs().max() < 2e-3 * float(mag_ref.abs().max())       # conv1d against a float32 DFT basis vs torch.stft
+    taco = RA.TacotronSTFT(1024, 256, 1024, 100, 24000, 0, 12000)                    # wav_to_univnet_mel's transform (audio.py:180-187)
+    want = taco.mel_spectrogram(wav)
+    fe = A.MelFrontEnd(mel_norms=torch.ones(80))
+    mag = A.stft_magnitude(torch.clamp(wav, -1.0, 1.0))
+    got = torch.log(torch.clamp(torch.matmul(fe.fb_diff, mag), min=1e-5))
+    assert got.shape == want.shape == (1, 100, 30000 // 256 + 1)
+    assert (got - want).abs().max() < 5e-3
+    # normalize / denormalize_tacotron_mel (audio.py:55-64) are the affine pair the sampler's fused output uses
+    m = torch.linspace(-11.0, 2.0, 50)
+    assert torch.allclose(RA.denormalize_tacotron_mel(RA.normalize_tacotron_mel(m)), m, atol=1e-5)
+    # pad_or_truncate (api.py:52-63) exec'd from the reference source
+    import ast
+    import os
+    from oracle import ref_shims
+    src = open(os.path.join(ref_shims.REFERENCE_ROOT, "tortoise", "api.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "pad_or_truncate")
+    ns = {"torch": torch, "F": torch.nn.functional}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "api.py", "exec"), ns)
+    for n in (10, 16, 20):
+        t = torch.arange(float(n))[None]
+        assert torch.equal(ns["pad_or_truncate"](t, 16), A.pad_or_truncate(t, 16))
