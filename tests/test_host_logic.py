@@ -174,7 +174,7 @@ def test_split_and_recombine_text_against_reference_source():
         assert split_and_recombine_text(s, d, m) == ref.split_and_recombine_text(s, d, m), repr(s)
 
 
-def test_tokenizer_contract_on_reference_vocabulary():
+def test_tokenizer_contract_on_reference_vocabulary(monkeypatch):
     """VoiceBpeTokenizer over the vocabulary file the reference ships (tortoise/data/tokenizer.json is data the user
     already has; it is located, not copied - so this runs only where the reference tree is).  The do_tts.py default
     sentence gives 54 ids, spaces map to the [SPACE] token and decode() inverts encode()."""
@@ -191,6 +191,11 @@ def test_tokenizer_contract_on_reference_vocabulary():
     assert ids.count(space) == text.count(" ")
     assert tok.decode(ids) == text.lower()
     assert tok.encode("  Mixed   CASE\tand\nwhitespace ") == tok.encode(" mixed case and whitespace ")
+    # no explicit file, no environment override, no models_dir copy and no installed `tortoise` package to fall back on
+    # (other tests of the session may have put the reference tree on sys.path)
+    import importlib.util
+    monkeypatch.delenv("TORTOISE_TOKENIZER", raising=False)
+    monkeypatch.setattr(importlib.util, "find_spec", lambda name, *a, **k: None)
     with pytest.raises(FileNotFoundError):
         VoiceBpeTokenizer(os.path.join(os.path.dirname(vocab), "missing.json"), use_basic_cleaners=True, models_dir="/nonexistent")
 
