@@ -56,7 +56,9 @@ def bw_probe(mode, waves, nblocks, footprint, bytes_per_wg, reps=10):
 
 
 EXTRA = {200: "128x64 4w ring3 2 blocks/CU", 500: "64x64 4w ring3 2 blocks/CU", 501: "64x64 4w ring2 4 blocks/CU", 502: "64x64 4w ring3 3 blocks/CU",
-         1300: "128x64 8w(2x4) ring3 2 blocks/CU", 1301: "128x64 8w(4x2) ring3 2 blocks/CU", 1600: "128x128 8w ring2 2 blocks/CU"}
+         1300: "128x64 8w(2x4) ring3 2 blocks/CU", 1301: "128x64 8w(4x2) ring3 2 blocks/CU", 1600: "128x128 8w ring2 2 blocks/CU",
+         2000: "256x128 8w(4x2) ring3", 2100: "256x128 16w(4x4) ring3", 2200: "256x256 16w(4x4) ring2", 2300: "256x256 8w(2x4) ring2",
+         2400: "128x256 8w(2x4) ring3"}
 
 
 def main():
@@ -94,6 +96,19 @@ def main():
                     us = gemm_exp(v, M, N, K, taps, seq, pad=pad)
                     label = EXTRA.get(v) or CFG[v // 100]
                     print(f"denoiser {name} M={M} exp {label:38s} row pad {pad:3d}: {us:7.2f} us {tf(M, N, K, us):7.1f} TFLOP/s", flush=True)
+    if "gemm_large" in which:
+        # the large-M users of the 128x128 product tile: CLVP speech tower (256 candidates x 200 codes), the conditioning-integrator
+        # pre-pass (200 timesteps x 870 positions), a 15-chunk batched denoiser (15 x 2 x 870 rows)
+        shapes = [("clvp qkv 768->2304", 51200, 2304, 768, 1, 0), ("clvp ff1 768->3072", 51200, 3072, 768, 1, 0), ("clvp ff2 1536->768", 51200, 768, 1536, 1, 0),
+                  ("prepass 1x1 1024->1024", 174000, 1024, 1024, 1, 0), ("prepass k3 1024->1024", 174000, 1024, 3072, 3, 870),
+                  ("batched denoiser 1x1", 26100, 1024, 1024, 1, 0), ("batched denoiser k3", 26100, 1024, 3072, 3, 870), ("batched denoiser qkv", 26100, 3072, 1024, 1, 0)]
+        for name, M, N, K, taps, seq in shapes:
+            us = gemm_prod(M, N, K, taps, seq, chain=4)
+            print(f"large {name:24s} M={M} PRODUCT gemm_launch: {us:8.2f} us {tf(M, N, K, us):7.1f} TFLOP/s", flush=True)
+            for v in (1600, 600, 2000, 2100, 2200, 2300, 2400):
+                us = gemm_exp(v, M, N, K, taps, seq, chain=4)
+                label = EXTRA.get(v) or CFG[v // 100]
+                print(f"large {name:24s} M={M} exp {label:30s}: {us:8.2f} us {tf(M, N, K, us):7.1f} TFLOP/s", flush=True)
     if "gemm_denoiser" in which:
         shapes = [("1x1 1024->1024", 1740, 1024, 1024, 1, 0, 150), ("k3 1024->1024", 1740, 1024, 3072, 3, 870, 56), ("qkv 1024->3072", 1740, 3072, 1024, 1, 0, 56)]
         for name, M, N, K, taps, seq, nwc in shapes:

@@ -264,6 +264,12 @@ static int launch_variant(int variant, const ExpArgs& a, hipStream_t s) {
     case 1300: return launch_exp<128, 64, 2, 4, 3, 0, 2>(a, s);  // 8 waves, 2 blocks / CU (72 KB LDS each)
     case 1301: return launch_exp<128, 64, 4, 2, 3, 0, 2>(a, s);
     case 1600: return launch_exp<128, 128, 2, 4, 2, 0, 2>(a, s); // the product's large-M tile: 2 stages, 2 blocks / CU
+    // large-M candidates (CLVP, conditioning-integrator pre-pass, a batched denoiser): more flops per byte through the per-CU load path
+    case 2000: return launch_exp<256, 128, 4, 2, 3, 0, 1>(a, s);  // 8 waves (64x64 per wave), 3 stages = 144 KB
+    case 2100: return launch_exp<256, 128, 4, 4, 3, 0, 1>(a, s);  // 16 waves (64x32 per wave), 3 stages
+    case 2200: return launch_exp<256, 256, 4, 4, 2, 0, 1>(a, s);  // 16 waves (64x64 per wave), 2 stages = 128 KB
+    case 2300: return launch_exp<256, 256, 2, 4, 2, 0, 1>(a, s);  // 8 waves (128x64 per wave), 2 stages
+    case 2400: return launch_exp<128, 256, 2, 4, 3, 0, 1>(a, s);  // 8 waves (64x64 per wave), 3 stages, W-heavy tile
 #undef V3
   }
   set_error("kbench: unknown gemm variant %d", variant);
