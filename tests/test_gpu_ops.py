@@ -59,6 +59,40 @@ def test_gemm_conv_taps(lib, name, dt, tdt, tol, taps):
     report(f"conv-gemm {name} taps={taps}", out, ref, 2e-5)
 
 
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+def test_gemm_large_m_tile(lib, name, dt, tdt, tol):
+    """Shapes with >= 256 tiles of 256 x 256 (gemm.hip pick_tile): the 16-wave tile with the skip read in the epilogue.  Ragged M
+    (not a multiple of 16), N = 768 (three column tiles), every output form (run-time epilogue with GELU + skip + both outputs,
+    bias + skip -> f32, 3-tap convolution over 20 sequences)."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 22003, 768, 192
+    A = dev(torch.randn(M, K, generator=g).to(tdt))
+    W = dev((torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt))
+    bias = dev(torch.randn(N, generator=g))
+    res = dev(torch.randn(M, N, generator=g))
+    out = torch.zeros(M, N, device="cuda")
+    out_t = torch.zeros(M, N, device="cuda", dtype=tdt)
+    E.check(lib.tt_op_gemm(dt, E.ptr(A), K, E.ptr(W), K, M, N, K, 1, 0, 1, E.ptr(bias), E.ACT_GELU_TANH, E.ptr(res), E.ptr(out), E.ptr(out_t), None))
+    torch.cuda.synchronize()
+    ref = F.gelu(A.float() @ W.float().t() + bias, approximate="tanh") + res
+    report(f"gemm 256-tile {name} gelu + skip {M}x{N}x{K}", out, ref, 2e-5)
+    report(f"gemm 256-tile {name} gelu + skip (T out)", out_t.float(), ref, tol)
+    out2 = res.clone()                                                                # in place on the skip operand, as the engines call it
+    E.check(lib.tt_op_gemm(dt, E.ptr(A), K, E.ptr(W), K, M, N, K, 1, 0, 1, E.ptr(bias), E.ACT_NONE, E.ptr(out2), E.ptr(out2), None, None))
+    torch.cuda.synchronize()
+    report(f"gemm 256-tile {name} bias + skip in place", out2, A.float() @ W.float().t() + bias + res, 2e-5)
+    B, S, Cin, Cout, taps = 20, 870, 64, 1024, 3
+    x = torch.randn(B, S, Cin, generator=g).to(tdt)
+    w = (torch.randn(Cout, Cin, taps, generator=g) / math.sqrt(Cin * taps)).to(tdt)
+    cb = torch.randn(Cout, generator=g)
+    xd, wd, bd = dev(x), dev(w.permute(0, 2, 1).reshape(Cout, taps * Cin).contiguous()), dev(cb)
+    oc = torch.zeros(B * S, Cout, device="cuda")
+    E.check(lib.tt_op_gemm(dt, E.ptr(xd), Cin, E.ptr(wd), taps * Cin, B * S, Cout, taps * Cin, taps, S, 1, E.ptr(bd), E.ACT_NONE, None, E.ptr(oc), None, None))
+    torch.cuda.synchronize()
+    refc = F.conv1d(xd.float().permute(0, 2, 1), w.float().cuda(), bd, padding=1).permute(0, 2, 1).reshape(B * S, Cout)
+    report(f"conv-gemm 256-tile {name} taps=3 over {B} sequences", oc, refc, 2e-5)
+
+
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES[:1])
 def test_gemm_splitk_slabs(lib, name, dt, tdt, tol):
     g = torch.Generator().manual_seed(7)

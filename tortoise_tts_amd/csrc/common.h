@@ -174,6 +174,7 @@ enum ProfId {  // one class per kernel instantiation that actually runs (names: 
   PROF_GEMM_64x64_STD = 0, PROF_GEMM_64x64_CONV, PROF_GEMM_64x64_QKV, PROF_GEMM_64x64_QKVDEC,
   PROF_GEMM_128x64_STD, PROF_GEMM_128x64_CONV, PROF_GEMM_128x64_QKV, PROF_GEMM_128x64_QKVDEC,
   PROF_GEMM_128x128_STD, PROF_GEMM_128x128_CONV, PROF_GEMM_128x128_QKV, PROF_GEMM_128x128_QKVDEC,
+  PROF_GEMM_256x256_STD, PROF_GEMM_256x256_CONV, PROF_GEMM_256x256_QKV, PROF_GEMM_256x256_QKVDEC,
   PROF_FLASH, PROF_DECODE_ATTN, PROF_ROWNORM, PROF_GROUPNORM, PROF_SAMPLE, PROF_GLUE, PROF_CONV1D, PROF_CONVT, PROF_LVC,
   PROF_COUNT
 };

@@ -12,13 +12,17 @@ extern template int gemm_init_typed<bf16>();
 extern template int gemm_init_typed<f16>();
 
 // Tile choice from the problem shape only (measured on MI355X, scripts/kbench.py):
-//   >= 256 tiles of 128x128 : 128x128, 8 waves, 2 stages (highest flop per L2 byte; 2 blocks per CU)
+//   >= 256 tiles of 256x256 : 256x256, 16 waves of 64x64, 2 stages of 64 KB (twice the flops per byte through the per-CU load
+//                             path of the 128x128 tile: +20 - 60 % at the CLVP / pre-pass shapes, profiles/r02_kbench_large.txt)
+//   >= 256 tiles of 128x128 : 128x128, 8 waves, 2 stages (2 blocks per CU)
 //   fewer, M > 1024         : 128x64, 8 waves, 4-stage ring (more blocks, 3 tiles in flight)
 //   decode / M <= 1024      : 64x64, 4 waves, 4-stage ring (weights stream from HBM: depth hides latency)
 // A GEMM that emits GroupNorm statistics keeps the 128x64 tile for every M > 256: the statistics are grouped per wave tile,
 // so the same tile at one and at two batch rows keeps the denoiser's conditioned row bit-identical whether it is evaluated
 // alone (split tail) or batched with the conditioning-free row.
 static int pick_tile(const GemmArgs& a) {
+  const long b256 = (long)cdiv(a.M, 256) * cdiv(a.N, 256) * a.splitk;
+  if (b256 >= 256 && a.N >= 256 && a.M >= 2048) return TILE_256x256;  // (the pre-pass, CLVP's speech tower, a batched denoiser)
   const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk;
   if (a.M > 256 && b128 >= 256 && a.N > 64) return TILE_128x128;  // (N <= 64: half of a 128-wide tile would be padding)
   if (a.M > 1024 || (a.M > 256 && a.gn_part != nullptr)) return TILE_128x64;
@@ -26,20 +30,20 @@ static int pick_tile(const GemmArgs& a) {
 }
 
 // rows per statistics tile (= the wave tile height TM of the kernel that pick_tile selects)
-static int tile_stat_rows(int tile) { return tile == TILE_128x128 ? 64 : 32; }  // 128x128: 2 x 4 waves; 128x64: 4 x 2; 64x64: 2 x 2
+static int tile_stat_rows(int tile) { return tile >= TILE_128x128 ? 64 : 32; }  // 256x256: 4 x 4 waves; 128x128: 2 x 4; 128x64: 4 x 2; 64x64: 2 x 2
 
 // ProfScope classes: (tile, epilogue, conv?) -> one class per kernel that actually runs
 static int prof_class(int tile, int epi, bool conv) {
-  if (epi == EPI_STD) return (tile == TILE_64x64 ? PROF_GEMM_64x64_STD : tile == TILE_128x64 ? PROF_GEMM_128x64_STD : PROF_GEMM_128x128_STD) + (conv ? 1 : 0);
-  if (epi == EPI_QKV_HEADS) return tile == TILE_64x64 ? PROF_GEMM_64x64_QKV : tile == TILE_128x64 ? PROF_GEMM_128x64_QKV : PROF_GEMM_128x128_QKV;
-  return tile == TILE_64x64 ? PROF_GEMM_64x64_QKVDEC : tile == TILE_128x64 ? PROF_GEMM_128x64_QKVDEC : PROF_GEMM_128x128_QKVDEC;
+  const int base = tile == TILE_64x64 ? PROF_GEMM_64x64_STD : tile == TILE_128x64 ? PROF_GEMM_128x64_STD : tile == TILE_128x128 ? PROF_GEMM_128x128_STD : PROF_GEMM_256x256_STD;
+  if (epi == EPI_STD) return base + (conv ? 1 : 0);
+  return base + (epi == EPI_QKV_HEADS ? 2 : 3);
 }
 
 // Device argument core: tile grid, XCD row bands (minimise the bytes one XCD pulls over the fabric, A / bands + W * bands / 8),
 // split-K ranges and the reciprocals the kernel divides by.
 static void plan_core(const GemmArgs& a, int epi, GemmPlan& p) {
   const int tile = pick_tile(a);
-  const int bm = tile == TILE_64x64 ? 64 : 128, bn = tile == TILE_128x128 ? 128 : 64;
+  const int bm = tile == TILE_64x64 ? 64 : tile == TILE_256x256 ? 256 : 128, bn = tile == TILE_256x256 ? 256 : tile == TILE_128x128 ? 128 : 64;
   GemmCore& c = p.core;
   memset(&c, 0, sizeof(c));
   c.A = a.A; c.W = a.W; c.lda = a.lda; c.ldw = a.ldw; c.M = a.M; c.N = a.N;

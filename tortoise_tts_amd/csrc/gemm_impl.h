@@ -130,17 +130,28 @@ struct EpiStd {
   static __device__ __forceinline__ bool has_f32(const Args& e) { return MODE < 0 ? e.out_f32 != nullptr : (MODE & EB_F32) != 0; }
   static __device__ __forceinline__ bool has_t(const Args& e) { return MODE < 0 ? e.out_t != nullptr : (MODE & EB_T) != 0; }
 
+  // Wave tiles of more than 8 fragments (the 256 x 256 tile: 16 waves per CU = 128 VGPRs each) cannot hold the prefetched skip
+  // quads next to the accumulators: there the skip is read in the epilogue (run_epilogue), where the fragment registers are free
+  // and a k-loop of >= 12 steps has long amortised the extra round trip.
+  template <int FM, int FN> static constexpr bool late_res() { return FM * FN > 8; }
+  template <bool AL>
+  static __device__ __forceinline__ float4 load_res(const GemmCore& c, const Args& e, int m, int n, int nvalid) {
+    if (AL) return *(const float4*)(e.res + (size_t)min(m, c.M - 1) * e.ldres + max(min(n, c.N - 4), 0));
+    return m < c.M ? load_upto4(e.res + (size_t)m * e.ldres + n, nvalid) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   template <int FM, int FN, bool AL>
   static __device__ __forceinline__ void fetch(const GemmCore& c, const Args& e, Ops<FM, FN>& o, int m0w, int n0w, int lane) {
     const int fr = lane & 15, fg = lane >> 4;
-    const bool use_bias = has_bias(e), use_res = has_res(e);
+    const bool use_bias = has_bias(e), use_res = has_res(e) && !late_res<FM, FN>();
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
       const int n = n0w + i * 16 + fg * 4;
       const int nvalid = c.N - n >= 4 ? 4 : c.N - n;
       o.bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (!late_res<FM, FN>()) {
 #pragma unroll
-      for (int j = 0; j < FM; ++j) o.rv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < FM; ++j) o.rv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       if (AL) {
         const int nc = max(min(n, c.N - 4), 0);
         if (use_bias) o.bv[i] = *(const float4*)(e.bias + nc);
@@ -307,6 +318,7 @@ template <typename Epi, int FM, int FN, int TM, int TN, bool AL, typename Ops>
 __device__ __forceinline__ void run_epilogue(const GemmCore& c, const typename Epi::Args& e, f32x4 (&acc)[FN][FM], const Ops& o, int step_t,
                                              int m0w, int n0w, int lane, int z) {
   const int fr = lane & 15, fg = lane >> 4;
+  constexpr bool BIG = FM * FN > 8;
   bool stats = false;
   if constexpr (Epi::kId == 0) {
     if constexpr (Epi::kStats < 0) stats = e.gn_part != nullptr && !Epi::slab(e);
@@ -331,8 +343,17 @@ __device__ __forceinline__ void run_epilogue(const GemmCore& c, const typename E
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
       const int m = m0w + j * 16 + fr;
-      if constexpr (Epi::kId == 0) Epi::apply(e, acc[i][j], o.bv[i], o.rv[i][j]);
-      else Epi::apply(e, acc[i][j], o.bv[i], make_float4(0.f, 0.f, 0.f, 0.f));
+      if constexpr (Epi::kId == 0) {
+        float4 rq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (Epi::template late_res<FM, FN>()) {
+          if (Epi::has_res(e)) rq = Epi::template load_res<AL>(c, e, m, n, nvalid);
+        } else {
+          rq = o.rv[i][j];
+        }
+        Epi::apply(e, acc[i][j], o.bv[i], rq);
+      } else {
+        Epi::apply(e, acc[i][j], o.bv[i], make_float4(0.f, 0.f, 0.f, 0.f));
+      }
       if (stats) {
         float sv = 0.f, qv = 0.f;
 #pragma unroll
@@ -348,16 +369,28 @@ __device__ __forceinline__ void run_epilogue(const GemmCore& c, const typename E
         q1[i] += first ? 0.f : qv;
       }
     }
+    // big wave tiles (16 waves per CU, 128 VGPRs): finish one 16-column strip at a time - its stores go out right here, so the
+    // accumulators die strip by strip instead of all FM * FN quads, their skip reads and their store addresses being live at once
+    if constexpr (BIG) {
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int m = m0w + j * 16 + fr;
+        if (m < c.M && n < c.N) Epi::template store<AL>(c, e, step_t, m, n, acc[i][j], nvalid, z);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   // phase 3: stores, back to back
+  if constexpr (!BIG) {
 #pragma unroll
-  for (int i = 0; i < FN; ++i) {
-    const int n = n0w + i * 16 + fg * 4;
-    const int nvalid = c.N - n >= 4 ? 4 : c.N - n;
+    for (int i = 0; i < FN; ++i) {
+      const int n = n0w + i * 16 + fg * 4;
+      const int nvalid = c.N - n >= 4 ? 4 : c.N - n;
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = m0w + j * 16 + fr;
-      if (m < c.M && n < c.N) Epi::template store<AL>(c, e, step_t, m, n, acc[i][j], nvalid, z);
+      for (int j = 0; j < FM; ++j) {
+        const int m = m0w + j * 16 + fr;
+        if (m < c.M && n < c.N) Epi::template store<AL>(c, e, step_t, m, n, acc[i][j], nvalid, z);
+      }
     }
   }
   if constexpr (Epi::kId == 0) {
@@ -755,7 +788,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv3s_kernel(const GemmDev<type
 }
 
 // ---------------------------------------------------------------------------------------------- host side (per operand type)
-enum Tile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2 };
+enum Tile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x256 = 3, TILE_COUNT = 4 };
 // EPI_STD kernel variants: the generic one tests everything at run time, the others compile the unused features out
 enum StdVariant { V_GEN = 0, V_NONE = 1, V_SLAB = 2, V_GELU_T = 3, V_ST_F32 = 4, V_ST_RES = 5, V_ST_A2 = 6, V_BIAS_T = 7, V_COUNT = 8 };
 constexpr int kNoKernel = -100;  // visit_*: this combination is not instantiated
@@ -826,6 +859,7 @@ static int visit_std_tile(int variant, bool conv, bool al, V&& v) {
 template <typename T, typename V>
 static int visit_std(int tile, int variant, bool conv, bool al, V&& v) {
   switch (tile) {
+    case TILE_256x256: return visit_std_tile<T, 256, 256, 16, 4, 2>(variant, conv, al, v);   // 4 x 4 waves of 64 x 64, two 64 KB stages
     case TILE_128x128: return visit_std_tile<T, 128, 128, 8, 2, 2>(variant, conv, al, v);
     case TILE_128x64: return visit_std_tile<T, 128, 64, 8, 4, 4>(variant, conv, al, v);   // 4 x 2 waves of 32 x 32: 1 LDS fragment read per MFMA (2 x 4 of 64 x 16: 1.25)
     default: return visit_std_tile<T, 64, 64, 4, 2, 4>(variant, conv, al, v);
@@ -834,6 +868,7 @@ static int visit_std(int tile, int variant, bool conv, bool al, V&& v) {
 template <typename T, typename Epi, typename V>
 static int visit_qkv(int tile, V&& v) {
   switch (tile) {
+    case TILE_256x256: return v(KernelRef<T, 256, 256, 16, 4, 2, Epi, false, true, 0>{});
     case TILE_128x128: return v(KernelRef<T, 128, 128, 8, 2, 2, Epi, false, true, 0>{});
     case TILE_128x64: return v(KernelRef<T, 128, 64, 8, 4, 4, Epi, false, true, 0>{});
     default: return v(KernelRef<T, 64, 64, 4, 2, 4, Epi, false, true, 0>{});
@@ -939,7 +974,7 @@ int gemm_init_typed() {
     if (hipFuncSetAttribute(decltype(kr)::fn(), hipFuncAttributeMaxDynamicSharedMemorySize, decltype(kr)::smem) != hipSuccess) ++bad;
     return 0;
   };
-  for (int tile = 0; tile < 3; ++tile) {
+  for (int tile = 0; tile < TILE_COUNT; ++tile) {
     for (int variant = 0; variant < V_COUNT; ++variant)
       for (int conv = 0; conv < 2; ++conv)
         for (int al = 0; al < 2; ++al) (void)visit_std<T>(tile, variant, conv != 0, al != 0, setattr);
