@@ -83,6 +83,23 @@ def import_reference():
     return ns
 
 
+def import_stream_generator():
+    """tortoise/models/stream_generator.py (the reference's in-tree fork of transformers 4.31's sampling loop) under the installed
+    transformers: the names its import line pulls in that 5.x no longer exports (beam-search / constraint classes, the
+    SampleOutput alias) are stubbed import-only - sample_stream (stream_generator.py:722-1000) touches none of them."""
+    install()
+    import transformers
+    import transformers.generation.utils as GU
+    for n in ("DisjunctiveConstraint", "BeamSearchScorer", "PhrasalConstraint", "ConstrainedBeamSearchScorer"):
+        if not hasattr(transformers, n):
+            setattr(transformers, n, type(n, (), {}))
+    for n in ("GenerateOutput", "SampleOutput"):
+        if not hasattr(GU, n):
+            setattr(GU, n, object)
+    import tortoise.models.stream_generator as SG
+    return SG
+
+
 def enable_generate(unified_voice):
     """Give the reference's GPT2InferenceModel back the `generate` it had under transformers 4.31 by mixing the
     INSTALLED GenerationMixin into a test-only subclass (5.x dropped the mixin from PreTrainedModel).

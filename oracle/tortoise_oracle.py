@@ -15,9 +15,12 @@ tortoise/models/stream_generator.py:916-1000 and the logits processors.  It is p
 `UnifiedVoice.inference_speech`, with the INSTALLED transformers (5.15) GenerationMixin mixed back in
 (oracle/ref_shims.enable_generate): identical codes bit for bit for both position rules, ragged stop
 rows and whole-batch early exit (tests/test_oracle_vs_reference.py::test_sampling_loop_equals_hf_generate,
-committed as tests/golden/sampling.npz).  What stays unpinned: 4.31.0 itself cannot be installed offline, so
-agreement is with 5.15's sampler, whose processor semantics for these options equal 4.31's by inspection of
-stream_generator.py and the processors' documented behaviour.
+committed as tests/golden/sampling.npz), AND against the reference's own in-tree copy of the 4.31 loop,
+NewGenerationMixin.sample_stream (stream_generator.py:722-1000, the generator api_fast.py iterates), run live on the reference
+model: identical codes in the same six cases, and its per-step latents equal ar_latents() of those codes
+(tests/test_oracle_vs_reference.py::test_sampling_loop_and_streamed_latents_equal_reference_sample_stream).  What stays
+unpinned: the processor / warper CLASSES come from the installed 5.15 in both pins (4.31.0 cannot be installed offline); their
+semantics for these options equal 4.31's by inspection of the processors' documented behaviour.
 
 All state is passed as reference-layout state_dicts (see tortoise_tts_amd/weights.py).
 """
@@ -264,17 +267,26 @@ def topk_indices(scores, k):
 
 
 # =============================================================================== AR latent re-pass
-def ar_latents(sd, cfg: ARConfig, cond_latent, text_tokens, codes):
+def ar_latents(sd, cfg: ARConfig, cond_latent, text_tokens, codes, stream_positions=False):
     """UnifiedVoice.forward(return_latent=True, clip_inputs=False) (autoregressive.py:454-506, 417-431)
     as api.py:521-524 calls it: wav_lengths = n * mel_length_compression so set_mel_padding is a no-op.
-    cond_latent [k, D]; text_tokens int [k, T]; codes int64 [k, n].  Returns [k, n, D]."""
+    cond_latent [k, D]; text_tokens int [k, T]; codes int64 [k, n].  Returns [k, n, D].
+
+    stream_positions: the latents the STREAMING path collects (api_fast.py:389-414: `final_norm(hidden_states[-1][:, -1])` of
+    every sampling step, stream_generator.py:980) under kv_cache=True, where the cached decode feeds mel input j > 0 with position
+    j + 1 (autoregressive.py:134-149: attention_mask.shape[1] - mel_len).  Causal attention makes those per-step states equal
+    to one full pass whose mel positions are 0, 2, 3, ...; with kv_cache=False they equal the plain pass (positions 0, 1, 2, ...).
+    Pinned live against the reference's own sample_stream (tests/test_oracle_vs_reference.py)."""
     k, n = codes.shape
     t = F.pad(text_tokens.long(), (0, 1), value=cfg.stop_text_token)
     t = F.pad(t, (1, 0), value=cfg.start_text_token)
     text_emb = sd["text_embedding.weight"][t] + sd["text_pos_embedding.emb.weight"][: t.shape[1]][None]
     m = F.pad(codes.long(), (0, 1), value=cfg.stop_mel_token)
     m = F.pad(m, (1, 0), value=cfg.start_mel_token)
-    mel_emb = sd["mel_embedding.weight"][m] + sd["mel_pos_embedding.emb.weight"][: m.shape[1]][None]
+    pos = torch.arange(m.shape[1])
+    if stream_positions:
+        pos = torch.where(pos > 0, pos + 1, pos)
+    mel_emb = sd["mel_embedding.weight"][m] + sd["mel_pos_embedding.emb.weight"][pos][None]
     emb = torch.cat([cond_latent[:, None, :], text_emb, mel_emb], dim=1)
     hidden, _ = gpt2_trunk(sd, cfg, emb)
     enc = hidden[:, 1:]

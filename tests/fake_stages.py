@@ -47,9 +47,11 @@ class FakeArStage:
                                  top_k, top_p, kv_cache=self.kv_cache)
         return codes, codes.shape[1]
 
-    def latents(self, cond_latent, text_tokens, codes):
+    def latents(self, cond_latent, text_tokens, codes, stream_positions=False):
         k = codes.shape[0]
-        return O.ar_latents(self.sd, self.cfg, cond_latent.float().cpu().expand(k, -1), text_tokens.cpu().expand(k, -1), codes.cpu())
+        self.latent_calls = getattr(self, "latent_calls", []) + [bool(stream_positions)]
+        return O.ar_latents(self.sd, self.cfg, cond_latent.float().cpu().expand(k, -1), text_tokens.cpu().expand(k, -1), codes.cpu(),
+                            stream_positions=stream_positions)
 
     def generate_stream(self, B, max_new, chunk, first_chunk=None, **kw):
         """The resumable loop of the streaming path: the oracle loop is not resumable, so the whole sequence is sampled once and

@@ -80,7 +80,41 @@ def test_tts_and_stream_flow_on_oracle_backed_stages(monkeypatch):
     chunks = list(tts.tts_stream(text, max_mel_tokens=70, use_deterministic_seed=4, stream_chunk_size=5, overlap_wav_len=128))
     assert len(chunks) == 3  # 60 tokens (first buffer), 65, 70
     assert sum(int(c.shape[0]) for c in chunks) == wav.shape[-1] - 128
+    # latents: tts() re-passes with the plain positions (api_fast.py:510-514), the stream asks for the cached decode's positions
+    # because this instance was built with kv_cache=True; with kv_cache=False both are the plain pass
+    assert tts.ar.latent_calls == [False, True, True, True]
+    tts2 = api_fast.TextToSpeech(state_dicts=sds, configs={"ar": a_cfg, "hifigan": h_cfg}, max_mel_tokens=80, max_text_tokens=40)
+    list(tts2.tts_stream(text, max_mel_tokens=64, use_deterministic_seed=4, stream_chunk_size=5, overlap_wav_len=128))
+    assert tts2.ar.latent_calls == [False, False]
     with pytest.raises(ValueError, match="Too much text"):
         tts.tts(list(range(1, 255)) * 2)
     with pytest.raises(NotImplementedError):
         tts.tts(text, cvvp_amount=0.5)
+
+
+@torch.no_grad()
+def test_latent_pass_embeddings_follow_the_oracle():
+    """stages.latent_pass_embeddings (the host side of ArStage.latents, plain tensor indexing) builds the same input rows as the
+    oracle's teacher-forced pass, for the plain positions and for the cached decode's 0, 2, 3, ... rule."""
+    from oracle import make_golden as G
+    from oracle import tortoise_oracle as O
+    from tortoise_tts_amd import stages
+    from tortoise_tts_amd import weights as W
+    from tortoise_tts_amd.config import ARConfig
+    cfg = ARConfig(**G.AR_CFG)
+    sd = W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.AR_SEED)
+    cond, text = G.ar_inputs(cfg)
+    g = torch.Generator().manual_seed(2)
+    codes = torch.randint(0, cfg.number_mel_codes - 2, (3, 17), generator=g)
+    for flag in (False, True):
+        emb, mel_rows = stages.latent_pass_embeddings(sd["text_embedding.weight"], sd["text_pos_embedding.emb.weight"], sd["mel_embedding.weight"],
+                                                      sd["mel_pos_embedding.emb.weight"], cfg, cond, text, codes, flag)
+        assert mel_rows == 17 + 2 and emb.shape == (3, 1 + text.shape[1] + 2 + 19, cfg.model_dim)
+        hidden, _ = O.gpt2_trunk(sd, cfg, emb)
+        enc = torch.nn.functional.layer_norm(hidden[:, 1:], (cfg.model_dim,), sd["final_norm.weight"], sd["final_norm.bias"], 1e-5)
+        got = enc[:, -mel_rows:][:, :-2]
+        want = O.ar_latents(sd, cfg, cond.expand(3, -1), text.expand(3, -1), codes, stream_positions=flag)
+        assert torch.equal(got, want)
+    plain, _ = stages.latent_pass_embeddings(sd["text_embedding.weight"], sd["text_pos_embedding.emb.weight"], sd["mel_embedding.weight"],
+                                             sd["mel_pos_embedding.emb.weight"], cfg, cond, text, codes, False)
+    assert torch.equal(plain[:, :-18], emb[:, :-18]) and not torch.equal(plain[:, -18:], emb[:, -18:])  # only mel inputs 1.. move

@@ -513,7 +513,7 @@ def test_api_fast_tts_and_stream():
     total = sum(int(c.shape[0]) for c in chunks)
     assert total == wav.shape[-1] - 256  # everything but the last overlap window is emitted (api_fast.py:277-281)
     # the first piece is the decode of the first 60 codes, minus its overlap tail
-    first = tts.hifi_decoder.inference(tts.ar.latents(lat[0].cuda(), F_pad_text(text), codes_full[:, :60]), lat[0]).reshape(-1)
+    first = tts.hifi_decoder.inference(tts._stream_latents(lat[0].cuda(), F_pad_text(text), codes_full[:, :60]), lat[0]).reshape(-1)
     assert torch.equal(chunks[0].cpu(), first[:-256].cpu())
     # voice_samples on the streaming path: only the autoregressive encoder exists there (api_fast.py:230-247); mel clips in, latent out
     mel_ar, _ = G.cond_inputs()

@@ -96,6 +96,56 @@ def test_sampling_loop_equals_hf_generate(ref, kv_cache, eos_boost):
         assert want.shape[1] < G.SAMPLE_N  # every row finished: generate() returned early
 
 
+@pytest.mark.parametrize("kv_cache,eos_boost", [(True, None), (True, 3.0), (True, 5.0), (False, None), (False, 3.0), (False, 5.0)])
+@torch.no_grad()
+def test_sampling_loop_and_streamed_latents_equal_reference_sample_stream(ref, kv_cache, eos_boost):
+    """the reference's OWN restatement of the transformers-4.31 sampling loop,
+    NewGenerationMixin.sample_stream (tortoise/models/stream_generator.py:722-1000, what api_fast.py:380-414 iterates), run on
+    the reference's GPT2InferenceModel with the processors / warpers in 4.31's order (repetition penalty; temperature, top-k 50,
+    top-p) and a 4.31-style boolean length criterion.  Same generator state =>
+      * the codes equal oracle.ar_sample_loop bit for bit (ragged stop rows, whole-batch early exit, both position rules);
+      * the per-step latents it yields (`final_norm(hidden_states[-1][:, -1])`) equal ONE teacher-forced pass over the codes:
+        oracle.ar_latents with the plain positions for kv_cache=False and with the cached decode's positions 0, 2, 3, ... for
+        kv_cache=True - which is how tortoise_tts_amd.api_fast.tts_stream obtains them (stages.ArStage.latents)."""
+    import torch.nn.functional as F
+    from transformers import (LogitsProcessorList, RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper,
+                              TopPLogitsWarper)
+    from oracle import make_golden as G
+    SG = ref_shims.import_stream_generator()
+    cfg = small_ar()
+    sd = G.sampling_state_dict(cfg, eos_boost)
+    m = ref_shims.enable_generate(G.build_ref_ar(ref, cfg, sd, kv_cache))
+    cond, text = G.ar_inputs(cfg)
+    t = F.pad(text, (0, 1), value=m.stop_text_token)                                  # inference_speech's prefix (autoregressive.py:535-556)
+    t, _ = m.build_aligned_inputs_and_targets(t, m.start_text_token, m.stop_text_token)
+    emb = torch.cat([cond.unsqueeze(1), m.text_embedding(t) + m.text_pos_embedding(t)], dim=1)
+    m.inference_model.store_mel_emb(emb)
+    P = emb.shape[1]
+    ids = torch.full((G.SAMPLE_B, P + 1), 1, dtype=torch.long)
+    ids[:, -1] = m.start_mel_token
+    max_len = P + 1 + G.SAMPLE_N
+    torch.manual_seed(G.SAMPLE_SEED)
+    toks, lats = [], []
+    for tk, lat in SG.NewGenerationMixin.sample_stream(
+            m.inference_model, ids, logits_processor=LogitsProcessorList([RepetitionPenaltyLogitsProcessor(2.0)]),
+            logits_warper=LogitsProcessorList([TemperatureLogitsWarper(0.8), TopKLogitsWarper(50), TopPLogitsWarper(0.8)]),
+            stopping_criteria=lambda input_ids, scores: input_ids.shape[-1] >= max_len,  # MaxLengthCriteria as 4.31 evaluated it
+            pad_token_id=m.stop_mel_token, eos_token_id=[m.stop_mel_token], output_hidden_states=True, use_cache=True,
+            attention_mask=torch.ones_like(ids)):
+        toks.append(tk)
+        lats.append(lat)
+    codes, streamed = torch.stack(toks, 1), torch.stack(lats, 1)
+    got = O.ar_sample_loop(sd, cfg, cond, text, G.SAMPLE_B, G.SAMPLE_N, G.sampling_noise(cfg), kv_cache=kv_cache)
+    assert got.shape == codes.shape and torch.equal(got, codes)
+    B = G.SAMPLE_B
+    one_pass = O.ar_latents(sd, cfg, cond.expand(B, -1), text.expand(B, -1), codes, stream_positions=kv_cache)
+    assert one_pass.shape == streamed.shape
+    assert (one_pass - streamed).abs().max() < 2e-5
+    if kv_cache:  # and the plain positions do NOT reproduce them under the cached rule (from step 1 on)
+        plain = O.ar_latents(sd, cfg, cond.expand(B, -1), text.expand(B, -1), codes)
+        assert (plain[:, 0] - streamed[:, 0]).abs().max() < 2e-5 and (plain[:, 1:] - streamed[:, 1:]).abs().max() > 1e-2
+
+
 @torch.no_grad()
 def test_ar_latents(ref):
     cfg = small_ar()

@@ -10,9 +10,11 @@ teacher-forced latent re-pass) and csrc/hifigan.hip.
   * tts_stream(text, ...)   api_fast.py:311-420: a generator of waveform chunks.  The reference pulls (token, latent) pairs out
                             of HF's sampling loop and, every `stream_chunk_size` tokens (first chunk: 60), decodes ALL latents so
                             far and cross-fades the new part in (handle_chunks).  Here the decode loop is resumed chunk by chunk
-                            on the device (tt_ar_generate_chunk) and the latents of the codes so far come from the teacher-forced
-                            pass - the same tensor tts() uses; under kv_cache=True the reference's per-step states differ from it
-                            only by that flag's mel-position quirk (autoregressive.py:134-149), which the re-pass does not have.
+                            on the device (tt_ar_generate_chunk) and the latents of the codes so far come from one teacher-forced
+                            pass: with kv_cache=False (the default) that is exactly the tensor the reference's per-step states
+                            form; with kv_cache=True the pass uses the cached decode's mel positions 0, 2, 3, ...
+                            (autoregressive.py:134-149), which reproduces the reference's per-step states as well
+                            (oracle.ar_latents(stream_positions=True), pinned live against the reference's sample_stream).
   * handle_chunks           api_fast.py:275-309, restated (host-side tensor slicing / cross-fade).
 
 Sampling noise comes from the engine's Philox streams keyed by use_deterministic_seed (seeds are not portable between
@@ -185,6 +187,11 @@ class TextToSpeech:
         wav_overlap = wav_gen[-overlap_len:]
         return wav_chunk, wav_gen, wav_overlap
 
+    def _stream_latents(self, cond, text_tokens, codes):
+        """The (token, latent) pairs of the reference's generator (api_fast.py:405-414) as one pass over the codes so far: with
+        kv_cache=False they are the teacher-forced latents; with kv_cache=True the cached decode's mel-position rule applies."""
+        return self.ar.latents(cond, text_tokens, codes, stream_positions=self.kv_cache)
+
     @torch.no_grad()
     def tts_stream(self, text, voice_samples=None, conditioning_latents=None, k=1, verbose=True, use_deterministic_seed=None,
                    return_deterministic_state=False, overlap_wav_len=1024, stream_chunk_size=40,
@@ -204,7 +211,7 @@ class TextToSpeech:
                 codes = codes[:, :-1]  # the reference's generator stops BEFORE yielding the stop token's pair
             if codes.shape[1] == 0:
                 break
-            latents = self.ar.latents(cond, text_tokens, codes)
+            latents = self._stream_latents(cond, text_tokens, codes)
             wav_gen = self.hifi_decoder.inference(latents, cond).reshape(-1)
             wav_chunk, wav_gen_prev, wav_overlap = self.handle_chunks(wav_gen, wav_gen_prev, wav_overlap, overlap_wav_len)
             yield wav_chunk

@@ -19,6 +19,26 @@ def _i32(t, device):
     return t.to(device=device, dtype=torch.int32).contiguous()
 
 
+def latent_pass_embeddings(text_emb_w, text_pos_w, mel_emb_w, mel_pos_w, cfg, cond, text_tokens, codes, stream_positions=False):
+    """Input rows of the teacher-forced pass (autoregressive.py:454-506): [cond | start text stop | start codes stop] with their
+    learned positions -> (emb f32 [k, 1 + T + 2 + n + 2, D], number of mel rows).  Plain tensor indexing (device or host)."""
+    k, n = codes.shape
+    t = F.pad(text_tokens.long(), (0, 1), value=cfg.stop_text_token)
+    t = F.pad(t, (1, 0), value=cfg.start_text_token)
+    text_emb = text_emb_w[t] + text_pos_w[: t.shape[1]][None]
+    m = F.pad(codes.long(), (0, 1), value=cfg.stop_mel_token)
+    m = F.pad(m, (1, 0), value=cfg.start_mel_token)
+    pos = torch.arange(m.shape[1], device=m.device)
+    if stream_positions:
+        pos = torch.where(pos > 0, pos + 1, pos)
+    mel_emb = mel_emb_w[m] + mel_pos_w[pos][None]
+    if text_emb.shape[0] == 1 and k > 1:
+        text_emb = text_emb.expand(k, -1, -1)
+    if cond.shape[0] == 1 and k > 1:
+        cond = cond.expand(k, -1)
+    return torch.cat([cond[:, None, :], text_emb, mel_emb], dim=1).contiguous(), m.shape[1]
+
+
 class ArStage:
     """UnifiedVoice hot path: prefill + sampling loop + latent re-pass (autoregressive.py:454-563)."""
 
@@ -124,21 +144,13 @@ class ArStage:
                 return
 
     # -- latent re-pass (autoregressive.py:454-506 as api.py:521-524 calls it)
-    def latents(self, cond_latent, text_tokens, codes):
-        cfg = self.cfg
-        k, n = codes.shape
-        t = F.pad(text_tokens.to(self.device).long(), (0, 1), value=cfg.stop_text_token)
-        t = F.pad(t, (1, 0), value=cfg.start_text_token)
-        text_emb = self.w.text_emb[t] + self.w.text_pos[: t.shape[1]][None]
-        m = F.pad(codes.to(self.device).long(), (0, 1), value=cfg.stop_mel_token)
-        m = F.pad(m, (1, 0), value=cfg.start_mel_token)
-        mel_emb = self.w.mel_emb[m] + self.w.mel_pos[: m.shape[1]][None]
-        if text_emb.shape[0] == 1 and k > 1:
-            text_emb = text_emb.expand(k, -1, -1)
-        cond = cond_latent.to(self.device).float()
-        if cond.shape[0] == 1 and k > 1:
-            cond = cond.expand(k, -1)
-        emb = torch.cat([cond[:, None, :], text_emb, mel_emb], dim=1).contiguous()
+    def latents(self, cond_latent, text_tokens, codes, stream_positions=False):
+        """stream_positions: mel positions 0, 2, 3, ... instead of 0, 1, 2, ... - the per-step states the reference's streaming
+        path collects under kv_cache=True (api_fast.py:389-414 with the cached-decode position rule of autoregressive.py:134-149)."""
+        emb, mel_rows = latent_pass_embeddings(self.w.text_emb, self.w.text_pos, self.w.mel_emb, self.w.mel_pos, self.cfg,
+                                               cond_latent.to(self.device).float(), text_tokens.to(self.device), codes.to(self.device),
+                                               stream_positions)
+        k = codes.shape[0]
         outs = []
         for i in range(0, k, self.max_latent_candidates):
             e = emb[i:i + self.max_latent_candidates].contiguous()
@@ -146,8 +158,8 @@ class ArStage:
             E.check(self.lib.tt_ar_latents(self.h, E.ptr(e), e.shape[0], e.shape[1], E.ptr(out), E.stream_ptr()))
             outs.append(out)
         out = torch.cat(outs, dim=0)
-        # enc = hidden[:, 1:]; mel part = last m.shape[1] rows; drop the final two (autoregressive.py:425-431, 503)
-        return out[:, -m.shape[1]:][:, :-2]
+        # enc = hidden[:, 1:]; mel part = last mel_rows rows; drop the final two (autoregressive.py:425-431, 503)
+        return out[:, -mel_rows:][:, :-2]
 
 
 class ClvpStage:
