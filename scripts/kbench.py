@@ -39,8 +39,16 @@ def attn(variant, B, H, P1, tgen, tmax, nl, chain=16, reps=10):
     return us.value, md.value
 
 
+def gemm_exp_na(variant, M, N, K, nw=1, na=1, chain=32, reps=10):
+    us = D(0)
+    chk(lib.tt_kb_gemm_exp_na(variant, M, N, K, nw, na, chain, reps, C.byref(us)))
+    return us.value
+
+
 CFG = {0: "128x64 8w(2x4) ring4 [product tile]", 1: "128x64 4w(2x2) ring4", 3: "128x64 8w(4x2) ring4", 4: "64x64 4w ring4 [product decode tile]",
-       6: "128x128 8w(2x4) ring3", 7: "128x128 4w(2x2) ring3", 8: "256x64 8w(4x2) ring3", 9: "128x64 8w(2x4) ring6"}
+       6: "128x128 8w(2x4) ring3", 7: "128x128 4w(2x2) ring3", 8: "256x64 8w(4x2) ring3", 9: "128x64 8w(2x4) ring6",
+       30: "64x64 4w ring8", 31: "64x64 4w ring10", 32: "32x32 4w ring16", 33: "32x32 4w ring20", 34: "64x64 8w(4x2) ring10", 35: "64x64 4w ring6",
+       36: "32x64 4w ring12"}
 MODE = {0: "full", 1: "no loads in k-loop", 2: "no LDS reads / MFMA"}
 
 
@@ -138,6 +146,25 @@ def main():
                             print(f"decode {name:8s} M={M:3d} N={N} K={K} exp {label:38s} row pad {pad:3d} cold W: {us:7.2f} us {N * K * 2 / us / 1e3:7.1f} GB/s weights", flush=True)
                     us = gemm_exp(400, M, N, K, nw=1)
                     print(f"decode {name:8s} M={M:3d} N={N} K={K} exp {CFG[4]:38s} hot W: {us:7.2f} us", flush=True)
+    if "bw2" in which:   # more waves / more loads in flight per lane than `bw`: where does the per-CU L2 -> CU rate saturate?
+        for fp, tag in ((2 << 20, "2 MiB (one L2)"), (160 << 20, "160 MiB (Infinity Cache)")):
+            for mode, mtag in ((0, "global_load_lds 16B"), (1, "global_load_dwordx4 -> VGPR, full lines")):
+                for waves, wtag in ((8, "8 waves x 8 loads"), (16, "16 waves x 8 loads"), (108, "8 waves x 16 loads"), (116, "16 waves x 16 loads")):
+                    for nb in (256, 512):
+                        per = 1 << 20
+                        us = bw_probe(mode, waves, nb, fp, per)
+                        print(f"bw2 {tag:24s} {mtag:40s} {wtag:20s} x {nb} blocks: {us:8.2f} us  {nb * per / us / 1e6:7.2f} TB/s  {per * (nb / 256) / us / 1e3:6.1f} GB/s per CU", flush=True)
+    if "ring" in which:  # ring depth / tile series at the decode shapes; rotating A (na = 4) like the decode step, cold W
+        for name, N, K in (("qkv", 3072, 1024), ("proj", 1024, 1024), ("fc", 4096, 1024), ("proj2", 1024, 4096)):
+            nw = max(8, int(700e6 // (N * K * 2)))
+            for M in (256, 32):
+                sk = 4 if N == 1024 else 1
+                us = gemm_prod(M, N, K, splitk=sk, nw=nw, na=4)
+                print(f"ring {name:6s} M={M:3d} N={N} K={K} PRODUCT splitk={sk} rotating A x4, cold W: {us:7.2f} us", flush=True)
+                vs = (400, 3500, 3000, 3100, 3400) + ((3200, 3300, 3600) if N == 1024 else ())
+                for v in vs:
+                    us = gemm_exp_na(v, M, N, K, nw=nw, na=4)
+                    print(f"ring {name:6s} M={M:3d} N={N} K={K} exp {CFG[v // 100]:24s} rotating A x4, cold W: {us:7.2f} us", flush=True)
     if "gemm_ablate" in which:
         for name, N, K, sk in (("qkv", 3072, 1024, 1), ("fc", 4096, 1024, 1)):
             nw = max(8, int(700e6 // (N * K * 2)))

@@ -78,8 +78,11 @@ def test_tts_and_stream_flow_on_oracle_backed_stages(monkeypatch):
     assert wav.dim() == 3 and wav.shape[:2] == (1, 1) and torch.isfinite(wav).all() and wav.abs().max() <= 1.0
     torch.manual_seed(0)
     chunks = list(tts.tts_stream(text, max_mel_tokens=70, use_deterministic_seed=4, stream_chunk_size=5, overlap_wav_len=128))
-    assert len(chunks) == 3  # 60 tokens (first buffer), 65, 70
-    assert sum(int(c.shape[0]) for c in chunks) == wav.shape[-1] - 128
+    # 60 tokens (first buffer), 65, 70 - and, because the 70-token limit falls exactly on a buffer boundary, the reference's final
+    # StopIteration pass over the same latents, which hands out the withheld overlap window (api_fast.py:405-420, 286-291)
+    assert len(chunks) == 4 and chunks[-1].shape[0] == 128
+    assert sum(int(c.shape[0]) for c in chunks) == wav.shape[-1]
+    assert torch.equal(tts.last_codes, tts.last_codes[:, :70])
     # latents: tts() re-passes with the plain positions (api_fast.py:510-514), the stream asks for the cached decode's positions
     # because this instance was built with kv_cache=True; with kv_cache=False both are the plain pass
     assert tts.ar.latent_calls == [False, True, True, True]
@@ -90,6 +93,81 @@ def test_tts_and_stream_flow_on_oracle_backed_stages(monkeypatch):
         tts.tts(list(range(1, 255)) * 2)
     with pytest.raises(NotImplementedError):
         tts.tts(text, cvvp_amount=0.5)
+    with pytest.raises(NotImplementedError, match="num_beams"):
+        list(tts.tts_stream(text, num_beams=4))
+    with pytest.raises(NotImplementedError, match="typical"):
+        tts.tts(text, typical_sampling=True)
+
+
+def reference_decode_points(n_pairs, stream_chunk_size):
+    """The reference's streaming loop (api_fast.py:399-420) restated over a generator that yields n_pairs (token, latent) pairs:
+    the number of latents handed to hifi_decoder.inference at every decode, in order."""
+    gen = iter(range(n_pairs))
+    points, all_latents, codes_, is_end, first_buffer = [], [], [], False, 60
+    while not is_end:
+        try:
+            all_latents.append(next(gen))
+            codes_.append(0)
+        except StopIteration:
+            is_end = True
+        if is_end or (stream_chunk_size > 0 and len(codes_) >= max(stream_chunk_size, first_buffer)):
+            first_buffer = 0
+            points.append(len(all_latents))
+            codes_ = []
+    return points
+
+
+@pytest.mark.parametrize("n_tokens,eos,chunk", [(70, False, 5), (64, False, 5), (61, True, 40), (60, True, 40), (100, True, 40), (99, False, 40),
+                                                (140, False, 40), (30, True, 40), (59, False, 20), (120, False, 20)])
+@torch.no_grad()
+def test_stream_decode_points_follow_the_reference_loop(monkeypatch, n_tokens, eos, chunk):
+    """Which prefixes of the latent sequence get decoded, and how often: the engine-side loop (resumable chunks + `done`) against
+    the reference's pull loop, including the extra decode of an unchanged prefix when the sequence ends on a buffer boundary.
+    eos: the sequence ends with a sampled stop token (which the reference's generator never yields) instead of the length limit."""
+    from tortoise_tts_amd import api_fast
+    stop = 8193
+
+    class Ar:
+        def prefill(self, *a):
+            pass
+
+        def generate_stream(self, B, max_new, chunk, first_chunk=None, **kw):
+            codes = torch.arange(n_tokens + (1 if eos else 0))[None] % 50
+            if eos:
+                codes[0, -1] = stop
+            total, pos, first = codes.shape[1], 0, True
+            while pos < total:
+                pos = min(pos + ((first_chunk or chunk) if first else chunk), total)
+                first = False
+                yield codes[:, :pos], pos >= total
+
+        def latents(self, cond, text, codes, stream_positions=False):
+            return torch.zeros(1, codes.shape[1], 4)
+
+    seen = []
+
+    class Hifi:
+        def inference(self, latents, g):
+            seen.append(latents.shape[1])
+            return torch.arange(latents.shape[1] * 256, dtype=torch.float32)[None, None]
+
+    tts = api_fast.TextToSpeech.__new__(api_fast.TextToSpeech)
+    tts.ar, tts.hifi_decoder, tts.kv_cache, tts.stop_mel_token, tts.max_mel_tokens_cap = Ar(), Hifi(), False, stop, 500
+    tts.device = torch.device("cpu")
+    monkeypatch.setattr(api_fast.TextToSpeech, "_prepare", lambda self, *a: (torch.zeros(1, 4, dtype=torch.int32), torch.zeros(1, 4)))
+    limit = n_tokens if not eos else 500
+    pieces = list(tts.tts_stream([1, 2, 3], max_mel_tokens=limit, stream_chunk_size=chunk, overlap_wav_len=64, use_deterministic_seed=1))
+    want = reference_decode_points(n_tokens, chunk)
+    # the engine decodes an unchanged prefix only once and re-runs handle_chunks on it: compare piece count and decoded prefixes
+    assert len(pieces) == len(want)
+    assert sorted(set(want)) == sorted(set(seen))
+    # and the pieces are what the reference's handle_chunks makes of those decodes
+    _, ref_fn = reference_method("handle_chunks")
+    prev = over = None
+    for n, got in zip(want, pieces):
+        wav = torch.arange(n * 256, dtype=torch.float32)
+        ch, prev, over = ref_fn(None, wav, prev, over, 64)
+        assert torch.equal(ch, got)
 
 
 @torch.no_grad()

@@ -142,7 +142,9 @@ def test_full_diffusion_s870(sds, name, dt, tdt, tol):
     want = denorm(torch.from_numpy(g["x0"]))
     r, m = rel_err(mel, want), max_err(mel, want)
     print(f"[parity] FULL diffusion {GF.DIFF_LOOP_STEPS}-step p_sample_loop S=870 {name} vs reference loop: mel rel_l2={r:.3e} max_abs={m:.3e}")
-    assert r < (8e-2 if name == "bf16" else 1.6e-2)
+    # 2 x the values measured on MI355X (profiles/r02_parity_gpu.txt: bf16 1.05e-2 / 2.27, fp16 1.39e-3 / 0.42)
+    rb, mb = (2.1e-2, 4.6) if name == "bf16" else (2.8e-3, 0.85)
+    assert r < rb and m < mb, f"{name}: rel_l2 {r:.3e} (bound {rb:.1e}) max_abs {m:.3e} (bound {mb})"
     st.close()
 
 
@@ -169,7 +171,9 @@ def test_drift_over_the_real_schedule_bf16_vs_fp16():
               f"max_abs={res[name][1]:.3e} (mel range [{float(want.min()):.2f}, {float(want.max()):.2f}])")
         assert torch.isfinite(mel).all()
         st.close()
-    assert res["f16"][0] < 0.1 and res["bf16"][0] < 0.5
+    # 2 x the values measured on MI355X (profiles/r02_parity_gpu.txt: bf16 1.03e-2 / 0.757, fp16 1.21e-3 / 0.096)
+    assert res["bf16"][0] < 2.1e-2 and res["bf16"][1] < 1.55, res["bf16"]
+    assert res["f16"][0] < 2.5e-3 and res["f16"][1] < 0.2, res["f16"]
 
 
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)

@@ -487,6 +487,17 @@ def test_ar_generate_chunks_equal_one_shot_loop():
         last, pieces = codes, pieces + 1
         assert torch.equal(codes, full[:, :codes.shape[1]])
     assert pieces >= 2 and last.shape[1] == n and torch.equal(last, full)
+    # the streaming caller runs the teacher-forced latent pass BETWEEN chunks (api_fast.tts_stream): that pass uses the handle's
+    # residual-stream buffer, so a resumed chunk must rebuild its input row from the device-side state, not find it there
+    st1 = stages.ArStage(sd, cfg, max_batch=1, max_text=40, max_new_tokens=40, max_latent_candidates=1)
+    st1.prefill(cond, text)
+    one, n1 = st1.generate(1, 36, seed=5)
+    st1.prefill(cond, text)
+    for codes, done in st1.generate_stream(1, 36, 5, first_chunk=7, seed=5):
+        assert torch.equal(codes, one[:, :codes.shape[1]]), "a resumed chunk consumed a stale input row"
+        st1.latents(cond, text, codes)
+    assert codes.shape[1] == n1
+    st1.close()
     st.close()
 
 
@@ -512,6 +523,7 @@ def test_api_fast_tts_and_stream():
     assert len(chunks) == 5  # 60 (first buffer, api_fast.py:401), then 12 tokens per piece: 72, 84, 96, 100
     total = sum(int(c.shape[0]) for c in chunks)
     assert total == wav.shape[-1] - 256  # everything but the last overlap window is emitted (api_fast.py:277-281)
+    assert torch.equal(tts.last_codes, codes_full), "tts_stream sampled different codes from tts() with the same seed"
     # the first piece is the decode of the first 60 codes, minus its overlap tail
     first = tts.hifi_decoder.inference(tts._stream_latents(lat[0].cuda(), F_pad_text(text), codes_full[:, :60]), lat[0]).reshape(-1)
     assert torch.equal(chunks[0].cpu(), first[:-256].cpu())

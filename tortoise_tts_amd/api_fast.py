@@ -137,18 +137,29 @@ class TextToSpeech:
             cond = self.get_random_conditioning_latents()
         return text_tokens, cond.to(self.device).float().reshape(1, -1)
 
+    @staticmethod
+    def _check_kwargs(k, cvvp_amount, hf_generate_kwargs):
+        """Same refusals as tortoise_tts_amd.api.TextToSpeech.tts: a sampling option the on-device sampler cannot honour raises
+        instead of being dropped.  `k` is accepted and unused exactly as in the reference, whose fast path always decodes one
+        autoregressive sample into one clip (api_fast.py:421-519).  Returns top_k."""
+        if cvvp_amount:
+            raise NotImplementedError("cvvp_amount != 0: CVVP was removed upstream")
+        unknown = sorted(set(hf_generate_kwargs) - {"top_k"})
+        if unknown:
+            raise NotImplementedError(f"hf_generate_kwargs {unknown} are not supported by the on-device sampler (only top_k)")
+        return int(hf_generate_kwargs.get("top_k", 50))
+
     # ------------------------------------------------------------------ non-streaming (api_fast.py:421-519)
     @torch.no_grad()
     def tts(self, text, voice_samples=None, k=1, verbose=True, use_deterministic_seed=None, conditioning_latents=None,
             num_autoregressive_samples=512, temperature=.8, length_penalty=1, repetition_penalty=2.0, top_p=.8, max_mel_tokens=500,
             cvvp_amount=.0, **hf_generate_kwargs):
-        if cvvp_amount:
-            raise NotImplementedError("cvvp_amount != 0: CVVP was removed upstream")
+        top_k = self._check_kwargs(k, cvvp_amount, hf_generate_kwargs)
         seed = self.deterministic_state(seed=use_deterministic_seed)
         text_tokens, cond = self._prepare(text, voice_samples, conditioning_latents, max_mel_tokens)
         self.ar.prefill(cond, text_tokens)
         codes, _ = self.ar.generate(1, max_mel_tokens, temperature=temperature, top_p=top_p, repetition_penalty=float(repetition_penalty),
-                                    top_k=int(hf_generate_kwargs.get("top_k", 50)), seed=seed, row_offset=0)
+                                    top_k=top_k, seed=seed, row_offset=0)
         self.last_codes = codes
         latents = self.ar.latents(cond, text_tokens, codes)          # api_fast.py:510-514 (return_latent=True)
         wav = self.hifi_decoder.inference(latents, cond)             # api_fast.py:517
@@ -198,22 +209,33 @@ class TextToSpeech:
                    num_autoregressive_samples=512, temperature=.8, length_penalty=1, repetition_penalty=2.0, top_p=.8, max_mel_tokens=500,
                    cvvp_amount=.0, diffusion_iterations=100, cond_free=True, cond_free_k=2, diffusion_temperature=1.0,
                    **hf_generate_kwargs):
+        top_k = self._check_kwargs(k, cvvp_amount, hf_generate_kwargs)
         seed = self.deterministic_state(seed=use_deterministic_seed)
         text_tokens, cond = self._prepare(text, voice_samples, conditioning_latents, max_mel_tokens)
         self.ar.prefill(cond, text_tokens)
         chunk = stream_chunk_size if stream_chunk_size > 0 else max_mel_tokens
         first = max(chunk, 60) if stream_chunk_size > 0 else max_mel_tokens  # first_buffer = 60 (api_fast.py:401, 412)
         wav_gen_prev, wav_overlap = None, None
+        emitted = 0          # (token, latent) pairs already decoded into an emitted chunk
+        threshold = first    # pairs the reference buffers before the next decode (api_fast.py:412)
         for codes, done in self.ar.generate_stream(1, max_mel_tokens, chunk, first_chunk=first, temperature=temperature, top_p=top_p,
-                                                   repetition_penalty=float(repetition_penalty),
-                                                   top_k=int(hf_generate_kwargs.get("top_k", 50)), seed=seed):
+                                                   repetition_penalty=float(repetition_penalty), top_k=top_k, seed=seed):
             if done and codes.shape[1] > 0 and int(codes[0, -1]) == self.stop_mel_token:
                 codes = codes[:, :-1]  # the reference's generator stops BEFORE yielding the stop token's pair
             if codes.shape[1] == 0:
                 break
+            self.last_codes = codes
             latents = self._stream_latents(cond, text_tokens, codes)
             wav_gen = self.hifi_decoder.inference(latents, cond).reshape(-1)
             wav_chunk, wav_gen_prev, wav_overlap = self.handle_chunks(wav_gen, wav_gen_prev, wav_overlap, overlap_wav_len)
             yield wav_chunk
             if done:
+                # The reference decodes once per filled buffer AND once more when its generator raises StopIteration
+                # (api_fast.py:405-420).  When the sequence ends exactly on a buffer boundary that last pass sees the same latents
+                # again and handle_chunks hands out the withheld overlap tail: mirror it.
+                if stream_chunk_size > 0 and codes.shape[1] - emitted == threshold:
+                    wav_chunk, wav_gen_prev, wav_overlap = self.handle_chunks(wav_gen, wav_gen_prev, wav_overlap, overlap_wav_len)
+                    yield wav_chunk
                 break
+            emitted = codes.shape[1]
+            threshold = chunk

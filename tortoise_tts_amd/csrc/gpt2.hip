@@ -309,6 +309,7 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
   sa.state = e->state; sa.unfinished = e->unfinished; sa.stop_token = e->cfg.stop_mel_token;
   sa.codes = codes; sa.ldcodes = ldcodes; sa.next_tok = e->next_tok; sa.unfinished_count = e->unfinished_count;
   sa.embed_x = e->x; sa.tok_emb = e->w.mel_emb; sa.pos_emb = e->w.mel_pos; sa.D = e->D; sa.pos_offset = e->cfg.mel_pos_offset;
+  sa.pos_len = e->cfg.mel_pos_len;
   if (fresh) {
     e->B = B;
     e->gen_done = 0;
@@ -324,6 +325,12 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
     e->gen_done = 1;
   }
   sa.logits = e->logits; sa.ldl = e->V;
+  if (!fresh) {
+    // Resumed chunk (streaming): between two chunks the caller may have run tt_ar_latents / tt_ar_prefill, which use e->x as
+    // their residual stream, so the input row the sampler fused into e->x for the next step is gone.  Rebuild it from the
+    // device-side state (newest token, its index): mel_embedding[next_tok] + mel_pos_embedding[state[1] + offset].
+    TT_TRY(ar_embed_launch(e->next_tok, e->state, e->w.mel_emb, e->w.mel_pos, e->x, B, e->D, e->cfg.mel_pos_offset, s));
+  }
 
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;

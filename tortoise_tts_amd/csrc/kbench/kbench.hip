@@ -257,6 +257,14 @@ static int launch_variant(int variant, const ExpArgs& a, hipStream_t s) {
     V3(7, 128, 128, 2, 2, 3)
     V3(8, 256, 64, 4, 2, 3)
     V3(9, 128, 64, 2, 4, 6)
+    // decode-shape ring-depth series: how much of the per-launch time is "bytes in flight" 
+    V3(30, 64, 64, 2, 2, 8)     // 64x64 4 waves, 8-stage ring (128 KB LDS, 7 tiles = 112 KB in flight)
+    V3(31, 64, 64, 2, 2, 10)    // 10-stage ring (160 KB LDS = the whole CU)
+    V3(32, 32, 32, 2, 2, 16)    // 32x32 4 waves, 16 stages of 8 KB: ALL of K = 1024 in flight at once (no-slab decode projection)
+    V3(33, 32, 32, 2, 2, 20)    // 32x32, 20 stages (160 KB): K = 4096 streamed through
+    V3(34, 64, 64, 4, 2, 10)    // 64x64 8 waves (16x32 per wave), 10 stages
+    V3(35, 64, 64, 2, 2, 6)     // 6-stage ring
+    V3(36, 32, 64, 2, 2, 12)    // 32x64 4 waves (16x32 per wave), 12 stages of 12 KB
     case 200: return launch_exp<128, 64, 2, 2, 3, 0, 2>(a, s);
     case 500: return launch_exp<64, 64, 2, 2, 3, 0, 2>(a, s);
     case 501: return launch_exp<64, 64, 2, 2, 2, 0, 4>(a, s);   // 4 blocks / CU (16 KB LDS each x 2 stages)
@@ -299,6 +307,37 @@ int tt_kb_gemm_exp(int variant, int M, int N, int K, int taps, int seq_len, int 
       memset(&a, 0, sizeof(a));
       a.A = (const bf16*)A; a.W = (const bf16*)W[i % nw]; a.out = (bf16*)out; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = N;
       a.taps = taps; a.seq_len = seq_len > 0 ? seq_len : M; a.cin = K / taps; a.bias = bias;
+      TT_TRY(launch_variant(variant, a, s));
+    }
+    return 0;
+  }, reps, us_out);
+  if (!rc) *us_out /= chain;
+  gt.destroy();
+  ar.release();
+  return rc;
+}
+
+// Same as tt_kb_gemm_exp with `na` distinct activation matrices visited round-robin as well (na > 1: the A operand is not
+// L2-resident from the previous launch - the in-situ situation of the decode step, where another kernel has just produced it).
+int tt_kb_gemm_exp_na(int variant, int M, int N, int K, int nw, int na, int chain, int reps, double* us_out) {
+  Arena ar;
+  GraphTimer gt;
+  TT_TRY(gt.init());
+  void* out = nullptr;
+  std::vector<void*> W(nw), Av(na);
+  float* bias = nullptr;
+  int rc = 0;
+  for (int i = 0; i < na && !rc; ++i) rc = dev_bf16(ar, &Av[i], (size_t)(M + 8) * K, 1u + i);
+  if (!rc) rc = ar.alloc(&out, (size_t)M * N * 2);
+  if (!rc) rc = dev_f32(ar, &bias, N + 64, 5u);
+  for (int i = 0; i < nw && !rc; ++i) rc = dev_bf16(ar, &W[i], (size_t)N * K, 77u + i);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
+  if (!rc) rc = gt.run([&](hipStream_t s) -> int {
+    for (int i = 0; i < chain; ++i) {
+      ExpArgs a;
+      memset(&a, 0, sizeof(a));
+      a.A = (const bf16*)Av[i % na]; a.W = (const bf16*)W[i % nw]; a.out = (bf16*)out; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N;
+      a.taps = 1; a.seq_len = M; a.cin = K; a.bias = bias;
       TT_TRY(launch_variant(variant, a, s));
     }
     return 0;
@@ -552,12 +591,11 @@ int tt_kb_decode_attn(int variant, int B, int heads, int P1, int tgen, int tmax,
 //   mode 0: global_load_lds_dwordx4 (direct to LDS, 1 KiB per wave instruction)
 //   mode 1: global_load_dwordx4 to VGPRs, full 128-B lines (8 lanes per line)
 //   mode 2: global_load_dwordx4 to VGPRs, MFMA-fragment shaped (16 rows x 64 B per instruction, row stride 2 KiB)
-template <int MODE, int NW>
+template <int MODE, int NW, int UNR = 8>
 __global__ __launch_bounds__(NW * 64) void bw_probe_kernel(const char* buf, size_t footprint, size_t bytes_per_wg, float* sink) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t wg_base = ((size_t)blockIdx.x * 1315423911ull * 4096) % footprint;  // scattered start, 4 KiB aligned
-  constexpr int UNR = 8;
   const size_t per_iter = (size_t)NW * UNR * 1024;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (size_t done = 0; done < bytes_per_wg; done += per_iter) {
@@ -567,7 +605,7 @@ __global__ __launch_bounds__(NW * 64) void bw_probe_kernel(const char* buf, size
         size_t off = (wg_base + done + ((size_t)(u * NW + wave)) * 1024 + lane * 16) % footprint;
         __builtin_amdgcn_global_load_lds((gbl_void_k*)(buf + off), (lds_void_k*)(smem_raw + ((u * NW + wave) % 32) * 1024), 16, 0, 0);
       }
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UNR) : "memory");
     } else {
       f32x4 v[UNR];
 #pragma unroll
@@ -595,9 +633,15 @@ extern "C" int tt_kb_bw_probe(int mode, int nw_waves, int nblocks, size_t footpr
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
   if (!rc) rc = gt.run([&](hipStream_t s) -> int {
 #define BWP(MODE, NW) bw_probe_kernel<MODE, NW><<<nblocks, NW * 64, 32 * 1024, s>>>((const char*)buf, footprint, bytes_per_wg, sink)
-    if (mode == 0 && nw_waves == 4) BWP(0, 4); else if (mode == 0) BWP(0, 8);
+    // nw_waves >= 100: 16 loads in flight per lane instead of 8 (waves = nw_waves - 100)
+#define BWP16(MODE, NW) bw_probe_kernel<MODE, NW, 16><<<nblocks, NW * 64, 32 * 1024, s>>>((const char*)buf, footprint, bytes_per_wg, sink)
+    if (nw_waves == 16) { if (mode == 0) BWP(0, 16); else if (mode == 1) BWP(1, 16); else BWP(2, 16); }
+    else if (nw_waves == 108) { if (mode == 0) BWP16(0, 8); else if (mode == 1) BWP16(1, 8); else BWP16(2, 8); }
+    else if (nw_waves == 116) { if (mode == 0) BWP16(0, 16); else if (mode == 1) BWP16(1, 16); else BWP16(2, 16); }
+    else if (mode == 0 && nw_waves == 4) BWP(0, 4); else if (mode == 0) BWP(0, 8);
     else if (mode == 1 && nw_waves == 4) BWP(1, 4); else if (mode == 1) BWP(1, 8);
     else if (nw_waves == 4) BWP(2, 4); else BWP(2, 8);
+#undef BWP16
 #undef BWP
     TT_CHECK_HIP(hipGetLastError());
     return 0;

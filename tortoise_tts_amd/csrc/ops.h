@@ -110,6 +110,7 @@ struct SampleArgs {
   const float* tok_emb;
   const float* pos_emb;
   int D, pos_offset;
+  int pos_len;               // rows of pos_emb: the embedding of a token whose position lies beyond the table is skipped (it is never fed)
 };
 int sample_launch(const SampleArgs& a, hipStream_t stream);
 int ar_state_advance_launch(int* state, hipStream_t stream);

@@ -264,7 +264,9 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     if (still) atomicAdd(&a.unfinished_count[step], 1);
     red_i[0] = tok;
   }
-  if (a.embed_x) {  // next decode step's input row: mel_embedding[tok] + mel_pos_embedding[index of this token + offset]
+  // next decode step's input row: mel_embedding[tok] + mel_pos_embedding[index of this token + offset].  The token sampled at
+  // the capacity limit is never fed back, and its position row would lie one past the table: skip it.
+  if (a.embed_x && step + a.pos_offset < a.pos_len) {
     __syncthreads();
     const int tok = red_i[0];
     const int pos = step + a.pos_offset;

@@ -44,11 +44,29 @@ def init_from_env(device_index=None):
                 dist.destroy_process_group()
             global FALLBACK_SINGLE
             FALLBACK_SINGLE = True
-            return rank, 1, local
+            # Only rank 0 keeps serving (as an ordinary single-GPU engine); every other rank must stop, or each of them would
+            # render the whole utterance again as an independent "rank 0".  This covers the failure that hits every rank
+            # (driver / IPC / topology).  A PARTIAL failure - some ranks inside the forced all_reduce, some out - is not
+            # recoverable here: the survivors block in the collective until the launcher's timeout tears the job down.
+            if rank != 0:
+                raise CollectiveInitFailed(f"rank {rank}: {backend} initialisation failed; rank 0 continues alone")
+            return 0, 1, local
     return rank, world, local
 
 
-FALLBACK_SINGLE = False  # set when a multi-rank launch could not initialise its collectives (ranks != 0 should exit)
+class CollectiveInitFailed(RuntimeError):
+    """Raised on ranks != 0 when the multi-rank launch could not initialise its collectives (rank 0 falls back to one GPU)."""
+
+
+FALLBACK_SINGLE = False  # set when a multi-rank launch could not initialise its collectives
+# Test hook (tests/test_gpu_dist.py): run the collectives' device-tensor paths through the backend even at world_size 1, so the
+# RCCL branches execute on a one-GPU box.  Never set by the product.
+FORCE_COLLECTIVES = False
+
+
+def _single():
+    """True when there is nobody to talk to (and the test hook does not insist on exercising the backend anyway)."""
+    return not dist.is_initialized() or (dist.get_world_size() == 1 and not FORCE_COLLECTIVES)
 
 
 def _host_staged():
@@ -71,7 +89,7 @@ def shard_range(n, rank, world_size):
 def gather_candidates(scores_local, codes_local):
     """all_gather of CLVP scores f32 [n] and codes [n, M] (sent as int16: mel codes are < 8194) -> global
     ([N] f32, [N, M] int32) on every rank, ordered by global candidate index."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return scores_local, codes_local
     ws = dist.get_world_size()
     scores_local = scores_local.contiguous()
@@ -98,7 +116,7 @@ def collect_on_rank0(wavs, k):
     """wavs: {winner index: CPU waveform} rendered on THIS rank (winner i is rendered by rank i % world, or by rank 0 when
     the diffusion tail is split).  Rank 0 receives the ones it does not hold by point-to-point sends and returns the full
     dict; every other rank returns None.  With k == 1 nothing is communicated at all."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return wavs
     rank, ws = dist.get_rank(), dist.get_world_size()
     gpu_backend = not _host_staged()
@@ -140,8 +158,8 @@ _PAIR = None
 def pair_group():
     """Process group {0, 1} for the split diffusion tail (created once; new_group is collective over ALL ranks)."""
     global _PAIR
-    if _PAIR is None and dist.is_initialized() and dist.get_world_size() >= 2:
-        _PAIR = dist.new_group([0, 1])
+    if _PAIR is None and dist.is_initialized() and (dist.get_world_size() >= 2 or FORCE_COLLECTIVES):
+        _PAIR = dist.new_group([0, 1] if dist.get_world_size() >= 2 else [0])
     return _PAIR
 
 
@@ -159,7 +177,7 @@ def exchange_rows(rows, mine):
 
 def broadcast_int(value, src=0):
     """`value` of rank `src` on every rank (host integer; e.g. the utterance seed)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return int(value)
     dev = "cpu" if _host_staged() or not torch.cuda.is_available() else "cuda"
     t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
@@ -169,7 +187,7 @@ def broadcast_int(value, src=0):
 
 def max_over_ranks(value):
     """MAX of a host scalar over all ranks (bench.py's timing contract)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return float(value)
     dev = "cpu" if _host_staged() or not torch.cuda.is_available() else "cuda"
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
