@@ -136,14 +136,14 @@ def roofline_leg(tts, run_step):
     import ctypes as C
     from tortoise_tts_amd import engine as E
     lib = E.load_library()
-    os.environ["TT_NO_GRAPH"] = "1"
+    lib.tt_graph_replay(0)
     lib.tt_prof_enable(1)
     try:
         run_step()
         torch.cuda.synchronize()
     finally:
         lib.tt_prof_enable(0)
-        os.environ.pop("TT_NO_GRAPH", None)
+        lib.tt_graph_replay(1)
     rows = []
     buf = (C.c_double * 4)()
     for i in range(lib.tt_prof_classes()):
@@ -204,6 +204,8 @@ def main():
                          "spread over the GPUs as replicas (BASELINE config #4, tortoise/read.py)")
     ap.add_argument("--diffusion-iterations", type=int, default=None,
                     help="override the preset's diffusion iterations (profiling passes only: the headline metric uses the preset's own)")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue the decode / sampler loops eagerly instead of replaying hipGraphs "
+                    "(counter passes only: rocprofv3 --pmc crashes under graph replay); same kernels, same order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -215,6 +217,9 @@ def main():
     from tortoise_tts_amd.api import TextToSpeech
     from tortoise_tts_amd.config import PRESETS, BASE_SETTINGS
 
+    if args.no_graph:
+        from tortoise_tts_amd import engine as E
+        E.load_library().tt_graph_replay(0)
     preset_kw = dict(BASE_SETTINGS)
     preset_kw.update(PRESETS[args.preset])
     extra_kw = {}

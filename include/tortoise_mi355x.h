@@ -265,10 +265,14 @@ void tt_voc_destroy(tt_voc* h);
 int tt_voc_run(tt_voc* h, const float* mel, int S, const float* z, float* audio, void* stream);
 
 /* ============================================================================================
- * Per-kernel-class timing for bench.py's roofline leg: while enabled every launch is bracketed by HIP
- * events on its own stream (run with TT_NO_GRAPH=1; never enabled on the product path).
- * tt_prof_read: out[4] = {launches, total_ms, algorithmic_flops, algorithmic_bytes}; synchronises.
+ * Diagnostics (bench.py's roofline leg, the graph-vs-eager tests, counter passes).  Never used on the product path.
+ * tt_prof_enable: while on, every kernel launch is timed - single-kernel launchers through the start / end timestamps of the
+ * dispatch itself (hipExtLaunchKernelGGL; the clock a rocprofv3 kernel trace reads), launchers that enqueue several kernels by a
+ * HIP-event bracket on their stream.  tt_prof_read: out[4] = {launches, total_ms, algorithmic_flops, algorithmic_bytes};
+ * synchronises.  tt_graph_replay(0) makes the decode / sampler loops enqueue their kernels eagerly instead of capturing and
+ * replaying a hipGraph (same kernels, same order; process-wide, default on); returns the previous setting.
  * ============================================================================================ */
+int tt_graph_replay(int on);
 int tt_prof_enable(int on);
 int tt_prof_classes(void);
 const char* tt_prof_class_name(int id);

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""In-situ A/B timing of ONE stage at the benchmark shape ('standard': 256 candidates x 200 mel tokens / 200 diffusion
+iterations at S = 870), without the rest of the pipeline: `TORTOISE_MI355X_LIB=<alt .so> python scripts/ab_stage.py ar diff`.
+Both builds of an A/B must run inside the same gpurun call (boxes differ by +-3 %).  Prints one line per stage:
+    ab <tag> ar   : ms per decode step (mean of R repetitions of the full 200-token generation, graph replay), min
+    ab <tag> diff : ms per sampler iteration
+and a checksum of the produced codes / mel so that bit-identity between two builds can be read off the log."""
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def digest(t):
+    return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:12]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("stages", nargs="*", default=["ar", "diff"])
+    ap.add_argument("--tag", default=os.environ.get("AB_TAG", "base"))
+    ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--candidates", type=int, default=256)
+    ap.add_argument("--mel-tokens", type=int, default=200)
+    ap.add_argument("--iterations", type=int, default=200)
+    args = ap.parse_args()
+    from bench import synthetic_prompt
+    from tortoise_tts_amd import stages, weights as W
+    from tortoise_tts_amd.config import ARConfig, DiffusionConfig
+    from tortoise_tts_amd.schedule import Schedule
+    import torch.nn.functional as F
+    text, (auto, diffc) = synthetic_prompt()
+    dev = "cuda"
+    with torch.no_grad():
+        if "ar" in args.stages:
+            cfg = ARConfig()
+            sd = W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(cfg), 1234), cfg)
+            ar = stages.ArStage(sd, cfg, max_batch=args.candidates, max_new_tokens=max(args.mel_tokens, 32), max_latent_candidates=1)
+            tt = F.pad(text.int()[None], (0, 1)).to(dev)
+            times = []
+            codes = None
+            for r in range(args.reps + 1):
+                ar.prefill(auto.to(dev), tt)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                codes, n = ar.generate(args.candidates, args.mel_tokens, seed=77)
+                torch.cuda.synchronize()
+                if r:
+                    times.append((time.perf_counter() - t0) / n)
+            print("ab %-10s ar   B=%d n=%d: %.4f ms/step (min %.4f)  total %.1f ms  codes %s" %
+                  (args.tag, args.candidates, n, 1e3 * sum(times) / len(times), 1e3 * min(times), 1e3 * n * sum(times) / len(times), digest(codes)), flush=True)
+            ar.close()
+            del ar
+        if "diff" in args.stages:
+            cfg = DiffusionConfig()
+            sd = W.synthetic_state_dict(W.diffusion_manifest(cfg), 1236)
+            M = args.mel_tokens
+            S = M * 4 * 24000 // 22050
+            df = stages.DiffusionStage(sd, cfg, max_seq=max(S, 128), max_codes=max(M, 64), max_steps=args.iterations)
+            g = torch.Generator().manual_seed(5)
+            lat = torch.randn(1, M, 1024, generator=g).to(dev)
+            sched = Schedule(args.iterations, cfg.trained_steps, True, 2)
+            x = torch.randn(1, 100, S, generator=g).to(dev)
+            noise = torch.randn(args.iterations, 1, 100, S, generator=g).to(dev)
+            times = []
+            mel = None
+            for r in range(args.reps + 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                df.condition(lat, diffc.to(dev), S)
+                mel = df.sample(sched, x, noise)
+                torch.cuda.synchronize()
+                if r:
+                    times.append((time.perf_counter() - t0) / args.iterations)
+            print("ab %-10s diff S=%d it=%d: %.4f ms/iteration (min %.4f)  total %.1f ms  mel %s" %
+                  (args.tag, S, args.iterations, 1e3 * sum(times) / len(times), 1e3 * min(times), 1e3 * args.iterations * sum(times) / len(times), digest(mel)), flush=True)
+            df.close()
+
+
+if __name__ == "__main__":
+    main()

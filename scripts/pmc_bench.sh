@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the hot path's kernels from PMC counters, collected as MI355X_MICROARCH.md prescribes: one counter per
 # pass (FETCH_SIZE and WRITE_SIZE do not fit one pass), --kernel-trace only, over one utterance of bench.py.
-# hipGraph replay under counter collection segfaults in this rocprofv3, so the engines run eagerly (TT_NO_GRAPH=1): same kernels,
+# hipGraph replay under counter collection segfaults in this rocprofv3, so the engines run eagerly (bench.py --no-graph): same kernels,
 # same launch parameters.  Per-dispatch rows are aggregated ON the GPU box (the raw CSVs are too large to pull) into gpurun_out/pmc_bench.json.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -13,7 +13,7 @@ i=0
 for set in "${SETS[@]}"; do
   i=$((i+1)); c=pass$i
   (cd /tmp && timeout 900 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$c -o p -- \
-     env TT_NO_GRAPH=1 python $OLDPWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline ${PMC_BENCH_ARGS:---diffusion-iterations 24} > $OUT/$c.log 2>&1)
+     python $OLDPWD/bench.py --no-graph --steps 1 --warmup 0 --no-cpu-baseline --no-roofline ${PMC_BENCH_ARGS:---diffusion-iterations 24} > $OUT/$c.log 2>&1)
   echo "pmc [$set] rc=$?" | tee -a $OUT/summary.txt
 done
 OUT=$OUT PMC_JSON=${PMC_JSON:-pmc_bench.json} python - <<'PY'
@@ -57,7 +57,7 @@ res = {}
 for k, cs in agg.items():
     res[k] = {c: {"dispatches": v[0], "sum": v[1], "avg": v[1] / max(v[0], 1)} for c, v in cs.items()}
 import bench
-res["_meta"] = {"source_digest": bench.source_digest(), "command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline " + os.environ.get("PMC_BENCH_ARGS", "--diffusion-iterations 24") + " (TT_NO_GRAPH=1; every kernel class at its benchmark shape, 24 instead of 200 denoiser steps: this rocprofv3 segfaults in counter collection on the full 80 000-dispatch utterance)",
+res["_meta"] = {"source_digest": bench.source_digest(), "command": "bench.py --no-graph --steps 1 --warmup 0 --no-cpu-baseline --no-roofline " + os.environ.get("PMC_BENCH_ARGS", "--diffusion-iterations 24") + " (every kernel class at its benchmark shape, 24 instead of 200 denoiser steps: this rocprofv3 segfaults in counter collection on the full 80 000-dispatch utterance)",
                 "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch as rocprofv3 reports them (FETCH_SIZE is doubled by bench.py)"}
 json.dump(res, open(out + "/../" + os.environ["PMC_JSON"], "w"), indent=1, sort_keys=True)
 for k in sorted(res):

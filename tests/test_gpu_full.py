@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from tests.gpu_util import report, rel_err
+from tortoise_tts_amd import engine as E
 
 pytestmark = pytest.mark.gpu
 
@@ -101,11 +102,11 @@ def test_diffusion_full_size_properties(full):
     sched.timestep_map = sched.timestep_map[:4]
     noise = torch.randn(4, 1, 100, S, generator=g)
     mel = df.sample(sched, x, noise)
-    os.environ["TT_NO_GRAPH"] = "1"
+    E.load_library().tt_graph_replay(0)
     try:
         mel2 = df.sample(sched, x, noise)
     finally:
-        os.environ.pop("TT_NO_GRAPH")
+        E.load_library().tt_graph_replay(1)
     assert torch.equal(mel, mel2) and torch.isfinite(mel).all()
     assert mel.shape == (1, 100, S) and mel.min() >= -11.6 and mel.max() <= 2.4  # x0 clamp -> tacotron range
 

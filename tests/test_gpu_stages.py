@@ -227,11 +227,11 @@ def test_diffusion(name, dt, tdt, tol):
     report(f"diffusion p_sample_loop mel ({G.DIFF_STEPS} steps) {name} vs oracle", mel, want, tol * 2)
     report(f"diffusion p_sample_loop mel {name} vs reference golden", mel, O.denormalize_tacotron_mel(torch.from_numpy(g["x0"])), tol * 3)
     # graph replay and eager launches are the same kernels: results must be bit-identical
-    os.environ["TT_NO_GRAPH"] = "1"
+    E.load_library().tt_graph_replay(0)
     try:
         mel2 = st.sample(sched, x, step_noise)
     finally:
-        os.environ.pop("TT_NO_GRAPH")
+        E.load_library().tt_graph_replay(1)
     assert torch.equal(mel, mel2), "hipGraph replay differs from eager launches"
     st.close()
 

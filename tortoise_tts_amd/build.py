@@ -45,7 +45,12 @@ def _headers():
     return hs
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, variant=None, defines=()):
+    """variant / defines: an alternative library lib/libtortoise_mi355x_<variant>.so compiled with extra -D knobs (csrc/knobs.h)
+    for in-situ A/B runs (TORTOISE_MI355X_LIB selects it); the product library is the one built without them."""
+    OBJ = os.path.join(CSRC, "build" if not variant else "build_" + variant)
+    LIB = os.path.join(LIBDIR, "libtortoise_mi355x.so" if not variant else "libtortoise_mi355x_%s.so" % variant)
+    FLAGS = globals()["FLAGS"] + ["-D" + d for d in defines]
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
@@ -56,7 +61,7 @@ def build(force=False, verbose=True):
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, src.replace(".hip", ".o"))
         stamp = op + ".sha"
-        dig = _digest([sp] + headers)
+        dig = _digest([sp] + headers) + "|" + " ".join(defines)
         objs.append(op)
         if not force and os.path.exists(op) and os.path.exists(stamp) and open(stamp).read() == dig:
             continue
@@ -108,5 +113,8 @@ def build_kbench(verbose=True):
 if __name__ == "__main__":
     if "--kbench" in sys.argv:
         build_kbench()
+    elif "--variant" in sys.argv:
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        build(variant=name, defines=[a[2:] for a in sys.argv if a.startswith("-D")])
     else:
         build(force="--force" in sys.argv)

@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
 }
 
 template <typename T, int NQ>
-static int launch_flash_lds(const FlashArgs& a, hipStream_t stream) {
+static int launch_flash_lds(const ProfScope& ps, const FlashArgs& a, hipStream_t stream) {
   constexpr int smem = 3 * 2 * 64 * 64 * 2 + 132 * 4;
   static bool attr_set = false;
   if (!attr_set) {
@@ -487,7 +487,7 @@ static int launch_flash_lds(const FlashArgs& a, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid(cdiv(a.n, 64 * NQ), a.BH);
-  flash_lds_kernel<T, NQ><<<grid, 256, smem, stream>>>(a);
+  launch_timed(ps, flash_lds_kernel<T, NQ>, grid, dim3(256), smem, stream, a);
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -498,19 +498,19 @@ int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.ldo % 4 == 0, "flash: ldo must be a multiple of 4");
   // 32 queries per wave once there is enough work to fill the chip; 16 otherwise.
   // QK^T + PV: 4 * n * n * 64 flops per (batch, head) (halved when causal); Q, K, V read + O written once
-  ProfScope ps(PROF_FLASH, stream, 4.0 * a.BH * (double)a.n * a.n * 64 * (a.causal ? 0.5 : 1.0), 4.0 * a.BH * (double)a.n * 64 * 2.0);
+  ProfScope ps(PROF_FLASH, stream, 4.0 * a.BH * (double)a.n * a.n * 64 * (a.causal ? 0.5 : 1.0), 4.0 * a.BH * (double)a.n * 64 * 2.0, true);
   if (a.n > 128) {
     // LDS-staged kernel: 64 queries per block while that keeps >= 2 blocks per CU busy, 128 otherwise (half the K / V traffic per
     // flop; measured on the kbench shapes: 32 queries per wave only pays from ~2048 blocks of 64 queries on)
     const long blocks64 = (long)cdiv(a.n, 64) * a.BH;
-    if (blocks64 >= 2048) return dtype == DT_BF16 ? launch_flash_lds<bf16, 2>(a, stream) : launch_flash_lds<f16, 2>(a, stream);
-    return dtype == DT_BF16 ? launch_flash_lds<bf16, 1>(a, stream) : launch_flash_lds<f16, 1>(a, stream);
+    if (blocks64 >= 2048) return dtype == DT_BF16 ? launch_flash_lds<bf16, 2>(ps, a, stream) : launch_flash_lds<f16, 2>(ps, a, stream);
+    return dtype == DT_BF16 ? launch_flash_lds<bf16, 1>(ps, a, stream) : launch_flash_lds<f16, 1>(ps, a, stream);
   }
   // short sequences (prefill of a few dozen rows, reduced test configurations): the register-prefetch kernel, the 4 waves of a
   // block share one 16-query block and split the keys
   dim3 grid(cdiv(a.n, 16), a.BH);
-  if (dtype == DT_BF16) flash_kernel<bf16, 1, true><<<grid, 256, 0, stream>>>(a);
-  else flash_kernel<f16, 1, true><<<grid, 256, 0, stream>>>(a);
+  if (dtype == DT_BF16) launch_timed(ps, flash_kernel<bf16, 1, true>, grid, dim3(256), 0, stream, a);
+  else launch_timed(ps, flash_kernel<f16, 1, true>, grid, dim3(256), 0, stream, a);
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -872,7 +872,7 @@ int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stre
   const int ctx_cap = a.P1 + a.tmax;
   // algorithmic bytes: every sequence reads its own generated K and V rows once (host_tgen keys) + the shared prefix once
   ProfScope ps(PROF_DECODE_ATTN, stream, 4.0 * a.B * a.heads * 64.0 * (a.P1 + a.host_tgen),
-               ((double)a.B * a.host_tgen + a.P1) * a.heads * 64 * 2 * 2.0 + 2.0 * a.B * a.heads * 64 * 2.0);
+               ((double)a.B * a.host_tgen + a.P1) * a.heads * 64 * 2 * 2.0 + 2.0 * a.B * a.heads * 64 * 2.0, true);
   // shared-prefix kernel with 4 sequences per workgroup (measured 2 % ahead of 16 at 256 candidates and 40 % ahead at 32:
   // more, smaller workgroups); the per-wave kernel only when the staged prefix + score rows do not fit the LDS (very long prompts)
   int nseq = a.variant == 1 ? 0 : a.variant == 2 ? 16 : 4;
@@ -890,7 +890,7 @@ int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stre
         TT_CHECK_HIP(hipFuncSetAttribute((const void*)decode_attn_lds_kernel<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         attr_done = true;                                                                                                            \
       }                                                                                                                              \
-      decode_attn_lds_kernel<T, NS><<<blocks, NS * 64, smem, stream>>>(a, ctx_cap, kl_bytes, vl_bytes);                              \
+      launch_timed(ps, decode_attn_lds_kernel<T, NS>, blocks, dim3(NS * 64), smem, stream, a, ctx_cap, kl_bytes, vl_bytes);          \
     } while (0)
     if (dtype == DT_BF16) { if (nseq == 16) TT_DEC(bf16, 16); else TT_DEC(bf16, 4); }
     else { if (nseq == 16) TT_DEC(f16, 16); else TT_DEC(f16, 4); }
@@ -901,8 +901,8 @@ int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stre
   const size_t smem = (size_t)4 * ctx_cap * sizeof(float);
   TT_REQUIRE(smem <= 64 * 1024, "decode_attention: context %d too long for the score buffer", ctx_cap);
   const int blocks = cdiv(a.B * a.heads, 4);
-  if (dtype == DT_BF16) decode_attn_kernel<bf16><<<blocks, 256, smem, stream>>>(a, ctx_cap);
-  else decode_attn_kernel<f16><<<blocks, 256, smem, stream>>>(a, ctx_cap);
+  if (dtype == DT_BF16) launch_timed(ps, decode_attn_kernel<bf16>, dim3(blocks), dim3(256), smem, stream, a, ctx_cap);
+  else launch_timed(ps, decode_attn_kernel<f16>, dim3(blocks), dim3(256), smem, stream, a, ctx_cap);
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -2,6 +2,7 @@
 // Everything here targets CDNA4 directly: 64-lane waves, v_mfma_f32_16x16x32_{bf16,f16}.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -180,14 +181,30 @@ enum ProfId {  // one class per kernel instantiation that actually runs (names: 
 };
 extern bool g_prof_on;
 void prof_record(int id, hipStream_t s, bool begin, double flops, double bytes);
+void prof_pair(int id, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
+// Two timing forms.  Bracket (default): an event recorded on the launch stream before and after the launcher's kernels - right
+// for launchers that enqueue several kernels, but the two hipEventRecord packets add ~2.5 us to a 7 us kernel.  Dispatch
+// (`dispatch = true`, single-kernel launchers): the scope only hands out an event pair and the launcher passes it to
+// hipExtLaunchKernelGGL, which stamps the pair with the start / end timestamps of the dispatch itself - the same clock a
+// rocprofv3 kernel trace reads, so the roofline leg of bench.py and profiles/ agree.
 struct ProfScope {
-  int id; hipStream_t s; bool on;
-  ProfScope(int id_, hipStream_t s_, double flops, double bytes) : id(id_), s(s_), on(g_prof_on) {
-    if (on) prof_record(id, s, true, flops, bytes);
+  int id; hipStream_t s; bool on; bool dispatch;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfScope(int id_, hipStream_t s_, double flops, double bytes, bool dispatch_ = false) : id(id_), s(s_), on(g_prof_on), dispatch(dispatch_) {
+    if (!on) return;
+    if (dispatch) prof_pair(id, flops, bytes, &e0, &e1);
+    else prof_record(id, s, true, flops, bytes);
   }
   ~ProfScope() {
-    if (on) prof_record(id, s, false, 0, 0);
+    if (on && !dispatch) prof_record(id, s, false, 0, 0);
   }
 };
 const char* prof_name(int id);
+
+// Launch `kernel` on `s`; under the profiler (dispatch-form scope) through hipExtLaunchKernelGGL with the scope's event pair.
+template <typename... P, typename... A>
+static inline void launch_timed(const ProfScope& ps, void (*kernel)(P...), dim3 grid, dim3 block, size_t smem, hipStream_t s, A&&... args) {
+  if (ps.on && ps.dispatch) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)smem, s, ps.e0, ps.e1, 0, static_cast<P>(args)...);
+  else kernel<<<grid, block, smem, s>>>(static_cast<P>(args)...);
+}
 }  // namespace tt

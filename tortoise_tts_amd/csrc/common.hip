@@ -19,6 +19,7 @@ const char* last_error() { return g_err; }
 #include <vector>
 namespace tt {
 bool g_prof_on = false;
+bool g_graph_replay = true;
 struct ProfClass {
   std::vector<hipEvent_t> start, stop;
   double flops = 0, bytes = 0;
@@ -46,6 +47,15 @@ void prof_record(int id, hipStream_t s, bool begin, double flops, double bytes) 
     c.stop.push_back(e);
   }
 }
+void prof_pair(int id, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1) {
+  ProfClass& c = g_prof[id];
+  *e0 = *e1 = nullptr;
+  if (hipEventCreate(e0) != hipSuccess || hipEventCreate(e1) != hipSuccess) return;
+  c.start.push_back(*e0);
+  c.stop.push_back(*e1);
+  c.flops += flops;
+  c.bytes += bytes;
+}
 }  // namespace tt
 
 extern "C" {
@@ -60,6 +70,11 @@ int tt_prof_enable(int on) {
   }
   g_prof_on = on != 0;
   return 0;
+}
+int tt_graph_replay(int on) {
+  const int prev = tt::g_graph_replay ? 1 : 0;
+  tt::g_graph_replay = on != 0;
+  return prev;
 }
 int tt_prof_classes(void) { return tt::PROF_COUNT; }
 const char* tt_prof_class_name(int id) { return tt::prof_name(id); }

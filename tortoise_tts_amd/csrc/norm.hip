@@ -171,23 +171,24 @@ __global__ __launch_bounds__(256) void rownorm_narrow_kernel(RowNormArgs a) {
 }
 
 template <typename T, int NSLAB>
-static void rownorm_narrow_dispatch(const RowNormArgs& a, hipStream_t stream) {
+static void rownorm_narrow_dispatch(const ProfScope& ps, const RowNormArgs& a, hipStream_t stream) {
   const bool bias = a.add_bias != nullptr, rms = a.mode == NORM_RMS;
-  if (bias && rms) rownorm_narrow_kernel<T, NSLAB, true, true><<<a.M, 256, 0, stream>>>(a);
-  else if (bias) rownorm_narrow_kernel<T, NSLAB, true, false><<<a.M, 256, 0, stream>>>(a);
-  else if (rms) rownorm_narrow_kernel<T, NSLAB, false, true><<<a.M, 256, 0, stream>>>(a);
-  else rownorm_narrow_kernel<T, NSLAB, false, false><<<a.M, 256, 0, stream>>>(a);
+  const int grid = a.M;
+  if (bias && rms) launch_timed(ps, rownorm_narrow_kernel<T, NSLAB, true, true>, dim3(grid), dim3(256), 0, stream, a);
+  else if (bias) launch_timed(ps, rownorm_narrow_kernel<T, NSLAB, true, false>, dim3(grid), dim3(256), 0, stream, a);
+  else if (rms) launch_timed(ps, rownorm_narrow_kernel<T, NSLAB, false, true>, dim3(grid), dim3(256), 0, stream, a);
+  else launch_timed(ps, rownorm_narrow_kernel<T, NSLAB, false, false>, dim3(grid), dim3(256), 0, stream, a);
 }
 
 template <typename T>
-static bool rownorm_narrow_launch(const RowNormArgs& a, hipStream_t stream) {
+static bool rownorm_narrow_launch(const ProfScope& ps, const RowNormArgs& a, hipStream_t stream) {
   if (a.D > 1024 || a.mode == NORM_NONE || a.g2 != nullptr) return false;
   switch (a.nslab) {
-    case 0: rownorm_narrow_dispatch<T, 0>(a, stream); return true;
-    case 1: rownorm_narrow_dispatch<T, 1>(a, stream); return true;
-    case 2: rownorm_narrow_dispatch<T, 2>(a, stream); return true;
-    case 4: rownorm_narrow_dispatch<T, 4>(a, stream); return true;
-    case 8: rownorm_narrow_dispatch<T, 8>(a, stream); return true;
+    case 0: rownorm_narrow_dispatch<T, 0>(ps, a, stream); return true;
+    case 1: rownorm_narrow_dispatch<T, 1>(ps, a, stream); return true;
+    case 2: rownorm_narrow_dispatch<T, 2>(ps, a, stream); return true;
+    case 4: rownorm_narrow_dispatch<T, 4>(ps, a, stream); return true;
+    case 8: rownorm_narrow_dispatch<T, 8>(ps, a, stream); return true;
     default: return false;
   }
 }
@@ -289,16 +290,16 @@ __global__ __launch_bounds__(256) void rownorm_wave_kernel(RowNormArgs a) {
 int rownorm_launch(int dtype, const RowNormArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.M > 0 && a.D > 0 && a.D % 4 == 0 && a.D <= 4096, "rownorm: bad shape M=%d D=%d", a.M, a.D);
   TT_REQUIRE(a.ldx % 4 == 0, "rownorm: ldx must be a multiple of 4");
-  ProfScope ps(PROF_ROWNORM, stream, 0.0, (double)a.M * a.D * (4.0 * (1 + a.nslab + (a.write_x ? 1 : 0)) + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)));
+  ProfScope ps(PROF_ROWNORM, stream, 0.0, (double)a.M * a.D * (4.0 * (1 + a.nslab + (a.write_x ? 1 : 0)) + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)), true);
   // few rows (decode): one block per row keeps 4x more loads in flight; many rows: wave per row, no barriers
   if (a.D <= 1024 && a.M >= 1024) {
-    if (dtype == DT_BF16) rownorm_wave_kernel<bf16><<<cdiv(a.M, 4), 256, 0, stream>>>(a);
-    else rownorm_wave_kernel<f16><<<cdiv(a.M, 4), 256, 0, stream>>>(a);
+    if (dtype == DT_BF16) launch_timed(ps, rownorm_wave_kernel<bf16>, dim3(cdiv(a.M, 4)), dim3(256), 0, stream, a);
+    else launch_timed(ps, rownorm_wave_kernel<f16>, dim3(cdiv(a.M, 4)), dim3(256), 0, stream, a);
   } else {
-    const bool narrow = dtype == DT_BF16 ? rownorm_narrow_launch<bf16>(a, stream) : rownorm_narrow_launch<f16>(a, stream);
+    const bool narrow = dtype == DT_BF16 ? rownorm_narrow_launch<bf16>(ps, a, stream) : rownorm_narrow_launch<f16>(ps, a, stream);
     if (!narrow) {
-      if (dtype == DT_BF16) rownorm_kernel<bf16, -1><<<a.M, 256, 0, stream>>>(a);
-      else rownorm_kernel<f16, -1><<<a.M, 256, 0, stream>>>(a);
+      if (dtype == DT_BF16) launch_timed(ps, rownorm_kernel<bf16, -1>, dim3(a.M), dim3(256), 0, stream, a);
+      else launch_timed(ps, rownorm_kernel<f16, -1>, dim3(a.M), dim3(256), 0, stream, a);
     }
   }
   TT_CHECK_HIP(hipGetLastError());
@@ -558,7 +559,8 @@ int groupnorm_launch(int dtype, const GroupNormArgs& a0, hipStream_t stream) {
   const int rpc = gn_rows_per_chunk(a.S);
   const int nchunk = cdiv(a.S, rpc);
   dim3 grid(nchunk, a.B);
-  ProfScope ps(PROF_GROUPNORM, stream, 0.0, (double)a.B * a.S * a.C * ((a.gemm_part ? 4.0 : 8.0) + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)));
+  // (dispatch-timed when the statistics come from the producing GEMM: then the apply kernel is the only launch of this scope)
+  ProfScope ps(PROF_GROUPNORM, stream, 0.0, (double)a.B * a.S * a.C * ((a.gemm_part ? 4.0 : 8.0) + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)), a.gemm_part != nullptr);
   if (a.gemm_part) {
     const int spg = (a.C / 32) / 16;
     TT_REQUIRE((a.C / 32) % 16 == 0 && (spg == 1 || spg == 2 || spg == 4) && a.part_rows > 0 && (a.part_rows & (a.part_rows - 1)) == 0 && a.S >= a.part_rows,
@@ -572,18 +574,18 @@ int groupnorm_launch(int dtype, const GroupNormArgs& a0, hipStream_t stream) {
   if (a.C == 1024) {
     const int variant = (dtype == DT_BF16 ? 0 : 4) + (a.gemm_part ? 2 : 0) + (a.scale_shift ? 1 : 0);
     switch (variant) {
-      case 0: gn_apply_c1024_kernel<bf16, false, false><<<grid2, 256, 0, stream>>>(a, nchunk); break;
-      case 1: gn_apply_c1024_kernel<bf16, false, true><<<grid2, 256, 0, stream>>>(a, nchunk); break;
-      case 2: gn_apply_c1024_kernel<bf16, true, false><<<grid2, 256, 0, stream>>>(a, nchunk); break;
-      case 3: gn_apply_c1024_kernel<bf16, true, true><<<grid2, 256, 0, stream>>>(a, nchunk); break;
-      case 4: gn_apply_c1024_kernel<f16, false, false><<<grid2, 256, 0, stream>>>(a, nchunk); break;
-      case 5: gn_apply_c1024_kernel<f16, false, true><<<grid2, 256, 0, stream>>>(a, nchunk); break;
-      case 6: gn_apply_c1024_kernel<f16, true, false><<<grid2, 256, 0, stream>>>(a, nchunk); break;
-      default: gn_apply_c1024_kernel<f16, true, true><<<grid2, 256, 0, stream>>>(a, nchunk); break;
+      case 0: launch_timed(ps, gn_apply_c1024_kernel<bf16, false, false>, grid2, dim3(256), 0, stream, a, nchunk); break;
+      case 1: launch_timed(ps, gn_apply_c1024_kernel<bf16, false, true>, grid2, dim3(256), 0, stream, a, nchunk); break;
+      case 2: launch_timed(ps, gn_apply_c1024_kernel<bf16, true, false>, grid2, dim3(256), 0, stream, a, nchunk); break;
+      case 3: launch_timed(ps, gn_apply_c1024_kernel<bf16, true, true>, grid2, dim3(256), 0, stream, a, nchunk); break;
+      case 4: launch_timed(ps, gn_apply_c1024_kernel<f16, false, false>, grid2, dim3(256), 0, stream, a, nchunk); break;
+      case 5: launch_timed(ps, gn_apply_c1024_kernel<f16, false, true>, grid2, dim3(256), 0, stream, a, nchunk); break;
+      case 6: launch_timed(ps, gn_apply_c1024_kernel<f16, true, false>, grid2, dim3(256), 0, stream, a, nchunk); break;
+      default: launch_timed(ps, gn_apply_c1024_kernel<f16, true, true>, grid2, dim3(256), 0, stream, a, nchunk); break;
     }
   } else {
-    if (dtype == DT_BF16) gn_apply_kernel<bf16><<<grid2, 256, 0, stream>>>(a, nchunk, rpc, rpb);
-    else gn_apply_kernel<f16><<<grid2, 256, 0, stream>>>(a, nchunk, rpc, rpb);
+    if (dtype == DT_BF16) launch_timed(ps, gn_apply_kernel<bf16>, grid2, dim3(256), 0, stream, a, nchunk, rpc, rpb);
+    else launch_timed(ps, gn_apply_kernel<f16>, grid2, dim3(256), 0, stream, a, nchunk, rpc, rpb);
   }
   TT_CHECK_HIP(hipGetLastError());
   return 0;

@@ -72,10 +72,8 @@ struct StreamBridge {
   }
 };
 
-static inline bool graphs_enabled() {
-  const char* v = getenv("TT_NO_GRAPH");
-  return !(v && v[0] == '1');
-}
+extern bool g_graph_replay;  // tt_graph_replay (common.hip): diagnostics switch, default on
+static inline bool graphs_enabled() { return g_graph_replay; }
 
 static inline GemmArgs gemm_args(const void* A, int lda, const void* W, int ldw, int M, int N, int K) {
   GemmArgs g;

@@ -144,26 +144,30 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     }
     __syncthreads();
     int base = nsurv;
-#pragma unroll 1
-    for (int j = 0; j < PER && base < SURV_CAP; ++j) {
-      const int t = tid + 256 * j;
-      const bool tie = t < V && f2key(val[j]) == kth;
-      const unsigned long long m = __ballot(tie);
-      const int before = __popcll(m & ((1ull << (tid & 63)) - 1ull));
-      if ((tid & 63) == 0) wtot[tid >> 6] = (unsigned)__popcll(m);
-      __syncthreads();
-      int off = base, total = 0;
-      for (int w = 0; w < 4; ++w) {
-        if (w < (tid >> 6)) off += (int)wtot[w];
-        total += (int)wtot[w];
+    // (fully unrolled although it is the rare path: a run-time index into val[] would move the whole array to scratch memory -
+    // 160 bytes per lane written and re-read five times by EVERY launch, 10.5 MB per decode step at 256 candidates)
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      if (base < SURV_CAP) {  // block-uniform
+        const int t = tid + 256 * j;
+        const bool tie = t < V && f2key(val[j]) == kth;
+        const unsigned long long m = __ballot(tie);
+        const int before = __popcll(m & ((1ull << (tid & 63)) - 1ull));
+        if ((tid & 63) == 0) wtot[tid >> 6] = (unsigned)__popcll(m);
+        __syncthreads();
+        int off = base, total = 0;
+        for (int w = 0; w < 4; ++w) {
+          if (w < (tid >> 6)) off += (int)wtot[w];
+          total += (int)wtot[w];
+        }
+        const int slot = off + before;
+        if (tie && slot < SURV_CAP) {
+          sv[slot] = val[j];
+          si[slot] = t;
+        }
+        base += total;
+        __syncthreads();
       }
-      const int slot = off + before;
-      if (tie && slot < SURV_CAP) {
-        sv[slot] = val[j];
-        si[slot] = t;
-      }
-      base += total;
-      __syncthreads();
     }
     if (tid == 0) nsurv = base;
     __syncthreads();
@@ -282,8 +286,8 @@ int sample_launch(const SampleArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.B > 0 && a.V > 0 && a.V <= 10240, "sample: V=%d unsupported (<= 10240)", a.V);
   TT_REQUIRE(a.top_k > 0 && a.top_k <= 256, "sample: top_k=%d unsupported (1..256; HF default 50)", a.top_k);
   TT_REQUIRE(a.temperature > 0.f && a.top_p > 0.f && a.rep_penalty > 0.f, "sample: bad sampling parameters");
-  ProfScope ps(PROF_SAMPLE, stream, 0.0, (double)a.B * a.V * 4.0);
-  sample_kernel<<<a.B, 256, 0, stream>>>(a);
+  ProfScope ps(PROF_SAMPLE, stream, 0.0, (double)a.B * a.V * 4.0, true);
+  launch_timed(ps, sample_kernel, dim3(a.B), dim3(256), 0, stream, a);
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -165,6 +165,7 @@ _PROTOS = {
     "tt_voc_destroy": (None, [vp]),
     "tt_voc_run": (_i, [vp, vp, _i, vp, vp, vp]),
     "tt_prof_enable": (_i, [_i]),
+    "tt_graph_replay": (_i, [_i]),
     "tt_prof_classes": (_i, []),
     "tt_prof_class_name": (C.c_char_p, [_i]),
     "tt_prof_read": (_i, [_i, C.POINTER(C.c_double)]),
