@@ -132,7 +132,8 @@ def source_digest():
 
 
 def roofline_leg(tts, run_step):
-    """One extra step with graphs off and per-launch HIP events (tt_prof_*): dominant kernel class."""
+    """One extra step with graph replay off and every launch timed (tt_prof_*; single-kernel launchers by the start / end
+    timestamps of the dispatch itself, the clock of a rocprofv3 kernel trace): dominant kernel class."""
     import ctypes as C
     from tortoise_tts_amd import engine as E
     lib = E.load_library()
@@ -165,13 +166,45 @@ def roofline_leg(tts, run_step):
         ach = d["bytes"] / sec / 1e9
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
     traffic, traffic_src, stale = pmc_traffic(d["kernel"])
-    roof.update({"traffic": traffic, "traffic_source": traffic_src, "traffic_stale": stale, "kernel": d["kernel"], "launches": d["launches"], "avg_launch_us": d["avg_us"],
+    roof.update({"timing": "dispatch start/end timestamps (hipExtLaunchKernelGGL event pair), graph replay off", "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": stale, "kernel": d["kernel"], "launches": d["launches"], "avg_launch_us": d["avg_us"],
                  "algorithmic_flops_per_launch": d["flops"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                  "arithmetic_intensity": intensity, "share_of_kernel_time": d["total_ms"] / sum(r["total_ms"] for r in rows)})
     return roof, rows
 
 
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_bench.json")
+def stage_rooflines(stages_s, N, M, iters, cond_free, text_tokens):
+    """Per-stage achieved fraction of the roofline: SURVEY.md 8(d)'s algorithmic work of each stage / its measured time.
+      AR      HBM: per decode step the trunk + head weights once (386.3e6 parameters, 2 bytes) + every candidate's own K/V rows
+              (30 layers x 16 heads x 64 x K,V x 2 bytes = 122 880 bytes per cached token) + the shared prefix K/V once
+      CLVP    MFMA: 133 GFLOP per candidate at 500 codes -> scaled by M / 500 rows: 500 * (236e6 + 4 * 500 * 768 * 20) at M = 500
+      denoiser MFMA: (249.0e6 * S + 13 * 4 * S^2 * 1024) flops per row; 2 rows per iteration with conditioning-free guidance
+      UnivNet fp32 VALU path: ~45 GFLOP at 880 frames (reported as achieved TFLOP/s only)."""
+    out = {}
+    S = M * 4 * 24000 // 22050
+    P1 = 1 + text_tokens + 2 + 1
+    ar_bytes = sum(386.3e6 * 2 + (N * (t + 1) + P1) * 122880.0 for t in range(M - 1))
+    if stages_s.get("ar_s"):
+        ach = ar_bytes / stages_s["ar_s"] / 1e9
+        out["ar_decode"] = {"bound": "hbm", "algorithmic_bytes": ar_bytes, "seconds": stages_s["ar_s"], "achieved": ach, "unit": "GB/s",
+                            "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS}
+    clvp_flops = N * M * (236e6 + 4.0 * M * 768 * 20)
+    if stages_s.get("clvp_s"):
+        ach = clvp_flops / stages_s["clvp_s"] / 1e12
+        out["clvp"] = {"bound": "mfma", "algorithmic_flops": clvp_flops, "seconds": stages_s["clvp_s"], "achieved": ach, "unit": "TFLOP/s",
+                       "peak": MFMA_PEAK_TFLOPS, "frac": ach / MFMA_PEAK_TFLOPS}
+    d_flops = iters * (2 if cond_free else 1) * (249.0e6 * S + 13 * 4.0 * S * S * 1024)
+    if stages_s.get("diffusion_s"):
+        ach = d_flops / stages_s["diffusion_s"] / 1e12
+        out["denoiser"] = {"bound": "mfma", "algorithmic_flops": d_flops, "seconds": stages_s["diffusion_s"], "achieved": ach, "unit": "TFLOP/s",
+                           "peak": MFMA_PEAK_TFLOPS, "frac": ach / MFMA_PEAK_TFLOPS}
+    if stages_s.get("vocoder_s"):
+        v_flops = 45e9 * (S + 10) / 880.0
+        out["univnet"] = {"bound": "valu-fp32", "algorithmic_flops": v_flops, "seconds": stages_s["vocoder_s"],
+                          "achieved": v_flops / stages_s["vocoder_s"] / 1e12, "unit": "TFLOP/s", "peak": None, "frac": None}
+    return out
+
+
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_bench.json")
 
 
 def pmc_traffic(kernel_class):
@@ -281,6 +314,10 @@ def main():
         cores = min(os.cpu_count() or 1, 64)
         cpu = cpu_baseline(sds, text, latents, preset_kw, M, cores)
 
+    stages_mean = {k_: v / args.steps for k_, v in stage_acc.items()}
+    if roof is not None and not read_mode:
+        roof["stages"] = stage_rooflines(stages_mean, N // world, M, preset_kw["diffusion_iterations"], bool(preset_kw.get("cond_free", True)),
+                                         int(text.numel()))
     if rank == 0:
         out = {
             "metric": "rtf_standard_preset" if not read_mode else "rtf_longform_read", "value": audio_s * args.steps / dt, "unit": "audio-s/wall-s",
@@ -296,7 +333,7 @@ def main():
                                        f"candidates sharded {N // world}/GPU, 1 all_gather of scores+codes, "
                                        + ("winner's diffusion tail split over ranks 0/1 (one denoiser row each, 1 exchange per step), vocoder on rank 0"
                                           if tts.split_diffusion else "winner rendered on rank 0"))},
-            "stages_s_per_step": {k_: v / args.steps for k_, v in stage_acc.items()},
+            "stages_s_per_step": stages_mean,
             "audio_seconds_per_step": audio_s, "engine_build_s": t_build,
             "roofline": roof, "cpu_baseline": cpu,
             "kernel_breakdown_ms": [{"kernel": r["kernel"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),

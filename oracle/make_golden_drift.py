@@ -56,14 +56,17 @@ def ref_loop(ref, m, N, S, x, code_emb, step_noise, cond_free):
 @torch.no_grad()
 def main():
     import bench
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(int(os.environ.get("ORACLE_THREADS", os.cpu_count() or 1)))
     ref = ref_shims.import_reference()
     sds = bench.synthetic_weights()
     cfg = DiffusionConfig()
     m = GF.build_ref_diffusion(ref, cfg, sds["diffusion"])
     _, _, cond = GF.prompt()
-    out = {}
+    path = os.path.join(OUT, "full_drift.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}  # cases already generated are kept (the 400-iteration one takes ~15 min)
     for name, N, cond_free, seed in CASES:
+        if name in out:
+            continue
         t0 = time.time()
         S, latents, x, step_noise = GF.diff_inputs(cfg, M=GF.DIFF_M, seed=seed, steps=N)
         code_emb = m.timestep_independent(latents, cond, S, False)

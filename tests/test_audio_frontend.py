@@ -1,12 +1,56 @@
-"""CPU checks of the wav -> mel front-end restatement (tortoise_tts_amd/audio.py).  torchaudio / librosa are absent offline,
-so the mel basis and the resampler are checked through DEFINITIONAL properties (mel-scale anchors, unit-area triangular filters,
-a band-limited sine through the polyphase resampler, output shapes of api.py:271-287); the STFT, the clip and the log
-compression around the basis ARE pinned against the reference's own TacotronSTFT / STFT classes (last test, reference tree only)."""
+"""CPU checks of the wav -> mel front-end restatement (tortoise_tts_amd/audio.py).  torchaudio / librosa are absent offline
+(third-party dependencies of the reference, requirements.txt: librosa==0.9.1, torchaudio), so
+  * the mel filter banks are pinned through oracle/audio_oracle.py - a loop-form numpy restatement of librosa.filters.mel's
+    published algorithm that is itself checked against the known-answer vectors of librosa's API documentation (hz_to_mel,
+    mel_to_hz, mel_frequencies(n_mels=40), filters.mel(sr=22050, n_fft=2048)); the HTK-scale bank of the torchaudio call site is
+    the same construction with htk=True (torchaudio's own tests assert that equality against librosa);
+  * the resampler is pinned against the oracle's loop form of torchaudio's published sinc_interp_hann kernel + its defining
+    properties (a band-limited sine, DC gain);
+  * the STFT, the clip and the log compression around the basis are pinned against the reference's own TacotronSTFT / STFT
+    classes (last test, reference tree only)."""
 import math
 
 import torch
 
 from tortoise_tts_amd import audio as A
+
+
+def test_oracle_mel_restatement_reproduces_librosa_documented_vectors():
+    """Known-answer vectors printed in librosa's API reference (0.9.x): they pin oracle/audio_oracle.py to the third-party code."""
+    import numpy as np
+    from oracle import audio_oracle as AO
+    assert abs(float(AO.hz_to_mel(60)) - 0.9) < 1e-12                                          # >>> librosa.hz_to_mel(60)  -> 0.9
+    assert np.allclose(AO.hz_to_mel([110, 220, 440]), [1.65, 3.3, 6.6], atol=1e-12)            # >>> librosa.hz_to_mel([110, 220, 440])
+    assert abs(float(AO.mel_to_hz(3)) - 200.0) < 1e-9                                          # >>> librosa.mel_to_hz(3)   -> 200.
+    assert np.allclose(AO.mel_to_hz([1, 2, 3, 4, 5]), [66.667, 133.333, 200., 266.667, 333.333], atol=6e-4)
+    doc40 = [0., 85.317, 170.635, 255.952, 341.269, 426.586, 511.904, 597.221, 682.538, 767.855, 853.173, 938.49, 1024.856, 1119.114,
+             1222.042, 1334.436, 1457.167, 1591.187, 1737.532, 1897.337, 2071.84, 2262.393, 2470.47, 2697.686, 2945.799, 3216.731,
+             3512.582, 3835.643, 4188.417, 4573.636, 4994.285, 5453.621, 5955.205, 6502.92, 7101.009, 7754.107, 8467.272, 9246.028,
+             10096.408, 11025.]                                                                # >>> librosa.mel_frequencies(n_mels=40)
+    assert np.abs(AO.mel_frequencies(40) - np.array(doc40)).max() < 6e-4                       # printed to 3 decimals
+    fb = AO.mel_filterbank(22050, 2048)                                                        # >>> librosa.filters.mel(sr=22050, n_fft=2048)
+    assert fb.shape == (128, 1025) and fb.dtype == np.float32
+    assert fb[0, 0] == 0.0 and round(float(fb[0, 1]), 3) == 0.016 and fb[0, -1] == 0.0 and fb[-1, 0] == 0.0 and fb[-1, -1] == 0.0
+    # HTK scale (torchaudio's default mel_scale): 1000 Hz is 1000 mel by construction of the formula
+    assert abs(float(AO.hz_to_mel(1000.0, htk=True)) - 1000.0) < 0.02
+
+
+def test_product_filterbanks_and_resampler_equal_the_oracle_restatement():
+    import numpy as np
+    from oracle import audio_oracle as AO
+    for sr, n_mels, fmax, htk in ((22050, 80, 8000.0, True), (24000, 100, 12000.0, False)):   # arch_util.py:295-331 / audio.py:151-178
+        got = A.mel_filterbank(sr, 1024, n_mels, 0.0, fmax, htk).numpy()
+        want = AO.mel_filterbank(sr, 1024, n_mels, 0.0, fmax, htk)
+        assert got.shape == want.shape and np.abs(got - want).max() <= 1e-7 * np.abs(want).max()
+    g = torch.Generator().manual_seed(1)
+    wav = torch.randn(1, 5000, generator=g)
+    got = A.resample_sinc(wav, 22050, 24000)[0].numpy()
+    want = AO.resample(wav[0].numpy(), 22050, 24000)
+    assert got.shape == want.shape == (math.ceil(5000 * 160 / 147),)
+    assert np.abs(got - want).max() < 5e-6
+    # DC gain of the interpolation filter: a constant stays that constant (interior samples)
+    dc = AO.resample(np.ones(3000), 22050, 24000)
+    assert np.abs(dc[100:-100] - 1.0).max() < 2e-3
 
 
 def test_mel_scales_hit_their_anchor_points():

@@ -10,12 +10,13 @@ image, so their algorithms are restated here from the call sites and their docum
     rolloff 0.99), pad / truncate to 102400 samples, TacotronSTFT(1024, 256, 1024, 100, 24000, 0, 12000)
     (tortoise/utils/audio.py:151-191) = |STFT| -> librosa Slaney-scale mel basis -> log(clamp(1e-5)).
 
-PARITY PARTLY PINNED: tests/test_audio_frontend.py runs the reference's own STFT / TacotronSTFT classes (librosa stubbed
-import-only, its mel basis replaced by ours) against stft_magnitude + the clip + the log compression, so framing, window,
-padding and compression are pinned; the mel bases and the torchaudio resampler have nothing to be checked against bit for bit
-here (torchaudio / librosa absent) and are covered by definitional properties only (filter centres, unit-area rows, a
-resampled sine).  The encoders that consume the mels (csrc/cond.hip) are pinned against the reference modules; callers that
-have the reference's own mels can pass them directly (TextToSpeech.get_conditioning_latents accepts (auto_mel, diffusion_mel) pairs).
+PARITY: the third-party pieces (librosa==0.9.1 filters.mel, torchaudio melscale_fbanks / resample) are not vendored in the
+reference tree; oracle/audio_oracle.py restates their published algorithms in loop-form numpy and is pinned against the
+known-answer vectors of librosa's API documentation; tests/test_audio_frontend.py holds this module's filter banks and resampler
+equal to that oracle, and runs the reference's own STFT / TacotronSTFT classes (librosa stubbed import-only) against
+stft_magnitude + the clip + the log compression, so framing, window, padding and compression are pinned to the reference itself.
+The encoders that consume the mels (csrc/cond.hip) are pinned against the reference modules; callers that have the reference's
+own mels can pass them directly (TextToSpeech.get_conditioning_latents accepts (auto_mel, diffusion_mel) pairs).
 This module is host-side glue (runs once per voice), not part of the accelerated path.
 """
 import math

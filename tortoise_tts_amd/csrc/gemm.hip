@@ -86,11 +86,12 @@ static void plan_core(const GemmArgs& a, int epi, GemmPlan& p) {
   p.conv3s = epi == EPI_STD && tile == TILE_128x64 && a.taps == 3 && a.dilation <= 1 && a.splitk == 1 && a.gn_part != nullptr && a.bias != nullptr &&
              a.out_t == nullptr && a.act == ACT_NONE && a.A2 == nullptr && al16 && a.cin >= 256;
   p.prof_id = prof_class(tile, epi, a.taps > 1);
-  // algorithmic work of this launch: 2*M*N*K flops; operands read once + result written once
+  // algorithmic work of this launch: 2*M*N*K flops; operands read once + ONE result written once (the extra split-K slabs
+  // a launch writes are an implementation cost: they show up in the PMC traffic, not here)
   const bool std_epi = epi == EPI_STD;
   const double out_bytes = (double)a.M * a.N * ((std_epi && a.out_f32 ? 4.0 : 0.0) + (a.out_t || !std_epi ? 2.0 : 0.0));
   p.flops = 2.0 * a.M * a.N * a.K;
-  p.bytes = ((double)a.N * a.K + (double)a.M * a.cin) * 2.0 + out_bytes * (a.splitk > 1 ? a.splitk : 1) + (a.res ? 4.0 * a.M * a.N : 0.0);
+  p.bytes = ((double)a.N * a.K + (double)a.M * a.cin) * 2.0 + out_bytes + (a.res ? 4.0 * a.M * a.N : 0.0);
 }
 
 static void normalise(GemmArgs& a) {
