@@ -224,6 +224,60 @@ def pmc_traffic(kernel_class):
         return None, None, None
 
 
+def stream_bench(args):
+    """tortoise.api_fast.TextToSpeech.tts_stream (api_fast.py:311-420) on the engine: one sampled sequence, the per-step latents the
+    decode steps file, HiFi-GAN re-decode of the growing prefix per chunk, cross-fade.  A step = one utterance of M mel tokens
+    (EOS suppressed), stream_chunk_size 40 and the 60-token first buffer of the reference.  Reports the wall time until the first
+    audio chunk is on the host side of the generator and wall-seconds per audio-second (the two figures README.md:34 quotes)."""
+    assert torch.cuda.is_available() and args.gpus == 1, "the streaming path is one sequence on one GPU"
+    from tortoise_tts_amd import weights as W
+    from tortoise_tts_amd.api_fast import TextToSpeech
+    from tortoise_tts_amd.config import ARConfig, HifiganConfig
+    a_cfg, h_cfg = ARConfig(), HifiganConfig()
+    t_build = time.perf_counter()
+    sds = {"autoregressive": W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(a_cfg), 1234), a_cfg),
+           "hifidecoder": W.synthetic_state_dict(W.hifigan_manifest(h_cfg), 1238)}
+    M = args.mel_tokens
+    tts = TextToSpeech(state_dicts=sds, dtype=args.dtype, max_mel_tokens=max(M, 64), kv_cache=True)
+    t_build = time.perf_counter() - t_build
+    text, (auto, _) = synthetic_prompt()
+
+    def run(i):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        first, samples, pieces = None, 0, 0
+        for chunk in tts.tts_stream(text, conditioning_latents=(auto,), max_mel_tokens=M, use_deterministic_seed=1000 + i,
+                                    stream_chunk_size=40, overlap_wav_len=1024, verbose=False):
+            chunk = chunk.cpu()  # the caller plays the piece: it has to be on the host
+            if first is None:
+                first = time.perf_counter() - t0
+            samples += int(chunk.shape[0])
+            pieces += 1
+        return first, samples, pieces, time.perf_counter() - t0
+
+    for i in range(args.warmup):
+        run(i)
+    firsts, walls, samples, pieces = [], [], 0, 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        f, samples, pieces, w = run(100 + i)
+        firsts.append(f)
+        walls.append(w)
+    dt = time.perf_counter() - t0
+    audio_s = samples / 24000.0
+    print(json.dumps({
+        "metric": "rtf_stream_api_fast", "value": audio_s * args.steps / dt, "unit": "audio-s/wall-s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "first_chunk_latency_s": sum(firsts) / len(firsts), "first_chunk_latency_s_max": max(firsts),
+        "wall_per_audio": dt / (audio_s * args.steps), "pieces_per_step": pieces, "audio_seconds_per_step": audio_s,
+        "reference_claim": "README.md:34: 0.25-0.3 wall/audio on a 4 GB GPU, < 500 ms to the first chunk with streaming (other hardware; not a BASELINE number)",
+        "config": {"workload": f"api_fast.tts_stream: 1 sequence x {M} mel tokens (EOS suppressed), first buffer 60 tokens then every 40, "
+                               f"HiFi-GAN re-decode of the prefix per piece, overlap 1024 samples; {pieces} pieces, {audio_s:.2f} s of 24 kHz audio",
+                   "weights": "seeded synthetic at the reference hyper-parameters", "parallelism": "1 GPU"},
+        "engine_build_s": t_build}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,9 +286,10 @@ def main():
     ap.add_argument("--preset", default="standard")
     ap.add_argument("--mel-tokens", type=int, default=200, help="fixed decode length M (SURVEY.md §8d: 200 and 500)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--workload", default="utterance", choices=["utterance", "read"],
+    ap.add_argument("--workload", default="utterance", choices=["utterance", "read", "stream"],
                     help="utterance: one tts_with_preset call per step (BASELINE metric); read: one long-form paragraph per step = 15 chunks "
-                         "spread over the GPUs as replicas (BASELINE config #4, tortoise/read.py)")
+                         "spread over the GPUs as replicas (BASELINE config #4, tortoise/read.py); stream: one api_fast.tts_stream "
+                         "utterance per step (SURVEY 8f-4; the reference's only published numbers: README.md:34)")
     ap.add_argument("--diffusion-iterations", type=int, default=None,
                     help="override the preset's diffusion iterations (profiling passes only: the headline metric uses the preset's own)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the decode / sampler loops eagerly instead of replaying hipGraphs "
@@ -243,6 +298,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.workload == "stream":
+        return stream_bench(args)
     from tortoise_tts_amd import dist as tdist
     rank, world, local = tdist.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"

@@ -106,6 +106,11 @@ int tt_ar_generate(tt_ar* h, int B, int max_new, const tt_sampling* s, int* code
  * *n_total_host = tokens per row so far, *finished_host = 1 once every row has emitted stop_mel_token. */
 int tt_ar_generate_chunk(tt_ar* h, int B, int first, int n_more, int ldcodes, const tt_sampling* s, int* codes, int* n_total_host,
                          int* finished_host, void* stream);
+/* The latent half of the (token, latent) pairs the reference's streaming generator yields (stream_generator.py:916-1000,
+ * consumed at api_fast.py:402-411): out f32 [B][n][D], latent i = final_norm(ln_f(hidden state that produced the logits of
+ * token i)) - latent 0 from the prefill's start-token row, latent i >= 1 from the decode step that fed token i - 1.  They are
+ * filed by the decode steps themselves (no extra pass); handles with max_batch <= 8 only; n <= tokens generated so far. */
+int tt_ar_stream_latents(tt_ar* h, int B, int n, float* out, void* stream);
 
 /* Teacher-forced single steps for parity tests: tt_ar_begin resets per-sequence state for B rows
  * after a prefill; tt_ar_decode_step feeds tokens int32 [B] (KV-cached position rule of

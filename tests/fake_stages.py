@@ -45,7 +45,14 @@ class FakeArStage:
             exp_noise = torch.stack(rows, dim=1)
         codes = O.ar_sample_loop(self.sd, self.cfg, self.cond, self.text, B, max_new, exp_noise.cpu(), repetition_penalty, temperature,
                                  top_k, top_p, kv_cache=self.kv_cache)
+        self.gen_codes = codes
         return codes, codes.shape[1]
+
+    def stream_latents(self, B, n):
+        """The latents the engine's decode steps file (tt_ar_stream_latents): by the pinned identity (oracle.ar_latents docstring) they
+        are one teacher-forced pass over the sampled codes with the position rule of this handle's kv_cache setting."""
+        self.latent_calls = getattr(self, "latent_calls", []) + ["steps"]
+        return O.ar_latents(self.sd, self.cfg, self.cond.expand(B, -1), self.text.expand(B, -1), self.gen_codes[:B, :n], stream_positions=self.kv_cache)
 
     def latents(self, cond_latent, text_tokens, codes, stream_positions=False):
         k = codes.shape[0]

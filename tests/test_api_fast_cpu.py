@@ -83,10 +83,17 @@ def test_tts_and_stream_flow_on_oracle_backed_stages(monkeypatch):
     assert len(chunks) == 4 and chunks[-1].shape[0] == 128
     assert sum(int(c.shape[0]) for c in chunks) == wav.shape[-1]
     assert torch.equal(tts.last_codes, tts.last_codes[:, :70])
-    # latents: tts() re-passes with the plain positions (api_fast.py:510-514), the stream asks for the cached decode's positions
-    # because this instance was built with kv_cache=True; with kv_cache=False both are the plain pass
-    assert tts.ar.latent_calls == [False, True, True, True]
+    # latents: tts() re-passes with the plain positions (api_fast.py:510-514); the stream takes the latents its decode steps filed
+    assert tts.ar.latent_calls == [False, "steps", "steps", "steps"]
+    # the earlier formulation (one teacher-forced pass per chunk) asks for the cached decode's positions because this instance was
+    # built with kv_cache=True; with kv_cache=False it is the plain pass.  Same audio either way (oracle stand-ins: identical tensors)
+    tts.stream_latents_from = "pass"
+    tts.ar.latent_calls = []
+    again = list(tts.tts_stream(text, max_mel_tokens=70, use_deterministic_seed=4, stream_chunk_size=5, overlap_wav_len=128))
+    assert tts.ar.latent_calls == [True, True, True]
+    assert len(again) == len(chunks) and all(torch.equal(a, b) for a, b in zip(again, chunks))
     tts2 = api_fast.TextToSpeech(state_dicts=sds, configs={"ar": a_cfg, "hifigan": h_cfg}, max_mel_tokens=80, max_text_tokens=40)
+    tts2.stream_latents_from = "pass"
     list(tts2.tts_stream(text, max_mel_tokens=64, use_deterministic_seed=4, stream_chunk_size=5, overlap_wav_len=128))
     assert tts2.ar.latent_calls == [False, False]
     with pytest.raises(ValueError, match="Too much text"):
@@ -153,6 +160,7 @@ def test_stream_decode_points_follow_the_reference_loop(monkeypatch, n_tokens, e
 
     tts = api_fast.TextToSpeech.__new__(api_fast.TextToSpeech)
     tts.ar, tts.hifi_decoder, tts.kv_cache, tts.stop_mel_token, tts.max_mel_tokens_cap = Ar(), Hifi(), False, stop, 500
+    tts.stream_latents_from = "pass"
     tts.device = torch.device("cpu")
     monkeypatch.setattr(api_fast.TextToSpeech, "_prepare", lambda self, *a: (torch.zeros(1, 4, dtype=torch.int32), torch.zeros(1, 4)))
     limit = n_tokens if not eos else 500

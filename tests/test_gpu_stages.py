@@ -501,6 +501,35 @@ def test_ar_generate_chunks_equal_one_shot_loop():
     st.close()
 
 
+@pytest.mark.parametrize("kv_cache", [False, True])
+@torch.no_grad()
+def test_stream_latents_filed_by_the_decode_steps(kv_cache):
+    """The (token, latent) pairs of the reference's streaming generator (stream_generator.py:916-1000 -> api_fast.py:402-411): the
+    engine's decode steps file final_norm(ln_f(hidden)) themselves (tt_ar_stream_latents).  They must equal one teacher-forced pass
+    over the sampled codes - plain mel positions for kv_cache=False, the cached decode's 0, 2, 3, ... for kv_cache=True - on the
+    engine (different kernels: M = 1 split-K GEMMs + cached attention vs full GEMMs + flash attention) and in the oracle."""
+    cfg = ARConfig(**G.AR_CFG)
+    sd = quantize_sd(W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.AR_SEED), cfg), torch.bfloat16)
+    cond, text = G.ar_inputs(cfg)
+    st = stages.ArStage(sd, cfg, max_batch=1, max_text=40, max_new_tokens=40, max_latent_candidates=1, kv_cache=kv_cache)
+    st.prefill(cond, text)
+    pieces = []
+    for codes, done in st.generate_stream(1, 30, 8, first_chunk=12, seed=11):
+        pieces.append(st.stream_latents(1, codes.shape[1]).clone())  # read between chunks, as api_fast.tts_stream does
+    n = codes.shape[1]
+    got = st.stream_latents(1, n)
+    assert got.shape == (1, n, cfg.model_dim) and n == 30 and torch.isfinite(got).all()
+    for p in pieces:
+        assert torch.equal(p, got[:, :p.shape[1]]), "a latent changed after it was filed"
+    want_pass = st.latents(cond, text, codes, stream_positions=kv_cache)
+    report(f"per-step stream latents (kv_cache={kv_cache}) bf16 vs the engine's teacher-forced pass", got, want_pass, 2.5e-2)
+    want = O.ar_latents(sd, cfg, cond, text, codes.cpu(), stream_positions=kv_cache)
+    report(f"per-step stream latents (kv_cache={kv_cache}) bf16 vs oracle", got.cpu(), want, 2.5e-2)
+    if kv_cache:  # and the position rule matters: the plain-position pass is a different tensor
+        assert rel_err(got.cpu(), O.ar_latents(sd, cfg, cond, text, codes.cpu(), stream_positions=False)) > 5e-2
+    st.close()
+
+
 @torch.no_grad()
 def test_api_fast_tts_and_stream():
     """tortoise.api_fast.TextToSpeech surface: tts() = generate -> latents -> HiFi-GAN; tts_stream() resumes the

@@ -42,6 +42,10 @@ struct tt_ar {
   int logits_rows = 0;
   bool logits_from_prefill = false;
   int host_slot = -1;  // host mirror of state[1]; only feeds the profiler's byte estimates
+  // streaming (api_fast.py:389-414 consumes the (token, latent) pairs of the sampling loop): lm_head's input norm also files its f32
+  // row - final_norm(ln_f(hidden)), the reference's per-step latent - under [latent index][sequence]; small batches only
+  float* lat = nullptr;
+  int lat_batch = 0;
   int gen_done = 0;    // tokens sampled by the running generation (tt_ar_generate / tt_ar_generate_chunk)
   bool gen_finished = false;
 };
@@ -118,8 +122,29 @@ static int pick_split(int B, int N, int K) {
 }
 
 // lm_head = Sequential(final_norm, mel_head) applied to ln_f(x) (autoregressive.py:42, 174)
-static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, hipStream_t s) {
-  TT_TRY(ar_rownorm(e, x, M, e->w.lnf_g, e->w.lnf_b, e->w.final_norm_g, e->w.final_norm_b, add_bias, nslab, e->B, s));
+// lat_index: >= 0 files the normalised row(s) as that latent (prefill: 0); -1: under the device-side step counter (decode step
+// feeding token i - 1 produces latent i); -2: no capture
+static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, hipStream_t s, int lat_index = -2) {
+  {
+    RowNormArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.ldx = e->D; a.M = M; a.D = e->D;
+    a.add_bias = add_bias;
+    a.add_slabs = nslab ? e->slabs : nullptr;
+    a.nslab = nslab; a.slab_stride = (size_t)e->B * e->D; a.ldslab = e->D;
+    a.write_x = (add_bias || nslab) ? 1 : 0;
+    a.mode = NORM_LAYER;
+    a.g1 = e->w.lnf_g; a.b1 = e->w.lnf_b; a.eps1 = 1e-5f;
+    a.g2 = e->w.final_norm_g; a.b2 = e->w.final_norm_b; a.eps2 = 1e-5f;
+    a.out_t = e->h; a.ldot = e->D;
+    if (e->lat && lat_index != -2 && M <= e->lat_batch) {
+      a.out_f32 = e->lat; a.ldo32 = e->D;
+      a.f32_slot_stride = (size_t)e->lat_batch * e->D;
+      if (lat_index >= 0) a.out_f32 += (size_t)lat_index * a.f32_slot_stride;
+      else { a.f32_slot = e->state + 1; a.f32_slot_base = 1; }
+    }
+    TT_TRY(rownorm_launch(e->cfg.dtype, a, s));
+  }
   GemmArgs g = ar_gemm(e, e->h, e->D, e->w.w_mel_head, e->D, M, e->V, e->D);
   g.bias = e->w.b_mel_head; g.out_f32 = e->logits; g.ldo32 = e->V;
   TT_TRY(gemm_launch(e->cfg.dtype, EPI_STD, g, s));
@@ -168,7 +193,7 @@ static int decode_step_enqueue(tt_ar* e, hipStream_t s, bool embedded = false) {
     pend_bias = w.b_proj2;
     pend_slabs = sk;
   }
-  return ar_head(e, e->x, B, pend_bias, pend_slabs, s);
+  return ar_head(e, e->x, B, pend_bias, pend_slabs, s, -1);
 }
 
 extern "C" {
@@ -212,6 +237,10 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
   if (!rc) rc = e->arena.alloc_t(&e->unfinished, cfg->max_batch);
   if (!rc) rc = e->arena.alloc_t(&e->unfinished_count, e->tmax + 8);
   if (!rc) rc = e->arena.alloc_t(&e->next_tok, cfg->max_batch);
+  if (!rc && cfg->max_batch <= 8) {  // the streaming path decodes one sequence (api_fast.py): [tmax + 1][max_batch][D] f32
+    e->lat_batch = cfg->max_batch;
+    rc = e->arena.alloc_t(&e->lat, (size_t)(e->tmax + 1) * e->lat_batch * D);
+  }
   if (!rc && hipHostMalloc((void**)&e->count_host, (e->tmax + 8) * sizeof(int)) != hipSuccess) {
     set_error("tt_ar_create: hipHostMalloc failed");
     rc = -2;
@@ -255,7 +284,7 @@ int tt_ar_prefill(tt_ar* e, const float* prefix_emb, int P, void* stream) {
   TT_TRY(gpt_trunk_full(e, 1, e->P1, true, s));
   const int B_saved = e->B;
   e->B = 1;
-  int rc = ar_head(e, e->x + (size_t)P * D, 1, nullptr, 0, s);
+  int rc = ar_head(e, e->x + (size_t)P * D, 1, nullptr, 0, s, 0);
   e->B = B_saved;
   TT_TRY(rc);
   e->logits_from_prefill = true;
@@ -425,6 +454,24 @@ int tt_ar_generate_chunk(tt_ar* e, int B, int first, int n_more, int ldcodes, co
     return e->sb.leave(us);
   }
   TT_TRY(ar_generate_run(e, B, first != 0, target, ldcodes, sp, codes, n_total_host, finished_host, s));
+  return e->sb.leave(us);
+}
+
+int tt_ar_stream_latents(tt_ar* e, int B, int n, float* out, void* stream) {
+  TT_REQUIRE(e && out, "tt_ar_stream_latents: null argument");
+  TT_REQUIRE(e->lat != nullptr, "tt_ar_stream_latents: this handle was created with max_batch %d > 8 (no per-step latent capture)", e->cfg.max_batch);
+  TT_REQUIRE(B >= 1 && B <= e->lat_batch && B == e->B && n >= 1 && n <= e->gen_done, "tt_ar_stream_latents: %d x %d latents requested, generation holds %d x %d", B, n, e->B, e->gen_done);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  const size_t row = (size_t)e->D * sizeof(float);
+  for (int b = 0; b < B; ++b) {
+    float* dst = out + (size_t)b * n * e->D;
+    // latent 0 is the start-token row of the shared prefill (one copy for every sequence)
+    TT_CHECK_HIP(hipMemcpyAsync(dst, e->lat, row, hipMemcpyDeviceToDevice, s));
+    if (n > 1)
+      TT_CHECK_HIP(hipMemcpy2DAsync(dst + e->D, row, e->lat + ((size_t)e->lat_batch + b) * e->D, (size_t)e->lat_batch * row, row, (size_t)(n - 1),
+                                    hipMemcpyDeviceToDevice, s));
+  }
   return e->sb.leave(us);
 }
 

@@ -50,13 +50,15 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
   }
   if (a.mode == NORM_NONE) return;
 
+  float* o32 = a.out_f32;
+  if (o32 && a.f32_slot) o32 += (size_t)(*a.f32_slot + a.f32_slot_base) * a.f32_slot_stride;
   auto emit = [&](const float4* y) {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const int c = (tid + 256 * j) * 4;
       if (c < a.D) {
         if (a.out_t) *(typename Vec<T>::x4*)((T*)a.out_t + (size_t)row * a.ldot + c) = pack4<T>(y[j].x, y[j].y, y[j].z, y[j].w);
-        if (a.out_f32) *(float4*)(a.out_f32 + (size_t)row * a.ldo32 + c) = y[j];
+        if (o32) *(float4*)(o32 + (size_t)row * a.ldo32 + c) = y[j];
       }
     }
   };
@@ -182,7 +184,7 @@ static void rownorm_narrow_dispatch(const ProfScope& ps, const RowNormArgs& a, h
 
 template <typename T>
 static bool rownorm_narrow_launch(const ProfScope& ps, const RowNormArgs& a, hipStream_t stream) {
-  if (a.D > 1024 || a.mode == NORM_NONE || a.g2 != nullptr) return false;
+  if (a.D > 1024 || a.mode == NORM_NONE || a.g2 != nullptr || a.f32_slot != nullptr) return false;
   switch (a.nslab) {
     case 0: rownorm_narrow_dispatch<T, 0>(ps, a, stream); return true;
     case 1: rownorm_narrow_dispatch<T, 1>(ps, a, stream); return true;

@@ -31,6 +31,11 @@ struct RowNormArgs {
   int ldot;
   float* out_f32;      // optional f32 copy of the normalised row
   int ldo32;
+  // optional (generic kernel only): the f32 copy goes to out_f32 + (*f32_slot + f32_slot_base) * f32_slot_stride - a device-side
+  // step counter selects the destination block, so a captured decode step can file its row under the step it belongs to
+  const int* f32_slot;
+  int f32_slot_base;
+  size_t f32_slot_stride;
 };
 int rownorm_launch(int dtype, const RowNormArgs& a, hipStream_t stream);
 

@@ -140,6 +140,7 @@ _PROTOS = {
     "tt_ar_begin": (_i, [vp, _i, vp]),
     "tt_ar_decode_step": (_i, [vp, vp, vp]),
     "tt_ar_latents": (_i, [vp, vp, _i, _i, vp, vp]),
+    "tt_ar_stream_latents": (_i, [vp, _i, _i, vp, vp]),
     "tt_clvp_create": (_i, [C.POINTER(ClvpConfig), C.POINTER(ClvpTower), C.POINTER(ClvpTower), vp, C.POINTER(vp)]),
     "tt_clvp_destroy": (None, [vp]),
     "tt_clvp_score": (_i, [vp, vp, _i, vp, _i, _i, vp, vp]),

@@ -143,6 +143,13 @@ class ArStage:
             if done:
                 return
 
+    def stream_latents(self, B, n):
+        """f32 [B, n, D]: the per-step latents the decode loop filed for the first n tokens of the running generation - the latent
+        half of the (token, latent) pairs of the reference's streaming generator (api_fast.py:402-411); max_batch <= 8 handles."""
+        out = torch.empty(B, n, self.cfg.model_dim, device=self.device, dtype=torch.float32)
+        E.check(self.lib.tt_ar_stream_latents(self.h, B, n, E.ptr(out), E.stream_ptr()))
+        return out
+
     # -- latent re-pass (autoregressive.py:454-506 as api.py:521-524 calls it)
     def latents(self, cond_latent, text_tokens, codes, stream_positions=False):
         """stream_positions: mel positions 0, 2, 3, ... instead of 0, 1, 2, ... - the per-step states the reference's streaming
