@@ -61,6 +61,8 @@ typedef struct tt_ar_config {
   int mel_pos_offset;    /* mel position row of generated token i (i >= 0; the start token uses row 0) = i + mel_pos_offset:
                           * 2 = TextToSpeech(kv_cache=True): rows 0,2,3,... (autoregressive.py:145-149, attention_mask.shape[1] - mel_len)
                           * 1 = TextToSpeech(kv_cache=False), the reference DEFAULT: rows 0,1,2,... (autoregressive.py:134-144) */
+  int max_groups;        /* utterances decoded in ONE batch (tt_ar_prefill_group), 1 .. 16; 0 is read as 1.  max_batch counts the
+                          * sequences of all groups together */
 } tt_ar_config;
 
 typedef struct tt_ar_weights {
@@ -82,6 +84,13 @@ void tt_ar_destroy(tt_ar* h);
  * here.  All candidates share this prefix, so it is evaluated ONCE (M = P+1 rows) and its K/V are
  * shared by every sequence of the following tt_ar_generate / tt_ar_decode_step calls. */
 int tt_ar_prefill(tt_ar* h, const float* prefix_emb, int P, void* stream);
+/* Several utterances in one decode batch (long-form reading, tortoise/read.py:66-71 renders its chunks one after the other; 288 GB
+ * of HBM hold the KV caches of many): group g of n_groups gets its own prefix (its own text, its own voice), evaluated once like
+ * tt_ar_prefill's.  After all n_groups groups have been prefilled, tt_ar_generate with B = n_groups * group_size decodes them
+ * together: sequences [g * group_size, (g + 1) * group_size) attend to prefix g, sample their first token from prefix g's logits
+ * and draw from Philox streams keyed by (tt_sampling.group_seeds[g] or seed, row_offset + index WITHIN the group) - so each
+ * group's codes are bit-identical to decoding it alone.  group_size must be a multiple of 4.  tt_ar_prefill == group 0 of 1. */
+int tt_ar_prefill_group(tt_ar* h, int group, int n_groups, const float* prefix_emb, int P, void* stream);
 
 /* Logits of the newest position: f32 [rows][vocab]; rows = 1 after prefill, B after a decode step. */
 int tt_ar_get_logits(tt_ar* h, float* dst, int rows, void* stream);
@@ -92,6 +101,7 @@ typedef struct tt_sampling {
   unsigned long long seed;   /* Philox key when exp_noise == NULL */
   int row_offset;            /* global index of candidate 0 of this rank */
   const float* exp_noise;    /* optional f32 [max_new][B][vocab] Exp(1) draws: multinomial == argmax(p/q) */
+  const unsigned long long* group_seeds;  /* optional HOST array [n_groups]: Philox key per group (NULL: `seed` for every group) */
 } tt_sampling;
 
 /* Replaces `self.inference_model.generate(... do_sample=True ...)` (autoregressive.py:560-563;

@@ -27,15 +27,39 @@ class FakeTimer:
 
 class FakeArStage:
     def __init__(self, sd, cfg, device="cpu", dtype=0, max_batch=256, max_text=402, max_new_tokens=500, max_latent_candidates=4,
-                 share_weights_with=None, kv_cache=True):
+                 share_weights_with=None, kv_cache=True, max_groups=1):
         self.sd = sd if sd is not None else share_weights_with.sd
-        self.cfg, self.kv_cache, self.max_batch = cfg, kv_cache, max_batch
+        self.cfg, self.kv_cache, self.max_batch, self.max_groups = cfg, kv_cache, max_batch, max_groups
+        self.groups = None
 
     def prefill(self, cond_latent, text_tokens):
         self.cond, self.text = cond_latent[:1].float().cpu(), text_tokens[:1].cpu()
+        self.groups = None
 
-    def generate(self, B, max_new, temperature=0.8, top_p=0.8, repetition_penalty=2.0, top_k=50, seed=0, row_offset=0, exp_noise=None):
+    def prefill_group(self, group, n_groups, cond_latent, text_tokens):
+        assert n_groups <= self.max_groups and 0 <= group < n_groups
+        if n_groups == 1:
+            return self.prefill(cond_latent, text_tokens)
+        if group == 0:
+            self.groups = [None] * n_groups
+        self.groups[group] = (cond_latent[:1].float().cpu(), text_tokens[:1].cpu())
+        self.group_batches = getattr(self, "group_batches", 0) + (1 if group == 0 else 0)
+
+    def generate(self, B, max_new, temperature=0.8, top_p=0.8, repetition_penalty=2.0, top_k=50, seed=0, row_offset=0, exp_noise=None,
+                 group_seeds=None):
         assert B <= self.max_batch
+        if self.groups is not None and len(self.groups) > 1:
+            # the engine decodes the groups in one batch with per-group prefixes and Philox keys; its contract is "every group's codes
+            # equal decoding it alone" (tests/test_gpu_stages.py), which is how the stand-in produces them
+            groups, self.groups = self.groups, None
+            Bg, outs = B // len(groups), []
+            for g, (cond, text) in enumerate(groups):
+                self.cond, self.text = cond, text
+                outs.append(self.generate(Bg, max_new, temperature, top_p, repetition_penalty, top_k, group_seeds[g] if group_seeds else seed,
+                                          row_offset, None)[0])
+            n = max(o.shape[1] for o in outs)
+            outs = [torch.nn.functional.pad(o, (0, n - o.shape[1]), value=self.cfg.stop_mel_token) for o in outs]
+            return torch.cat(outs, dim=0), n
         V = self.cfg.number_mel_codes
         if exp_noise is None:  # one generator per GLOBAL candidate: sharding-invariant like the engine's Philox streams
             rows = []

@@ -78,6 +78,34 @@ def test_do_tts_call_sequence(tts):
 
 
 @torch.no_grad()
+def test_tts_many_equals_one_utterance_after_the_other(monkeypatch):
+    """tts_many (the long-form path: read.py:66-71 renders its chunks one after the other with the same seed) batches the
+    autoregressive stage over `utterance_batch` utterances; everything it returns must equal tts() called per text."""
+    if not os.path.exists(VOCAB):
+        pytest.skip("tokenizer.json (reference data file) not present")
+    fake_stages.install(monkeypatch)
+    from tortoise_tts_amd.api import TextToSpeech
+    sds, cfgs = small_setup()
+    t = TextToSpeech(models_dir="/nonexistent", tokenizer_vocab_file=VOCAB, tokenizer_basic=True, state_dicts=sds, configs=cfgs,
+                     max_candidates=8, max_mel_tokens=40, candidate_sharding=False, utterance_batch=2)
+    lat = voice_latents(cfgs)
+    texts = ["Once upon a time.", "There lived a girl.", list(range(10, 31))]
+    kw = dict(num_autoregressive_samples=8, diffusion_iterations=3, max_mel_tokens=32)
+    one_by_one = [t.tts(x, conditioning_latents=lat, use_deterministic_seed=5, verbose=False, **kw) for x in texts]
+    many = t.tts_many(texts, conditioning_latents=lat, use_deterministic_seed=5, **kw)
+    assert t.ar.group_batches == 1  # 3 utterances, 2 per decode batch: one grouped generation + one single
+    assert len(many) == 3 and all(torch.equal(a, b) for a, b in zip(many, one_by_one))
+    assert set(t.timings) >= {"ar_s", "diffusion_s", "total_s"}
+    # what the grouped decode cannot hold falls back to tts() per utterance (same results): a candidate count that is not a multiple of 4
+    odd = t.tts_many(texts[:2], conditioning_latents=lat, use_deterministic_seed=5, num_autoregressive_samples=6, diffusion_iterations=3, max_mel_tokens=32)
+    want = [t.tts(x, conditioning_latents=lat, use_deterministic_seed=5, verbose=False, num_autoregressive_samples=6, diffusion_iterations=3, max_mel_tokens=32)
+            for x in texts[:2]]
+    assert all(torch.equal(a, b) for a, b in zip(odd, want))
+    with pytest.raises(NotImplementedError):
+        t.tts_many(texts, conditioning_latents=lat, k=2, **kw)
+
+
+@torch.no_grad()
 def test_random_voice_and_error_behaviour(tts):
     # voice='random' (do_tts.py default): no samples, no latents -> RandomLatentConverter pair (api.py:398-399, 301-309)
     torch.manual_seed(3)

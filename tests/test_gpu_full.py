@@ -128,3 +128,26 @@ def test_vocoder_and_end_to_end(full):
     c = tts.tts(text, **dict(kw, use_deterministic_seed=8))
     assert not torch.equal(a, c)
     print("[parity] end-to-end stage seconds:", {k: round(v, 4) for k, v in tts.timings.items()})
+
+
+@torch.no_grad()
+def test_tts_many_shares_decode_batches_and_equals_tts_per_text(full):
+    """Long-form path: TextToSpeech(utterance_batch=G).tts_many decodes the candidates of G utterances in one batch (own prefix and
+    Philox key per utterance); every clip must be bit-identical to tts() on that text alone - full-width engines, three texts of
+    different lengths, two per decode batch."""
+    import bench
+    from tortoise_tts_amd.api import TextToSpeech
+    _, sds, _, latents = full
+    tts = TextToSpeech(state_dicts=sds, dtype="bf16", max_candidates=16, max_mel_tokens=64, kv_cache=True, candidate_sharding=False,
+                       utterance_batch=2)
+    g = torch.Generator().manual_seed(11)
+    texts = [torch.randint(1, 255, (n,), generator=g) for n in (23, 61, 40)]
+    kw = dict(conditioning_latents=latents, num_autoregressive_samples=16, diffusion_iterations=4, max_mel_tokens=36)
+    one_by_one = [tts.tts(t, use_deterministic_seed=7, verbose=False, **kw) for t in texts]
+    many = tts.tts_many(texts, use_deterministic_seed=7, **kw)
+    assert len(many) == 3
+    for a, b in zip(many, one_by_one):
+        assert a.shape == b.shape and torch.equal(a, b), "an utterance rendered inside a shared decode batch differs from tts() alone"
+    assert tts.timings["ar_s"] > 0
+    for st in (tts.ar, tts.clvp, tts.diffusion, tts.vocoder):
+        st.close()

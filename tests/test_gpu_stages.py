@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import make_golden as G
 from oracle import tortoise_oracle as O
@@ -498,6 +499,43 @@ def test_ar_generate_chunks_equal_one_shot_loop():
         st1.latents(cond, text, codes)
     assert codes.shape[1] == n1
     st1.close()
+    st.close()
+
+
+@pytest.mark.parametrize("eos_boost", [None, 2.0])
+@torch.no_grad()
+def test_ar_utterance_groups_decode_like_single_utterances(eos_boost):
+    """Several utterances in ONE decode batch (tt_ar_prefill_group; long-form reading renders its chunks one after the other in the
+    reference, read.py:66-71): every group has its own text / voice / prefix length / Philox key, and its codes must be bit-identical to
+    decoding that utterance alone - the batched GEMMs pick other tiles (M = 12 .. 48 rows instead of 4 .. 16) but keep every output
+    element's k order, the row norms stay one workgroup per row, attention and sampling are per sequence."""
+    cfg = ARConfig(**G.AR_CFG)
+    sd = G.sampling_state_dict(cfg, eos_boost) if eos_boost else W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.AR_SEED), cfg)
+    gen = torch.Generator().manual_seed(21)
+    utts = []
+    for T_ in (11, 27, 18):
+        utts.append((torch.randn(1, cfg.model_dim, generator=gen), F.pad(torch.randint(1, 255, (1, T_), generator=gen).int(), (0, 1))))
+    seeds, Bg, max_new = [5, 9, 5], 8, 24
+    st = stages.ArStage(sd, cfg, max_batch=len(utts) * Bg, max_text=40, max_new_tokens=32, max_latent_candidates=1, max_groups=4)
+    singles = []
+    for (cond, text), seed in zip(utts, seeds):
+        st.prefill(cond, text)
+        codes, n = st.generate(Bg, max_new, seed=seed, row_offset=3)
+        singles.append(codes.clone())
+    for g, (cond, text) in enumerate(utts):
+        st.prefill_group(g, len(utts), cond, text)
+    codes, n = st.generate(len(utts) * Bg, max_new, group_seeds=seeds, row_offset=3)
+    assert n == max(c.shape[1] for c in singles)
+    stop = cfg.stop_mel_token
+    for g, single in enumerate(singles):
+        mine = codes[g * Bg:(g + 1) * Bg]
+        assert torch.equal(mine[:, :single.shape[1]], single), f"utterance {g} decoded differently inside the batch"
+        assert (mine[:, single.shape[1]:] == stop).all()  # a group that finished early is padded like any finished row
+    assert not torch.equal(singles[0], singles[2])  # same key, different text: different codes
+    # and a plain single-utterance call on the same handle afterwards is unaffected by the group state
+    st.prefill(*utts[1])
+    again, _ = st.generate(Bg, max_new, seed=seeds[1], row_offset=3)
+    assert torch.equal(again, singles[1])
     st.close()
 
 

@@ -111,7 +111,7 @@ class TextToSpeech:
     def __init__(self, autoregressive_batch_size=None, models_dir=MODELS_DIR, enable_redaction=True, kv_cache=False,
                  use_deepspeed=False, half=False, device=None, tokenizer_vocab_file=None, tokenizer_basic=False, *,
                  state_dicts=None, dtype=None, max_candidates=256, configs=None, max_mel_tokens=500, max_text_tokens=402,
-                 candidate_sharding=True):
+                 candidate_sharding=True, utterance_batch=1):
         self.models_dir = models_dir
         if use_deepspeed:
             raise NotImplementedError("use_deepspeed: DeepSpeed kernel injection is a CUDA-only reference option; the MI355X engine "
@@ -153,8 +153,14 @@ class TextToSpeech:
         self._tokenizer = None
         self.max_mel_tokens_cap = max_mel_tokens
         max_S = max_mel_tokens * 4 * 24000 // 22050 + 8
-        self.ar = stages.ArStage(sd("autoregressive"), self.ar_cfg, self.device, self.dtype, max_batch=cap,
-                                 max_text=max_text_tokens, max_new_tokens=max_mel_tokens, max_latent_candidates=4, kv_cache=self.kv_cache)
+        # utterance_batch > 1 (tts_many, long-form reading): that many utterances share ONE decode batch - the KV caches of
+        # utterance_batch x max_candidates sequences are resident (122 880 B per cached token: 8 x 256 x 200 tokens = 50 GB of the 288)
+        self.utterance_batch = max(1, int(utterance_batch))
+        if self.utterance_batch > 16:
+            raise ValueError("utterance_batch is limited to 16 utterances per decode batch")
+        self.ar = stages.ArStage(sd("autoregressive"), self.ar_cfg, self.device, self.dtype, max_batch=cap * self.utterance_batch,
+                                 max_text=max_text_tokens, max_new_tokens=max_mel_tokens, max_latent_candidates=4, kv_cache=self.kv_cache,
+                                 max_groups=self.utterance_batch)
         self.clvp = stages.ClvpStage(sd("clvp"), self.clvp_cfg, self.device, self.dtype, max_rows=max(cap, 8) * max_mel_tokens)
         self.diffusion = stages.DiffusionStage(sd("diffusion"), self.diff_cfg, self.device, self.dtype, max_seq=max_S,
                                                max_codes=max_mel_tokens + 8, max_steps=512)
@@ -290,7 +296,10 @@ class TextToSpeech:
         stop = self.ar_cfg.stop_mel_token
         exp_noise = noise.get("exp_noise")
         batches = []
-        for c0 in range(lo, hi, self.autoregressive_batch_size):
+        pre = noise.get("_ar_samples")  # tts_many: this utterance's candidates were decoded in a shared batch already
+        if pre is not None:
+            batches.append(pre.to(dev).long())
+        for c0 in ([] if pre is not None else range(lo, hi, self.autoregressive_batch_size)):
             B = min(self.autoregressive_batch_size, hi - c0)
             self.ar.prefill(auto_conditioning, text_tokens)
             en = exp_noise[:, c0 - lo:c0 - lo + B] if exp_noise is not None else None
@@ -362,3 +371,74 @@ class TextToSpeech:
         if return_deterministic_state:
             return res, (seed, text, voice_samples, conditioning_latents)
         return res
+
+    @torch.no_grad()
+    def tts_many(self, texts, voice_samples=None, conditioning_latents=None, use_deterministic_seed=None, verbose=False, **kwargs):
+        """Several utterances of one voice in one call - what tortoise/read.py:66-71 does chunk after chunk with the same seed.
+        Returns [tts(text, ...) for text in texts] (k = 1: one clip f32 [1, 1, n] per text), computed with the autoregressive stage
+        batched over `utterance_batch` utterances at a time: their candidates share one decode batch (own prefix, own Philox key per
+        utterance), so every weight matrix streams once per step for all of them and the sampled codes of an utterance are
+        bit-identical to rendering it alone.  CLVP ranking, the latent re-pass, diffusion and UnivNet then run per utterance exactly
+        as in tts().  Single-rank instances only (long-form reading spreads whole chunks over the ranks, longform.py)."""
+        if self.world != 1:
+            raise ValueError("tts_many batches utterances on one GPU: build TextToSpeech(candidate_sharding=False)")
+        settings = dict(kwargs)
+        k = int(settings.pop("k", 1))
+        if k != 1:
+            raise NotImplementedError("tts_many renders the top-ranked candidate of every utterance (k = 1)")
+        if settings.pop("return_deterministic_state", False):
+            raise NotImplementedError("tts_many: return_deterministic_state is a per-call option of tts()")
+        N = int(settings.get("num_autoregressive_samples", 512))
+        max_mel_tokens = int(settings.get("max_mel_tokens", 500))
+        hf = {k_: settings[k_] for k_ in list(settings) if k_ not in (
+            "num_autoregressive_samples", "temperature", "length_penalty", "repetition_penalty", "top_p", "max_mel_tokens", "cvvp_amount",
+            "diffusion_iterations", "cond_free", "cond_free_k", "diffusion_temperature")}
+        top_k = int(hf.get("top_k", 50))
+        if set(hf) - {"top_k"} or settings.get("cvvp_amount", 0) != 0 or N > self.autoregressive_batch_size or N % 4 != 0:
+            # anything tts() refuses or the grouped decode cannot hold: let tts() handle (or refuse) it, one utterance at a time
+            return [self.tts(t, voice_samples=voice_samples, conditioning_latents=conditioning_latents, k=1, verbose=verbose,
+                             use_deterministic_seed=use_deterministic_seed, **settings) for t in texts]
+        seed = self.deterministic_state(seed=use_deterministic_seed)
+        dev = self.device
+        toks = []
+        for text in texts:
+            if self.enable_redaction and isinstance(text, str) and "[" in text and "]" in text:
+                raise NotImplementedError("text with [bracketed] passages needs the wav2vec2 aligner (api.py:583-587); see tts()")
+            t = torch.IntTensor(self.tokenizer.encode(text)).unsqueeze(0) if isinstance(text, str) else torch.as_tensor(text, dtype=torch.int32).reshape(1, -1)
+            t = F.pad(t.to(dev), (0, 1))
+            if t.shape[-1] >= 400:
+                raise ValueError("Too much text provided. Break the text up into separate segments and re-try inference.")
+            toks.append(t)
+        if voice_samples is not None:
+            conditioning_latents = self.get_conditioning_latents(voice_samples)
+        elif conditioning_latents is None:
+            conditioning_latents = self.get_random_conditioning_latents()
+        auto_conditioning = conditioning_latents[0].to(dev).float()
+        if max_mel_tokens > self.max_mel_tokens_cap:
+            raise ValueError(f"max_mel_tokens={max_mel_tokens} exceeds the capacity this engine was built with")
+        stop = self.ar_cfg.stop_mel_token
+        ev = _StageTimer(2)
+        ev.mark(0)
+        samples = []
+        for w0 in range(0, len(toks), self.utterance_batch):
+            wave = toks[w0:w0 + self.utterance_batch]
+            for g, t in enumerate(wave):
+                self.ar.prefill_group(g, len(wave), auto_conditioning, t)
+            codes, _ = self.ar.generate(N * len(wave), max_mel_tokens, temperature=settings.get("temperature", .8), top_p=settings.get("top_p", .8),
+                                        repetition_penalty=settings.get("repetition_penalty", 2.0), top_k=top_k, seed=seed, row_offset=0,
+                                        group_seeds=[seed] * len(wave))
+            codes = F.pad(codes, (0, max_mel_tokens - codes.shape[1]), value=stop)
+            samples.extend(codes[g * N:(g + 1) * N] for g in range(len(wave)))
+        ev.mark(1)
+        out, acc = [], {}
+        for t, smp in zip(toks, samples):
+            out.append(self.tts(t[0, :-1], conditioning_latents=conditioning_latents, k=1, verbose=verbose, use_deterministic_seed=seed,
+                                noise_override={"_ar_samples": smp}, **settings))
+            for k_, v in self.timings.items():
+                acc[k_] = acc.get(k_, 0.0) + v
+        ev.synchronize()
+        acc["ar_s"] = acc.get("ar_s", 0.0) + ev.seconds(0, 1)
+        acc["total_s"] = acc.get("total_s", 0.0) + ev.seconds(0, 1)
+        self.timings = acc
+        return out
+

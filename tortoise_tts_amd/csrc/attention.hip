@@ -43,15 +43,16 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(FlashArgs a) {  // 2 wave
   const int h = bh % a.heads, b = bh / a.heads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int n = a.n;
+  const int ns = a.n;                                             // row stride of the operands
+  const int n = a.nv_period > 0 ? a.nv[b % a.nv_period] : a.n;    // valid keys / queries of this batch row (padded batches)
   if (a.relpos) {
     if (threadIdx.x < 129) rp[threadIdx.x] = a.relpos[h * 129 + threadIdx.x];
     __syncthreads();
   }
   const int qbase = (SPLIT ? bx : bx * 4 + wave) * 16 * NQ;
   if (qbase >= n) return;
-  const T* Q = (const T*)a.q + (size_t)bh * n * 64;
-  const T* K = (const T*)a.k + (size_t)bh * n * 64;
+  const T* Q = (const T*)a.q + (size_t)bh * ns * 64;
+  const T* K = (const T*)a.k + (size_t)bh * ns * 64;
   const T* VT = (const T*)a.vt + (size_t)bh * 64 * a.n_pad;
 
   x8 qf[NQ][2];
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(FlashArgs a) {  // 2 wave
     const int qi = qbase + iq * 16 + fr;
     if (qi < n) {
       const float inv = 1.0f / l_run[iq];
-      T* o = (T*)a.out + ((size_t)b * n + qi) * a.ldo + h * 64 + fg * 4;
+      T* o = (T*)a.out + ((size_t)b * ns + qi) * a.ldo + h * 64 + fg * 4;
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk)
         *(x4*)(o + blk * 16) = pack4<T>(acc[iq][blk][0] * inv, acc[iq][blk][1] * inv, acc[iq][blk][2] * inv, acc[iq][blk][3] * inv);
@@ -293,15 +294,17 @@ __global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
   const int h = bh % a.heads, b = bh / a.heads;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int n = a.n;
+  const int ns = a.n;                                             // row stride of the operands
+  const int n = a.nv_period > 0 ? a.nv[b % a.nv_period] : a.n;    // valid keys / queries of this batch row (padded batches)
+  const int qblock = bx * 64 * NQ;               // first query of the block
+  if (qblock >= n) return;                       // a block of padding queries only (block-uniform, before the first barrier)
   if (a.relpos) {
     if (threadIdx.x < 129) rp[threadIdx.x] = a.relpos[h * 129 + threadIdx.x];
     __syncthreads();
   }
-  const int qblock = bx * 64 * NQ;               // first query of the block
   const int qbase = qblock + wave * 16 * NQ;     // first query of this wave (may be >= n: the wave then only helps loading)
-  const T* Q = (const T*)a.q + (size_t)bh * n * 64;
-  const T* K = (const T*)a.k + (size_t)bh * n * 64;
+  const T* Q = (const T*)a.q + (size_t)bh * ns * 64;
+  const T* K = (const T*)a.k + (size_t)bh * ns * 64;
   const T* VT = (const T*)a.vt + (size_t)bh * 64 * a.n_pad;
 
   x8 qf[NQ][2];
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
     const int qi = qbase + iq * 16 + fr;
     if (qi < n) {
       const float inv = 1.0f / l_run[iq];
-      T* o = (T*)a.out + ((size_t)b * n + qi) * a.ldo + h * 64 + fg * 4;
+      T* o = (T*)a.out + ((size_t)b * ns + qi) * a.ldo + h * 64 + fg * 4;
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk)
         *(x4*)(o + blk * 16) = pack4<T>(acc[iq][blk][0] * inv, acc[iq][blk][1] * inv, acc[iq][blk][2] * inv, acc[iq][blk][3] * inv);
@@ -693,9 +696,15 @@ __global__ __launch_bounds__(NSEQ * 64, 4) void decode_attn_lds_kernel(DecodeAtt
   const int h = (int)blockIdx.x;      // grid = (heads, sequence groups)
   const int b_raw = (int)blockIdx.y * NSEQ + wave;
   const int b = min(b_raw, a.B - 1);  // surplus waves of the last group repeat its last sequence (never stored)
-  const int P1 = a.P1;
-  const T* kp = (const T*)a.kp + (size_t)h * P1 * 64;
-  const T* vp = (const T*)a.vp + (size_t)h * P1 * 64;
+  int P1 = a.P1;
+  size_t goff = 0;
+  if (a.ngroups > 1) {  // several utterances in one batch: this workgroup's sequences all belong to one of them (group_size % NSEQ == 0)
+    const int grp = ((int)blockIdx.y * NSEQ) / a.group_size;
+    P1 = a.p1_tab[grp];
+    goff = (size_t)grp * a.prefix_group_stride;
+  }
+  const T* kp = (const T*)a.kp + goff + (size_t)h * P1 * 64;
+  const T* vp = (const T*)a.vp + goff + (size_t)h * P1 * 64;
   unsigned char* Kl = smem_dec;                 // [slot][8 chunks][64 keys][8]  (chunk-major like the per-sequence cache)
   unsigned char* Vl = smem_dec + kl_bytes;      // [key][64]
   float* sc = (float*)(smem_dec + kl_bytes + vl_bytes) + (size_t)wave * ctx_cap;
@@ -876,6 +885,11 @@ int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stre
   // shared-prefix kernel with 4 sequences per workgroup (measured 2 % ahead of 16 at 256 candidates and 40 % ahead at 32:
   // more, smaller workgroups); the per-wave kernel only when the staged prefix + score rows do not fit the LDS (very long prompts)
   int nseq = a.variant == 1 ? 0 : a.variant == 2 ? 16 : 4;
+  if (a.ngroups > 1) {
+    TT_REQUIRE(a.ngroups <= 16 && a.group_size > 0 && a.group_size % 4 == 0 && a.B == a.ngroups * a.group_size,
+               "decode_attention: %d groups of %d sequences (a multiple of 4) do not make %d sequences", a.ngroups, a.group_size, a.B);
+    nseq = 4;
+  }
   const int kl_bytes = ((a.P1 + 63) >> 6) * 8 * 1024, vl_bytes = ((a.P1 + 7) >> 3) * 1024;
   if (a.P1 < 1) nseq = 0;
   if (nseq && (size_t)kl_bytes + vl_bytes + (size_t)nseq * ctx_cap * sizeof(float) > 160 * 1024) nseq = nseq == 16 ? 4 : 0;
@@ -898,6 +912,7 @@ int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stre
     TT_CHECK_HIP(hipGetLastError());
     return 0;
   }
+  TT_REQUIRE(a.ngroups <= 1, "decode_attention: the prefixes of a multi-utterance batch (%d rows) do not fit the LDS", a.P1);
   const size_t smem = (size_t)4 * ctx_cap * sizeof(float);
   TT_REQUIRE(smem <= 64 * 1024, "decode_attention: context %d too long for the score buffer", ctx_cap);
   const int blocks = cdiv(a.B * a.heads, 4);

@@ -29,7 +29,12 @@ struct tt_diff {
   int C, H, NR;  // NR = number of ResBlocks (3 + L + 3)
   Arena arena;
   StreamBridge sb;
-  int S = 0;
+  int S = 0;        // rows per sample of the current pass (a padded batch: the common padded length)
+  int UB = 1;       // utterance capacity of a batched sampling run (cfg.max_batch)
+  int U = 1;        // utterances of the current batch (tt_diff_batch_begin); sample index = guidance row * U + utterance
+  int Su[16] = {0}; // their valid lengths
+  unsigned conditioned = 0;  // bit u: tt_diff_condition_slot ran for utterance u of the current batch
+  bool masked = false;       // the kernels of the current pass take per-sample valid lengths (Su) - off while one utterance is conditioned
   int rows_max = 0;
   float* code_emb = nullptr;   // [2][S][C]: row 0 conditioned, row 1 unconditioned embedding broadcast
   float* tmp_a = nullptr;      // [rows][C] f32 scratch
@@ -77,6 +82,10 @@ static int run_gn(tt_diff* e, const float* x, int B, int S, const float* g, cons
   // per-step scale / shift rows are staged at a fixed address (e->ss_cur): no step-dependent addressing in the kernel
   a.out_t = out_t; a.ldot = ldot; a.out_f32 = out_f32; a.ldo32 = e->C;
   a.partial = e->gn_partial;
+  if (e->masked) {
+    a.vperiod = e->U;
+    for (int u = 0; u < e->U; ++u) a.vlen[u] = e->Su[u];
+  }
   if (x == e->stats_ptr && e->stats_seq == S && S >= e->stats_rows) {
     a.gemm_part = e->gn_gemm_part;
     a.part_rows = e->stats_rows;
@@ -90,6 +99,10 @@ static int gemm_with_stats(tt_diff* e, GemmArgs& g, int S, hipStream_t s) {
   if (fused) {
     g.gn_part = e->gn_gemm_part;
     g.gn_seq = S;
+    if (e->masked) {
+      g.gn_vperiod = e->U;
+      for (int u = 0; u < e->U; ++u) g.gn_vlen[u] = e->Su[u];
+    }
   }
   TT_TRY(gemm_launch(e->cfg.dtype, EPI_STD, g, s));
   if (fused) {
@@ -115,6 +128,10 @@ static int run_attn_block(tt_diff* e, const tt_attn_block& w, const float* in, i
   memset(&f, 0, sizeof(f));
   f.q = e->q; f.k = e->k; f.vt = e->vt; f.out = e->att; f.ldo = C; f.BH = B * H; f.heads = H; f.n = S; f.n_pad = n_pad;
   f.relpos = w.relpos;
+  if (e->masked) {
+    f.nv_period = e->U;
+    for (int u = 0; u < e->U; ++u) f.nv[u] = e->Su[u];
+  }
   TT_TRY(flash_attention_launch(dt, f, s));
   g = gemm_args(e->att, C, w.w_proj, C, M, C, C);
   g.bias = w.b_proj; g.res = in; g.ldres = C; g.out_f32 = out_f32; g.ldo32 = C; g.out_t = out_t; g.ldot = ldot;
@@ -246,8 +263,10 @@ int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff*
   TT_REQUIRE(cfg->heads * 64 == cfg->channels, "tt_diff_create: head_dim must be 64");
   TT_REQUIRE(cfg->in_pad % 64 == 0 && cfg->in_pad >= cfg->in_channels && cfg->latent_channels % 64 == 0, "tt_diff_create: in_pad/latent must be multiples of 64");
   TT_REQUIRE(cfg->max_steps >= 1 && cfg->max_seq >= 1 && cfg->max_codes >= 1, "tt_diff_create: bad capacity");
+  TT_REQUIRE(cfg->max_batch >= 0 && cfg->max_batch <= 16, "tt_diff_create: max_batch %d outside 0 .. 16", cfg->max_batch);
   tt_diff* e = new tt_diff();
   e->cfg = *cfg;
+  e->UB = cfg->max_batch > 1 ? cfg->max_batch : 1;
   e->w = *w;
   e->C = cfg->channels; e->H = cfg->heads; e->NR = 3 + cfg->num_layers + 3;
   e->latent_attn.assign(w->latent_attn_host, w->latent_attn_host + 4);
@@ -255,18 +274,19 @@ int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff*
   e->res.assign(w->res_host, w->res_host + e->NR);
   const int C = e->C;
   // batched integrator chunk: as many (step, row) samples as fit ~32k rows, at least one step's two rows
-  e->chunk_rows = std::max(2 * cfg->max_seq, std::min(32768, cfg->max_steps * 2 * cfg->max_seq));
+  e->chunk_rows = std::max(2 * e->UB * cfg->max_seq, std::min(32768, cfg->max_steps * 2 * cfg->max_seq));
   e->rows_max = std::max(e->chunk_rows, cfg->max_codes);
   const size_t rows = (size_t)e->rows_max + 64;
   int rc = e->sb.init();
-  if (!rc) rc = e->arena.alloc_t(&e->code_emb, (size_t)2 * cfg->max_seq * C);
+  const size_t B2 = (size_t)2 * e->UB;  // samples of one denoiser pass: (conditioned, conditioning-free) x utterances
+  if (!rc) rc = e->arena.alloc_t(&e->code_emb, B2 * cfg->max_seq * C);
   if (!rc) rc = e->arena.alloc_t(&e->tmp_a, rows * C);
   if (!rc) rc = e->arena.alloc_t(&e->tmp_b, rows * C);
   if (!rc) rc = e->arena.alloc_t(&e->tmp_c, rows * C);
   if (!rc) rc = e->arena.alloc_t(&e->rep_in, rows * C);
   if (!rc) rc = e->arena.alloc(&e->act, rows * C * 2);
-  if (!rc) rc = e->arena.alloc(&e->cat, ((size_t)2 * cfg->max_seq + 64) * C * 2);
-  if (!rc) rc = e->arena.alloc(&e->integ_all, ((size_t)cfg->max_steps * 2 * cfg->max_seq + 64) * C * 2, false);
+  if (!rc) rc = e->arena.alloc(&e->cat, (B2 * cfg->max_seq + 64) * C * 2);
+  if (!rc) rc = e->arena.alloc(&e->integ_all, ((size_t)cfg->max_steps * B2 * cfg->max_seq + 64) * C * 2, false);
   if (!rc) rc = e->arena.alloc(&e->q, rows * C * 2);
   if (!rc) rc = e->arena.alloc(&e->k, rows * C * 2);
   if (!rc) rc = e->arena.alloc(&e->vt, (size_t)C * (2 * rows + 64) * 2);  // per sample C x round_up(S, 32) keys: <= 2x the rows for short sequences
@@ -283,9 +303,9 @@ int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff*
   if (!rc) rc = e->arena.alloc_t(&e->ss_cur, (size_t)e->NR * 2 * C);
   if (!rc) rc = e->arena.alloc_t(&e->steps_dev, cfg->max_steps);
   if (!rc) rc = e->arena.alloc_t(&e->slot, 4);
-  if (!rc) rc = e->arena.alloc_t(&e->x, (size_t)cfg->max_seq * cfg->in_channels);
-  if (!rc) rc = e->arena.alloc(&e->x_t, ((size_t)2 * cfg->max_seq + 8) * cfg->in_pad * 2);
-  if (!rc) rc = e->arena.alloc_t(&e->out, (size_t)2 * cfg->max_seq * cfg->out_channels);
+  if (!rc) rc = e->arena.alloc_t(&e->x, (size_t)e->UB * cfg->max_seq * cfg->in_channels);
+  if (!rc) rc = e->arena.alloc(&e->x_t, (B2 * cfg->max_seq + 8) * cfg->in_pad * 2);
+  if (!rc) rc = e->arena.alloc_t(&e->out, B2 * cfg->max_seq * cfg->out_channels);
   if (rc) {
     tt_diff_destroy(e);
     return rc;
@@ -303,13 +323,13 @@ void tt_diff_destroy(tt_diff* e) {
   delete e;
 }
 
-int tt_diff_condition(tt_diff* e, const float* latents, int M, const float* cond, const int* interp_idx, int S, void* stream) {
-  TT_REQUIRE(e && latents && cond && interp_idx, "tt_diff_condition: null argument");
-  TT_REQUIRE(M >= 1 && M <= e->cfg.max_codes && S >= 1 && S <= e->cfg.max_seq, "tt_diff_condition: M=%d S=%d exceed capacity (%d, %d)", M, S, e->cfg.max_codes, e->cfg.max_seq);
-  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
-  TT_TRY(e->sb.enter(us));
+// DiffusionTts.timestep_independent for ONE utterance: its S conditioned rows -> dst_cond, the unconditioned embedding
+// broadcast -> dst_uncond (both [S][C] f32).  Runs on the M code rows alone (no padding, no masks).
+static int diff_condition_into(tt_diff* e, const float* latents, int M, const float* cond, const int* interp_idx, int S, float* dst_cond,
+                               float* dst_uncond, hipStream_t s) {
   const int C = e->C, dt = e->cfg.dtype, LC = e->cfg.latent_channels;
-  e->S = S;
+  const bool masked = e->masked;
+  e->masked = false;
   e->stats_ptr = nullptr;
   TT_TRY(cast_pad_launch(dt, latents, LC, e->lat_t, LC, M, LC, LC, s));
   GemmArgs g = gemm_args(e->lat_t, LC, e->w.w_latent_conv, 3 * LC, M, C, 3 * LC);
@@ -323,8 +343,49 @@ int tt_diff_condition(tt_diff* e, const float* latents, int M, const float* cond
   }
   // code_norm(h) * (1 + cond_scale) + cond_shift   (diffusion_decoder.py:249-250)
   TT_TRY(run_gn(e, cur, 1, M, e->w.code_norm_g, e->w.code_norm_b, cond, 0, 1, ACT_NONE, nullptr, 0, oth, s));
-  TT_TRY(gather_rows_launch(oth, interp_idx, e->code_emb, S, C, s));                 // F.interpolate(nearest)
-  TT_TRY(broadcast_rows_launch(e->w.uncond_emb, e->code_emb + (size_t)S * C, S, C, s));  // unconditioned_embedding.repeat
+  TT_TRY(gather_rows_launch(oth, interp_idx, dst_cond, S, C, s));        // F.interpolate(nearest)
+  TT_TRY(broadcast_rows_launch(e->w.uncond_emb, dst_uncond, S, C, s));   // unconditioned_embedding.repeat
+  e->stats_ptr = nullptr;
+  e->masked = masked;
+  return 0;
+}
+
+int tt_diff_condition(tt_diff* e, const float* latents, int M, const float* cond, const int* interp_idx, int S, void* stream) {
+  TT_REQUIRE(e && latents && cond && interp_idx, "tt_diff_condition: null argument");
+  TT_REQUIRE(M >= 1 && M <= e->cfg.max_codes && S >= 1 && S <= e->cfg.max_seq, "tt_diff_condition: M=%d S=%d exceed capacity (%d, %d)", M, S, e->cfg.max_codes, e->cfg.max_seq);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  e->S = S;
+  e->U = 1; e->Su[0] = S; e->masked = false; e->conditioned = 1;
+  TT_TRY(diff_condition_into(e, latents, M, cond, interp_idx, S, e->code_emb, e->code_emb + (size_t)S * e->C, s));
+  return e->sb.leave(us);
+}
+
+int tt_diff_batch_begin(tt_diff* e, int U, int S_pad, void* stream) {
+  TT_REQUIRE(e != nullptr, "tt_diff_batch_begin: null handle");
+  TT_REQUIRE(U >= 1 && U <= e->UB, "tt_diff_batch_begin: %d utterances exceed this handle's capacity (%d; tt_diff_config.max_batch)", U, e->UB);
+  TT_REQUIRE(S_pad >= 1 && S_pad <= e->cfg.max_seq, "tt_diff_batch_begin: padded length %d exceeds capacity %d", S_pad, e->cfg.max_seq);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  e->U = U; e->S = S_pad; e->conditioned = 0; e->masked = false;
+  for (int u = 0; u < 16; ++u) e->Su[u] = 0;
+  // rows past an utterance's own length stay zero for the whole run: they are the zero padding its convolutions read
+  TT_CHECK_HIP(hipMemsetAsync(e->code_emb, 0, (size_t)2 * U * S_pad * e->C * sizeof(float), s));
+  TT_CHECK_HIP(hipMemsetAsync(e->x_t, 0, (size_t)2 * U * S_pad * e->cfg.in_pad * 2, s));
+  TT_CHECK_HIP(hipMemsetAsync(e->x, 0, (size_t)U * S_pad * e->cfg.in_channels * sizeof(float), s));
+  return e->sb.leave(us);
+}
+
+int tt_diff_condition_slot(tt_diff* e, int u, const float* latents, int M, const float* cond, const int* interp_idx, int S, void* stream) {
+  TT_REQUIRE(e && latents && cond && interp_idx, "tt_diff_condition_slot: null argument");
+  TT_REQUIRE(u >= 0 && u < e->U, "tt_diff_condition_slot: utterance %d outside the batch of %d (tt_diff_batch_begin)", u, e->U);
+  TT_REQUIRE(M >= 1 && M <= e->cfg.max_codes && S >= 1 && S <= e->S, "tt_diff_condition_slot: M=%d S=%d exceed capacity (%d codes, padded length %d)", M, S, e->cfg.max_codes, e->S);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  const size_t slot = (size_t)e->S * e->C;
+  e->Su[u] = S;
+  e->conditioned |= 1u << u;
+  TT_TRY(diff_condition_into(e, latents, M, cond, interp_idx, S, e->code_emb + (size_t)u * slot, e->code_emb + (size_t)(e->U + u) * slot, s));
   return e->sb.leave(us);
 }
 
@@ -354,13 +415,11 @@ int tt_diff_forward(tt_diff* e, const float* x, int timestep, int cond_free, flo
   return e->sb.leave(us);
 }
 
-int tt_diff_sample(tt_diff* e, const float* x_T, const float* step_noise, const tt_diff_step* steps_host, int n_steps, int cond_free,
-                   float* mel_out, void* stream) {
-  TT_REQUIRE(e && x_T && steps_host && mel_out && e->S > 0, "tt_diff_sample: call tt_diff_condition first");
-  TT_REQUIRE(n_steps >= 1 && n_steps <= e->cfg.max_steps, "tt_diff_sample: %d steps exceed capacity %d", n_steps, e->cfg.max_steps);
-  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
-  TT_TRY(e->sb.enter(us));
-  const int S = e->S, IC = e->cfg.in_channels, IP = e->cfg.in_pad, dt = e->cfg.dtype;
+// p_sample_loop for the U utterances of the current batch (U = 1: the plain single-utterance run).  All of them walk the same
+// schedule; utterance u has Su[u] positions inside the padded length e->S.
+static int diff_sample_run(tt_diff* e, const float* const* x_T, const float* const* step_noise, const tt_diff_step* steps_host, int n_steps,
+                           int cond_free, float* const* mel_out, hipStream_t s) {
+  const int S = e->S, U = e->U, IC = e->cfg.in_channels, IP = e->cfg.in_pad, dt = e->cfg.dtype;
   std::vector<int> ts(n_steps);
   for (int i = 0; i < n_steps; ++i) ts[i] = steps_host[i].timestep;
   TT_CHECK_HIP(hipMemcpyAsync(e->ts_dev, ts.data(), n_steps * sizeof(int), hipMemcpyHostToDevice, s));
@@ -368,32 +427,41 @@ int tt_diff_sample(tt_diff* e, const float* x_T, const float* step_noise, const 
   TT_CHECK_HIP(hipStreamSynchronize(s));  // host staging buffers may go away
   TT_CHECK_HIP(hipMemsetAsync(e->slot, 0, sizeof(int), s));
   TT_TRY(diff_prepare_timesteps(e, n_steps, s));
-  TT_TRY(transpose_launch(x_T, e->x, IC, S, s));  // [C][S] -> [S][C]
-  TT_TRY(cast_pad_launch(dt, e->x, IC, e->x_t, IP, S, IC, IP, s));
-  TT_TRY(cast_pad_launch(dt, e->x, IC, offset_t(e->x_t, (size_t)S * IP), IP, S, IC, IP, s));
-  const int B = cond_free ? 2 : 1;
-  TT_TRY(diff_integrator_all(e, n_steps, B, 0, s));  // every step's conditioning integrator, batched over the schedule
-  PSampleArgs pa;
-  memset(&pa, 0, sizeof(pa));
-  pa.steps = e->steps_dev; pa.slot = e->slot; pa.x = e->x; pa.x_t = e->x_t; pa.cpad = IP; pa.out = e->out;
-  pa.has_uncond = cond_free ? 1 : 0; pa.noise = step_noise; pa.S = S; pa.C = IC;
-  pa.mel_out = mel_out;
-  pa.mel_scale = 2.3143386840820312f - (-11.512925148010254f);
-  pa.mel_shift = -11.512925148010254f;
-
+  const int R = cond_free ? 2 : 1, B = R * U;
+  for (int u = 0; u < U; ++u) {
+    float* xu = e->x + (size_t)u * S * IC;
+    TT_TRY(transpose_launch(x_T[u], xu, IC, e->Su[u], s));  // [C][S_u] -> [S_u][C]
+    for (int r = 0; r < R; ++r) TT_TRY(cast_pad_launch(dt, xu, IC, offset_t(e->x_t, (size_t)(r * U + u) * S * IP), IP, e->Su[u], IC, IP, s));
+  }
+  e->masked = U > 1;
+  int rc = diff_integrator_all(e, n_steps, B, 0, s);  // every step's conditioning integrator, batched over the schedule
+  std::vector<PSampleArgs> pa(U);
+  for (int u = 0; u < U && !rc; ++u) {
+    PSampleArgs& p = pa[u];
+    memset(&p, 0, sizeof(p));
+    p.steps = e->steps_dev; p.slot = e->slot; p.x = e->x + (size_t)u * S * IC; p.x_t = offset_t(e->x_t, (size_t)u * S * IP); p.cpad = IP;
+    p.out = e->out + (size_t)u * S * e->cfg.out_channels;
+    p.has_uncond = cond_free ? 1 : 0; p.noise = step_noise[u]; p.S = e->Su[u]; p.C = IC;
+    p.ld_rows = U * S;
+    p.mel_out = mel_out[u];
+    p.mel_scale = 2.3143386840820312f - (-11.512925148010254f);
+    p.mel_shift = -11.512925148010254f;
+  }
   auto one_step = [&]() -> int {
     TT_TRY(diff_forward(e, B, s));
-    TT_TRY(psample_launch(dt, pa, s));
+    for (int u = 0; u < U; ++u) TT_TRY(psample_launch(dt, pa[u], s));
     return slot_advance_launch(e->slot, e->ss_all, e->ss_cur, e->NR * 2 * e->C, e->n_steps_cur - 1, s);
   };
-  int rc = 0;
-  if (graphs_enabled() && n_steps > 2) {
+  if (!rc && graphs_enabled() && n_steps > 2) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    TT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    rc = one_step();
-    hipError_t ce = hipStreamEndCapture(s, &graph);
-    if (!rc && ce != hipSuccess) { set_error("tt_diff_sample: capture failed: %s", hipGetErrorString(ce)); rc = -2; }
+    hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (ce != hipSuccess) { set_error("tt_diff_sample: capture failed: %s", hipGetErrorString(ce)); rc = -2; }
+    if (!rc) {
+      rc = one_step();
+      ce = hipStreamEndCapture(s, &graph);
+      if (!rc && ce != hipSuccess) { set_error("tt_diff_sample: capture failed: %s", hipGetErrorString(ce)); rc = -2; }
+    }
     if (!rc) {
       ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
       if (ce != hipSuccess) { set_error("tt_diff_sample: instantiate failed: %s", hipGetErrorString(ce)); rc = -2; }
@@ -407,7 +475,30 @@ int tt_diff_sample(tt_diff* e, const float* x_T, const float* step_noise, const 
   } else {
     for (int i = 0; i < n_steps && !rc; ++i) rc = one_step();
   }
-  TT_TRY(rc);
+  e->masked = false;
+  return rc;
+}
+
+int tt_diff_sample(tt_diff* e, const float* x_T, const float* step_noise, const tt_diff_step* steps_host, int n_steps, int cond_free,
+                   float* mel_out, void* stream) {
+  TT_REQUIRE(e && x_T && steps_host && mel_out && e->S > 0, "tt_diff_sample: call tt_diff_condition first");
+  TT_REQUIRE(e->U == 1 && e->conditioned == 1u, "tt_diff_sample: the handle holds a batch of %d utterances (tt_diff_sample_batch)", e->U);
+  TT_REQUIRE(n_steps >= 1 && n_steps <= e->cfg.max_steps, "tt_diff_sample: %d steps exceed capacity %d", n_steps, e->cfg.max_steps);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  TT_TRY(diff_sample_run(e, &x_T, &step_noise, steps_host, n_steps, cond_free, &mel_out, s));
+  return e->sb.leave(us);
+}
+
+int tt_diff_sample_batch(tt_diff* e, int U, const float* const* x_T, const float* const* step_noise, const tt_diff_step* steps_host, int n_steps,
+                         int cond_free, float* const* mel_out, void* stream) {
+  TT_REQUIRE(e && x_T && step_noise && steps_host && mel_out, "tt_diff_sample_batch: null argument");
+  TT_REQUIRE(U == e->U && e->conditioned == (U >= 32 ? ~0u : (1u << U) - 1u), "tt_diff_sample_batch: %d utterances, but the batch has %d and conditioning mask %#x (tt_diff_batch_begin / tt_diff_condition_slot)", U, e->U, e->conditioned);
+  TT_REQUIRE(n_steps >= 1 && n_steps <= e->cfg.max_steps, "tt_diff_sample_batch: %d steps exceed capacity %d", n_steps, e->cfg.max_steps);
+  for (int u = 0; u < U; ++u) TT_REQUIRE(x_T[u] && mel_out[u] && (step_noise[u] || n_steps == 1), "tt_diff_sample_batch: null tensor for utterance %d", u);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  TT_TRY(diff_sample_run(e, x_T, step_noise, steps_host, n_steps, cond_free, mel_out, s));
   return e->sb.leave(us);
 }
 

@@ -49,6 +49,8 @@ struct GemmArgs {
   float* gn_part;  // optional: per-(row tile, 16-column strip) sum / sum-of-squares of the f32 output (see gemm.hip)
   int gn_seq;      // rows per sequence for those statistics
   int gn_ncol16;   // set by gemm_launch
+  int gn_vperiod;  // padded batches: sequence b has gn_vlen[b % gn_vperiod] valid rows; the rest are left out of the statistics (0: all valid)
+  int gn_vlen[32];
   // EPI_QKV_HEADS: n -> (part = n / dmodel, head = (n % dmodel) / 64, d = n % 64), m -> (b, s)
   int dmodel, heads;
   void* q;        // [b*heads + h][seq_len][64]

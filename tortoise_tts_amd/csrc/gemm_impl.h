@@ -79,6 +79,8 @@ struct EpiStdArgs {
   float slope_t;
   int gn_ncol16;
   FastDiv gn_seq;
+  int gn_vperiod;   // padded batches (cold tail of the block: only the statistics epilogue of such a launch reads it)
+  int gn_vlen[32];
 };
 struct EpiQkvHeadsArgs {
   const float* bias;
@@ -328,11 +330,16 @@ __device__ __forceinline__ void run_epilogue(const GemmCore& c, const typename E
   }
   const int rt = m0w / TM;  // row-tile index (m0w is a multiple of TM, a power of two)
   int next_start = 0x7fffffff, b_first = 0;
+  int end0 = 0x7fffffff, end1 = 0x7fffffff;  // padded batches: first row PAST the valid rows of the two sequences this tile can touch
   if constexpr (Epi::kId == 0) {
     if (stats) {
       unsigned r_;
       b_first = (int)fdiv((unsigned)m0w, e.gn_seq, r_);
       next_start = (b_first + 1) * (int)e.gn_seq.d;  // first row of the next sequence
+      if (e.gn_vperiod > 0) {
+        end0 = b_first * (int)e.gn_seq.d + e.gn_vlen[b_first % e.gn_vperiod];
+        end1 = next_start + e.gn_vlen[(b_first + 1) % e.gn_vperiod];
+      }
     }
   }
   // phase 2: arithmetic and GroupNorm partial statistics, registers only
@@ -358,13 +365,14 @@ __device__ __forceinline__ void run_epilogue(const GemmCore& c, const typename E
       }
       if (stats) {
         float sv = 0.f, qv = 0.f;
+        const bool first = m < next_start;
+        const bool row_ok = m < c.M && m < (first ? end0 : end1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float ev = (r < nvalid && m < c.M) ? acc[i][j][r] : 0.f;
+          const float ev = (r < nvalid && row_ok) ? acc[i][j][r] : 0.f;
           sv += ev;
           qv += ev * ev;
         }
-        const bool first = m < next_start;
         s0[i] += first ? sv : 0.f;
         q0[i] += first ? qv : 0.f;
         s1[i] += first ? 0.f : sv;
@@ -885,6 +893,8 @@ static inline EpiStdArgs make_epi_std(const GemmArgs& a) {
   e.gn_ncol16 = a.gn_ncol16;
   e.act_t = a.act_t; e.slope_t = a.slope_t;
   e.gn_seq = make_fastdiv(a.gn_seq > 0 ? a.gn_seq : 1);
+  e.gn_vperiod = a.gn_part ? a.gn_vperiod : 0;
+  for (int i = 0; i < 32; ++i) e.gn_vlen[i] = a.gn_vlen[i];
   return e;
 }
 

@@ -37,7 +37,10 @@ struct tt_ar {
   int* next_tok = nullptr;
   int* count_host = nullptr;  // pinned
   int max_rows = 0;
-  int P1 = 0;      // current prefix length (incl. start token)
+  int P1 = 0;      // current prefix length (incl. start token); with several groups the longest one
+  int G = 1;       // utterances (groups) of the current batch, each with its own prefix: kp / vp are [group][layer][H][max_prefix][64]
+  int P1g[16] = {0};
+  unsigned prefilled = 0;  // bit g: group g's prefix has been evaluated for the current batch
   int B = 0;       // current batch
   int logits_rows = 0;
   bool logits_from_prefill = false;
@@ -69,11 +72,12 @@ static int ar_rownorm(tt_ar* e, float* x, int M, const float* g1, const float* b
   a.g1 = g1; a.b1 = b1; a.eps1 = 1e-5f;
   a.g2 = g2; a.b2 = b2; a.eps2 = 1e-5f;
   a.out_t = e->h; a.ldot = e->D;
+  a.row_blocks = 1;
   return rownorm_launch(e->cfg.dtype, a, s);
 }
 
 // GPT2Model.forward over full sequences (causal), in place on e->x [B*n][D].
-static int gpt_trunk_full(tt_ar* e, int B, int n, bool to_prefix, hipStream_t s) {
+static int gpt_trunk_full(tt_ar* e, int B, int n, bool to_prefix, hipStream_t s, int group = 0) {
   const int D = e->D, H = e->H, M = B * n, dt = e->cfg.dtype;
   const int n_pad = round_up(n, 32);
   for (int l = 0; l < e->cfg.layers; ++l) {
@@ -82,8 +86,9 @@ static int gpt_trunk_full(tt_ar* e, int B, int n, bool to_prefix, hipStream_t s)
     GemmArgs g = ar_gemm(e, e->h, D, w.w_qkv, D, M, 3 * D, D);
     g.bias = w.b_qkv; g.seq_len = n; g.dmodel = D; g.heads = H;
     g.q = e->q;
-    g.k = to_prefix ? offset_t(e->kp, (size_t)l * e->prefix_layer_elems) : e->kfull;
-    g.v = to_prefix ? offset_t(e->vp, (size_t)l * e->prefix_layer_elems) : nullptr;
+    const size_t pl = ((size_t)group * e->cfg.layers + l) * e->prefix_layer_elems;
+    g.k = to_prefix ? offset_t(e->kp, pl) : e->kfull;
+    g.v = to_prefix ? offset_t(e->vp, pl) : nullptr;
     g.vt = e->vt; g.seq_pad = n_pad; g.q_scale = 0.125f;
     TT_TRY(gemm_launch(dt, EPI_QKV_HEADS, g, s));
     FlashArgs f;
@@ -124,7 +129,7 @@ static int pick_split(int B, int N, int K) {
 // lm_head = Sequential(final_norm, mel_head) applied to ln_f(x) (autoregressive.py:42, 174)
 // lat_index: >= 0 files the normalised row(s) as that latent (prefill: 0); -1: under the device-side step counter (decode step
 // feeding token i - 1 produces latent i); -2: no capture
-static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, hipStream_t s, int lat_index = -2) {
+static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, hipStream_t s, int lat_index = -2, int logits_row0 = 0) {
   {
     RowNormArgs a;
     memset(&a, 0, sizeof(a));
@@ -137,6 +142,7 @@ static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, 
     a.g1 = e->w.lnf_g; a.b1 = e->w.lnf_b; a.eps1 = 1e-5f;
     a.g2 = e->w.final_norm_g; a.b2 = e->w.final_norm_b; a.eps2 = 1e-5f;
     a.out_t = e->h; a.ldot = e->D;
+    a.row_blocks = 1;
     if (e->lat && lat_index != -2 && M <= e->lat_batch) {
       a.out_f32 = e->lat; a.ldo32 = e->D;
       a.f32_slot_stride = (size_t)e->lat_batch * e->D;
@@ -146,9 +152,9 @@ static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, 
     TT_TRY(rownorm_launch(e->cfg.dtype, a, s));
   }
   GemmArgs g = ar_gemm(e, e->h, e->D, e->w.w_mel_head, e->D, M, e->V, e->D);
-  g.bias = e->w.b_mel_head; g.out_f32 = e->logits; g.ldo32 = e->V;
+  g.bias = e->w.b_mel_head; g.out_f32 = e->logits + (size_t)logits_row0 * e->V; g.ldo32 = e->V;
   TT_TRY(gemm_launch(e->cfg.dtype, EPI_STD, g, s));
-  e->logits_rows = M;
+  e->logits_rows = logits_row0 + M;
   return 0;
 }
 
@@ -174,6 +180,11 @@ static int decode_step_enqueue(tt_ar* e, hipStream_t s, bool embedded = false) {
     a.q = e->q;
     a.kp = offset_t(e->kp, (size_t)l * e->prefix_layer_elems);
     a.vp = offset_t(e->vp, (size_t)l * e->prefix_layer_elems);
+    if (e->G > 1) {
+      a.ngroups = e->G; a.group_size = B / e->G;
+      a.prefix_group_stride = (size_t)e->cfg.layers * e->prefix_layer_elems;
+      for (int gi = 0; gi < e->G; ++gi) a.p1_tab[gi] = e->P1g[gi];
+    }
     a.P1 = e->P1; a.kc = g.kc; a.vc = g.vc; a.tmax = e->tmax; a.step = e->state + 1;
     a.out = e->attn; a.B = B; a.heads = H; a.host_tgen = e->host_slot + 1;
     TT_TRY(decode_attention_launch(dt, a, s));
@@ -205,8 +216,10 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
   TT_REQUIRE(cfg->max_batch > 0 && cfg->max_prefix > 1 && cfg->max_new_tokens > 0, "tt_ar_create: bad capacity");
   TT_REQUIRE(cfg->vocab <= 10240, "tt_ar_create: vocab %d exceeds the sampler's 10240 limit", cfg->vocab);
   TT_REQUIRE(cfg->mel_pos_offset == 1 || cfg->mel_pos_offset == 2, "tt_ar_create: mel_pos_offset must be 2 (kv_cache=True rule) or 1 (kv_cache=False rule), got %d", cfg->mel_pos_offset);
+  TT_REQUIRE(cfg->max_groups >= 0 && cfg->max_groups <= 16, "tt_ar_create: max_groups %d outside 0 .. 16", cfg->max_groups);
   tt_ar* e = new tt_ar();
   e->cfg = *cfg;
+  if (e->cfg.max_groups < 1) e->cfg.max_groups = 1;
   e->w = *w;
   e->L.assign(w->layers_host, w->layers_host + cfg->layers);
   e->D = cfg->model_dim; e->H = cfg->heads; e->V = cfg->vocab;
@@ -218,8 +231,8 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
   e->prefix_layer_elems = (size_t)H * cfg->max_prefix * 64;
   e->gen_layer_elems = (size_t)cfg->max_batch * H * e->tmax * 64;
   const int npad_max = round_up(e->max_rows, 32) + 32;
-  if (!rc) rc = e->arena.alloc(&e->kp, (e->prefix_layer_elems * cfg->layers + 4096) * 2);
-  if (!rc) rc = e->arena.alloc(&e->vp, (e->prefix_layer_elems * cfg->layers + 4096) * 2);
+  if (!rc) rc = e->arena.alloc(&e->kp, (e->prefix_layer_elems * cfg->layers * e->cfg.max_groups + 4096) * 2);
+  if (!rc) rc = e->arena.alloc(&e->vp, (e->prefix_layer_elems * cfg->layers * e->cfg.max_groups + 4096) * 2);
   if (!rc) rc = e->arena.alloc(&e->kc, (e->gen_layer_elems * cfg->layers + 4096) * 2);
   if (!rc) rc = e->arena.alloc(&e->vc, (e->gen_layer_elems * cfg->layers + 4096) * 2);
   if (!rc) rc = e->arena.alloc_t(&e->x, rows * D);
@@ -262,14 +275,24 @@ void tt_ar_destroy(tt_ar* e) {
   delete e;
 }
 
-int tt_ar_prefill(tt_ar* e, const float* prefix_emb, int P, void* stream) {
+int tt_ar_prefill_group(tt_ar* e, int group, int n_groups, const float* prefix_emb, int P, void* stream) {
   TT_REQUIRE(e && prefix_emb, "tt_ar_prefill: null argument");
+  TT_REQUIRE(n_groups >= 1 && n_groups <= e->cfg.max_groups && group >= 0 && group < n_groups, "tt_ar_prefill_group: group %d of %d (capacity %d groups)", group, n_groups, e->cfg.max_groups);
   TT_REQUIRE(P >= 1 && P + 1 <= e->cfg.max_prefix, "tt_ar_prefill: prefix of %d rows exceeds capacity %d", P + 1, e->cfg.max_prefix);
   hipStream_t us = (hipStream_t)stream, s = e->sb.own;
   TT_TRY(e->sb.enter(us));
   const int D = e->D;
-  e->P1 = P + 1;
-  e->prefix_layer_elems = (size_t)e->H * e->P1 * 64;  // dense per-layer stride for this prefix length
+  if (n_groups != e->G || group == 0) {  // a new batch starts with its group 0
+    e->G = n_groups;
+    e->prefilled = 0;
+  }
+  const int P1 = P + 1;
+  e->P1g[group] = P1;
+  e->prefilled |= 1u << group;
+  e->P1 = 0;
+  for (int gi = 0; gi < n_groups; ++gi)
+    if ((e->prefilled >> gi) & 1u) e->P1 = std::max(e->P1, e->P1g[gi]);
+  // per-layer stride of the prefix cache = its capacity (H * max_prefix * 64): group g, layer l at (g * layers + l) strides
   TT_CHECK_HIP(hipMemcpyAsync(e->x, prefix_emb, (size_t)P * D * sizeof(float), hipMemcpyDeviceToDevice, s));
   // start-token row: mel_embedding[start] + mel_pos_embedding[0]  (autoregressive.py:137-141)
   {
@@ -281,15 +304,17 @@ int tt_ar_prefill(tt_ar* e, const float* prefix_emb, int P, void* stream) {
     a.write_x = 1; a.mode = NORM_NONE;
     TT_TRY(rownorm_launch(e->cfg.dtype, a, s));
   }
-  TT_TRY(gpt_trunk_full(e, 1, e->P1, true, s));
+  TT_TRY(gpt_trunk_full(e, 1, P1, true, s, group));
   const int B_saved = e->B;
   e->B = 1;
-  int rc = ar_head(e, e->x + (size_t)P * D, 1, nullptr, 0, s, 0);
+  int rc = ar_head(e, e->x + (size_t)P * D, 1, nullptr, 0, s, group == 0 ? 0 : -2, group);  // logits row `group`
   e->B = B_saved;
   TT_TRY(rc);
-  e->logits_from_prefill = true;
+  e->logits_from_prefill = e->prefilled == (n_groups >= 32 ? ~0u : (1u << n_groups) - 1u);
   return e->sb.leave(us);
 }
+
+int tt_ar_prefill(tt_ar* e, const float* prefix_emb, int P, void* stream) { return tt_ar_prefill_group(e, 0, 1, prefix_emb, P, stream); }
 
 int tt_ar_get_logits(tt_ar* e, float* dst, int rows, void* stream) {
   TT_REQUIRE(e && dst && rows >= 1 && rows <= e->logits_rows, "tt_ar_get_logits: %d rows requested, %d available", rows, e ? e->logits_rows : 0);
@@ -339,6 +364,11 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
   sa.codes = codes; sa.ldcodes = ldcodes; sa.next_tok = e->next_tok; sa.unfinished_count = e->unfinished_count;
   sa.embed_x = e->x; sa.tok_emb = e->w.mel_emb; sa.pos_emb = e->w.mel_pos; sa.D = e->D; sa.pos_offset = e->cfg.mel_pos_offset;
   sa.pos_len = e->cfg.mel_pos_len;
+  if (e->G > 1) {
+    TT_REQUIRE(B % e->G == 0 && (B / e->G) % 4 == 0, "tt_ar_generate: %d sequences do not split into %d groups of a multiple of 4", B, e->G);
+    sa.ngroups = e->G; sa.group_size = B / e->G;
+    for (int gi = 0; gi < e->G; ++gi) sa.group_seeds[gi] = sp->group_seeds ? sp->group_seeds[gi] : sp->seed;
+  }
   if (fresh) {
     e->B = B;
     e->gen_done = 0;
@@ -347,7 +377,7 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
     TT_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)codes, e->cfg.stop_mel_token, (size_t)B * ldcodes, s));
     // token 0: every row samples from the shared prefill logits
     sa.logits = e->logits; sa.ldl = 0;
-    TT_REQUIRE(e->logits_from_prefill, "tt_ar_generate: the logits buffer does not hold prefill logits; call tt_ar_prefill first");
+    TT_REQUIRE(e->logits_from_prefill, "tt_ar_generate: the logits buffer does not hold the prefill logits of all %d group(s); call tt_ar_prefill / tt_ar_prefill_group first", e->G);
     e->logits_from_prefill = false;
     TT_TRY(sample_launch(sa, s));
     TT_TRY(ar_state_advance_launch(e->state, s));

@@ -208,8 +208,9 @@ template <typename T>
 __global__ void psample_kernel(PSampleArgs a) {
   const int S = a.S, C = a.C;
   const long total = (long)S * a.cpad;
+  const int ld = a.ld_rows > 0 ? a.ld_rows : S;  // rows between the conditioned and the conditioning-free batch row
   const float* oc = a.out;
-  const float* ou = a.out + (size_t)S * 2 * C;
+  const float* ou = a.out + (size_t)ld * 2 * C;
   const int slot = *a.slot;
   const PSampleStep st = a.steps[slot];
   const float* noise = a.noise ? a.noise + (size_t)slot * C * S : nullptr;
@@ -234,7 +235,7 @@ __global__ void psample_kernel(PSampleArgs a) {
     if (a.x_t) {
       T* d = (T*)a.x_t;
       d[(size_t)s * a.cpad + c] = xt;
-      d[((size_t)S + s) * a.cpad + c] = xt;
+      if (a.has_uncond) d[((size_t)ld + s) * a.cpad + c] = xt;  // the conditioning-free batch row reads the same state
     }
   }
 }

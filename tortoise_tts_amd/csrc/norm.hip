@@ -294,7 +294,7 @@ int rownorm_launch(int dtype, const RowNormArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.ldx % 4 == 0, "rownorm: ldx must be a multiple of 4");
   ProfScope ps(PROF_ROWNORM, stream, 0.0, (double)a.M * a.D * (4.0 * (1 + a.nslab + (a.write_x ? 1 : 0)) + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)), true);
   // few rows (decode): one block per row keeps 4x more loads in flight; many rows: wave per row, no barriers
-  if (a.D <= 1024 && a.M >= 1024) {
+  if (a.D <= 1024 && a.M >= 1024 && !a.row_blocks) {
     if (dtype == DT_BF16) launch_timed(ps, rownorm_wave_kernel<bf16>, dim3(cdiv(a.M, 4)), dim3(256), 0, stream, a);
     else launch_timed(ps, rownorm_wave_kernel<f16>, dim3(cdiv(a.M, 4)), dim3(256), 0, stream, a);
   } else {
@@ -315,9 +315,12 @@ constexpr int GN_ROWS = 16;
 constexpr int GN_MAX_CHUNKS = 64;  // the apply kernel's finalize prologue reduces <= 8 partials per thread
 static inline int gn_rows_per_chunk(int S) { return std::max(GN_ROWS, cdiv(S, GN_MAX_CHUNKS)); }
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int S, int C, float* __restrict__ partial, int rows_per_chunk) {
+// (vl: valid rows of sample b in a padded batch, see GroupNormArgs::vlen; a chunk past them contributes zeros)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int S, int C, float* __restrict__ partial, int rows_per_chunk,
+                                                       GroupNormArgs va) {
   __shared__ float ls[256][2];
   const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
+  const int vl = va.vperiod > 0 ? va.vlen[b % va.vperiod] : S;
   const int tid = threadIdx.x;
   const int c4n = C >> 2;                       // float4 columns per row
   const int CL = c4n < 256 ? c4n : 256;         // column lanes
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   const int cl = tid % CL, rl = tid / CL;
   const int cpg4 = (C / 32) >> 2;               // float4 columns per group
   const int r0 = chunk * rows_per_chunk;
-  const int r1 = min(S, r0 + rows_per_chunk);
+  const int r1 = min(vl, r0 + rows_per_chunk);
   // With C > 1024 a thread owns several columns in different groups: handle one column set per pass.
   for (int cb = 0; cb < c4n; cb += 256) {
     float s = 0.f, q = 0.f;
@@ -440,7 +443,8 @@ __device__ __forceinline__ void gn_finalize(const GroupNormArgs& a, int b, int t
     }
     // the sums are combined in fp64 (E[x^2] - E[x]^2 cancels in fp32); the reciprocal square root of the O(1) result is an
     // fp32 instruction, not an fp64 divide + square root (hundreds of cycles on the one wave every block waits for)
-    const double inv_n = a.inv_count;  // 1 / (S * C / 32), set by groupnorm_launch
+    // 1 / (S * C / 32), set by groupnorm_launch; a padded batch counts the sample's valid rows only
+    const double inv_n = a.vperiod > 0 ? 1.0 / ((double)a.vlen[b % a.vperiod] * (double)(a.C / 32)) : a.inv_count;
     const double m = ss * inv_n;
     double var = qq * inv_n - m * m;
     if (var < 0.0) var = 0.0;
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchu
   const int r0 = chunk * rows_per_block;
   const int r1 = min(S, r0 + rows_per_block);
   const int total = (r1 - r0) * c4n;
+  const int vl = a.vperiod > 0 ? a.vlen[b % a.vperiod] : S;
   for (int f = tid; f < total; f += 256) {
     const int r = r0 + f / c4n;
     const int c = (f % c4n) * 4;
@@ -492,6 +497,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchu
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[i] = apply_act(y[i], a.act, 0.f);
     }
+    if (r >= vl) y[0] = y[1] = y[2] = y[3] = 0.f;  // padding rows of a shorter sequence: exact zeros (the next conv's zero padding)
     if (a.out_t) *(typename Vec<T>::x4*)((T*)a.out_t + off * a.ldot + c) = pack4<T>(y[0], y[1], y[2], y[3]);
     if (a.out_f32) *(float4*)(a.out_f32 + off * a.ldo32 + c) = make_float4(y[0], y[1], y[2], y[3]);
   }
@@ -529,6 +535,7 @@ __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, in
   __builtin_amdgcn_sched_barrier(0);  // keep every request above in flight before the first consumer waits
   gn_finalize<1>(a, b, tid, nchunk, mean_s, rstd_s, part_s, part_q, FUSED ? head : nullptr);
   const float mu = mean_s[tid >> 3], rs = rstd_s[tid >> 3];
+  const int vl = a.vperiod > 0 ? a.vlen[b % a.vperiod] : S;
 #pragma unroll
   for (int i = 0; i < GN_APPLY_ROWS; ++i) {
     const int r = r0 + i;
@@ -546,6 +553,7 @@ __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, in
 #pragma unroll
       for (int k = 0; k < 4; ++k) y[k] = apply_act(y[k], a.act, 0.f);
     }
+    if (r >= vl) y[0] = y[1] = y[2] = y[3] = 0.f;  // padding rows of a shorter sequence: exact zeros
     const size_t off = (size_t)b * S + r;
     if (a.out_t) *(typename Vec<T>::x4*)((T*)a.out_t + off * a.ldot + c) = pack4<T>(y[0], y[1], y[2], y[3]);
     if (a.out_f32) *(float4*)(a.out_f32 + off * a.ldo32 + c) = make_float4(y[0], y[1], y[2], y[3]);
@@ -568,7 +576,7 @@ int groupnorm_launch(int dtype, const GroupNormArgs& a0, hipStream_t stream) {
     TT_REQUIRE((a.C / 32) % 16 == 0 && (spg == 1 || spg == 2 || spg == 4) && a.part_rows > 0 && (a.part_rows & (a.part_rows - 1)) == 0 && a.S >= a.part_rows,
                "groupnorm: fused statistics need 16 / 32 / 64 channels per group, a power-of-two row tile and S >= the row tile");
   } else {
-    gn_stats_kernel<<<grid, 256, 0, stream>>>(a.x, a.S, a.C, a.partial, rpc);
+    gn_stats_kernel<<<grid, 256, 0, stream>>>(a.x, a.S, a.C, a.partial, rpc, a);
     TT_CHECK_HIP(hipGetLastError());
   }
   const int rpb = GN_APPLY_ROWS;  // apply is pure streaming: many small blocks

@@ -36,6 +36,7 @@ struct RowNormArgs {
   const int* f32_slot;
   int f32_slot_base;
   size_t f32_slot_stride;
+  int row_blocks;      // 1: always one workgroup per row (the decode step: a row's arithmetic order must not depend on how many rows the batch has)
 };
 int rownorm_launch(int dtype, const RowNormArgs& a, hipStream_t stream);
 
@@ -59,6 +60,11 @@ struct GroupNormArgs {
                            // run_epilogue) as [row_tile][2][C/16][2]; the separate statistics pass is skipped
   int part_rows;           // rows per row tile of gemm_part
   double inv_count;        // set by groupnorm_launch: 1 / (S * C / 32)
+  // padded batches (several utterances of different lengths in one pass): sample b has vlen[b % vperiod] valid rows <= S; the
+  // statistics cover the valid rows only and the rows beyond them are written as ZEROS (they are the zero padding the next
+  // convolution sees past the end of a shorter sequence).  vperiod == 0: every sample has S rows.
+  int vperiod;
+  int vlen[32];
 };
 int groupnorm_launch(int dtype, const GroupNormArgs& a, hipStream_t stream);
 size_t groupnorm_partial_floats(int B, int S);
@@ -73,6 +79,10 @@ struct FlashArgs {
   int BH, heads, n, n_pad;
   int causal;
   const float* relpos;  // optional [heads][129] additive bias indexed by clamp(key - query, -64, 64) + 64
+  // padded batches: batch row b attends to its first nv[b % nv_period] keys only (and only those queries are computed); n stays
+  // the row stride of the operands.  nv_period == 0: all n rows are valid.
+  int nv_period;
+  int nv[32];
 };
 int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream);
 
@@ -89,6 +99,11 @@ struct DecodeAttnArgs {
   void* out;        // [B][heads*64]
   int B, heads;
   int variant;      // 0: chosen from the shape; 1: per-wave prefix kernel; 2 / 3: shared-prefix kernel with 16 / 4 sequences per workgroup
+  // several utterances in one batch (ngroups > 1): sequence b belongs to group b / group_size, whose prefix K / V start
+  // prefix_group_stride ELEMENTS after the previous group's and hold p1_tab[group] rows (P1 = the largest of them: LDS sizing)
+  int ngroups, group_size;
+  size_t prefix_group_stride;
+  int p1_tab[16];
 };
 int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stream);
 
@@ -116,6 +131,10 @@ struct SampleArgs {
   const float* pos_emb;
   int D, pos_offset;
   int pos_len;               // rows of pos_emb: the embedding of a token whose position lies beyond the table is skipped (it is never fed)
+  // several utterances in one batch (ngroups > 1): row b is candidate b % group_size of group b / group_size; Philox key
+  // group_seeds[group], broadcast logits (ldl == 0) row `group`
+  int ngroups, group_size;
+  unsigned long long group_seeds[16];
 };
 int sample_launch(const SampleArgs& a, hipStream_t stream);
 int ar_state_advance_launch(int* state, hipStream_t stream);
@@ -167,6 +186,7 @@ struct PSampleArgs {
   int S, C;
   float* mel_out;       // optional [C][S] channels-first denormalised mel written on the last step
   float mel_scale, mel_shift;
+  int ld_rows;          // rows between the two batch rows of `out` / `x_t` (0: S; padded batches: the common padded length)
 };
 int psample_launch(int dtype, const PSampleArgs& a, hipStream_t stream);
 int slot_advance_launch(int* slot, const float* ss_all, float* ss_cur, int row_floats, int last_slot, hipStream_t stream);

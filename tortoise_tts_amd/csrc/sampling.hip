@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int V = a.V;
   const int step = a.state[0];
-  const float* lg = a.logits + (size_t)b * a.ldl;
+  const int grp = a.ngroups > 1 ? b / a.group_size : 0;  // utterance of this row (block-uniform)
+  const float* lg = a.logits + (a.ldl ? (size_t)b * a.ldl : (size_t)grp * V);
   unsigned* seen = a.seen + (size_t)b * ((V + 31) / 32);
   constexpr int PER = 40;  // supports V <= 10240
   float val[PER];
@@ -227,7 +228,9 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       q = a.exp_noise[((size_t)step * a.B + b) * V + id];
     } else {
       unsigned r[4];
-      philox4x32_10((unsigned)id, (unsigned)step, (unsigned)(a.row_offset + b), 0u, (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
+      const unsigned long long key = a.ngroups > 1 ? a.group_seeds[grp] : a.seed;
+      const int cand = a.ngroups > 1 ? b - grp * a.group_size : b;  // index within the utterance: the draw does not depend on the batching
+      philox4x32_10((unsigned)id, (unsigned)step, (unsigned)(a.row_offset + cand), 0u, (unsigned)key, (unsigned)(key >> 32), r);
       const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
       q = -__logf(u);
     }
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
 
 int sample_launch(const SampleArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.B > 0 && a.V > 0 && a.V <= 10240, "sample: V=%d unsupported (<= 10240)", a.V);
+  TT_REQUIRE(a.ngroups <= 1 || (a.ngroups <= 16 && a.group_size > 0 && a.B == a.ngroups * a.group_size), "sample: %d groups of %d rows do not make %d rows", a.ngroups, a.group_size, a.B);
   TT_REQUIRE(a.top_k > 0 && a.top_k <= 256, "sample: top_k=%d unsupported (1..256; HF default 50)", a.top_k);
   TT_REQUIRE(a.temperature > 0.f && a.top_p > 0.f && a.rep_penalty > 0.f, "sample: bad sampling parameters");
   ProfScope ps(PROF_SAMPLE, stream, 0.0, (double)a.B * a.V * 4.0, true);

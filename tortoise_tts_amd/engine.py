@@ -27,7 +27,7 @@ class GptLayer(C.Structure):
 class ArConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("dtype", "layers", "model_dim", "heads", "vocab", "start_mel_token", "stop_mel_token",
                                        "mel_pos_len", "max_batch", "max_prefix", "max_new_tokens", "max_full_rows",
-                                       "mel_pos_offset")]
+                                       "mel_pos_offset", "max_groups")]
 
 
 class ArWeights(C.Structure):
@@ -37,7 +37,7 @@ class ArWeights(C.Structure):
 
 class Sampling(C.Structure):
     _fields_ = [("temperature", C.c_float), ("top_p", C.c_float), ("repetition_penalty", C.c_float), ("top_k", C.c_int),
-                ("seed", C.c_ulonglong), ("row_offset", C.c_int), ("exp_noise", vp)]
+                ("seed", C.c_ulonglong), ("row_offset", C.c_int), ("exp_noise", vp), ("group_seeds", C.POINTER(C.c_ulonglong))]
 
 
 class ClvpLayer(C.Structure):
@@ -134,6 +134,7 @@ _PROTOS = {
     "tt_ar_create": (_i, [C.POINTER(ArConfig), C.POINTER(ArWeights), C.POINTER(vp)]),
     "tt_ar_destroy": (None, [vp]),
     "tt_ar_prefill": (_i, [vp, vp, _i, vp]),
+    "tt_ar_prefill_group": (_i, [vp, _i, _i, vp, _i, vp]),
     "tt_ar_get_logits": (_i, [vp, vp, _i, vp]),
     "tt_ar_generate": (_i, [vp, _i, _i, C.POINTER(Sampling), vp, C.POINTER(_i), vp]),
     "tt_ar_generate_chunk": (_i, [vp, _i, _i, _i, _i, C.POINTER(Sampling), vp, C.POINTER(_i), C.POINTER(_i), vp]),

@@ -5,6 +5,8 @@ the same seed (read.py:66-71) and concatenates the clips (read.py:87).  Chunks a
 node they are spread over the ranks as replicas: chunk j -> rank j % R, every rank runs the complete pipeline
 for its chunks on its own GPU (no candidate sharding, no collective on the data path), rank 0 receives the clips point to
 point and concatenates them in chunk order.  The audio of a chunk does not depend on R: same seed, same GPU-local pipeline.
+With TextToSpeech(utterance_batch=G) a rank renders its chunks G at a time (tts_many): the candidates of G chunks share one decode
+batch - per-chunk codes bit-identical to the sequential order - which is what 288 GB of HBM per GPU are for.
 """
 import torch
 
@@ -36,10 +38,20 @@ def read_long_form(tts, text, preset="standard", conditioning_latents=None, voic
         seed = int(time.time())
     seed = tdist.broadcast_int(seed)
     mine = {}
-    for j, chunk in enumerate(texts):
-        if chunk_owner(j, world) != rank:
-            continue
-        gen = tts.tts_with_preset(chunk, voice_samples=voice_samples, conditioning_latents=conditioning_latents, preset=preset, k=1,
+    my_chunks = [j for j in range(len(texts)) if chunk_owner(j, world) == rank]
+    if getattr(tts, "utterance_batch", 1) > 1 and len(my_chunks) > 1:
+        # this rank's chunks share decode batches (TextToSpeech.tts_many): same seed, same per-chunk codes as one after the other
+        from .config import BASE_SETTINGS, PRESETS
+        settings = dict(BASE_SETTINGS)
+        settings.update(PRESETS[preset])
+        settings.update(tts_kwargs)
+        settings.pop("k", None)
+        wavs = tts.tts_many([texts[j] for j in my_chunks], voice_samples=voice_samples, conditioning_latents=conditioning_latents,
+                            use_deterministic_seed=seed, **settings)
+        mine = {j: w.cpu() for j, w in zip(my_chunks, wavs)}
+        my_chunks = []
+    for j in my_chunks:
+        gen = tts.tts_with_preset(texts[j], voice_samples=voice_samples, conditioning_latents=conditioning_latents, preset=preset, k=1,
                                   use_deterministic_seed=seed, **tts_kwargs)  # read.py:70-71
         mine[j] = gen.cpu()
     parts = tdist.collect_on_rank0(mine, len(texts))

@@ -43,7 +43,7 @@ class ArStage:
     """UnifiedVoice hot path: prefill + sampling loop + latent re-pass (autoregressive.py:454-563)."""
 
     def __init__(self, sd, cfg: ARConfig = ARConfig(), device="cuda", dtype=E.TT_BF16, max_batch=256, max_text=402,
-                 max_new_tokens=500, max_latent_candidates=4, share_weights_with=None, kv_cache=True):
+                 max_new_tokens=500, max_latent_candidates=4, share_weights_with=None, kv_cache=True, max_groups=1):
         self.lib = E.init()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -63,6 +63,8 @@ class ArStage:
         # TextToSpeech(kv_cache=...) only changes WHICH mel position row a generated token gets (autoregressive.py:134-149):
         # the engine always keeps a KV cache; kv_cache=False (the reference default) selects rows 0,1,2,... instead of 0,2,3,...
         c.mel_pos_offset = 2 if kv_cache else 1
+        c.max_groups = max_groups  # utterances decoded in one batch (prefill_group); max_batch counts the sequences of all of them
+        self.max_groups = max_groups
         self.max_latent_candidates = max_latent_candidates
         self.ccfg = c
         self.h = E.vp()
@@ -93,6 +95,13 @@ class ArStage:
         self.P = emb.shape[0]
         E.check(self.lib.tt_ar_prefill(self.h, E.ptr(emb), self.P, E.stream_ptr()))
 
+    def prefill_group(self, group, n_groups, cond_latent, text_tokens):
+        """Prefix of utterance `group` of a batch of n_groups utterances that generate() then decodes together (sequences
+        [group * B / n_groups, (group + 1) * B / n_groups)).  Call for group 0 first."""
+        emb = self.prefix_embedding(cond_latent[:1], text_tokens[:1])[0].contiguous()
+        self.P = emb.shape[0]
+        E.check(self.lib.tt_ar_prefill_group(self.h, group, n_groups, E.ptr(emb), self.P, E.stream_ptr()))
+
     def logits(self, rows):
         out = torch.empty(rows, self.cfg.number_mel_codes, device=self.device, dtype=torch.float32)
         E.check(self.lib.tt_ar_get_logits(self.h, E.ptr(out), rows, E.stream_ptr()))
@@ -106,11 +115,15 @@ class ArStage:
         E.check(self.lib.tt_ar_decode_step(self.h, E.ptr(t), E.stream_ptr()))
 
     def generate(self, B, max_new, temperature=0.8, top_p=0.8, repetition_penalty=2.0, top_k=50, seed=0, row_offset=0,
-                 exp_noise=None):
-        """Returns (codes int64 [B, n_steps], n_steps).  exp_noise: optional f32 [max_new, B, V] Exp(1) draws."""
+                 exp_noise=None, group_seeds=None):
+        """Returns (codes int64 [B, n_steps], n_steps).  exp_noise: optional f32 [max_new, B, V] Exp(1) draws.
+        group_seeds: after prefill_group calls, one Philox key per utterance (default: `seed` for all of them)."""
         s = E.Sampling()
         s.temperature, s.top_p, s.repetition_penalty, s.top_k = temperature, top_p, repetition_penalty, top_k
         s.seed, s.row_offset = seed, row_offset
+        if group_seeds is not None:
+            gs = (C.c_ulonglong * len(group_seeds))(*[int(v) for v in group_seeds])
+            s.group_seeds = C.cast(gs, C.POINTER(C.c_ulonglong))
         if exp_noise is not None:
             exp_noise = exp_noise.to(device=self.device, dtype=torch.float32).contiguous()
             assert exp_noise.shape == (max_new, B, self.cfg.number_mel_codes)
