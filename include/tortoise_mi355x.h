@@ -190,6 +190,7 @@ typedef struct tt_diff_config {
   int max_seq;                              /* max S */
   int max_codes;                            /* max M */
   int max_steps;
+  int max_batch;                            /* utterances one tt_diff_sample_batch run may hold, 1 .. 16 (0 is read as 1) */
 } tt_diff_config;
 typedef struct tt_diff_weights {
   /* timestep-independent conditioning (diffusion_decoder.py:232-255) */
@@ -238,6 +239,20 @@ int tt_diff_forward(tt_diff* h, const float* x, int timestep, int cond_free, flo
  * (utils/audio.py:59-64).  Each step replays one hipGraph. */
 int tt_diff_sample(tt_diff* h, const float* x_T, const float* step_noise, const tt_diff_step* steps_host, int n_steps,
                    int cond_free, float* mel_out, void* stream);
+
+/* Several utterances through ONE denoiser pass per step (long-form reading: tortoise/read.py:66-71 renders its chunks one after the
+ * other; BASELINE config #4 asks for them "batched through DiffusionTts").  The utterances may differ in length: every one is
+ * laid out in a slot of S_pad >= max S_u positions and handled EXACTLY as if it ran alone - GroupNorm statistics cover its own S_u
+ * positions, attention sees its own S_u keys, and the positions past S_u are kept at zero in every convolution operand, which is
+ * precisely the zero padding its convolutions read at the sequence end (arch_util.py / diffusion_decoder.py Conv1d padding=1).
+ *   tt_diff_batch_begin    : U utterances, common padded length S_pad
+ *   tt_diff_condition_slot : tt_diff_condition for utterance u (its own M codes, its own S <= S_pad)
+ *   tt_diff_sample_batch   : tt_diff_sample for all of them on one schedule; x_T[u] f32 [in][S_u], step_noise[u] f32
+ *                            [n_steps][in][S_u], mel_out[u] f32 [in][S_u] (HOST arrays of U device pointers) */
+int tt_diff_batch_begin(tt_diff* h, int U, int S_pad, void* stream);
+int tt_diff_condition_slot(tt_diff* h, int u, const float* latents, int M, const float* cond, const int* interp_idx, int S, void* stream);
+int tt_diff_sample_batch(tt_diff* h, int U, const float* const* x_T, const float* const* step_noise, const tt_diff_step* steps_host,
+                         int n_steps, int cond_free, float* const* mel_out, void* stream);
 
 /* Split sampling (the reference evaluates both rows on one device, utils/diffusion.py:340-384): the
  * conditioned and the conditioning-free denoiser rows of ONE utterance run on two GPUs.  Every participant holds the

@@ -114,8 +114,19 @@ class FakeClvpStage:
 
 
 class FakeDiffusionStage:
-    def __init__(self, sd, cfg, device="cpu", dtype=0, max_seq=0, max_codes=0, max_steps=0):
-        self.sd, self.cfg = sd, cfg
+    def __init__(self, sd, cfg, device="cpu", dtype=0, max_seq=0, max_codes=0, max_steps=0, max_batch=1):
+        self.sd, self.cfg, self.max_batch = sd, cfg, max_batch
+
+    def sample_many(self, sched, items):
+        """The engine pushes the utterances through shared denoiser passes with every one treated as if alone (tests/test_gpu_parity_r3.py):
+        the stand-in renders them alone."""
+        assert 1 <= len(items) <= self.max_batch
+        self.batched = getattr(self, "batched", []) + [len(items)]
+        out = []
+        for lat, cond, S, x_T, noise in items:
+            self.condition(lat, cond, S)
+            out.append(self.sample(sched, x_T, noise))
+        return out
 
     def condition(self, latents, cond_latent, S):
         self.S = S

@@ -94,6 +94,7 @@ def test_tts_many_equals_one_utterance_after_the_other(monkeypatch):
     one_by_one = [t.tts(x, conditioning_latents=lat, use_deterministic_seed=5, verbose=False, **kw) for x in texts]
     many = t.tts_many(texts, conditioning_latents=lat, use_deterministic_seed=5, **kw)
     assert t.ar.group_batches == 1  # 3 utterances, 2 per decode batch: one grouped generation + one single
+    assert t.diffusion.batched == [2]  # and the same for the denoiser passes: the two nearest in length together, one alone
     assert len(many) == 3 and all(torch.equal(a, b) for a, b in zip(many, one_by_one))
     assert set(t.timings) >= {"ar_s", "diffusion_s", "total_s"}
     # what the grouped decode cannot hold falls back to tts() per utterance (same results): a candidate count that is not a multiple of 4

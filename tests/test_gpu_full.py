@@ -143,11 +143,21 @@ def test_tts_many_shares_decode_batches_and_equals_tts_per_text(full):
     g = torch.Generator().manual_seed(11)
     texts = [torch.randint(1, 255, (n,), generator=g) for n in (23, 61, 40)]
     kw = dict(conditioning_latents=latents, num_autoregressive_samples=16, diffusion_iterations=4, max_mel_tokens=36)
-    one_by_one = [tts.tts(t, use_deterministic_seed=7, verbose=False, **kw) for t in texts]
+    one_by_one, codes = [], []
+    for t in texts:
+        one_by_one.append(tts.tts(t, use_deterministic_seed=7, verbose=False, **kw))
+        codes.append(tts.last_best_codes.clone())
+    tts.batch_diffusion = False  # shared decode batches only: every clip bit-identical to tts() alone
     many = tts.tts_many(texts, use_deterministic_seed=7, **kw)
     assert len(many) == 3
     for a, b in zip(many, one_by_one):
         assert a.shape == b.shape and torch.equal(a, b), "an utterance rendered inside a shared decode batch differs from tts() alone"
+    tts.batch_diffusion = True   # + shared denoiser passes (padded to the longest): same winner, clip within the operand tolerance
+    many = tts.tts_many(texts, use_deterministic_seed=7, **kw)
+    assert torch.equal(tts.last_best_codes, codes[-1])
+    for j, (a, b) in enumerate(zip(many, one_by_one)):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        report(f"tts_many (batched AR + batched denoiser) clip {j} bf16 vs tts() alone", a, b, 8e-2)
     assert tts.timings["ar_s"] > 0
     for st in (tts.ar, tts.clvp, tts.diffusion, tts.vocoder):
         st.close()

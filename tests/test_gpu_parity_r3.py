@@ -210,3 +210,80 @@ def test_tts_end_to_end_vs_composed_oracle_pipeline():
     report("END-TO-END tts(noise_override) waveform f16 vs composed oracle pipeline", wav, want, 4e-2)
     for s_ in (tts.ar, tts.clvp, tts.diffusion, tts.vocoder):
         s_.close()
+
+
+def _utterances(cfg, Ms, steps, seed):
+    g = torch.Generator().manual_seed(seed)
+    items = []
+    for M in Ms:
+        S = M * 4 * 24000 // 22050
+        items.append((torch.randn(1, M, cfg.in_latent_channels, generator=g), torch.randn(1, 2 * cfg.model_channels, generator=g) * 0.5, S,
+                      torch.randn(1, 100, S, generator=g), torch.randn(steps, 1, 100, S, generator=g)))
+    return items
+
+
+@pytest.mark.parametrize("cond_free", [True, False])
+@torch.no_grad()
+def test_sample_many_treats_every_utterance_as_if_it_ran_alone(cond_free):
+    """tt_diff_sample_batch (BASELINE config #4: long-form chunks "batched through DiffusionTts"; the reference renders them one
+    after the other, read.py:66-71): three utterances of different lengths share every denoiser pass, padded to the longest.  Each
+    must come out as from sample() alone - its own GroupNorm statistics, its own attention span, zero padding past its own end.
+    Reduced width (statistics by the separate pass, whose row chunks are anchored at the sample start): bit-identical, as long as
+    the batch does not change WHICH attention kernel an utterance gets (sequences of <= 128 positions run the register-prefetch
+    flash kernel when alone and the LDS-staged one inside a longer batch: different key tiling, i.e. different bf16 rounding points
+    of the online softmax - that case is held to the operand tolerance instead)."""
+    cfg = DiffusionConfig(**G.DIFF_CFG)
+    sd = W.synthetic_state_dict(W.diffusion_manifest(cfg), seed=G.DIFF_SEED)
+    N = 6
+    items = _utterances(cfg, (46, 31, 38), N, 5)
+    sched = Schedule(N, 4000, cond_free, 2.0)
+    st = stages.DiffusionStage(sd, cfg, max_seq=256, max_codes=64, max_steps=16, max_batch=4)
+    alone = []
+    for lat, cond, S, x, nz in items:
+        st.condition(lat, cond, S)
+        alone.append(st.sample(sched, x, nz).clone())
+    many = st.sample_many(sched, items)
+    for u, (a, b) in enumerate(zip(many, alone)):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        print(f"[parity] sample_many (cond_free={cond_free}) utterance {u} S={a.shape[-1]} vs sample() alone: rel_l2={rel_err(a, b):.3e} max_abs={max_err(a, b):.3e}")
+        assert torch.equal(a, b), f"utterance {u} of the padded batch differs from the same utterance alone"
+    # any order, any subset: an utterance does not depend on its neighbours
+    again = st.sample_many(sched, [items[1], items[0]])
+    assert torch.equal(again[0], alone[1]) and torch.equal(again[1], alone[0])
+    # and the handle goes back to single-utterance work afterwards
+    st.condition(*items[2][:3])
+    assert torch.equal(st.sample(sched, items[2][3], items[2][4]), alone[2])
+    # a short utterance (52 positions) next to a long one: other attention kernel than alone -> operand tolerance
+    short = _utterances(cfg, (12,), N, 6)[0]
+    st.condition(*short[:3])
+    want = st.sample(sched, short[3], short[4]).clone()
+    got = st.sample_many(sched, [items[0], short])
+    assert torch.equal(got[0], alone[0])
+    report(f"sample_many (cond_free={cond_free}) 52-position utterance beside a 200-position one vs alone", got[1], want, 2.5e-2)
+    st.close()
+
+
+@torch.no_grad()
+def test_sample_many_full_width(sds):
+    """The same at the benchmarked width (1024 channels, 10 layers), where the GroupNorm statistics ride the producing GEMM's
+    epilogue in row-tile groups anchored at the start of the BATCH: the grouping of the f32 partial sums differs from the
+    single-utterance run (not the set of values summed).  A perturbation of one ulp of f32 flips a few bf16 roundings of the next
+    operand, and after three or four layers the rounding decisions of the two runs are uncorrelated - two equally valid
+    evaluations that differ by the operand noise floor.  So the bar is the operand tolerance of each type (fp16: 8x tighter,
+    which is what tells a masking error from rounding noise)."""
+    cfg = DiffusionConfig()
+    N = 5
+    items = _utterances(cfg, (60, 35), N, 9)
+    sched = Schedule(N, 4000, True, 2.0)
+    for name, dt, tdt, tol in DTYPES:
+        st = stages.DiffusionStage(sds["diffusion"], cfg, dtype=dt, max_seq=272, max_codes=64, max_steps=8, max_batch=2)
+        alone = []
+        for lat, cond, S, x, nz in items:
+            st.condition(lat, cond, S)
+            alone.append(st.sample(sched, x, nz).clone())
+        many = st.sample_many(sched, items)
+        for u, (a, b) in enumerate(zip(many, alone)):
+            r, m = rel_err(a, b), max_err(a, b)
+            print(f"[parity] FULL-WIDTH sample_many {name} utterance {u} S={a.shape[-1]} vs sample() alone: rel_l2={r:.3e} max_abs={m:.3e} (tol rel_l2 {tol:.1e})")
+            assert torch.isfinite(a).all() and r < tol
+        st.close()

@@ -162,8 +162,10 @@ class TextToSpeech:
                                  max_text=max_text_tokens, max_new_tokens=max_mel_tokens, max_latent_candidates=4, kv_cache=self.kv_cache,
                                  max_groups=self.utterance_batch)
         self.clvp = stages.ClvpStage(sd("clvp"), self.clvp_cfg, self.device, self.dtype, max_rows=max(cap, 8) * max_mel_tokens)
+        # tts_many also pushes utterance_batch utterances through ONE denoiser pass per diffusion step (padded to the longest)
+        self.batch_diffusion = self.utterance_batch > 1
         self.diffusion = stages.DiffusionStage(sd("diffusion"), self.diff_cfg, self.device, self.dtype, max_seq=max_S,
-                                               max_codes=max_mel_tokens + 8, max_steps=512)
+                                               max_codes=max_mel_tokens + 8, max_steps=512, max_batch=self.utterance_batch)
         voc_sd = sd("vocoder")
         if any(k.endswith("weight_v") for k in voc_sd):
             voc_sd = W.fold_weight_norm(voc_sd)  # UnivNetGenerator.eval(inference=True), vocoder.py:284-298
@@ -430,12 +432,55 @@ class TextToSpeech:
             codes = F.pad(codes, (0, max_mel_tokens - codes.shape[1]), value=stop)
             samples.extend(codes[g * N:(g + 1) * N] for g in range(len(wave)))
         ev.mark(1)
-        out, acc = [], {}
-        for t, smp in zip(toks, samples):
-            out.append(self.tts(t[0, :-1], conditioning_latents=conditioning_latents, k=1, verbose=verbose, use_deterministic_seed=seed,
-                                noise_override={"_ar_samples": smp}, **settings))
-            for k_, v in self.timings.items():
-                acc[k_] = acc.get(k_, 0.0) + v
+        out, acc = [None] * len(toks), {}
+        if not self.batch_diffusion:
+            for j, (t, smp) in enumerate(zip(toks, samples)):
+                out[j] = self.tts(t[0, :-1], conditioning_latents=conditioning_latents, k=1, verbose=verbose, use_deterministic_seed=seed,
+                                  noise_override={"_ar_samples": smp}, **settings)
+                for k_, v in self.timings.items():
+                    acc[k_] = acc.get(k_, 0.0) + v
+        else:
+            # ---- per utterance: CLVP winner + latent re-pass (api.py:447-524), then its diffusion inputs with the noise tts() would draw
+            diffusion_conditioning = conditioning_latents[1].to(dev).float()
+            sched = Schedule(int(settings.get("diffusion_iterations", 100)), self.diff_cfg.trained_steps, settings.get("cond_free", True),
+                             settings.get("cond_free_k", 2))
+            ev2 = _StageTimer(4)
+            ev2.mark(0)
+            items, zs = [], []
+            for t, smp in zip(toks, samples):
+                fixed = fix_autoregressive_output(smp.to(dev).long(), stop)
+                scores = self.clvp.score(t, fixed)
+                best = tdist.topk_lowest_index(scores, 1)
+                best_results = fixed.to(torch.int32)[best].long()
+                best_latents = self.ar.latents(auto_conditioning, t, best_results)
+                latents = best_latents[0:1][:, :calm_trim_length(best_results[0])]
+                S = latents.shape[1] * 4 * 24000 // 22050
+                gen = torch.Generator(device=dev).manual_seed(seed + 7919)
+                x_T = torch.randn(1, 100, S, device=dev, generator=gen) * float(settings.get("diffusion_temperature", 1.0))
+                step_noise = torch.randn(sched.num_timesteps, 1, 100, S, device=dev, generator=gen)
+                zs.append(torch.randn(1, self.voc_cfg.noise_dim, S + 10, device=dev, generator=gen))
+                items.append((latents, diffusion_conditioning, S, x_T, step_noise))
+            self.last_best_codes = best_results
+            ev2.mark(1)
+            # ---- diffusion: utterance_batch utterances per pass, neighbours in length together (least padding)
+            order = sorted(range(len(items)), key=lambda j: items[j][2])
+            mels = [None] * len(items)
+            for w0 in range(0, len(order), self.utterance_batch):
+                idx = order[w0:w0 + self.utterance_batch]
+                if len(idx) == 1:
+                    lat_, dc_, S_, x_, n_ = items[idx[0]]
+                    self.diffusion.condition(lat_, dc_, S_)
+                    mels[idx[0]] = self.diffusion.sample(sched, x_, n_)
+                else:
+                    for j, mel in zip(idx, self.diffusion.sample_many(sched, [items[j] for j in idx])):
+                        mels[j] = mel
+            ev2.mark(2)
+            for j in range(len(items)):
+                out[j] = self.vocoder.inference(mels[j], zs[j]).cpu()
+            ev2.mark(3)
+            ev2.synchronize()
+            acc = {"ar_s": 0.0, "clvp_s": ev2.seconds(0, 1), "latents_s": 0.0, "diffusion_s": ev2.seconds(1, 2), "vocoder_s": ev2.seconds(2, 3),
+                   "total_s": ev2.seconds(0, 3)}
         ev.synchronize()
         acc["ar_s"] = acc.get("ar_s", 0.0) + ev.seconds(0, 1)
         acc["total_s"] = acc.get("total_s", 0.0) + ev.seconds(0, 1)

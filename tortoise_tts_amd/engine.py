@@ -62,7 +62,7 @@ class ResBlock(C.Structure):
 
 class DiffConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("dtype", "channels", "heads", "num_layers", "in_channels", "in_pad", "out_channels",
-                                       "latent_channels", "max_seq", "max_codes", "max_steps")]
+                                       "latent_channels", "max_seq", "max_codes", "max_steps", "max_batch")]
 
 
 class DiffWeights(C.Structure):
@@ -151,6 +151,9 @@ _PROTOS = {
     "tt_diff_get_code_emb": (_i, [vp, vp, vp]),
     "tt_diff_forward": (_i, [vp, vp, _i, _i, vp, vp]),
     "tt_diff_sample": (_i, [vp, vp, vp, C.POINTER(DiffStep), _i, _i, vp, vp]),
+    "tt_diff_batch_begin": (_i, [vp, _i, _i, vp]),
+    "tt_diff_condition_slot": (_i, [vp, _i, vp, _i, vp, vp, _i, vp]),
+    "tt_diff_sample_batch": (_i, [vp, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(DiffStep), _i, _i, C.POINTER(C.c_void_p), vp]),
     "tt_diff_split_begin": (_i, [vp, vp, C.POINTER(DiffStep), _i, _i, vp]),
     "tt_diff_split_forward": (_i, [vp, vp, vp]),
     "tt_diff_split_update": (_i, [vp, vp, vp, vp, vp]),

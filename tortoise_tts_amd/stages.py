@@ -235,7 +235,7 @@ class DiffusionStage:
     """DiffusionTts + SpacedDiffusion.p_sample_loop (api.py:117-130)."""
 
     def __init__(self, sd, cfg: DiffusionConfig = DiffusionConfig(), device="cuda", dtype=E.TT_BF16, max_seq=2304, max_codes=512,
-                 max_steps=512):
+                 max_steps=512, max_batch=1):
         self.lib = E.init()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -244,6 +244,8 @@ class DiffusionStage:
         c.dtype, c.channels, c.heads, c.num_layers = dtype, cfg.model_channels, cfg.num_heads, cfg.num_layers
         c.in_channels, c.in_pad, c.out_channels = cfg.in_channels, self.w.in_pad, cfg.out_channels
         c.latent_channels, c.max_seq, c.max_codes, c.max_steps = cfg.in_latent_channels, max_seq, max_codes, max_steps
+        c.max_batch = max_batch  # utterances one sample_many() pass may hold
+        self.max_batch = max_batch
         self.h = E.vp()
         E.check(self.lib.tt_diff_create(C.byref(c), C.byref(self.w.weights), C.byref(self.h)))
         self.S = 0
@@ -309,6 +311,34 @@ class DiffusionStage:
         mel = torch.empty(self.cfg.in_channels, self.S, device=self.device, dtype=torch.float32)
         E.check(self.lib.tt_diff_sample(self.h, E.ptr(x), E.ptr(noise), steps, N, int(sched.cond_free), E.ptr(mel), E.stream_ptr()))
         return mel[None]
+
+    def sample_many(self, sched: Schedule, items):
+        """Several utterances through one denoiser pass per step (tt_diff_sample_batch).  items: list of
+        (latents f32 [1, M_u, latent], cond_latent f32 [1, 2C], S_u, x_T f32 [1, 100, S_u], step_noise f32 [N, 1, 100, S_u]); all of them
+        walk `sched`.  Returns the list of denormalised mels [1, 100, S_u].  Each utterance is treated exactly as if it ran alone
+        (its own statistics / attention span / zero padding); only the accumulation grouping of the GroupNorm partial sums
+        differs from sample(), i.e. results agree within the operand tolerance, not bit for bit."""
+        U = len(items)
+        if not 1 <= U <= self.max_batch:
+            raise ValueError(f"{U} utterances exceed this stage's batch capacity {self.max_batch}")
+        N = sched.num_timesteps
+        steps, order = self._run_order_steps(sched)
+        S_pad = max(int(it[2]) for it in items)
+        E.check(self.lib.tt_diff_batch_begin(self.h, U, S_pad, E.stream_ptr()))
+        keep = []
+        for u, (lat, cond, S, x_T, noise) in enumerate(items):
+            lat_ = lat[0].to(self.device).float().contiguous()
+            cond_ = cond[0].to(self.device).float().contiguous()
+            idx = torch.from_numpy(nearest_interp_index(lat_.shape[0], S)).to(self.device)
+            E.check(self.lib.tt_diff_condition_slot(self.h, u, E.ptr(lat_), lat_.shape[0], E.ptr(cond_), E.ptr(idx), int(S), E.stream_ptr()))
+            x = x_T[0].to(self.device).float().contiguous()
+            nz = noise.to(self.device).float()[order, 0].contiguous()
+            mel = torch.empty(self.cfg.in_channels, int(S), device=self.device, dtype=torch.float32)
+            keep.append((lat_, cond_, idx, x, nz, mel))
+        arr = lambda k: (C.c_void_p * U)(*[E.ptr(t[k]) for t in keep])
+        E.check(self.lib.tt_diff_sample_batch(self.h, U, arr(3), arr(4), steps, N, int(sched.cond_free), arr(5), E.stream_ptr()))
+        self.S = 0  # the handle holds a batch: condition() again before sample()
+        return [t[5][None] for t in keep]
 
     # ---- split sampling (SURVEY.md §8f-2): this engine evaluates ONE denoiser row per step ---------------------
     def split_begin(self, sched: Schedule, x_T, step_noise, row):
