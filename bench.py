@@ -293,7 +293,7 @@ def main():
     ap.add_argument("--diffusion-iterations", type=int, default=None,
                     help="override the preset's diffusion iterations (profiling passes only: the headline metric uses the preset's own)")
     ap.add_argument("--utterance-batch", type=int, default=None, help="read workload: chunks per shared decode batch (TextToSpeech(utterance_batch=)); "
-                    "default 8; 1 = one chunk after the other like tortoise/read.py")
+                    "default 16; 1 = one chunk after the other like tortoise/read.py")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the decode / sampler loops eagerly instead of replaying hipGraphs "
                     "(counter passes only: rocprofv3 --pmc crashes under graph replay); same kernels, same order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -325,7 +325,7 @@ def main():
     text, latents = synthetic_prompt()
     read_mode = args.workload == "read"
     # read: every rank holds a complete engine with the full candidate batch and renders whole chunks (no candidate sharding)
-    ubatch = (args.utterance_batch or 8) if read_mode else 1
+    ubatch = (args.utterance_batch or 16) if read_mode else 1
     tts = TextToSpeech(state_dicts=sds, dtype=args.dtype, max_candidates=N if read_mode else N // world, max_mel_tokens=max(M, 32),
                        candidate_sharding=not read_mode, utterance_batch=ubatch)
     t_build = time.perf_counter() - t_build

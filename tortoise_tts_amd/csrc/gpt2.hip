@@ -16,6 +16,9 @@ struct tt_ar {
   tt_ar_weights w;
   std::vector<tt_gpt_layer> L;
   int D, H, V;
+  int Vp = 0;               // vocabulary padded to a multiple of 4: row stride of the logits and rows of the padded head copy
+  void* w_head_p = nullptr; // [Vp][D] T  lm_head weight with zero rows appended (8194 -> 8196: every epilogue access of the head GEMM
+  float* b_head_p = nullptr;//            is a whole aligned quad - the run-time-ragged generic kernel cost 24 us per step instead of ~12)
   Arena arena;
   StreamBridge sb;
   // shared prefix cache [layers][H][P1][64] (row-major) and per-sequence cache
@@ -151,8 +154,8 @@ static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, 
     }
     TT_TRY(rownorm_launch(e->cfg.dtype, a, s));
   }
-  GemmArgs g = ar_gemm(e, e->h, e->D, e->w.w_mel_head, e->D, M, e->V, e->D);
-  g.bias = e->w.b_mel_head; g.out_f32 = e->logits + (size_t)logits_row0 * e->V; g.ldo32 = e->V;
+  GemmArgs g = ar_gemm(e, e->h, e->D, e->w_head_p, e->D, M, e->Vp, e->D);
+  g.bias = e->b_head_p; g.out_f32 = e->logits + (size_t)logits_row0 * e->Vp; g.ldo32 = e->Vp;
   TT_TRY(gemm_launch(e->cfg.dtype, EPI_STD, g, s));
   e->logits_rows = logits_row0 + M;
   return 0;
@@ -244,7 +247,12 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
   // V^T scratch: per (batch, head) 64 rows of n_pad keys; total keys <= max_rows (+ padding per sequence)
   if (!rc) rc = e->arena.alloc(&e->vt, ((size_t)H * 64 * ((size_t)npad_max + 32 * (size_t)cfg->max_batch)) * 2);
   if (!rc) rc = e->arena.alloc_t(&e->slabs, (size_t)MAX_SPLIT * cfg->max_batch * D);
-  if (!rc) rc = e->arena.alloc_t(&e->logits, (size_t)cfg->max_batch * e->V);
+  e->Vp = round_up(e->V, 4);
+  if (!rc) rc = e->arena.alloc_t(&e->logits, (size_t)cfg->max_batch * e->Vp);
+  if (!rc) rc = e->arena.alloc(&e->w_head_p, (size_t)e->Vp * D * 2);   // (arena memory is zeroed: the padding rows / bias entries are 0)
+  if (!rc) rc = e->arena.alloc_t(&e->b_head_p, e->Vp);
+  if (!rc && hipMemcpy(e->w_head_p, w->w_mel_head, (size_t)e->V * D * 2, hipMemcpyDeviceToDevice) != hipSuccess) { set_error("tt_ar_create: copying the head weight failed"); rc = -2; }
+  if (!rc && hipMemcpy(e->b_head_p, w->b_mel_head, (size_t)e->V * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) { set_error("tt_ar_create: copying the head bias failed"); rc = -2; }
   if (!rc) rc = e->arena.alloc_t(&e->state, 4);
   if (!rc) rc = e->arena.alloc_t(&e->seen, (size_t)cfg->max_batch * ((e->V + 31) / 32));
   if (!rc) rc = e->arena.alloc_t(&e->unfinished, cfg->max_batch);
@@ -320,7 +328,8 @@ int tt_ar_get_logits(tt_ar* e, float* dst, int rows, void* stream) {
   TT_REQUIRE(e && dst && rows >= 1 && rows <= e->logits_rows, "tt_ar_get_logits: %d rows requested, %d available", rows, e ? e->logits_rows : 0);
   hipStream_t us = (hipStream_t)stream;
   TT_TRY(e->sb.enter(us));
-  TT_CHECK_HIP(hipMemcpyAsync(dst, e->logits, (size_t)rows * e->V * sizeof(float), hipMemcpyDeviceToDevice, e->sb.own));
+  TT_CHECK_HIP(hipMemcpy2DAsync(dst, (size_t)e->V * sizeof(float), e->logits, (size_t)e->Vp * sizeof(float), (size_t)e->V * sizeof(float), (size_t)rows,
+                                hipMemcpyDeviceToDevice, e->sb.own));
   return e->sb.leave(us);
 }
 
@@ -376,14 +385,14 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
     TT_TRY(ar_begin_launch(e->state, e->seen, e->unfinished, e->unfinished_count, B, e->V, e->tmax + 8, e->cfg.start_mel_token, s));
     TT_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)codes, e->cfg.stop_mel_token, (size_t)B * ldcodes, s));
     // token 0: every row samples from the shared prefill logits
-    sa.logits = e->logits; sa.ldl = 0;
+    sa.logits = e->logits; sa.ldl = 0; sa.ldg = e->Vp;
     TT_REQUIRE(e->logits_from_prefill, "tt_ar_generate: the logits buffer does not hold the prefill logits of all %d group(s); call tt_ar_prefill / tt_ar_prefill_group first", e->G);
     e->logits_from_prefill = false;
     TT_TRY(sample_launch(sa, s));
     TT_TRY(ar_state_advance_launch(e->state, s));
     e->gen_done = 1;
   }
-  sa.logits = e->logits; sa.ldl = e->V;
+  sa.logits = e->logits; sa.ldl = e->Vp;
   if (!fresh) {
     // Resumed chunk (streaming): between two chunks the caller may have run tt_ar_latents / tt_ar_prefill, which use e->x as
     // their residual stream, so the input row the sampler fused into e->x for the next step is gone.  Rebuild it from the

@@ -109,8 +109,8 @@ int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stre
 
 // ------------------------------------------------------------------------------ AR sampling
 struct SampleArgs {
-  const float* logits;  // [B][ldl]; ldl == 0 broadcasts one row (the shared-prefix prefill logits)
-  int ldl;
+  const float* logits;  // [B][ldl]; ldl == 0 broadcasts one row per utterance group (the shared-prefix prefill logits), ldg apart
+  int ldl, ldg;
   int B, V;
   unsigned* seen;       // [B][(V+31)/32] bitmask of ids already in input_ids (repetition penalty)
   float rep_penalty, temperature, top_p;

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   const int V = a.V;
   const int step = a.state[0];
   const int grp = a.ngroups > 1 ? b / a.group_size : 0;  // utterance of this row (block-uniform)
-  const float* lg = a.logits + (a.ldl ? (size_t)b * a.ldl : (size_t)grp * V);
+  const float* lg = a.logits + (a.ldl ? (size_t)b * a.ldl : (size_t)grp * (a.ldg ? a.ldg : V));
   unsigned* seen = a.seen + (size_t)b * ((V + 31) / 32);
   constexpr int PER = 40;  // supports V <= 10240
   float val[PER];
