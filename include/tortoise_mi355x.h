@@ -97,7 +97,8 @@ int tt_ar_get_logits(tt_ar* h, float* dst, int rows, void* stream);
 
 typedef struct tt_sampling {
   float temperature, top_p, repetition_penalty;
-  int top_k;                 /* HF GenerationConfig default 50 (api.py never overrides it) */
+  int top_k;                 /* HF GenerationConfig default 50 (api.py never overrides it).  Any value: 1 .. 256 run the fast sampler,
+                              * larger ones a full-sort sampler; <= 0 or >= vocab means no top-k filter (HF drops the warper at 0) */
   unsigned long long seed;   /* Philox key when exp_noise == NULL */
   int row_offset;            /* global index of candidate 0 of this rank */
   const float* exp_noise;    /* optional f32 [max_new][B][vocab] Exp(1) draws: multinomial == argmax(p/q) */

@@ -37,6 +37,33 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// one thread: finished rows emit the stop token (stream_generator.py:980-996), bookkeeping of the sampled token; returns it
+__device__ __forceinline__ int sample_commit(const SampleArgs& a, int b, int step, int best_i, unsigned* seen) {
+  const int unf = a.unfinished[b];
+  const int tok = unf ? best_i : a.stop_token;
+  const int still = unf && tok != a.stop_token;
+  a.unfinished[b] = still;
+  a.codes[(size_t)b * a.ldcodes + step] = tok;
+  a.next_tok[b] = tok;
+  atomicOr(&seen[tok >> 5], 1u << (tok & 31));
+  if (still) atomicAdd(&a.unfinished_count[step], 1);
+  return tok;
+}
+// whole block: next decode step's input row, mel_embedding[tok] + mel_pos_embedding[index of this token + offset].  The token
+// sampled at the capacity limit is never fed back, and its position row would lie one past the table: skip it.
+__device__ __forceinline__ void sample_embed(const SampleArgs& a, int b, int step, const int* tok_s, int tid, int nthreads) {
+  if (a.embed_x && step + a.pos_offset < a.pos_len) {
+    __syncthreads();
+    const int tok = tok_s[0];
+    const int pos = step + a.pos_offset;
+    for (int c = tid * 4; c < a.D; c += nthreads * 4) {
+      const float4 e = *(const float4*)(a.tok_emb + (size_t)tok * a.D + c);
+      const float4 p = *(const float4*)(a.pos_emb + (size_t)pos * a.D + c);
+      *(float4*)(a.embed_x + (size_t)b * a.D + c) = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __shared__ unsigned hist[256];
   __shared__ unsigned sel_prefix, sel_remaining;
@@ -261,37 +288,165 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         best = red_v[w];
         best_i = red_i[w];
       }
-    const int unf = a.unfinished[b];
-    int tok = unf ? best_i : a.stop_token;
-    const int still = unf && tok != a.stop_token;
-    a.unfinished[b] = still;
-    a.codes[(size_t)b * a.ldcodes + step] = tok;
-    a.next_tok[b] = tok;
-    atomicOr(&seen[tok >> 5], 1u << (tok & 31));
-    if (still) atomicAdd(&a.unfinished_count[step], 1);
-    red_i[0] = tok;
+    red_i[0] = sample_commit(a, b, step, best_i, seen);
   }
-  // next decode step's input row: mel_embedding[tok] + mel_pos_embedding[index of this token + offset].  The token sampled at
-  // the capacity limit is never fed back, and its position row would lie one past the table: skip it.
-  if (a.embed_x && step + a.pos_offset < a.pos_len) {
-    __syncthreads();
-    const int tok = red_i[0];
-    const int pos = step + a.pos_offset;
-    for (int c = tid * 4; c < a.D; c += 1024) {
-      const float4 e = *(const float4*)(a.tok_emb + (size_t)tok * a.D + c);
-      const float4 p = *(const float4*)(a.pos_emb + (size_t)pos * a.D + c);
-      *(float4*)(a.embed_x + (size_t)b * a.D + c) = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+  sample_embed(a, b, step, red_i, tid, 256);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Any top_k (HF accepts every value: TopKLogitsWarper clamps k to the vocabulary, top_k == 0 drops the warper; reference loop
+// stream_generator.py:43-57 builds the same warper list).  The kernel above keeps its <= 512 survivors in a rank-sorted buffer,
+// which is what the reference's own default (k = 50) and anything up to 256 need; beyond that the whole row is sorted: one
+// 1024-thread workgroup per candidate, bitonic sort of (score key, token) pairs in LDS (16384 slots: 96 KB + 40 KB of exponentials),
+// descending score / ascending token on ties, then exactly the same top-p arithmetic and argmax(p / q) draw on the first n entries.
+// ~40 us per step instead of ~15: a correct slow path, not the default.
+constexpr int WIDE_N = 16384;
+constexpr int WIDE_V = 10240;
+__device__ __forceinline__ float key2f(unsigned k) {
+  const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(1024) void sample_wide_kernel(SampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_wide[];
+  unsigned* key = (unsigned*)smem_wide;                    // [WIDE_N]
+  unsigned short* tok = (unsigned short*)(key + WIDE_N);   // [WIDE_N]
+  float* ef = (float*)(tok + WIDE_N);                      // [WIDE_V]
+  __shared__ int n_s, kept;
+  __shared__ float kept_total;
+  __shared__ float red_v[16];
+  __shared__ int red_i[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int V = a.V;
+  const int step = a.state[0];
+  const int grp = a.ngroups > 1 ? b / a.group_size : 0;
+  const float* lg = a.logits + (a.ldl ? (size_t)b * a.ldl : (size_t)grp * (a.ldg ? a.ldg : V));
+  unsigned* seen = a.seen + (size_t)b * ((V + 31) / 32);
+  for (int t = tid; t < WIDE_N; t += 1024) {
+    unsigned kk = 0u;  // padding slots sort behind every real score (f2key(-inf) = 0x007FFFFF > 0)
+    if (t < V) {
+      float s = lg[t];
+      if (a.rep_penalty != 1.0f && ((seen[t >> 5] >> (t & 31)) & 1u)) s = s < 0.f ? s * a.rep_penalty : s / a.rep_penalty;
+      if (a.temperature != 1.0f) s = s / a.temperature;
+      kk = f2key(s);
+    }
+    key[t] = kk;
+    tok[t] = (unsigned short)(t < V ? t : 0xFFFF);
+  }
+  // bitonic sort: final order = descending key, ascending token on equal keys
+  for (int k2 = 2; k2 <= WIDE_N; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int p = tid; p < WIDE_N / 2; p += 1024) {
+        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i | j;
+        const unsigned ki = key[i], kl = key[l];
+        const unsigned short ti = tok[i], tl = tok[l];
+        const bool i_first = ki > kl || (ki == kl && ti < tl);  // i already precedes l in the final order
+        const bool up = (i & k2) == 0;                           // this sub-sequence is built in final order (else reversed)
+        if (up != i_first) {
+          key[i] = kl; key[l] = ki;
+          tok[i] = tl; tok[l] = ti;
+        }
+      }
     }
   }
+  __syncthreads();
+  // survivors of top-k: everything >= the k-th score (ties kept, like TopKLogitsWarper's `scores < kth` removal)
+  const int k_eff = (a.top_k <= 0 || a.top_k > V) ? V : a.top_k;
+  const unsigned kth = key[k_eff - 1];
+  for (int t = tid; t < V; t += 1024)
+    if (key[t] >= kth && (t + 1 == V || key[t + 1] < kth)) n_s = t + 1;
+  __syncthreads();
+  const int n = n_s;
+  const float v0 = key2f(key[0]);
+  for (int i = tid; i < n; i += 1024) ef[i] = __expf(key2f(key[i]) - v0);
+  __syncthreads();
+  if (tid == 0) {  // same sequential arithmetic as sample_kernel
+    float total = 0.f;
+    for (int i = 0; i < n; ++i) total += ef[i];
+    int keep = n;
+    if (a.top_p < 1.0f) {
+      float tail = 0.f;
+      keep = 1;
+      const float thr = 1.0f - a.top_p;
+      for (int r = n - 1; r >= 1; --r) {
+        tail += ef[r] / total;
+        if (tail > thr) {
+          keep = r + 1;
+          break;
+        }
+      }
+    }
+    float kt = 0.f;
+    for (int i = 0; i < keep; ++i) kt += ef[i];
+    kept = keep;
+    kept_total = kt;
+  }
+  __syncthreads();
+  const int keep = kept;
+  float best = -1.f;
+  int best_i = 0x7fffffff;
+  for (int i = tid; i < keep; i += 1024) {
+    const int id = tok[i];
+    const float p = __expf(key2f(key[i]) - v0) / kept_total;
+    float q;
+    if (a.exp_noise) {
+      q = a.exp_noise[((size_t)step * a.B + b) * V + id];
+    } else {
+      unsigned r[4];
+      const unsigned long long pk = a.ngroups > 1 ? a.group_seeds[grp] : a.seed;
+      const int cand = a.ngroups > 1 ? b - grp * a.group_size : b;
+      philox4x32_10((unsigned)id, (unsigned)step, (unsigned)(a.row_offset + cand), 0u, (unsigned)pk, (unsigned)(pk >> 32), r);
+      const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      q = -__logf(u);
+    }
+    const float sc = p / q;
+    if (sc > best || (sc == best && id < best_i)) {
+      best = sc;
+      best_i = id;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(best_i, o, 64);
+    if (ov > best || (ov == best && oi < best_i)) {
+      best = ov;
+      best_i = oi;
+    }
+  }
+  if ((tid & 63) == 0) {
+    red_v[tid >> 6] = best;
+    red_i[tid >> 6] = best_i;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (red_v[w] > best || (red_v[w] == best && red_i[w] < best_i)) {
+        best = red_v[w];
+        best_i = red_i[w];
+      }
+    red_i[0] = sample_commit(a, b, step, best_i, seen);
+  }
+  sample_embed(a, b, step, red_i, tid, 1024);
 }
 
 int sample_launch(const SampleArgs& a, hipStream_t stream) {
-  TT_REQUIRE(a.B > 0 && a.V > 0 && a.V <= 10240, "sample: V=%d unsupported (<= 10240)", a.V);
+  TT_REQUIRE(a.B > 0 && a.V > 0 && a.V <= WIDE_V, "sample: V=%d unsupported (<= %d)", a.V, WIDE_V);
   TT_REQUIRE(a.ngroups <= 1 || (a.ngroups <= 16 && a.group_size > 0 && a.B == a.ngroups * a.group_size), "sample: %d groups of %d rows do not make %d rows", a.ngroups, a.group_size, a.B);
-  TT_REQUIRE(a.top_k > 0 && a.top_k <= 256, "sample: top_k=%d unsupported (1..256; HF default 50)", a.top_k);
   TT_REQUIRE(a.temperature > 0.f && a.top_p > 0.f && a.rep_penalty > 0.f, "sample: bad sampling parameters");
   ProfScope ps(PROF_SAMPLE, stream, 0.0, (double)a.B * a.V * 4.0, true);
-  launch_timed(ps, sample_kernel, dim3(a.B), dim3(256), 0, stream, a);
+  if (a.top_k >= 1 && a.top_k <= 256) {
+    launch_timed(ps, sample_kernel, dim3(a.B), dim3(256), 0, stream, a);
+  } else {  // top_k == 0 (HF: no top-k warper), > 256, or beyond the vocabulary: the full-sort kernel
+    constexpr size_t smem = (size_t)WIDE_N * 6 + (size_t)WIDE_V * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+      TT_CHECK_HIP(hipFuncSetAttribute((const void*)sample_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      attr_done = true;
+    }
+    launch_timed(ps, sample_wide_kernel, dim3(a.B), dim3(1024), smem, stream, a);
+  }
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
