@@ -270,11 +270,21 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(FlashArgs a) {  // 2 wave
 // ring with counted vmcnt, one raw barrier per tile.  Against the register-prefetch kernel this divides the L2 -> CU traffic
 // by 4 (a K / V byte is fetched once per block, not once per wave), puts two more tiles in flight per wave without spending
 // VGPRs on them, and removes the 4-way partial-state merge.
+// max without the operand canonicalisation fmaxf() implies (the inputs are MFMA results / finite floats or -inf)
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 typedef __attribute__((address_space(3))) void lds_void_a;
 typedef __attribute__((address_space(1))) const void gbl_void_a;
 
-template <typename T, int NQ>
-__global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
+// KS = 2 ("key split"): 8 waves per block - wave w works on query group w & 3 like before, but only on half w >> 2 (32 keys) of
+// every staged 64-key tile, and the two partial softmax states of a query group are merged through the LDS at the end.  At the
+// denoiser's shape (n = 870, 32 (batch, head) pairs) the chip holds 1741 sixteen-query chains for 1024 SIMDs, each a strictly
+// dependent LDS read -> QK^T MFMA -> softmax VALU -> PV MFMA sequence per half tile: the launch is paid for the length of that
+// chain, not for MFMA or VALU throughput (~1.5 us of MFMA work per block in a 22 us launch).  Halving the chain per wave doubles
+// the chains in flight at no extra K / V traffic (the same staged tile serves both halves).
+template <typename T, int NQ, int KS>
+__global__ __launch_bounds__(256 * KS, 2) void flash_lds_kernel(FlashArgs a) {
   typedef typename Vec<T>::x8 x8;
   typedef typename Vec<T>::x4 x4;
   constexpr int ST = 3, KT = 64;                 // ring stages, keys per tile
@@ -292,7 +302,8 @@ __global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
     bx = lin2 - bh * gx;
   }
   const int h = bh % a.heads, b = bh / a.heads;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = wave_id & 3, kp_own = wave_id >> 2;  // query group of this wave; with KS == 2 the half of every key tile it owns
   const int fr = lane & 15, fg = lane >> 4;
   const int ns = a.n;                                             // row stride of the operands
   const int n = a.nv_period > 0 ? a.nv[b % a.nv_period] : a.n;    // valid keys / queries of this batch row (padded batches)
@@ -335,8 +346,8 @@ __global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
     const int key0 = t * KT;
     T* base = ring + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int piece = wave + 4 * i;
+    for (int i = 0; i < 4 / KS; ++i) {
+      const int piece = wave_id + 4 * KS * i;
       const int row = (piece & 7) * 8 + lr;
       const int chunk = lc ^ ((row >> 1) & 7);
       const T* src;
@@ -383,19 +394,15 @@ __global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) sv[kb][r] = st[r];
       }
+      // Relative-position bias.  A tile that lies entirely >= 64 positions after (or before) every query of the group gets ONE
+      // saturated bucket value for all its scores: a uniform shift, which is folded into the row maximum and the exponent below
+      // instead of being added to the 8 scores (most tiles at n = 870).  Only the tiles inside the +-64 window look the table up.
+      float cbias = 0.f;
       if (a.relpos) {
         if (key0 - (q0 + 15) >= 64) {          // every key is >= 64 after every query: bucket saturated
-          const float bconst = rp[128];
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sv[kb][r] += bconst;
+          cbias = rp[128];
         } else if (q0 - (key0 + 31) >= 64) {   // every key is >= 64 before every query
-          const float bconst = rp[0];
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sv[kb][r] += bconst;
+          cbias = rp[0];
         } else {
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb)
@@ -416,11 +423,17 @@ __global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
             if (key >= n || (a.causal && key > qi)) sv[kb][r] = -INFINITY;
           }
       }
-      float mx = fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
-                       fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])));
-      mx = max_xor16(mx);
-      mx = max_xor32(mx);
-      const float m_new = fmaxf(m_run[iq], mx);
+      // row maximum: v_max3 / v_max straight on the MFMA results (fmaxf() would first canonicalise every operand: 8 extra VALU)
+      float mx = vmax3(vmax3(vmax3(sv[0][0], sv[0][1], sv[0][2]), sv[0][3], sv[1][0]), sv[1][1], sv[1][2]);
+      mx = vmax(mx, sv[1][3]);
+      {
+        float x0, x1;
+        pair_xor16(mx, x0, x1);
+        mx = vmax(x0, x1);
+        pair_xor32(mx, x0, x1);
+        mx = vmax(x0, x1) + cbias;
+      }
+      const float m_new = vmax(m_run[iq], mx);
       if (__any(m_new > m_run[iq])) {  // some row maximum moved: rescale the running state (exact when skipped)
         const float alpha = __builtin_amdgcn_exp2f((m_run[iq] - m_new) * LOG2E);
         l_run[iq] *= alpha;
@@ -430,24 +443,25 @@ __global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
         }
         m_run[iq] = m_new;
       }
-      const float mc = m_new * LOG2E;
-      float psum = 0.f;
+      const float mc = (m_new - cbias) * LOG2E;  // exp2(s * log2e - mc) == exp(s + cbias - m_new)
+      float pv[2][4];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[kb][r] = __builtin_amdgcn_exp2f(fmaf(sv[kb][r], LOG2E, -mc));
       x8 pf;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sv[kb][r], LOG2E, -mc));
-          psum += pv;
-          pf[kb * 4 + r] = (T)pv;
-        }
+        for (int r = 0; r < 4; ++r) pf[kb * 4 + r] = (T)pv[kb][r];
+      const float psum = ((pv[0][0] + pv[0][1]) + (pv[0][2] + pv[0][3])) + ((pv[1][0] + pv[1][1]) + (pv[1][2] + pv[1][3]));
       l_run[iq] += psum;  // lane-partial: reduced over the four key groups once, after the loop
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk) acc[iq][blk] = mfma16(vf[blk], pf, acc[iq][blk]);
     }
   };
 
-  constexpr int G = 4;  // LDS-DMA instructions per wave per tile
+  constexpr int G = 4 / KS;  // LDS-DMA instructions per wave per tile
   const int last = ntile - 1;
 #pragma unroll
   for (int s_ = 0; s_ < ST - 1; ++s_) issue(min(s_, last), s_);
@@ -461,11 +475,46 @@ __global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
     const int key0 = t * KT;
     const T* kt = ring + slot * STAGE;
     const T* vt = kt + KT * 64;
-    if (key0 < kend) process(kt, vt, 0, key0);            // wave-uniform: tiles beyond this wave's causal horizon are skipped
-    if (key0 + 32 < kend) process(kt, vt, 1, key0 + 32);
+    if constexpr (KS == 1) {
+      if (key0 < kend) process(kt, vt, 0, key0);            // wave-uniform: tiles beyond this wave's causal horizon are skipped
+      if (key0 + 32 < kend) process(kt, vt, 1, key0 + 32);
+    } else {
+      if (key0 + kp_own * 32 < kend) process(kt, vt, kp_own, key0 + kp_own * 32);
+    }
     slot = slot + 1 == ST ? 0 : slot + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (KS == 2) {
+    // merge the two halves' (m, l, acc) per query row: the upper waves park theirs in the ring (free now), the lower ones combine
+    float* mg = (float*)ring;  // [4 query groups][NQ][18][64 lanes]
+    __syncthreads();            // every wave is done reading the ring
+    if (kp_own == 1) {
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        float* d = mg + ((size_t)(wave * NQ + iq) * 18) * 64 + lane;
+        d[0] = m_run[iq];
+        d[64] = l_run[iq];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) d[(2 + blk * 4 + r) * 64] = acc[iq][blk][r];
+      }
+    }
+    __syncthreads();
+    if (kp_own == 1) return;
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) {
+      const float* d = mg + ((size_t)(wave * NQ + iq) * 18) * 64 + lane;
+      const float m1 = d[0], l1 = d[64];
+      const float mm = fmaxf(m_run[iq], m1);
+      const float a0 = __builtin_amdgcn_exp2f((m_run[iq] - mm) * LOG2E), a1 = __builtin_amdgcn_exp2f((m1 - mm) * LOG2E);
+      l_run[iq] = l_run[iq] * a0 + l1 * a1;
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[iq][blk][r] = acc[iq][blk][r] * a0 + d[(2 + blk * 4 + r) * 64] * a1;
+    }
+  }
 #pragma unroll
   for (int iq = 0; iq < NQ; ++iq) {
     l_run[iq] = add_xor16(l_run[iq]);
@@ -481,16 +530,17 @@ __global__ __launch_bounds__(256, 2) void flash_lds_kernel(FlashArgs a) {
   }
 }
 
-template <typename T, int NQ>
+template <typename T, int NQ, int KS>
 static int launch_flash_lds(const ProfScope& ps, const FlashArgs& a, hipStream_t stream) {
   constexpr int smem = 3 * 2 * 64 * 64 * 2 + 132 * 4;
+  static_assert(KS == 1 || 4 * NQ * 18 * 64 * 4 <= 3 * 2 * 64 * 64 * 2, "the merge scratch must fit the ring");
   static bool attr_set = false;
   if (!attr_set) {
-    TT_CHECK_HIP(hipFuncSetAttribute((const void*)flash_lds_kernel<T, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TT_CHECK_HIP(hipFuncSetAttribute((const void*)flash_lds_kernel<T, NQ, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   dim3 grid(cdiv(a.n, 64 * NQ), a.BH);
-  launch_timed(ps, flash_lds_kernel<T, NQ>, grid, dim3(256), smem, stream, a);
+  launch_timed(ps, flash_lds_kernel<T, NQ, KS>, grid, dim3(256 * KS), smem, stream, a);
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -506,8 +556,11 @@ int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
     // LDS-staged kernel: 64 queries per block while that keeps >= 2 blocks per CU busy, 128 otherwise (half the K / V traffic per
     // flop; measured on the kbench shapes: 32 queries per wave only pays from ~2048 blocks of 64 queries on)
     const long blocks64 = (long)cdiv(a.n, 64) * a.BH;
-    if (blocks64 >= 2048) return dtype == DT_BF16 ? launch_flash_lds<bf16, 2>(ps, a, stream) : launch_flash_lds<f16, 2>(ps, a, stream);
-    return dtype == DT_BF16 ? launch_flash_lds<bf16, 1>(ps, a, stream) : launch_flash_lds<f16, 1>(ps, a, stream);
+    if (blocks64 >= 2048) return dtype == DT_BF16 ? launch_flash_lds<bf16, 2, 1>(ps, a, stream) : launch_flash_lds<f16, 2, 1>(ps, a, stream);
+    // fewer than ~4 blocks per CU: the launch is paid for the per-wave dependency chain - split every key tile over two wave groups
+    // (in-situ A/B, profiles/r03_ab_flash_split.txt: denoiser iteration 1.555 -> 1.520 ms; the softmax VALU diet of this round -4 % per launch)
+    if (blocks64 < 1024 && a.variant != 1) return dtype == DT_BF16 ? launch_flash_lds<bf16, 1, 2>(ps, a, stream) : launch_flash_lds<f16, 1, 2>(ps, a, stream);
+    return dtype == DT_BF16 ? launch_flash_lds<bf16, 1, 1>(ps, a, stream) : launch_flash_lds<f16, 1, 1>(ps, a, stream);
   }
   // short sequences (prefill of a few dozen rows, reduced test configurations): the register-prefetch kernel, the 4 waves of a
   // block share one 16-query block and split the keys
