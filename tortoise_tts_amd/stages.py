@@ -304,6 +304,8 @@ class DiffusionStage:
     def sample(self, sched: Schedule, x_T, step_noise):
         """x_T f32 [1, 100, S]; step_noise f32 [N, 1, 100, S] with step_noise[i] the draw of spaced index i
         (same convention as the oracle).  Returns the denormalised mel [1, 100, S]."""
+        if self.S <= 0:
+            raise ValueError("sample() needs condition() first (after sample_many the handle holds a batch)")
         N = sched.num_timesteps
         steps, order = self._run_order_steps(sched)
         x = x_T[0].to(self.device).float().contiguous()
@@ -345,6 +347,8 @@ class DiffusionStage:
         """row 0 = conditioned, 1 = conditioning-free.  Keeps the run-order noise and the output buffers alive."""
         if not sched.cond_free:
             raise ValueError("split sampling needs conditioning_free (two rows per step)")
+        if self.S <= 0:
+            raise ValueError("split sampling needs condition() first (the handle holds no single-utterance conditioning)")
         steps, order = self._run_order_steps(sched)
         x = x_T[0].to(self.device).float().contiguous()
         self._split_noise = step_noise.to(self.device).float()[order, 0].contiguous()
