@@ -573,6 +573,30 @@ def test_ar_utterance_groups_decode_like_single_utterances(eos_boost):
     st.close()
 
 
+@torch.no_grad()
+def test_ar_large_group_batches_fold_split_k_in_the_launch():
+    """From 1024 sequences per decode batch on, the two projections fold their split-K partial sums inside the launch ("serial
+    split-K", gemm.h): ((x + bias) + P0) + P1 + ... in slab order - the same bits as the slab + row-norm path a single utterance takes.
+    4 utterances x 256 candidates (1024 rows, serial path) against each utterance alone (256 rows, slab path): identical codes."""
+    cfg = ARConfig(**G.AR_CFG)
+    sd = W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.AR_SEED), cfg)
+    gen = torch.Generator().manual_seed(22)
+    utts = [(torch.randn(1, cfg.model_dim, generator=gen), F.pad(torch.randint(1, 255, (1, T_), generator=gen).int(), (0, 1))) for T_ in (9, 30, 17, 22)]
+    Bg, max_new = 256, 10
+    st = stages.ArStage(sd, cfg, max_batch=len(utts) * Bg, max_text=40, max_new_tokens=16, max_latent_candidates=1, max_groups=4)
+    singles = []
+    for cond, text in utts:
+        st.prefill(cond, text)
+        singles.append(st.generate(Bg, max_new, seed=31)[0].clone())
+    for g, (cond, text) in enumerate(utts):
+        st.prefill_group(g, len(utts), cond, text)
+    codes, n = st.generate(len(utts) * Bg, max_new, seed=31)
+    assert n == max_new
+    for g, single in enumerate(singles):
+        assert torch.equal(codes[g * Bg:(g + 1) * Bg], single), f"utterance {g}: the in-launch split-K fold changed the sampled codes"
+    st.close()
+
+
 @pytest.mark.parametrize("kv_cache", [False, True])
 @torch.no_grad()
 def test_stream_latents_filed_by_the_decode_steps(kv_cache):

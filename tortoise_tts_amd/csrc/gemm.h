@@ -31,6 +31,8 @@ struct GemmArgs {
   int seq_len;  // rows per sequence (conv boundary / head-layout epilogues)
   int cin;      // K / taps
   int splitk;   // >1: raw partial sums go to out_f32 + z * M * ldo32 (EPI_STD only)
+  int serial_k; // >1: "serial split-K" - out_f32 = (((res + bias) + P0) + P1) + ... over serial_k equal K ranges inside ONE launch,
+                //     bit-identical to splitk = serial_k slabs folded by the row-norm kernel (needs bias, res, out_f32; no out_t / stats / taps)
   int xcd_rows; // row bands the tile grid is cut into for XCD ownership (1, 2, 4 or 8); 0 = chosen by gemm_launch from the operand sizes
   int xcd_band; // set by gemm_launch: row tiles per band
   int sk_quot, sk_rem;  // set by gemm_launch: k-tiles per split-K slab (quotient, remainder)

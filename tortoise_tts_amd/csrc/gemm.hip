@@ -22,7 +22,7 @@ extern template int gemm_init_typed<f16>();
 // alone (split tail) or batched with the conditioning-free row.
 static int pick_tile(const GemmArgs& a) {
   const long b256 = (long)cdiv(a.M, 256) * cdiv(a.N, 256) * a.splitk;
-  if (b256 >= 256 && a.N >= 256 && a.M >= 2048) return TILE_256x256;  // (the pre-pass, CLVP's speech tower, a batched denoiser)
+  if (b256 >= 256 && a.N >= 256 && a.M >= 2048 && a.serial_k <= 1) return TILE_256x256;  // (the pre-pass, CLVP's speech tower, a batched denoiser)
   const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk;
   if (a.M > 256 && b128 >= 256 && a.N > 64) return TILE_128x128;  // (N <= 64: half of a 128-wide tile would be padding)
   if (a.M > 1024 || (a.M > 256 && a.gn_part != nullptr)) return TILE_128x64;
@@ -114,6 +114,11 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   TT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda=%d / ldw=%d must be multiples of 8 elements", a.lda, a.ldw);
   TT_REQUIRE(a.splitk == 1 || (epi == EPI_STD && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
   TT_REQUIRE(a.splitk <= a.K / 64, "gemm: splitk=%d exceeds the %d k-tiles", a.splitk, a.K / 64);
+  if (a.serial_k > 1)
+    TT_REQUIRE(epi == EPI_STD && a.splitk == 1 && a.bias && a.res && a.out_f32 && !a.out_t && !a.gn_part && a.taps == 1 && !a.A2 && a.act == ACT_NONE &&
+                   (a.K / 64) % a.serial_k == 0 && (a.N & 3) == 0 && ((size_t)a.bias & 15) == 0 && ((size_t)a.res & 15) == 0 && (a.ldres & 3) == 0 &&
+                   ((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0,
+               "gemm: serial split-K needs the plain aligned bias + skip + f32 form and K / 64 = %d divisible by serial_k = %d", a.K / 64, a.serial_k);
   if (a.A2) TT_REQUIRE(a.taps == 1 && a.k_split > 0 && a.k_split < a.K && a.k_split % 64 == 0 && a.lda2 % 8 == 0, "gemm: bad second activation source (k_split=%d lda2=%d)", a.k_split, a.lda2);
   TT_REQUIRE(a.act_t == ACT_NONE || (a.act_t == ACT_LRELU && epi == EPI_STD && a.out_t && a.splitk == 1), "gemm: act_t supports LeakyReLU on the T-typed output of the standard epilogue only");
   if (a.gn_part) {

@@ -125,6 +125,7 @@ struct EpiStd {
   typedef EpiStdArgs Args;
   static constexpr int kId = 0;
   static constexpr int kStats = STATS;
+  static constexpr bool kSerial = false;
   template <int FM, int FN> struct Ops { float4 bv[FN], rv[FN][FM]; __device__ __forceinline__ int step() const { return 0; } };
   static __device__ __forceinline__ bool slab(const Args& e) { return MODE < 0 ? e.splitk > 1 : (MODE & EB_SLAB) != 0; }
   static __device__ __forceinline__ bool has_bias(const Args& e) { return MODE < 0 ? (e.bias != nullptr && e.splitk <= 1) : (MODE & EB_BIAS) != 0; }
@@ -235,6 +236,7 @@ struct EpiQkvHeads {
   typedef EpiQkvHeadsArgs Args;
   static constexpr int kId = 1;
   static constexpr int kStats = 0;
+  static constexpr bool kSerial = false;
   template <int FM, int FN> struct Ops { float4 bv[FN]; __device__ __forceinline__ int step() const { return 0; } };
   template <int FM, int FN, bool AL>
   static __device__ __forceinline__ void fetch(const GemmCore& c, const Args& e, Ops<FM, FN>& o, int, int n0w, int lane) {
@@ -280,6 +282,7 @@ struct EpiQkvDecode {
   typedef EpiQkvDecodeArgs Args;
   static constexpr int kId = 2;
   static constexpr int kStats = 0;
+  static constexpr bool kSerial = false;
   template <int FM, int FN> struct Ops { float4 bv[FN]; int t; __device__ __forceinline__ int step() const { return t; } };
   template <int FM, int FN, bool AL>
   static __device__ __forceinline__ void fetch(const GemmCore& c, const Args& e, Ops<FM, FN>& o, int, int n0w, int lane) {
@@ -311,6 +314,16 @@ struct EpiQkvDecode {
       *(typename Vec<T>::x4*)o = pack4<T>(v[0], v[1], v[2], v[3]);
     }
   }
+};
+
+// "Serial split-K": out = (((res + bias) + P0) + P1) + ... with P_q the partial product over the q-th of e.splitk equal K ranges,
+// each accumulated from zero in k order and folded into the running value in ONE launch.  That is bit for bit what the split-K
+// slab path computes in two kernels (slab z = P_z, then the LayerNorm kernel's x + bias + slab0 + slab1 + ...), without writing
+// and re-reading splitk f32 slabs: the decode projections of a batch of >= 1024 sequences (several utterances per decode batch),
+// where one block per output tile already fills the chip.  The candidates' codes stay independent of the batch size.
+template <typename T>
+struct EpiSerial : EpiStd<T, ACT_NONE, 0, EB_BIAS | EB_RES | EB_F32> {
+  static constexpr bool kSerial = true;
 };
 
 // Epilogue.  With GroupNorm statistics on (EPI_STD, f32 output feeding a GroupNorm32) every wave also emits (sum, sum of
@@ -566,6 +579,32 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   typename Epi::template Ops<FM, FN> eo;
+  // serial split-K (EpiSerial): running value res + bias + P0 + P1 + ..., folded every `ser_per` k-tiles
+  f32x4 tser[Epi::kSerial ? FN : 1][Epi::kSerial ? FM : 1];
+  int ser_per = 0, ser_left = 0;
+  auto ser_fold = [&]() {
+    if constexpr (Epi::kSerial) {
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          tser[i][j][0] += acc[i][j][0]; tser[i][j][1] += acc[i][j][1]; tser[i][j][2] += acc[i][j][2]; tser[i][j][3] += acc[i][j][3];
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      ser_left = ser_per;
+    }
+  };
+  auto ser_begin = [&]() {  // after the operand fetch has been issued: x + bias, exactly the LayerNorm kernel's `t = x; t += bias`
+    if constexpr (Epi::kSerial) {
+      ser_per = (kt_end - kt_begin) / g.e.splitk;
+      ser_left = ser_per;
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+          tser[i][j] = f32x4{eo.rv[i][j].x + eo.bv[i].x, eo.rv[i][j].y + eo.bv[i].y, eo.rv[i][j].z + eo.bv[i].z, eo.rv[i][j].w + eo.bv[i].w};
+    }
+  };
 
   const int fr = lane & 15, fg = lane >> 4;
   auto compute = [&](int buf) {
@@ -597,10 +636,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
     issue(0);
     Epi::template fetch<FM, FN, AL>(c, g.e, eo, m0 + wm * TM, n0 + wn * TN, lane);
     __syncthreads();  // (drains the LDS-DMA: hipcc emits vmcnt(0) before the barrier while a global_load_lds is pending)
+    ser_begin();
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       if (kt + 1 < kt_end) issue(cur ^ 1);
       compute(cur);
+      if constexpr (Epi::kSerial) {
+        if (--ser_left == 0) ser_fold();
+      }
       __syncthreads();
       cur ^= 1;
     }
@@ -616,6 +659,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
     // requested first would have to land before the first k-step may start; here it only has to land before stage ST - 1
     // is consumed (the counted waits below over-wait by these few loads during the first two k-steps, nothing more).
     Epi::template fetch<FM, FN, AL>(c, g.e, eo, m0 + wm * TM, n0 + wn * TN, lane);
+    if constexpr (Epi::kSerial) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the skip / bias quads (and the ring fill in front of them) have landed
+      ser_begin();
+    }
     int slot = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * G) : "memory");
@@ -624,12 +671,27 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
       if (nslot >= ST) nslot -= ST;
       issue(nslot);
       compute(slot);
+      if constexpr (Epi::kSerial) {
+        if (--ser_left == 0) ser_fold();
+      }
       slot = slot + 1 == ST ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 
-  run_epilogue<Epi, FM, FN, TM, TN, AL>(c, g.e, acc, eo, eo.step(), m0 + wm * TM, n0 + wn * TN, lane, z);
+  if constexpr (Epi::kSerial) {
+    typedef EpiStd<T, ACT_NONE, 0, EB_F32> EOut;  // the running value already holds skip + bias: store it, nothing else
+    typename EOut::template Ops<FM, FN> none;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      none.bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < FM; ++j) none.rv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    run_epilogue<EOut, FM, FN, TM, TN, AL>(c, g.e, tser, none, 0, m0 + wm * TM, n0 + wn * TN, lane, z);
+  } else {
+    run_epilogue<Epi, FM, FN, TM, TN, AL>(c, g.e, acc, eo, eo.step(), m0 + wm * TM, n0 + wn * TN, lane, z);
+  }
 }
 
 
@@ -800,7 +862,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv3s_kernel(const GemmDev<type
 // ---------------------------------------------------------------------------------------------- host side (per operand type)
 enum Tile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x256 = 3, TILE_COUNT = 4 };
 // EPI_STD kernel variants: the generic one tests everything at run time, the others compile the unused features out
-enum StdVariant { V_GEN = 0, V_NONE = 1, V_SLAB = 2, V_GELU_T = 3, V_ST_F32 = 4, V_ST_RES = 5, V_ST_A2 = 6, V_BIAS_T = 7, V_COUNT = 8 };
+enum StdVariant { V_GEN = 0, V_NONE = 1, V_SLAB = 2, V_GELU_T = 3, V_ST_F32 = 4, V_ST_RES = 5, V_ST_A2 = 6, V_BIAS_T = 7, V_SERIAL = 8, V_COUNT = 9 };
 constexpr int kNoKernel = -100;  // visit_*: this combination is not instantiated
 
 struct GemmPlan {   // what gemm_launch (gemm.hip) decided: tile, grid, the device argument core
@@ -863,6 +925,12 @@ static int visit_std_tile(int variant, bool conv, bool al, V&& v) {
     case V_BIAS_T:
       if (!al) return kNoKernel;
       return conv ? v(KernelRef<T, BM, BN, NW, WM, ST, EBiasT, true, true, 0>{}) : v(KernelRef<T, BM, BN, NW, WM, ST, EBiasT, false, true, 0>{});
+    case V_SERIAL:
+      if constexpr ((BM / WM / 16) * (BN / (NW / WM) / 16) > 8) return kNoKernel;  // needs the skip quads in registers next to two accumulator sets
+      else {
+        if (!al || conv) return kNoKernel;
+        return v(KernelRef<T, BM, BN, NW, WM, ST, EpiSerial<T>, false, true, 0>{});
+      }
   }
   return kNoKernel;
 }
@@ -928,7 +996,10 @@ int gemm_launch_typed(int epi, const GemmArgs& a, const GemmPlan& plan, hipStrea
                     (!a.out_f32 || (((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0)) && (!a.out_t || (((size_t)a.out_t & 7) == 0 && (a.ldot & 3) == 0));
     const bool conv = a.taps > 1, stats = a.gn_part != nullptr, a2 = a.A2 != nullptr;
     int variant = V_GEN;
-    if (al) {
+    if (a.serial_k > 1) {
+      variant = V_SERIAL;
+      d.e.splitk = a.serial_k;  // K ranges folded inside the launch
+    } else if (al) {
       const int mode = a.splitk > 1 ? EB_SLAB : ((a.bias ? EB_BIAS : 0) | (a.res ? EB_RES : 0) | (a.out_f32 ? EB_F32 : 0) | (a.out_t ? EB_T : 0));
       if (a.act == ACT_NONE) {
         if (stats) {
@@ -947,7 +1018,7 @@ int gemm_launch_typed(int epi, const GemmArgs& a, const GemmPlan& plan, hipStrea
       return 0;
     };
     rc = visit_std<T>(plan.tile, variant, conv, al, go);
-    if (rc == kNoKernel) rc = visit_std<T>(plan.tile, V_GEN, conv, al, go);
+    if (rc == kNoKernel && variant != V_SERIAL) rc = visit_std<T>(plan.tile, V_GEN, conv, al, go);
   } else if (epi == EPI_QKV_HEADS) {
     GemmDev<EpiQkvHeadsArgs> d;
     d.c = plan.core;

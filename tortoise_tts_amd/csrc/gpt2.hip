@@ -191,21 +191,37 @@ static int decode_step_enqueue(tt_ar* e, hipStream_t s, bool embedded = false) {
     a.P1 = e->P1; a.kc = g.kc; a.vc = g.vc; a.tmax = e->tmax; a.step = e->state + 1;
     a.out = e->attn; a.B = B; a.heads = H; a.host_tgen = e->host_slot + 1;
     TT_TRY(decode_attention_launch(dt, a, s));
+    // >= 1024 sequences (several utterances per batch): one block per output tile fills the chip, so the split-K partial sums are
+    // folded inside the launch in slab order (gemm.h serial_k: the same bits as slabs + row norm, without 2 x 4 x B x D x 4 bytes of slab traffic)
+    const bool serial = B >= 1024;
     int sk = pick_split(B, D, D);
     g = ar_gemm(e, e->attn, D, w.w_proj, D, B, D, D);
-    g.splitk = sk; g.out_f32 = e->slabs; g.ldo32 = D;
-    if (sk == 1) { g.bias = nullptr; }
-    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
-    TT_TRY(ar_rownorm(e, e->x, B, w.ln2_g, w.ln2_b, nullptr, nullptr, w.b_proj, sk, B, s));
+    if (serial && sk > 1) {
+      g.serial_k = sk; g.bias = w.b_proj; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
+      TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+      TT_TRY(ar_rownorm(e, e->x, B, w.ln2_g, w.ln2_b, nullptr, nullptr, nullptr, 0, B, s));
+    } else {
+      g.splitk = sk; g.out_f32 = e->slabs; g.ldo32 = D;
+      if (sk == 1) { g.bias = nullptr; }
+      TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+      TT_TRY(ar_rownorm(e, e->x, B, w.ln2_g, w.ln2_b, nullptr, nullptr, w.b_proj, sk, B, s));
+    }
     g = ar_gemm(e, e->h, D, w.w_fc, D, B, 4 * D, D);
     g.bias = w.b_fc; g.act = ACT_GELU_TANH; g.out_t = e->ff; g.ldot = 4 * D;
     TT_TRY(gemm_launch(dt, EPI_STD, g, s));
     sk = pick_split(B, D, 4 * D);
     g = ar_gemm(e, e->ff, 4 * D, w.w_proj2, 4 * D, B, D, 4 * D);
-    g.splitk = sk; g.out_f32 = e->slabs; g.ldo32 = D;
-    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
-    pend_bias = w.b_proj2;
-    pend_slabs = sk;
+    if (serial && sk > 1) {
+      g.serial_k = sk; g.bias = w.b_proj2; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
+      TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+      pend_bias = nullptr;
+      pend_slabs = 0;
+    } else {
+      g.splitk = sk; g.out_f32 = e->slabs; g.ldo32 = D;
+      TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+      pend_bias = w.b_proj2;
+      pend_slabs = sk;
+    }
   }
   return ar_head(e, e->x, B, pend_bias, pend_slabs, s, -1);
 }
