@@ -164,6 +164,11 @@ class TextToSpeech:
         self.clvp = stages.ClvpStage(sd("clvp"), self.clvp_cfg, self.device, self.dtype, max_rows=max(cap, 8) * max_mel_tokens)
         # tts_many also pushes utterance_batch utterances through ONE denoiser pass per diffusion step (padded to the longest)
         self.batch_diffusion = self.utterance_batch > 1
+        # Optional: with more utterances than one batch holds, decode batch i + 1 on a second stream (worker thread) while batch i's
+        # denoiser passes run.  Off by default: measured on 15 chunks at 8 per batch both phases slow down by what the other takes
+        # (decode 3.1 -> 4.35 s, rendering 2.85 -> 3.93 s: they contend for the same memory system), 6.4 -> 6.19 s in total, and one
+        # batch of 16 is faster still (6.06 s; profiles/r03_bench_read_overlap.txt).  Bit-identical results either way (tested).
+        self.overlap_waves = False
         self.diffusion = stages.DiffusionStage(sd("diffusion"), self.diff_cfg, self.device, self.dtype, max_seq=max_S,
                                                max_codes=max_mel_tokens + 8, max_steps=512, max_batch=self.utterance_batch)
         voc_sd = sd("vocoder")
@@ -419,71 +424,129 @@ class TextToSpeech:
         if max_mel_tokens > self.max_mel_tokens_cap:
             raise ValueError(f"max_mel_tokens={max_mel_tokens} exceeds the capacity this engine was built with")
         stop = self.ar_cfg.stop_mel_token
-        ev = _StageTimer(2)
-        ev.mark(0)
-        samples = []
-        for w0 in range(0, len(toks), self.utterance_batch):
-            wave = toks[w0:w0 + self.utterance_batch]
-            for g, t in enumerate(wave):
-                self.ar.prefill_group(g, len(wave), auto_conditioning, t)
-            codes, _ = self.ar.generate(N * len(wave), max_mel_tokens, temperature=settings.get("temperature", .8), top_p=settings.get("top_p", .8),
+        G = self.utterance_batch
+        waves = [list(range(w0, min(w0 + G, len(toks)))) for w0 in range(0, len(toks), G)]
+
+        def ar_wave(idx):
+            """One shared decode batch: the candidates of the utterances `idx` -> their code tensors [N, max_mel_tokens]."""
+            for g, j in enumerate(idx):
+                self.ar.prefill_group(g, len(idx), auto_conditioning, toks[j])
+            codes, _ = self.ar.generate(N * len(idx), max_mel_tokens, temperature=settings.get("temperature", .8), top_p=settings.get("top_p", .8),
                                         repetition_penalty=settings.get("repetition_penalty", 2.0), top_k=top_k, seed=seed, row_offset=0,
-                                        group_seeds=[seed] * len(wave))
+                                        group_seeds=[seed] * len(idx))
             codes = F.pad(codes, (0, max_mel_tokens - codes.shape[1]), value=stop)
-            samples.extend(codes[g * N:(g + 1) * N] for g in range(len(wave)))
-        ev.mark(1)
+            return [codes[g * N:(g + 1) * N] for g in range(len(idx))]
+
         out, acc = [None] * len(toks), {}
         if not self.batch_diffusion:
+            ev = _StageTimer(2)
+            ev.mark(0)
+            samples = [smp for idx in waves for smp in ar_wave(idx)]
+            ev.mark(1)
             for j, (t, smp) in enumerate(zip(toks, samples)):
                 out[j] = self.tts(t[0, :-1], conditioning_latents=conditioning_latents, k=1, verbose=verbose, use_deterministic_seed=seed,
                                   noise_override={"_ar_samples": smp}, **settings)
                 for k_, v in self.timings.items():
                     acc[k_] = acc.get(k_, 0.0) + v
-        else:
-            # ---- per utterance: CLVP winner + latent re-pass (api.py:447-524), then its diffusion inputs with the noise tts() would draw
-            diffusion_conditioning = conditioning_latents[1].to(dev).float()
-            sched = Schedule(int(settings.get("diffusion_iterations", 100)), self.diff_cfg.trained_steps, settings.get("cond_free", True),
-                             settings.get("cond_free_k", 2))
-            ev2 = _StageTimer(4)
-            ev2.mark(0)
-            items, zs = [], []
-            for t, smp in zip(toks, samples):
-                fixed = fix_autoregressive_output(smp.to(dev).long(), stop)
-                scores = self.clvp.score(t, fixed)
-                best = tdist.topk_lowest_index(scores, 1)
-                best_results = fixed.to(torch.int32)[best].long()
-                best_latents = self.ar.latents(auto_conditioning, t, best_results)
-                latents = best_latents[0:1][:, :calm_trim_length(best_results[0])]
-                S = latents.shape[1] * 4 * 24000 // 22050
-                gen = torch.Generator(device=dev).manual_seed(seed + 7919)
-                x_T = torch.randn(1, 100, S, device=dev, generator=gen) * float(settings.get("diffusion_temperature", 1.0))
-                step_noise = torch.randn(sched.num_timesteps, 1, 100, S, device=dev, generator=gen)
-                zs.append(torch.randn(1, self.voc_cfg.noise_dim, S + 10, device=dev, generator=gen))
-                items.append((latents, diffusion_conditioning, S, x_T, step_noise))
+            ev.synchronize()
+            acc["ar_s"] = acc.get("ar_s", 0.0) + ev.seconds(0, 1)
+            acc["total_s"] = acc.get("total_s", 0.0) + ev.seconds(0, 1)
+            self.timings = acc
+            return out
+
+        diffusion_conditioning = conditioning_latents[1].to(dev).float()
+        sched = Schedule(int(settings.get("diffusion_iterations", 100)), self.diff_cfg.trained_steps, settings.get("cond_free", True),
+                         settings.get("cond_free_k", 2))
+
+        def prepare(t, smp):
+            """CLVP winner + latent re-pass of one utterance (api.py:447-524) and its diffusion inputs with the noise tts() would draw."""
+            fixed = fix_autoregressive_output(smp.to(dev).long(), stop)
+            scores = self.clvp.score(t, fixed)
+            best = tdist.topk_lowest_index(scores, 1)
+            best_results = fixed.to(torch.int32)[best].long()
             self.last_best_codes = best_results
-            ev2.mark(1)
-            # ---- diffusion: utterance_batch utterances per pass, neighbours in length together (least padding)
-            order = sorted(range(len(items)), key=lambda j: items[j][2])
-            mels = [None] * len(items)
-            for w0 in range(0, len(order), self.utterance_batch):
-                idx = order[w0:w0 + self.utterance_batch]
-                if len(idx) == 1:
-                    lat_, dc_, S_, x_, n_ = items[idx[0]]
+            best_latents = self.ar.latents(auto_conditioning, t, best_results)
+            latents = best_latents[0:1][:, :calm_trim_length(best_results[0])]
+            S = latents.shape[1] * 4 * 24000 // 22050
+            gen = torch.Generator(device=dev).manual_seed(seed + 7919)
+            x_T = torch.randn(1, 100, S, device=dev, generator=gen) * float(settings.get("diffusion_temperature", 1.0))
+            step_noise = torch.randn(sched.num_timesteps, 1, 100, S, device=dev, generator=gen)
+            z = torch.randn(1, self.voc_cfg.noise_dim, S + 10, device=dev, generator=gen)
+            return (latents, diffusion_conditioning, S, x_T, step_noise), z
+
+        def render(idx, items, zs):
+            """Diffusion in shared, padded passes (neighbours in length together: least padding) + UnivNet for the utterances `idx`."""
+            order = sorted(range(len(idx)), key=lambda k_: items[k_][2])
+            mels = [None] * len(idx)
+            for w0 in range(0, len(order), G):
+                sel = order[w0:w0 + G]
+                if len(sel) == 1:
+                    lat_, dc_, S_, x_, n_ = items[sel[0]]
                     self.diffusion.condition(lat_, dc_, S_)
-                    mels[idx[0]] = self.diffusion.sample(sched, x_, n_)
+                    mels[sel[0]] = self.diffusion.sample(sched, x_, n_)
                 else:
-                    for j, mel in zip(idx, self.diffusion.sample_many(sched, [items[j] for j in idx])):
-                        mels[j] = mel
-            ev2.mark(2)
-            for j in range(len(items)):
-                out[j] = self.vocoder.inference(mels[j], zs[j]).cpu()
-            ev2.mark(3)
-            ev2.synchronize()
-            acc = {"ar_s": 0.0, "clvp_s": ev2.seconds(0, 1), "latents_s": 0.0, "diffusion_s": ev2.seconds(1, 2), "vocoder_s": ev2.seconds(2, 3),
-                   "total_s": ev2.seconds(0, 3)}
-        ev.synchronize()
-        acc["ar_s"] = acc.get("ar_s", 0.0) + ev.seconds(0, 1)
-        acc["total_s"] = acc.get("total_s", 0.0) + ev.seconds(0, 1)
+                    for k_, mel in zip(sel, self.diffusion.sample_many(sched, [items[k_] for k_ in sel])):
+                        mels[k_] = mel
+            for k_, j in enumerate(idx):
+                out[j] = self.vocoder.inference(mels[k_], zs[k_]).cpu()
+
+        import contextlib
+        import time as _time
+        on_gpu = torch.device(dev).type == "cuda"  # (the CPU stand-ins of the tests drive the same schedule without streams)
+
+        def sync_current():
+            if on_gpu:
+                torch.cuda.current_stream().synchronize()
+
+        t_host = {"ar_s": 0.0, "rank_s": 0.0, "render_s": 0.0}
+        t_all = _time.perf_counter()
+        if self.overlap_waves and len(waves) > 1:
+            # While wave i's denoiser passes run (MFMA / VALU-bound, under-filled launches), wave i + 1 decodes (HBM- and launch-bound)
+            # on a second stream from a worker thread: the two engines own separate arenas and streams.  The latent re-pass of wave i
+            # uses the autoregressive engine's buffers, so the next decode is only submitted after it.
+            from concurrent.futures import ThreadPoolExecutor
+            side = torch.cuda.Stream(device=dev) if on_gpu else None
+
+            def job(idx):
+                t0 = _time.perf_counter()
+                with (torch.cuda.stream(side) if on_gpu else contextlib.nullcontext()):
+                    smp = ar_wave(idx)
+                    if on_gpu:
+                        side.synchronize()
+                return smp, _time.perf_counter() - t0
+
+            with ThreadPoolExecutor(max_workers=1) as ex:
+                fut = ex.submit(job, waves[0])
+                for i, idx in enumerate(waves):
+                    samples, dt_ar = fut.result()
+                    t_host["ar_s"] += dt_ar
+                    t0 = _time.perf_counter()
+                    prepared = [prepare(toks[j], smp) for j, smp in zip(idx, samples)]
+                    sync_current()  # the latent re-passes are done with the decode engine's buffers
+                    t_host["rank_s"] += _time.perf_counter() - t0
+                    if i + 1 < len(waves):
+                        fut = ex.submit(job, waves[i + 1])
+                    t0 = _time.perf_counter()
+                    render(idx, [p_[0] for p_ in prepared], [p_[1] for p_ in prepared])
+                    t_host["render_s"] += _time.perf_counter() - t0
+        else:
+            for idx in waves:
+                t0 = _time.perf_counter()
+                samples = ar_wave(idx)
+                sync_current()
+                t_host["ar_s"] += _time.perf_counter() - t0
+                t0 = _time.perf_counter()
+                prepared = [prepare(toks[j], smp) for j, smp in zip(idx, samples)]
+                sync_current()
+                t_host["rank_s"] += _time.perf_counter() - t0
+                t0 = _time.perf_counter()
+                render(idx, [p_[0] for p_ in prepared], [p_[1] for p_ in prepared])
+                t_host["render_s"] += _time.perf_counter() - t0
+        if on_gpu:
+            torch.cuda.synchronize()
+        # host-clock stage sums (with overlapping waves the stages run concurrently: they add up to more than total_s)
+        acc = {"ar_s": t_host["ar_s"], "clvp_s": t_host["rank_s"], "latents_s": 0.0, "diffusion_s": t_host["render_s"], "vocoder_s": 0.0,
+               "total_s": _time.perf_counter() - t_all}
         self.timings = acc
         return out
 
