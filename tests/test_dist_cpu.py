@@ -134,8 +134,9 @@ def _riding_hood_chunks():
     return [[1 + (ord(c) % 250) for c in ch][:24] for ch in chunks]
 
 
-def _longform_worker(rank, world, port, out_dir):
-    """BASELINE config #4 on CPU stand-ins: chunk j is rendered by rank j % world with the complete (unsharded) pipeline."""
+def _longform_worker(rank, world, port, out_dir, ubatch=1, nsamp=2, tag=""):
+    """BASELINE config #4 on CPU stand-ins: chunk j is rendered by rank j % world with the complete (unsharded) pipeline;
+    ubatch > 1: a rank renders its chunks in shared batches (TextToSpeech.tts_many)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     if world > 1:
         tdist.init_from_env()
@@ -148,17 +149,23 @@ def _longform_worker(rank, world, port, out_dir):
         from tortoise_tts_amd.api import TextToSpeech
         from tortoise_tts_amd.longform import read_long_form
         sds, cfgs = small_setup()
-        tts = TextToSpeech(state_dicts=sds, configs=cfgs, max_candidates=8, max_mel_tokens=16, kv_cache=True, candidate_sharding=False)
+        tts = TextToSpeech(state_dicts=sds, configs=cfgs, max_candidates=8, max_mel_tokens=16, kv_cache=True, candidate_sharding=False,
+                           utterance_batch=ubatch)
         calls = []
         orig = tts.tts_with_preset
         tts.tts_with_preset = lambda *a, **k: (calls.append(k.get("use_deterministic_seed")), orig(*a, **k))[1]
         full, clips = read_long_form(tts, _riding_hood_chunks(), preset="ultra_fast", conditioning_latents=voice_latents(cfgs), seed=5,
-                                     texts_are_chunks=True, num_autoregressive_samples=2, diffusion_iterations=2, max_mel_tokens=10)
-        assert calls and all(c == 5 for c in calls)  # the same seed for every chunk (read.py:54, 70-71)
-        assert len(calls) == len([j for j in range(15) if j % world == rank])
+                                     texts_are_chunks=True, num_autoregressive_samples=nsamp, diffusion_iterations=2, max_mel_tokens=10)
+        mine = len([j for j in range(15) if j % world == rank])
+        if ubatch > 1 and mine > 1:
+            assert not calls and tts.ar.group_batches >= 1  # the chunks went through shared decode batches, not one call per chunk
+            assert sum(tts.diffusion.batched) + (mine - sum(tts.diffusion.batched)) == mine
+        else:
+            assert calls and all(c == 5 for c in calls)  # the same seed for every chunk (read.py:54, 70-71)
+            assert len(calls) == mine
         if rank == 0:
             assert len(clips) == 15 and full.shape[-1] == sum(c.shape[-1] for c in clips)
-            torch.save((full, clips), os.path.join(out_dir, f"longform_w{world}.pt"))
+            torch.save((full, clips), os.path.join(out_dir, f"longform_w{world}{tag}.pt"))
         else:
             assert full is None and clips is None
     finally:
@@ -176,3 +183,13 @@ def test_longform_chunks_spread_over_ranks_match_sequential(tmp_path):
     assert torch.equal(f1, f2), "spreading the chunks over two ranks changed the audio"
     assert all(torch.equal(a, b) for a, b in zip(c1, c2))  # chunk order preserved
     assert len({tuple(c.flatten()[:64].tolist()) for c in c1}) > 1  # different chunks give different audio
+
+
+def test_longform_shared_batches_match_one_chunk_after_the_other(tmp_path):
+    """A rank that renders its chunks 3 at a time (shared decode batches + shared denoiser passes, tts_many) inside a 2-rank job
+    returns the audio of the sequential single-process reading (same seed, same candidate count)."""
+    _longform_worker(0, 1, 0, str(tmp_path), 1, 4, "_seq")
+    mp.spawn(_longform_worker, args=(2, _free_port(), str(tmp_path), 3, 4, "_ub3"), nprocs=2, join=True)
+    f1, c1 = torch.load(tmp_path / "longform_w1_seq.pt")
+    f2, c2 = torch.load(tmp_path / "longform_w2_ub3.pt")
+    assert torch.equal(f1, f2) and all(torch.equal(a, b) for a, b in zip(c1, c2))
