@@ -92,7 +92,6 @@ def test_tts_many_equals_one_utterance_after_the_other(monkeypatch):
     texts = ["Once upon a time.", "There lived a girl.", list(range(10, 31))]
     kw = dict(num_autoregressive_samples=8, diffusion_iterations=3, max_mel_tokens=32)
     one_by_one = [t.tts(x, conditioning_latents=lat, use_deterministic_seed=5, verbose=False, **kw) for x in texts]
-    t.overlap_waves = True  # the two-batch schedule with the next decode on a worker thread (same results by construction)
     many = t.tts_many(texts, conditioning_latents=lat, use_deterministic_seed=5, **kw)
     assert t.ar.group_batches == 1  # 3 utterances, 2 per decode batch: one grouped generation + one single
     assert t.diffusion.batched == [2]  # and the same for the denoiser passes: the two nearest in length together, one alone

@@ -158,11 +158,8 @@ def test_tts_many_shares_decode_batches_and_equals_tts_per_text(full):
     for j, (a, b) in enumerate(zip(many, one_by_one)):
         assert a.shape == b.shape and torch.isfinite(a).all()
         report(f"tts_many (batched AR + batched denoiser) clip {j} bf16 vs tts() alone", a, b, 8e-2)
-    # decoding batch i + 1 on a second stream while batch i renders is scheduling only: the same bits as one after the other
-    tts.overlap_waves = True
-    par = tts.tts_many(texts, use_deterministic_seed=7, **kw)
-    tts.overlap_waves = False
-    assert all(torch.equal(a, b) for a, b in zip(many, par)), "overlapping the decode of the next batch with rendering changed a clip"
+    again = tts.tts_many(texts, use_deterministic_seed=7, **kw)
+    assert all(torch.equal(a, b) for a, b in zip(many, again)), "tts_many is not reproducible run to run"
     assert tts.timings["ar_s"] > 0
     for st in (tts.ar, tts.clvp, tts.diffusion, tts.vocoder):
         st.close()

@@ -164,11 +164,9 @@ class TextToSpeech:
         self.clvp = stages.ClvpStage(sd("clvp"), self.clvp_cfg, self.device, self.dtype, max_rows=max(cap, 8) * max_mel_tokens)
         # tts_many also pushes utterance_batch utterances through ONE denoiser pass per diffusion step (padded to the longest)
         self.batch_diffusion = self.utterance_batch > 1
-        # Optional: with more utterances than one batch holds, decode batch i + 1 on a second stream (worker thread) while batch i's
-        # denoiser passes run.  Off by default: measured on 15 chunks at 8 per batch both phases slow down by what the other takes
-        # (decode 3.1 -> 4.35 s, rendering 2.85 -> 3.93 s: they contend for the same memory system), 6.4 -> 6.19 s in total, and one
-        # batch of 16 is faster still (6.06 s; profiles/r03_bench_read_overlap.txt).  Bit-identical results either way (tested).
-        self.overlap_waves = False
+        # (Decoding batch i + 1 on a second stream while batch i's denoiser passes run was built and measured: both phases slow down by
+        # what the other takes - decode 3.1 -> 4.35 s, rendering 2.85 -> 3.93 s for 15 chunks at 8 per batch, 6.4 -> 6.19 s in total, and
+        # one batch of 16 is faster still, 6.06 s: profiles/r03_bench_read_overlap.txt - and removed again.)
         self.diffusion = stages.DiffusionStage(sd("diffusion"), self.diff_cfg, self.device, self.dtype, max_seq=max_S,
                                                max_codes=max_mel_tokens + 8, max_steps=512, max_batch=self.utterance_batch)
         voc_sd = sd("vocoder")
@@ -490,7 +488,6 @@ class TextToSpeech:
             for k_, j in enumerate(idx):
                 out[j] = self.vocoder.inference(mels[k_], zs[k_]).cpu()
 
-        import contextlib
         import time as _time
         on_gpu = torch.device(dev).type == "cuda"  # (the CPU stand-ins of the tests drive the same schedule without streams)
 
@@ -500,51 +497,21 @@ class TextToSpeech:
 
         t_host = {"ar_s": 0.0, "rank_s": 0.0, "render_s": 0.0}
         t_all = _time.perf_counter()
-        if self.overlap_waves and len(waves) > 1:
-            # While wave i's denoiser passes run (MFMA / VALU-bound, under-filled launches), wave i + 1 decodes (HBM- and launch-bound)
-            # on a second stream from a worker thread: the two engines own separate arenas and streams.  The latent re-pass of wave i
-            # uses the autoregressive engine's buffers, so the next decode is only submitted after it.
-            from concurrent.futures import ThreadPoolExecutor
-            side = torch.cuda.Stream(device=dev) if on_gpu else None
-
-            def job(idx):
-                t0 = _time.perf_counter()
-                with (torch.cuda.stream(side) if on_gpu else contextlib.nullcontext()):
-                    smp = ar_wave(idx)
-                    if on_gpu:
-                        side.synchronize()
-                return smp, _time.perf_counter() - t0
-
-            with ThreadPoolExecutor(max_workers=1) as ex:
-                fut = ex.submit(job, waves[0])
-                for i, idx in enumerate(waves):
-                    samples, dt_ar = fut.result()
-                    t_host["ar_s"] += dt_ar
-                    t0 = _time.perf_counter()
-                    prepared = [prepare(toks[j], smp) for j, smp in zip(idx, samples)]
-                    sync_current()  # the latent re-passes are done with the decode engine's buffers
-                    t_host["rank_s"] += _time.perf_counter() - t0
-                    if i + 1 < len(waves):
-                        fut = ex.submit(job, waves[i + 1])
-                    t0 = _time.perf_counter()
-                    render(idx, [p_[0] for p_ in prepared], [p_[1] for p_ in prepared])
-                    t_host["render_s"] += _time.perf_counter() - t0
-        else:
-            for idx in waves:
-                t0 = _time.perf_counter()
-                samples = ar_wave(idx)
-                sync_current()
-                t_host["ar_s"] += _time.perf_counter() - t0
-                t0 = _time.perf_counter()
-                prepared = [prepare(toks[j], smp) for j, smp in zip(idx, samples)]
-                sync_current()
-                t_host["rank_s"] += _time.perf_counter() - t0
-                t0 = _time.perf_counter()
-                render(idx, [p_[0] for p_ in prepared], [p_[1] for p_ in prepared])
-                t_host["render_s"] += _time.perf_counter() - t0
+        for idx in waves:
+            t0 = _time.perf_counter()
+            samples = ar_wave(idx)
+            sync_current()
+            t_host["ar_s"] += _time.perf_counter() - t0
+            t0 = _time.perf_counter()
+            prepared = [prepare(toks[j], smp) for j, smp in zip(idx, samples)]
+            sync_current()
+            t_host["rank_s"] += _time.perf_counter() - t0
+            t0 = _time.perf_counter()
+            render(idx, [p_[0] for p_ in prepared], [p_[1] for p_ in prepared])
+            t_host["render_s"] += _time.perf_counter() - t0
         if on_gpu:
             torch.cuda.synchronize()
-        # host-clock stage sums (with overlapping waves the stages run concurrently: they add up to more than total_s)
+        # host-clock stage sums
         acc = {"ar_s": t_host["ar_s"], "clvp_s": t_host["rank_s"], "latents_s": 0.0, "diffusion_s": t_host["render_s"], "vocoder_s": 0.0,
                "total_s": _time.perf_counter() - t_all}
         self.timings = acc
