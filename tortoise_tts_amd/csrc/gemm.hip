@@ -25,6 +25,10 @@ static int pick_tile(const GemmArgs& a) {
   if (b256 >= 256 && a.N >= 256 && a.M >= 2048 && a.serial_k <= 1) return TILE_256x256;  // (the pre-pass, CLVP's speech tower, a batched denoiser)
   const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk;
   if (a.M > 256 && b128 >= 256 && a.N > 64) return TILE_128x128;  // (N <= 64: half of a 128-wide tile would be padding)
+  // one denoiser pass (1024 < M <= 2048 rows, N = 1024): 448 tiles of 64x64 put two workgroups on every CU (70 instead of 46 GB/s of
+  // L2 -> LDS per CU) where 224 tiles of 128x64 leave one - in-situ A/B -1.1 % on the sampler iteration; same statistics rows (32), same bits
+  if (a.taps == 1 && a.M > 1024 && a.M <= 2048 && a.N <= 1024) return TILE_64x64;
+  if (a.taps > 1 && a.gn_part == nullptr && a.M > 1024 && a.M <= 2048 && a.N <= 1024) return TILE_64x64;  // inp_block, final conv: -0.9 % more
   if (a.M > 1024 || (a.M > 256 && a.gn_part != nullptr)) return TILE_128x64;
   return TILE_64x64;  // also one denoiser row (M = S <= 1024, the split diffusion tail): 2x the workgroups of 128x64
 }

@@ -119,7 +119,7 @@ static int gpt_trunk_full(tt_ar* e, int B, int n, bool to_prefix, hipStream_t s,
 static int pick_split(int B, int N, int K) {
   (void)B;
   // decode GEMMs run 64x64 tiles with 256-deep k-stages: aim for ~256 blocks at the full candidate batch
-  // (4 row tiles) and at least one whole stage per split.
+  // (4 row tiles) and at least one whole stage per split.  (In-situ A/B, round 3: 8 slabs for proj2 +4.8 %, 2 slabs for proj +0.9 %.)
   const int tiles = 4 * cdiv(N, 64);
   int sk = 256 / (tiles > 0 ? tiles : 1);
   const int nk = K / 256;

@@ -506,21 +506,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs a, int nchu
 // C == 1024 fast path: thread t owns channels 4t..4t+3 (group t/8) of GN_APPLY_ROWS consecutive rows.  The x rows
 // are requested BEFORE the statistics are finalised, so the streaming loads overlap the (latency-bound) prologue.
 constexpr int GN_APPLY_ROWS = 4;  // 4 rows per block: 2 blocks per CU at the denoiser's 1740 rows, so one block's statistics prologue overlaps the other's stream
-template <typename T, bool FUSED, bool SS>
+// ROWS per block: 4 in general (two blocks per CU overlap each other's statistics prologue); 2 for passes of <= 4096 rows (the
+// denoiser alone, 1740 rows: 870 blocks instead of 435 - in-situ A/B -1.7 % on the sampler iteration; 1 row and 8 rows are slower)
+template <typename T, bool FUSED, bool SS, int ROWS>
 __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, int nchunk) {
   __shared__ float mean_s[32], rstd_s[32];
   __shared__ double part_s[8][32], part_q[8][32];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int S = a.S;
   constexpr int C = 1024;
-  const int r0 = blockIdx.x * GN_APPLY_ROWS;
+  const int r0 = blockIdx.x * ROWS;
   const int c = tid * 4;
   // request order = need order: statistics partials, then the rows and the affine parameters
   float2 head[GN_HEAD];
   if constexpr (FUSED) gn_partial_head<1>(a, b, tid, head);  // FUSED <=> a.gemm_part != nullptr (compile time: no branch to sink consumers into)
-  float4 xr[GN_APPLY_ROWS];
+  float4 xr[ROWS];
 #pragma unroll
-  for (int i = 0; i < GN_APPLY_ROWS; ++i) {
+  for (int i = 0; i < ROWS; ++i) {
     const int r = min(r0 + i, S - 1);
     xr[i] = *(const float4*)(a.x + ((size_t)b * S + r) * C + c);
   }
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(256) void gn_apply_c1024_kernel(GroupNormArgs a, in
   const float mu = mean_s[tid >> 3], rs = rstd_s[tid >> 3];
   const int vl = a.vperiod > 0 ? a.vlen[b % a.vperiod] : S;
 #pragma unroll
-  for (int i = 0; i < GN_APPLY_ROWS; ++i) {
+  for (int i = 0; i < ROWS; ++i) {
     const int r = r0 + i;
     if (r >= S) break;
     const float4 t = xr[i];
@@ -579,20 +581,27 @@ int groupnorm_launch(int dtype, const GroupNormArgs& a0, hipStream_t stream) {
     gn_stats_kernel<<<grid, 256, 0, stream>>>(a.x, a.S, a.C, a.partial, rpc, a);
     TT_CHECK_HIP(hipGetLastError());
   }
-  const int rpb = GN_APPLY_ROWS;  // apply is pure streaming: many small blocks
+  const bool few = a.C == 1024 && (long)a.B * a.S <= 4096;
+  const int rpb = few ? 2 : GN_APPLY_ROWS;  // apply is pure streaming: many small blocks
   dim3 grid2(cdiv(a.S, rpb), a.B);
   if (a.C == 1024) {
     const int variant = (dtype == DT_BF16 ? 0 : 4) + (a.gemm_part ? 2 : 0) + (a.scale_shift ? 1 : 0);
+#define TT_GN(T, F, SSV)                                                                                              \
+    do {                                                                                                                \
+      if (few) launch_timed(ps, gn_apply_c1024_kernel<T, F, SSV, 2>, grid2, dim3(256), 0, stream, a, nchunk);          \
+      else launch_timed(ps, gn_apply_c1024_kernel<T, F, SSV, GN_APPLY_ROWS>, grid2, dim3(256), 0, stream, a, nchunk);  \
+    } while (0)
     switch (variant) {
-      case 0: launch_timed(ps, gn_apply_c1024_kernel<bf16, false, false>, grid2, dim3(256), 0, stream, a, nchunk); break;
-      case 1: launch_timed(ps, gn_apply_c1024_kernel<bf16, false, true>, grid2, dim3(256), 0, stream, a, nchunk); break;
-      case 2: launch_timed(ps, gn_apply_c1024_kernel<bf16, true, false>, grid2, dim3(256), 0, stream, a, nchunk); break;
-      case 3: launch_timed(ps, gn_apply_c1024_kernel<bf16, true, true>, grid2, dim3(256), 0, stream, a, nchunk); break;
-      case 4: launch_timed(ps, gn_apply_c1024_kernel<f16, false, false>, grid2, dim3(256), 0, stream, a, nchunk); break;
-      case 5: launch_timed(ps, gn_apply_c1024_kernel<f16, false, true>, grid2, dim3(256), 0, stream, a, nchunk); break;
-      case 6: launch_timed(ps, gn_apply_c1024_kernel<f16, true, false>, grid2, dim3(256), 0, stream, a, nchunk); break;
-      default: launch_timed(ps, gn_apply_c1024_kernel<f16, true, true>, grid2, dim3(256), 0, stream, a, nchunk); break;
+      case 0: TT_GN(bf16, false, false); break;
+      case 1: TT_GN(bf16, false, true); break;
+      case 2: TT_GN(bf16, true, false); break;
+      case 3: TT_GN(bf16, true, true); break;
+      case 4: TT_GN(f16, false, false); break;
+      case 5: TT_GN(f16, false, true); break;
+      case 6: TT_GN(f16, true, false); break;
+      default: TT_GN(f16, true, true); break;
     }
+#undef TT_GN
   } else {
     if (dtype == DT_BF16) launch_timed(ps, gn_apply_kernel<bf16>, grid2, dim3(256), 0, stream, a, nchunk, rpc, rpb);
     else launch_timed(ps, gn_apply_kernel<f16>, grid2, dim3(256), 0, stream, a, nchunk, rpc, rpb);
