@@ -15,7 +15,8 @@ extern template int gemm_init_typed<f16>();
 //   >= 256 tiles of 256x256 : 256x256, 16 waves of 64x64, 2 stages of 64 KB (twice the flops per byte through the per-CU load
 //                             path of the 128x128 tile: +20 - 60 % at the CLVP / pre-pass shapes, profiles/r02_kbench_large.txt)
 //   >= 256 tiles of 128x128 : 128x128, 8 waves, 2 stages (2 blocks per CU)
-//   fewer, M > 1024         : 128x64, 8 waves, 4-stage ring (more blocks, 3 tiles in flight)
+//   fewer, M > 2048 (or the 3-tap statistics convolutions of one denoiser pass: shared-halo kernel) : 128x64, 8 waves, 4-stage ring
+//   one denoiser pass, 1024 < M <= 2048, N <= 1024 (1x1 GEMMs, inp_block, final conv) : 64x64 - two workgroups per CU (profiles/r03_ab_geometry.txt)
 //   decode / M <= 1024      : 64x64, 4 waves, 4-stage ring (weights stream from HBM: depth hides latency)
 // A GEMM that emits GroupNorm statistics keeps the 128x64 tile for every M > 256: the statistics are grouped per wave tile,
 // so the same tile at one and at two batch rows keeps the denoiser's conditioned row bit-identical whether it is evaluated
@@ -37,7 +38,8 @@ static int pick_tile(const GemmArgs& a) {
 static int tile_stat_rows(int tile) { return tile >= TILE_128x128 ? 64 : 32; }  // 256x256: 4 x 4 waves; 128x128: 2 x 4; 128x64: 4 x 2; 64x64: 2 x 2
 
 // ProfScope classes: (tile, epilogue, conv?) -> one class per kernel that actually runs
-static int prof_class(int tile, int epi, bool conv) {
+static int prof_class(int tile, int epi, bool conv, bool stats = false) {
+  if (tile == TILE_64x64 && epi == EPI_STD && !conv && stats) return PROF_GEMM_64x64_STATS;
   const int base = tile == TILE_64x64 ? PROF_GEMM_64x64_STD : tile == TILE_128x64 ? PROF_GEMM_128x64_STD : tile == TILE_128x128 ? PROF_GEMM_128x128_STD : PROF_GEMM_256x256_STD;
   if (epi == EPI_STD) return base + (conv ? 1 : 0);
   return base + (epi == EPI_QKV_HEADS ? 2 : 3);
@@ -89,7 +91,7 @@ static void plan_core(const GemmArgs& a, int epi, GemmPlan& p) {
                     a.out_f32 && ((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0;
   p.conv3s = epi == EPI_STD && tile == TILE_128x64 && a.taps == 3 && a.dilation <= 1 && a.splitk == 1 && a.gn_part != nullptr && a.bias != nullptr &&
              a.out_t == nullptr && a.act == ACT_NONE && a.A2 == nullptr && al16 && a.cin >= 256;
-  p.prof_id = prof_class(tile, epi, a.taps > 1);
+  p.prof_id = prof_class(tile, epi, a.taps > 1, a.gn_part != nullptr);
   // algorithmic work of this launch: 2*M*N*K flops; operands read once + ONE result written once (the extra split-K slabs
   // a launch writes are an implementation cost: they show up in the PMC traffic, not here)
   const bool std_epi = epi == EPI_STD;
