@@ -279,10 +279,11 @@ typedef __attribute__((address_space(1))) const void gbl_void_a;
 
 // KS = 2 ("key split"): 8 waves per block - wave w works on query group w & 3 like before, but only on half w >> 2 (32 keys) of
 // every staged 64-key tile, and the two partial softmax states of a query group are merged through the LDS at the end.  At the
-// denoiser's shape (n = 870, 32 (batch, head) pairs) the chip holds 1741 sixteen-query chains for 1024 SIMDs, each a strictly
-// dependent LDS read -> QK^T MFMA -> softmax VALU -> PV MFMA sequence per half tile: the launch is paid for the length of that
-// chain, not for MFMA or VALU throughput (~1.5 us of MFMA work per block in a 22 us launch).  Halving the chain per wave doubles
-// the chains in flight at no extra K / V traffic (the same staged tile serves both halves).
+// denoiser's shape (n = 870, 32 (batch, head) pairs) the chip holds 1741 sixteen-query chains for 1024 SIMDs: the launch under-fills
+// it, and splitting every key tile over two wave groups doubles the waves per SIMD at no extra K / V traffic (the same staged tile
+// serves both halves): -2 % on the sampler iteration (profiles/r03_ab_flash_split.txt).  The kernel itself is bound by VALU issue -
+// 15.7 VALU instructions per MFMA, VALU pipe ~76 % busy at four waves per SIMD (profiles/r03_pmc_flash_kbench.txt) - so what
+// moves it further is fewer softmax instructions per score, not more parallelism.
 template <typename T, int NQ, int KS>
 __global__ __launch_bounds__(256 * KS, 2) void flash_lds_kernel(FlashArgs a) {
   typedef typename Vec<T>::x8 x8;
