@@ -158,6 +158,16 @@ class TextToSpeech:
         self.utterance_batch = max(1, int(utterance_batch))
         if self.utterance_batch > 16:
             raise ValueError("utterance_batch is limited to 16 utterances per decode batch")
+        if self.utterance_batch > 1 and torch.device(self.device).type == "cuda":
+            # the two arenas that grow with utterance_batch: per-sequence KV cache (layers x heads x 64 x K,V x 2 bytes per cached token) and
+            # the conditioning-integrator outputs of every step (steps x 2 x utterances x S x channels x 2 bytes); refuse what cannot fit
+            kv = self.utterance_batch * cap * (max_mel_tokens + 2) * self.ar_cfg.layers * self.ar_cfg.model_dim * 2 * 2
+            integ = 512 * 2 * self.utterance_batch * max_S * self.diff_cfg.model_channels * 2
+            total = torch.cuda.get_device_properties(self.device).total_memory
+            if kv + integ > 0.8 * total:
+                raise ValueError(f"utterance_batch={self.utterance_batch} x max_candidates={cap} x max_mel_tokens={max_mel_tokens} needs "
+                                 f"{(kv + integ) / 2 ** 30:.0f} GiB of KV cache + integrator slices, the device has {total / 2 ** 30:.0f} GiB: "
+                                 f"lower utterance_batch or max_mel_tokens")
         self.ar = stages.ArStage(sd("autoregressive"), self.ar_cfg, self.device, self.dtype, max_batch=cap * self.utterance_batch,
                                  max_text=max_text_tokens, max_new_tokens=max_mel_tokens, max_latent_candidates=4, kv_cache=self.kv_cache,
                                  max_groups=self.utterance_batch)
