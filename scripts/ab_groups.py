@@ -36,7 +36,10 @@ def main():
                 if r:
                     times.append(time.perf_counter() - t0)
             t = sum(times) / len(times)
-            print("groups %2d x %d candidates x %d tokens: %.1f ms total, %.3f ms/step, %.1f ms per utterance" % (G, N, n, 1e3 * t, 1e3 * t / n, 1e3 * t / G), flush=True)
+            import hashlib
+            dig = hashlib.sha256(codes.cpu().numpy().tobytes()).hexdigest()[:12]
+            print("%-8s groups %2d x %d candidates x %d tokens: %.1f ms total, %.3f ms/step, %.1f ms per utterance  codes %s" %
+                  (os.environ.get("AB_NAME", "base"), G, N, n, 1e3 * t, 1e3 * t / n, 1e3 * t / G, dig), flush=True)
 
 
 if __name__ == "__main__":
