@@ -204,7 +204,7 @@ class TextToSpeech:
         """api.py:258-299 on the engine: ConditioningEncoder (autoregressive.py:204-228) and contextual_embedder
         (diffusion_decoder.py:186-192, 222-230) run on the device (csrc/cond.hip).  voice_samples is, as in
         the reference, a list of 22.05 kHz waveform tensors (the mel front-end of api.py:271-287 then runs in torch,
-        tortoise_tts_amd/audio.py: restated without torchaudio / librosa; mel bases and resampler parity-unpinned), or a list of ready
+        tortoise_tts_amd/audio.py: restated without torchaudio / librosa, pinned through oracle/audio_oracle.py), or a list of ready
         (auto_mel f32 [1, 80, T_a], diffusion_mel f32 [1, 100, T_d]) pairs, one per clip."""
         if torch.is_tensor(voice_samples):
             voice_samples = [voice_samples]  # api.py:269-270
