@@ -229,3 +229,20 @@ def test_committed_bench_line_follows_the_contract():
         traffic, src, stale = bench.pmc_traffic(r["kernel"])
         assert src and abs(traffic - r["traffic"]) < 1.0
         assert "ar_step_s_by_threads" in c  # thread sweep of the CPU baseline is part of the line
+
+
+def test_utterance_batch_capacity_arithmetic():
+    """TextToSpeech(utterance_batch=) refuses what cannot fit the device: the arithmetic behind the message, at the reference sizes."""
+    from tortoise_tts_amd.api import utterance_batch_bytes
+    from tortoise_tts_amd.config import ARConfig, DiffusionConfig
+    ar, df = ARConfig(), DiffusionConfig()
+    per_token = ar.layers * ar.model_dim * 2 * 2  # K and V, 2 bytes each: 122 880 B per cached token (DESIGN.md 5.4)
+    assert per_token == 122880
+    # the long-form benchmark: 16 utterances x 256 candidates x 200 tokens
+    need = utterance_batch_bytes(16, 256, 200, ar, df)
+    kv = 16 * 256 * 202 * per_token
+    S = 200 * 4 * 24000 // 22050 + 8
+    assert need == kv + 512 * 2 * 16 * S * df.model_channels * 2
+    assert 100 * 2 ** 30 < need < 0.8 * 288 * 2 ** 30           # fits one MI355X
+    assert utterance_batch_bytes(16, 256, 500, ar, df) > 0.8 * 288 * 2 ** 30   # the full 500-token capacity at 16 x 256 does not
+    assert utterance_batch_bytes(1, 256, 500, ar, df) < 0.1 * 288 * 2 ** 30

@@ -102,6 +102,16 @@ def _load_file(models_dir, filename):
     return torch.load(path, map_location="cpu")
 
 
+def utterance_batch_bytes(utterance_batch, max_candidates, max_mel_tokens, ar_cfg, diff_cfg, max_steps=512):
+    """Bytes of the two arenas that grow with TextToSpeech(utterance_batch=): the per-sequence KV cache (layers x model_dim x K,V x 2
+    bytes per cached token, utterance_batch x max_candidates sequences of max_mel_tokens + 2 slots) and the conditioning-integrator outputs
+    of every sampler step (max_steps x 2 guidance rows x utterances x S x channels x 2 bytes)."""
+    max_S = max_mel_tokens * 4 * 24000 // 22050 + 8
+    kv = utterance_batch * max_candidates * (max_mel_tokens + 2) * ar_cfg.layers * ar_cfg.model_dim * 2 * 2
+    integ = max_steps * 2 * utterance_batch * max_S * diff_cfg.model_channels * 2
+    return kv + integ
+
+
 class TextToSpeech:
     """Main entry point; see the module docstring.  Engine-only keyword arguments (all optional, after
     the reference's): `state_dicts` (dict of reference-layout state_dicts instead of files in
@@ -159,14 +169,11 @@ class TextToSpeech:
         if self.utterance_batch > 16:
             raise ValueError("utterance_batch is limited to 16 utterances per decode batch")
         if self.utterance_batch > 1 and torch.device(self.device).type == "cuda":
-            # the two arenas that grow with utterance_batch: per-sequence KV cache (layers x heads x 64 x K,V x 2 bytes per cached token) and
-            # the conditioning-integrator outputs of every step (steps x 2 x utterances x S x channels x 2 bytes); refuse what cannot fit
-            kv = self.utterance_batch * cap * (max_mel_tokens + 2) * self.ar_cfg.layers * self.ar_cfg.model_dim * 2 * 2
-            integ = 512 * 2 * self.utterance_batch * max_S * self.diff_cfg.model_channels * 2
+            need = utterance_batch_bytes(self.utterance_batch, cap, max_mel_tokens, self.ar_cfg, self.diff_cfg)
             total = torch.cuda.get_device_properties(self.device).total_memory
-            if kv + integ > 0.8 * total:
+            if need > 0.8 * total:
                 raise ValueError(f"utterance_batch={self.utterance_batch} x max_candidates={cap} x max_mel_tokens={max_mel_tokens} needs "
-                                 f"{(kv + integ) / 2 ** 30:.0f} GiB of KV cache + integrator slices, the device has {total / 2 ** 30:.0f} GiB: "
+                                 f"{need / 2 ** 30:.0f} GiB of KV cache + integrator slices, the device has {total / 2 ** 30:.0f} GiB: "
                                  f"lower utterance_batch or max_mel_tokens")
         self.ar = stages.ArStage(sd("autoregressive"), self.ar_cfg, self.device, self.dtype, max_batch=cap * self.utterance_batch,
                                  max_text=max_text_tokens, max_new_tokens=max_mel_tokens, max_latent_candidates=4, kv_cache=self.kv_cache,
