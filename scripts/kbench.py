@@ -154,6 +154,12 @@ def main():
                         per = 1 << 20
                         us = bw_probe(mode, waves, nb, fp, per)
                         print(f"bw2 {tag:24s} {mtag:40s} {wtag:20s} x {nb} blocks: {us:8.2f} us  {nb * per / us / 1e6:7.2f} TB/s  {per * (nb / 256) / us / 1e3:6.1f} GB/s per CU", flush=True)
+    if "bw3" in which:   # working-set series: what does a set resident in the Infinity Cache (256 MiB) stream at, against one that only HBM holds?
+        for mib in (16, 64, 128, 192, 512, 2048, 8192):
+            for nb in (512, 1024):
+                per = 1 << 20
+                us = bw_probe(0, 8, nb, mib << 20, per)
+                print(f"bw3 working set {mib:5d} MiB  global_load_lds 16B, 8 waves x 8 loads x {nb:4d} blocks of 1 MiB: {us:8.2f} us  {nb * per / us / 1e6:6.2f} TB/s", flush=True)
     if "ring" in which:  # ring depth / tile series at the decode shapes; rotating A (na = 4) like the decode step, cold W
         for name, N, K in (("qkv", 3072, 1024), ("proj", 1024, 1024), ("fc", 4096, 1024), ("proj2", 1024, 4096)):
             nw = max(8, int(700e6 // (N * K * 2)))
