@@ -663,3 +663,42 @@ def test_api_fast_tts_and_stream():
 def F_pad_text(ids):
     import torch.nn.functional as F_
     return F_.pad(torch.tensor(ids, dtype=torch.int32, device="cuda")[None], (0, 1))
+
+
+@torch.no_grad()
+def test_ar_step_graph_is_kept_between_calls_and_seeds_are_data():
+    """The captured decode step is kept on the handle between tt_ar_generate calls (csrc/gpt2.hip step_key): the Philox keys live in
+    device memory, so a second call with another seed replays the SAME graph and must sample what eager launches sample for that seed;
+    a call that changes what the graph bakes in (batch, prefix length, sampling scalars) must re-capture."""
+    cfg = ARConfig(**G.AR_CFG)
+    sd = W.suppress_stop_token(quantize_sd(W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.AR_SEED), torch.bfloat16), cfg)
+    cond, text = G.ar_inputs(cfg)
+    text_short = text[:, : max(2, text.shape[1] // 2)].contiguous()
+    st = stages.ArStage(sd, cfg, dtype=E.TT_BF16, max_batch=8, max_text=40, max_new_tokens=32, max_latent_candidates=1)
+    steps = 12
+    calls = [  # (text, B, seed, sampler kwargs)
+        (text, 4, 5, {}), (text, 4, 6, {}), (text, 4, 5, {}),            # same key three times, two seeds
+        (text_short, 4, 6, {}),                                           # other prefix length
+        (text, 8, 6, {}),                                                 # other batch
+        (text, 4, 6, {"temperature": 0.5}), (text, 4, 6, {"top_k": 300}),  # other sampler scalars / the wide sampler kernel
+        (text, 4, 5, {}),                                                 # back to the first key
+    ]
+    got = []
+    for t, B, seed, kw in calls:
+        st.prefill(cond, t)
+        got.append(st.generate(B, steps, seed=seed, **kw)[0].clone())
+    E.load_library().tt_graph_replay(0)
+    try:
+        for (t, B, seed, kw), g in zip(calls, got):
+            st.prefill(cond, t)
+            eager = st.generate(B, steps, seed=seed, **kw)[0]
+            assert torch.equal(eager, g), f"kept step graph differs from eager launches for B={B} seed={seed} {kw} prefix {t.shape[1]}"
+    finally:
+        E.load_library().tt_graph_replay(1)
+    assert torch.equal(got[0], got[2]) and torch.equal(got[0], got[7]) and not torch.equal(got[0], got[1])
+    # a fresh handle (first capture) samples the same as the handle that has been through all of the above
+    st2 = stages.ArStage(sd, cfg, dtype=E.TT_BF16, max_batch=8, max_text=40, max_new_tokens=32, max_latent_candidates=1)
+    st2.prefill(cond, text)
+    assert torch.equal(st2.generate(4, steps, seed=6)[0], got[1])
+    st2.close()
+    st.close()

@@ -54,7 +54,23 @@ struct tt_ar {
   int lat_batch = 0;
   int gen_done = 0;    // tokens sampled by the running generation (tt_ar_generate / tt_ar_generate_chunk)
   bool gen_finished = false;
+  // The captured decode step is kept between calls: everything a call can change is either device data (token / slot counters, the
+  // Philox keys below, the prefix caches) or part of step_key - the bytes of the sampler's argument block plus the batch / group /
+  // prefix-length values the launchers bake into the graph.  A call with the same key replays step_exec; any other key re-captures.
+  unsigned long long* keys_dev = nullptr;   // [16] Philox key per utterance group (group 0 alone without groups)
+  unsigned long long* keys_host = nullptr;  // pinned staging of the same
+  hipGraph_t step_graph = nullptr;
+  hipGraphExec_t step_exec = nullptr;
+  std::vector<unsigned char> step_key;
 };
+
+static void ar_drop_step_graph(tt_ar* e) {
+  if (e->step_exec) (void)hipGraphExecDestroy(e->step_exec);
+  if (e->step_graph) (void)hipGraphDestroy(e->step_graph);
+  e->step_exec = nullptr;
+  e->step_graph = nullptr;
+  e->step_key.clear();
+}
 
 static const int MAX_SPLIT = 8;
 
@@ -278,7 +294,9 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
     e->lat_batch = cfg->max_batch;
     rc = e->arena.alloc_t(&e->lat, (size_t)(e->tmax + 1) * e->lat_batch * D);
   }
-  if (!rc && hipHostMalloc((void**)&e->count_host, (e->tmax + 8) * sizeof(int)) != hipSuccess) {
+  if (!rc) rc = e->arena.alloc_t(&e->keys_dev, 16);
+  if (!rc && (hipHostMalloc((void**)&e->count_host, (e->tmax + 8) * sizeof(int)) != hipSuccess ||
+              hipHostMalloc((void**)&e->keys_host, 16 * sizeof(unsigned long long)) != hipSuccess)) {
     set_error("tt_ar_create: hipHostMalloc failed");
     rc = -2;
   }
@@ -293,7 +311,9 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
 void tt_ar_destroy(tt_ar* e) {
   if (!e) return;
   (void)hipDeviceSynchronize();
+  ar_drop_step_graph(e);
   if (e->count_host) (void)hipHostFree(e->count_host);
+  if (e->keys_host) (void)hipHostFree(e->keys_host);
   e->arena.release();
   e->sb.destroy();
   delete e;
@@ -384,16 +404,22 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
   memset(&sa, 0, sizeof(sa));
   sa.B = B; sa.V = e->V; sa.seen = e->seen;
   sa.rep_penalty = sp->repetition_penalty; sa.temperature = sp->temperature; sa.top_p = sp->top_p; sa.top_k = sp->top_k;
-  sa.exp_noise = sp->exp_noise; sa.seed = sp->seed; sa.row_offset = sp->row_offset;
+  sa.exp_noise = sp->exp_noise; sa.row_offset = sp->row_offset;
   sa.state = e->state; sa.unfinished = e->unfinished; sa.stop_token = e->cfg.stop_mel_token;
   sa.codes = codes; sa.ldcodes = ldcodes; sa.next_tok = e->next_tok; sa.unfinished_count = e->unfinished_count;
   sa.embed_x = e->x; sa.tok_emb = e->w.mel_emb; sa.pos_emb = e->w.mel_pos; sa.D = e->D; sa.pos_offset = e->cfg.mel_pos_offset;
   sa.pos_len = e->cfg.mel_pos_len;
+  // the Philox keys go through device memory (sa.seed / sa.group_seeds stay zero): the seed of a call is not part of the step graph
+  sa.seed = 0;
+  sa.keys_dev = e->keys_dev;
+  for (int gi = 0; gi < 16; ++gi) e->keys_host[gi] = sp->seed;
   if (e->G > 1) {
     TT_REQUIRE(B % e->G == 0 && (B / e->G) % 4 == 0, "tt_ar_generate: %d sequences do not split into %d groups of a multiple of 4", B, e->G);
     sa.ngroups = e->G; sa.group_size = B / e->G;
-    for (int gi = 0; gi < e->G; ++gi) sa.group_seeds[gi] = sp->group_seeds ? sp->group_seeds[gi] : sp->seed;
+    for (int gi = 0; gi < e->G; ++gi) e->keys_host[gi] = sp->group_seeds ? sp->group_seeds[gi] : sp->seed;
   }
+  // (keys_host is free again: every earlier generation ended with a stream synchronisation)
+  TT_CHECK_HIP(hipMemcpyAsync(e->keys_dev, e->keys_host, 16 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
   if (fresh) {
     e->B = B;
     e->gen_done = 0;
@@ -408,7 +434,7 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
     TT_TRY(ar_state_advance_launch(e->state, s));
     e->gen_done = 1;
   }
-  sa.logits = e->logits; sa.ldl = e->Vp;
+  sa.logits = e->logits; sa.ldl = e->Vp; sa.ldg = e->Vp;  // (ldg is unused with per-row logits; set so that fresh and resumed runs share one step key)
   if (!fresh) {
     // Resumed chunk (streaming): between two chunks the caller may have run tt_ar_latents / tt_ar_prefill, which use e->x as
     // their residual stream, so the input row the sampler fused into e->x for the next step is gone.  Rebuild it from the
@@ -416,25 +442,38 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
     TT_TRY(ar_embed_launch(e->next_tok, e->state, e->w.mel_emb, e->w.mel_pos, e->x, B, e->D, e->cfg.mel_pos_offset, s));
   }
 
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
   const bool use_graph = graphs_enabled() && target - e->gen_done > 1;
   int rc = 0;
   if (use_graph) {
-    TT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    rc = decode_step_enqueue(e, s, true);
-    if (!rc) rc = sample_launch(sa, s);
-    if (!rc) rc = ar_state_advance_launch(e->state, s);
-    hipError_t ce = hipStreamEndCapture(s, &graph);
-    if (rc) {
-      if (graph) (void)hipGraphDestroy(graph);
-      return rc;
-    }
-    if (ce == hipSuccess) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (ce != hipSuccess) {
-      if (graph) (void)hipGraphDestroy(graph);
-      set_error("tt_ar_generate: graph capture / instantiate failed: %s", hipGetErrorString(ce));
-      return -2;
+    // what the captured step bakes in besides device pointers owned by the handle: the sampler's argument block (scalars, the caller's
+    // code buffer, the optional injected-noise pointer) and the batch geometry the launchers read from the handle
+    std::vector<unsigned char> key(sizeof(sa) + 20 * sizeof(int));
+    memcpy(key.data(), &sa, sizeof(sa));
+    int geo[20] = {B, e->G, e->P1, g_prof_on ? 1 : 0};
+    for (int gi = 0; gi < 16; ++gi) geo[4 + gi] = gi < e->G ? e->P1g[gi] : 0;
+    memcpy(key.data() + sizeof(sa), geo, sizeof(geo));
+    if (!e->step_exec || key != e->step_key) {
+      ar_drop_step_graph(e);
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      TT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      rc = decode_step_enqueue(e, s, true);
+      if (!rc) rc = sample_launch(sa, s);
+      if (!rc) rc = ar_state_advance_launch(e->state, s);
+      hipError_t ce = hipStreamEndCapture(s, &graph);
+      if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      if (ce == hipSuccess) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (ce != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        set_error("tt_ar_generate: graph capture / instantiate failed: %s", hipGetErrorString(ce));
+        return -2;
+      }
+      e->step_graph = graph;
+      e->step_exec = exec;
+      e->step_key.swap(key);
     }
   }
   const int first_step = e->gen_done;
@@ -443,7 +482,7 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
   int first_zero = -1;
   for (int step = first_step; step < target && !finished; ++step) {
     if (use_graph) {
-      hipError_t le = hipGraphLaunch(exec, s);
+      hipError_t le = hipGraphLaunch(e->step_exec, s);
       if (le != hipSuccess) { set_error("hipGraphLaunch: %s", hipGetErrorString(le)); rc = -2; break; }
     } else {
       e->host_slot = step - 1;
@@ -468,8 +507,7 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
     for (int i = 0; i < steps_done && !rc; ++i)
       if (e->count_host[i] == 0) { first_zero = i; finished = true; break; }
   }
-  if (exec) (void)hipGraphExecDestroy(exec);
-  if (graph) (void)hipGraphDestroy(graph);
+  if (rc) ar_drop_step_graph(e);  // a failed replay leaves nothing to trust
   TT_TRY(rc);
   e->gen_done = first_zero >= 0 ? first_zero + 1 : steps_done;
   e->gen_finished = finished;

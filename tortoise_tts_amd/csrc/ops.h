@@ -136,6 +136,9 @@ struct SampleArgs {
   // group_seeds[group], broadcast logits (ldl == 0) row `group`
   int ngroups, group_size;
   unsigned long long group_seeds[16];
+  // keys_dev != null: the Philox keys are read from device memory instead (keys_dev[group], keys_dev[0] without groups), so that a
+  // captured step graph does not bake the seed of one call in and can be replayed by the next (tt_ar_generate)
+  const unsigned long long* keys_dev;
 };
 int sample_launch(const SampleArgs& a, hipStream_t stream);
 int ar_state_advance_launch(int* state, hipStream_t stream);

@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   const int V = a.V;
   const int step = a.state[0];
   const int grp = a.ngroups > 1 ? b / a.group_size : 0;  // utterance of this row (block-uniform)
+  // Philox key of this row's utterance: from device memory when the caller replays a cached step graph (the seed of a call is then
+  // data, not a baked-in kernel argument), else from the argument block; block-uniform, read once
+  const unsigned long long philox_key = a.keys_dev ? a.keys_dev[grp] : (a.ngroups > 1 ? a.group_seeds[grp] : a.seed);
   const float* lg = a.logits + (a.ldl ? (size_t)b * a.ldl : (size_t)grp * (a.ldg ? a.ldg : V));
   unsigned* seen = a.seen + (size_t)b * ((V + 31) / 32);
   constexpr int PER = 40;  // supports V <= 10240
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       q = a.exp_noise[((size_t)step * a.B + b) * V + id];
     } else {
       unsigned r[4];
-      const unsigned long long key = a.ngroups > 1 ? a.group_seeds[grp] : a.seed;
+      const unsigned long long key = philox_key;
       const int cand = a.ngroups > 1 ? b - grp * a.group_size : b;  // index within the utterance: the draw does not depend on the batching
       philox4x32_10((unsigned)id, (unsigned)step, (unsigned)(a.row_offset + cand), 0u, (unsigned)key, (unsigned)(key >> 32), r);
       const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
@@ -320,6 +323,9 @@ __global__ __launch_bounds__(1024) void sample_wide_kernel(SampleArgs a) {
   const int V = a.V;
   const int step = a.state[0];
   const int grp = a.ngroups > 1 ? b / a.group_size : 0;
+  // Philox key of this row's utterance: from device memory when the caller replays a cached step graph (the seed of a call is then
+  // data, not a baked-in kernel argument), else from the argument block; block-uniform, read once
+  const unsigned long long philox_key = a.keys_dev ? a.keys_dev[grp] : (a.ngroups > 1 ? a.group_seeds[grp] : a.seed);
   const float* lg = a.logits + (a.ldl ? (size_t)b * a.ldl : (size_t)grp * (a.ldg ? a.ldg : V));
   unsigned* seen = a.seen + (size_t)b * ((V + 31) / 32);
   for (int t = tid; t < WIDE_N; t += 1024) {
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(1024) void sample_wide_kernel(SampleArgs a) {
       q = a.exp_noise[((size_t)step * a.B + b) * V + id];
     } else {
       unsigned r[4];
-      const unsigned long long pk = a.ngroups > 1 ? a.group_seeds[grp] : a.seed;
+      const unsigned long long pk = philox_key;
       const int cand = a.ngroups > 1 ? b - grp * a.group_size : b;
       philox4x32_10((unsigned)id, (unsigned)step, (unsigned)(a.row_offset + cand), 0u, (unsigned)pk, (unsigned)(pk >> 32), r);
       const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);

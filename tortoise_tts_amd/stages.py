@@ -114,6 +114,15 @@ class ArStage:
         t = _i32(tokens, self.device)
         E.check(self.lib.tt_ar_decode_step(self.h, E.ptr(t), E.stream_ptr()))
 
+    def _codes_buffer(self, B, max_new):
+        """The int32 [B, max_new] buffer the sampler writes: kept per shape, because its address is part of the key under which the
+        engine keeps the captured decode step (csrc/gpt2.hip step_key) - a fresh tensor per call would re-capture the graph per call.
+        Callers receive copies (`.long()`)."""
+        buf = getattr(self, "_codes", None)
+        if buf is None or buf.shape != (B, max_new):
+            buf = self._codes = torch.empty(B, max_new, device=self.device, dtype=torch.int32)
+        return buf
+
     def generate(self, B, max_new, temperature=0.8, top_p=0.8, repetition_penalty=2.0, top_k=50, seed=0, row_offset=0,
                  exp_noise=None, group_seeds=None):
         """Returns (codes int64 [B, n_steps], n_steps).  exp_noise: optional f32 [max_new, B, V] Exp(1) draws.
@@ -128,7 +137,7 @@ class ArStage:
             exp_noise = exp_noise.to(device=self.device, dtype=torch.float32).contiguous()
             assert exp_noise.shape == (max_new, B, self.cfg.number_mel_codes)
         s.exp_noise = E.ptr(exp_noise)
-        codes = torch.empty(B, max_new, device=self.device, dtype=torch.int32)
+        codes = self._codes_buffer(B, max_new)
         n = C.c_int(0)
         E.check(self.lib.tt_ar_generate(self.h, B, max_new, C.byref(s), E.ptr(codes), C.byref(n), E.stream_ptr()))
         return codes[:, :n.value].long(), n.value
@@ -141,7 +150,7 @@ class ArStage:
         s.temperature, s.top_p, s.repetition_penalty, s.top_k = temperature, top_p, repetition_penalty, top_k
         s.seed, s.row_offset = seed, row_offset
         s.exp_noise = None
-        codes = torch.empty(B, max_new, device=self.device, dtype=torch.int32)
+        codes = self._codes_buffer(B, max_new)
         n, fin = C.c_int(0), C.c_int(0)
         first = True
         while True:
