@@ -109,7 +109,10 @@ typedef struct tt_sampling {
  * loop spec stream_generator.py:916-1000): samples B candidates for up to max_new tokens, stops
  * early when every row has emitted stop_mel_token.  codes int32 [B][max_new], pre-filled with
  * stop_mel_token past each row's end (api.py:425-426 padding).  The per-token step is replayed
- * from a hipGraph.  Synchronises `stream` before returning; *n_steps_host = tokens per row. */
+ * from a hipGraph that stays on the handle: a later call with the same B, prefix length(s), sampling
+ * scalars, row_offset, exp_noise and `codes` POINTER replays it as it is (the seed(s) are device data),
+ * anything else re-captures - pass the same code buffer again to stay on the kept graph.
+ * Synchronises `stream` before returning; *n_steps_host = tokens per row. */
 int tt_ar_generate(tt_ar* h, int B, int max_new, const tt_sampling* s, int* codes, int* n_steps_host, void* stream);
 /* The same loop in resumable pieces (the streaming path, api_fast.py:389-420 pulls tokens from
  * get_generator() chunk by chunk): first != 0 starts a generation (token 0 from the prefill logits), first == 0 resumes it;
