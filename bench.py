@@ -124,6 +124,14 @@ def cpu_baseline(sds, text, latents, preset_kw, M, cores):
             "stages_s": {"ar": ar_total, "clvp": clvp_total, "latents": lat_total, "diffusion": diff_total, "vocoder": voc_total}}
 
 
+def dtype_label(per_stage):
+    """'bf16' / 'fp16' when every stage runs the same operand type, else e.g. 'bf16(ar,clvp)+fp16(diffusion,vocoder)'."""
+    kinds = sorted(set(per_stage.values()))
+    if len(kinds) == 1:
+        return kinds[0]
+    return "+".join("%s(%s)" % (k, ",".join(n for n, v in per_stage.items() if v == k)) for k in kinds)
+
+
 def source_digest():
     """sha256 over the engine sources: ties a committed PMC summary to the build it was collected on."""
     import hashlib
@@ -244,7 +252,7 @@ def stream_bench(args):
     sds = {"autoregressive": W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(a_cfg), 1234), a_cfg),
            "hifidecoder": W.synthetic_state_dict(W.hifigan_manifest(h_cfg), 1238)}
     M = args.mel_tokens
-    tts = TextToSpeech(state_dicts=sds, dtype=args.dtype, max_mel_tokens=max(M, 64), kv_cache=True)
+    tts = TextToSpeech(state_dicts=sds, dtype=args.dtype or "bf16", max_mel_tokens=max(M, 64), kv_cache=True)
     t_build = time.perf_counter() - t_build
     text, (auto, _) = synthetic_prompt()
 
@@ -274,7 +282,7 @@ def stream_bench(args):
     print(json.dumps({
         "metric": "rtf_stream_api_fast", "value": audio_s * args.steps / dt, "unit": "audio-s/wall-s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": args.dtype or "bf16", "data": "synthetic",
         "first_chunk_latency_s": sum(firsts) / len(firsts), "first_chunk_latency_s_max": max(firsts),
         "wall_per_audio": dt / (audio_s * args.steps), "pieces_per_step": pieces, "audio_seconds_per_step": audio_s,
         "reference_claim": "README.md:34: 0.25-0.3 wall/audio on a 4 GB GPU, < 500 ms to the first chunk with streaming (other hardware; not a BASELINE number)",
@@ -291,7 +299,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--preset", default="standard")
     ap.add_argument("--mel-tokens", type=int, default=200, help="fixed decode length M (SURVEY.md §8d: 200 and 500)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16"],
+                    help="MFMA operand type of EVERY stage; default: the engine's per-stage defaults (bf16 for the autoregressive + CLVP "
+                         "stages, fp16 for the diffusion decoder + vocoder, which the reference runs in fp32: api.py resolve_stage_dtypes)")
     ap.add_argument("--workload", default="utterance", choices=["utterance", "read", "stream"],
                     help="utterance: one tts_with_preset call per step (BASELINE metric); read: one long-form paragraph per step = 15 chunks "
                          "spread over the GPUs as replicas (BASELINE config #4, tortoise/read.py); stream: one api_fast.tts_stream "
@@ -311,7 +321,9 @@ def main():
     from tortoise_tts_amd import dist as tdist
     rank, world, local = tdist.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    # (a launch whose collectives could not initialise continues on rank 0 alone: the line then reports n_gpus = 1 and says so)
+    fell_back = tdist.FALLBACK_SINGLE and world == 1
+    assert world == args.gpus or fell_back, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     from tortoise_tts_amd.api import TextToSpeech
     from tortoise_tts_amd.config import PRESETS, BASE_SETTINGS
 
@@ -389,7 +401,8 @@ def main():
             "metric": "rtf_standard_preset" if not read_mode else "rtf_longform_read", "value": audio_s * args.steps / dt, "unit": "audio-s/wall-s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "latency_s": dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": dtype_label(tts.dtype_names()), "dtype_per_stage": tts.dtype_names(), "overflow_demotions": list(tts.demotions),
+            "data": "synthetic",
             "config": {"workload": ("read.py long-form: 15 chunks per step, each = " if read_mode else "") +
                                    f"tts_with_preset('{args.preset}'): {N} AR candidates x {M} mel tokens (EOS suppressed, fixed length), "
                                    f"CLVP top-1, {preset_kw['diffusion_iterations']} diffusion iterations cond_free={preset_kw.get('cond_free', True)}, "
@@ -400,6 +413,7 @@ def main():
                                        + ("winner's diffusion tail split over ranks 0/1 (one denoiser row each, 1 exchange per step), vocoder on rank 0"
                                           if tts.split_diffusion else "winner rendered on rank 0"))},
             "stages_s_per_step": stages_mean,
+            "collective_fallback": bool(fell_back),
             "audio_seconds_per_step": audio_s, "engine_build_s": t_build,
             "roofline": roof, "cpu_baseline": cpu,
             "kernel_breakdown_ms": [{"kernel": r["kernel"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),

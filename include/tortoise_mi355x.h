@@ -110,9 +110,9 @@ typedef struct tt_sampling {
  * early when every row has emitted stop_mel_token.  codes int32 [B][max_new], pre-filled with
  * stop_mel_token past each row's end (api.py:425-426 padding).  The per-token step is replayed
  * from a hipGraph that stays on the handle: a later call with the same B, prefix length(s), sampling
- * scalars, row_offset, exp_noise and `codes` POINTER replays it as it is (the seed(s) are device data),
- * anything else re-captures - pass the same code buffer again to stay on the kept graph.
- * Synchronises `stream` before returning; *n_steps_host = tokens per row. */
+ * scalars and exp_noise replays it as it is - seeds, row_offset and the caller's `codes` buffer are
+ * data (the sampler fills a buffer the handle owns; the finished columns are copied out at the end) -
+ * anything else re-captures.  Synchronises `stream` before returning; *n_steps_host = tokens per row. */
 int tt_ar_generate(tt_ar* h, int B, int max_new, const tt_sampling* s, int* codes, int* n_steps_host, void* stream);
 /* The same loop in resumable pieces (the streaming path, api_fast.py:389-420 pulls tokens from
  * get_generator() chunk by chunk): first != 0 starts a generation (token 0 from the prefill logits), first == 0 resumes it;
@@ -125,6 +125,28 @@ int tt_ar_generate_chunk(tt_ar* h, int B, int first, int n_more, int ldcodes, co
  * token i)) - latent 0 from the prefill's start-token row, latent i >= 1 from the decode step that fed token i - 1.  They are
  * filed by the decode steps themselves (no extra pass); handles with max_batch <= 8 only; n <= tokens generated so far. */
 int tt_ar_stream_latents(tt_ar* h, int B, int n, float* out, void* stream);
+
+/* Engine options of a handle (not part of the reference's surface; defaults in brackets).  The decode step of B candidates can be
+ * cut into row ranges that run their 30 layers concurrently on separate streams - candidates are independent until the sampler, every
+ * kernel is row-local, so the sampled codes are bit-identical for any setting:
+ *   TT_AR_OPT_SUBBATCHES [1]  1, 2 or 4 ranges (used when B divides into ranges of >= 16 sequences, a multiple of 4)
+ *   TT_AR_OPT_STAGGER    [0]  range i starts after range i - 1 has issued its first attention launch
+ *   TT_AR_OPT_GRAPH_MODE [0]  0: one hipGraph with parallel branches; 1: one linear graph per range + one for lm_head / sampler
+ *   TT_AR_OPT_LOOKAHEAD  [6]  decode steps the host may launch ahead of the device (the loop is paced by progress words the
+ *                             last kernel of a step publishes to pinned memory; no queue drain inside the loop) */
+#define TT_AR_OPT_SUBBATCHES 1
+#define TT_AR_OPT_STAGGER 2
+#define TT_AR_OPT_GRAPH_MODE 3
+#define TT_AR_OPT_LOOKAHEAD 4
+int tt_ar_set_option(tt_ar* h, int option, int value);
+/* Operand-overflow guard: the row norms and the sampler count launches that met a non-finite value (an fp16 operand beyond 65504
+ * upstream).  Returns the count as of the last finished tt_ar_generate[_chunk] / tt_ar_latents (>= 0; tt_last_error() then names
+ * the stage) or a negative error; reset != 0 clears it.  The reference autocasts this stage to fp16 only under half=True
+ * (api.py:413-414); the host side re-runs a tripped stage with bf16 operands. */
+int tt_ar_guard(tt_ar* h, int reset);
+/* Counters for tests: which = 0 decode-step graph captures so far, 1 queue drains the launch loop fell back to (expected 0),
+ * 2 row ranges of the kept step graph. */
+int tt_ar_stat(tt_ar* h, int which);
 
 /* Teacher-forced single steps for parity tests: tt_ar_begin resets per-sequence state for B rows
  * after a prefill; tt_ar_decode_step feeds tokens int32 [B] (KV-cached position rule of
@@ -168,6 +190,7 @@ void tt_clvp_destroy(tt_clvp* h);
 /* text int32 [T] (one prompt, evaluated once instead of B times — api.py:463 repeats it),
  * codes int32 [B][n] -> scores f32 [B]. */
 int tt_clvp_score(tt_clvp* h, const int* text, int T, const int* codes, int B, int n, float* scores, void* stream);
+int tt_clvp_guard(tt_clvp* h, int reset);  /* operand-overflow guard of this stage, see tt_ar_guard */
 
 /* ============================================================================================
  * Stage 2 — DiffusionTts + SpacedDiffusion.p_sample_loop
@@ -272,6 +295,10 @@ int tt_diff_split_begin(tt_diff* h, const float* x_T, const tt_diff_step* steps_
 int tt_diff_split_forward(tt_diff* h, float* out_row, void* stream);
 int tt_diff_split_update(tt_diff* h, const float* rows, const float* step_noise, float* mel_out, void* stream);
 int tt_diff_split_end(tt_diff* h);
+/* Operand-overflow guard of this stage (see tt_ar_guard): GroupNorm statistics / sampler inputs that came out non-finite, as of the
+ * last finished sampling run (after the caller synchronised its stream).  The reference runs this stage in fp32 (api.py:540-560). */
+int tt_diff_guard(tt_diff* h, int reset);
+int tt_diff_stat(tt_diff* h, int which);  /* which = 0: sampler-step graph captures so far (the step graph stays on the handle) */
 
 /* ============================================================================================
  * Stage 3 — UnivNetGenerator.inference   (reference: tortoise/models/vocoder.py:300-312, api.py:559)

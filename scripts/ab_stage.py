@@ -28,6 +28,10 @@ def main():
     ap.add_argument("--candidates", type=int, default=256)
     ap.add_argument("--mel-tokens", type=int, default=200)
     ap.add_argument("--iterations", type=int, default=200)
+    ap.add_argument("--ar-variants", default="",
+                    help="';'-separated 'ranges,graph_form,stagger[,lookahead]' settings of tt_ar_set_option to time one after the other on ONE "
+                         "handle (same weights, same box, same process), e.g. '1,0,0;2,0,0;2,1,0;2,0,1;4,0,0'")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     args = ap.parse_args()
     from bench import synthetic_prompt
     from tortoise_tts_amd import stages, weights as W
@@ -40,20 +44,33 @@ def main():
         if "ar" in args.stages:
             cfg = ARConfig()
             sd = W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(cfg), 1234), cfg)
-            ar = stages.ArStage(sd, cfg, max_batch=args.candidates, max_new_tokens=max(args.mel_tokens, 32), max_latent_candidates=1)
+            from tortoise_tts_amd import engine as E
+            dt = E.dtype_code(args.dtype)
+            ar = stages.ArStage(sd, cfg, dtype=dt, max_batch=args.candidates, max_new_tokens=max(args.mel_tokens, 32), max_latent_candidates=1)
             tt = F.pad(text.int()[None], (0, 1)).to(dev)
-            times = []
-            codes = None
-            for r in range(args.reps + 1):
-                ar.prefill(auto.to(dev), tt)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                codes, n = ar.generate(args.candidates, args.mel_tokens, seed=77)
-                torch.cuda.synchronize()
-                if r:
-                    times.append((time.perf_counter() - t0) / n)
-            print("ab %-10s ar   B=%d n=%d: %.4f ms/step (min %.4f)  total %.1f ms  codes %s" %
-                  (args.tag, args.candidates, n, 1e3 * sum(times) / len(times), 1e3 * min(times), 1e3 * n * sum(times) / len(times), digest(codes)), flush=True)
+            variants = [tuple(int(v) for v in item.split(",")) for item in args.ar_variants.split(";") if item.strip()] or [None]
+            for var in variants:
+                tag = args.tag
+                if var is not None:
+                    ar.set_option(E.TT_AR_OPT_SUBBATCHES, var[0])
+                    ar.set_option(E.TT_AR_OPT_GRAPH_MODE, var[1])
+                    ar.set_option(E.TT_AR_OPT_STAGGER, var[2])
+                    if len(var) > 3:
+                        ar.set_option(E.TT_AR_OPT_LOOKAHEAD, var[3])
+                    tag = "r%d/g%d/s%d%s" % (var[0], var[1], var[2], "/l%d" % var[3] if len(var) > 3 else "")
+                times = []
+                codes = None
+                for r in range(args.reps + 1):
+                    ar.prefill(auto.to(dev), tt)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    codes, n = ar.generate(args.candidates, args.mel_tokens, seed=77)
+                    torch.cuda.synchronize()
+                    if r:
+                        times.append((time.perf_counter() - t0) / n)
+                print("ab %-12s ar   B=%d n=%d: %.4f ms/step (min %.4f)  total %.1f ms  codes %s  drains %d" %
+                      (tag, args.candidates, n, 1e3 * sum(times) / len(times), 1e3 * min(times), 1e3 * n * sum(times) / len(times), digest(codes),
+                       ar.stat(1)), flush=True)
             ar.close()
             del ar
         if "diff" in args.stages:
@@ -61,7 +78,8 @@ def main():
             sd = W.synthetic_state_dict(W.diffusion_manifest(cfg), 1236)
             M = args.mel_tokens
             S = M * 4 * 24000 // 22050
-            df = stages.DiffusionStage(sd, cfg, max_seq=max(S, 128), max_codes=max(M, 64), max_steps=args.iterations)
+            from tortoise_tts_amd import engine as E
+            df = stages.DiffusionStage(sd, cfg, dtype=E.dtype_code(args.dtype), max_seq=max(S, 128), max_codes=max(M, 64), max_steps=args.iterations)
             g = torch.Generator().manual_seed(5)
             lat = torch.randn(1, M, 1024, generator=g).to(dev)
             sched = Schedule(args.iterations, cfg.trained_steps, True, 2)

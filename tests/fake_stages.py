@@ -115,7 +115,7 @@ class FakeClvpStage:
 
 class FakeDiffusionStage:
     def __init__(self, sd, cfg, device="cpu", dtype=0, max_seq=0, max_codes=0, max_steps=0, max_batch=1):
-        self.sd, self.cfg, self.max_batch = sd, cfg, max_batch
+        self.sd, self.cfg, self.max_batch, self.dtype = sd, cfg, max_batch, dtype
 
     def sample_many(self, sched, items):
         """The engine pushes the utterances through shared denoiser passes with every one treated as if alone (tests/test_gpu_parity_r3.py):
@@ -131,6 +131,26 @@ class FakeDiffusionStage:
     def condition(self, latents, cond_latent, S):
         self.S = S
         self.emb = O.diffusion_timestep_independent(self.sd, self.cfg, latents.float().cpu(), cond_latent.float().cpu(), S)
+
+    def guard(self, reset=True):
+        """Operand-overflow guard of the engine stage: the stand-in trips `self.trip` times (tests of the demotion path)."""
+        n = getattr(FakeDiffusionStage, "trip", 0) if self.dtype == 1 else 0
+        if n and reset:
+            FakeDiffusionStage.trip = 0
+        return n
+
+    def close(self):
+        self.closed = True
+
+    def sample_split(self, sched, x_T, step_noise, row, exchange):
+        """The split tail's host protocol (one row exchange per step over the pair group); the stand-in has no per-row denoiser, so
+        both participants walk the whole loop and exchange a tag per step - what is exercised is the collective pattern."""
+        rows = torch.zeros(2, 4, 3)
+        for step in range(sched.num_timesteps):
+            exchange(rows, torch.full((4, 3), float(10 * step + row)))
+            assert float(rows[0, 0, 0]) == 10.0 * step and float(rows[1, 0, 0]) == 10.0 * step + 1
+        self.split_steps = sched.num_timesteps
+        return self.sample(sched, x_T, step_noise)
 
     def sample(self, sched, x_T, step_noise):
         osched = O.Schedule(sched.num_timesteps, self.cfg.trained_steps, sched.cond_free, sched.cond_free_k)

@@ -1,0 +1,221 @@
+"""-m gpu, round 4: what changed in the engines' control structure, each asserted as an EQUALITY (these are scheduling changes, the
+arithmetic of a row must not move):
+  * the decode step cut into row ranges on parallel streams (tt_ar_set_option): codes bit-identical for 1 / 2 / 4 ranges, both graph
+    forms, with and without the stagger, with ragged stop tokens, eager or replayed;
+  * the launch loop paced by progress words in pinned memory (no queue drain inside the loop): same codes, same early exit;
+  * seeds, row_offset and the caller's code buffer are DATA of the kept decode-step graph (one capture for all of them);
+  * the sampler-step graph of the diffusion stage stays on the handle (one capture for several calls with fresh tensors);
+  * the operand-overflow guards trip on fp16 overflow, stay silent otherwise, and TextToSpeech re-renders with bf16 operands.
+"""
+import pytest
+import torch
+
+from oracle import make_golden as G
+from tortoise_tts_amd import engine as E
+from tortoise_tts_amd import stages
+from tortoise_tts_amd import weights as W
+from tortoise_tts_amd.config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
+from tortoise_tts_amd.schedule import Schedule
+from tests.gpu_util import quantize_sd
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [(2, 0, 0), (2, 0, 1), (2, 1, 0), (4, 0, 0), (4, 0, 1), (4, 1, 0)]  # (row ranges, graph form, stagger)
+
+
+def _set(st, nsub, mode, stagger, lookahead=None):
+    st.set_option(E.TT_AR_OPT_SUBBATCHES, nsub)
+    st.set_option(E.TT_AR_OPT_GRAPH_MODE, mode)
+    st.set_option(E.TT_AR_OPT_STAGGER, stagger)
+    if lookahead is not None:
+        st.set_option(E.TT_AR_OPT_LOOKAHEAD, lookahead)
+
+
+@pytest.mark.parametrize("eos_boost", [None, 3.0])
+@torch.no_grad()
+def test_ar_row_ranges_sample_identical_codes(eos_boost):
+    """64 candidates in 1 / 2 / 4 row ranges on parallel streams: the sampled codes are the same bits (every kernel of the step is
+    row-local), whatever the graph form, the stagger or the host's lookahead; with a reachable stop token the rows end raggedly and
+    the loop leaves at the same step."""
+    cfg = ARConfig(**G.AR_CFG)
+    sd = G.sampling_state_dict(cfg, eos_boost) if eos_boost else W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.AR_SEED), cfg)
+    cond, text = G.ar_inputs(cfg)
+    B, steps = 64, 40
+    st = stages.ArStage(sd, cfg, dtype=E.TT_BF16, max_batch=B, max_text=40, max_new_tokens=48, max_latent_candidates=1)
+    st.prefill(cond, text)
+    base, n0 = st.generate(B, steps, seed=11)
+    base = base.clone()
+    assert st.stat(2) == 1
+    if eos_boost:
+        stop = cfg.stop_mel_token
+        ends = [(int((r == stop).nonzero()[0]) if (r == stop).any() else steps) for r in base.cpu()]
+        assert min(ends) < max(ends), "rows did not finish at different steps: the test lost its point"
+    for nsub, mode, stagger in VARIANTS:
+        for look in (1, 6):
+            _set(st, nsub, mode, stagger, look)
+            st.prefill(cond, text)
+            got, n = st.generate(B, steps, seed=11)
+            assert st.stat(2) == nsub, f"the kept step graph has {st.stat(2)} ranges, asked for {nsub}"
+            assert n == n0 and torch.equal(got, base), f"{nsub} row ranges (graph form {mode}, stagger {stagger}, lookahead {look}) changed the codes"
+    # eager launches take the same fork / join on real streams
+    _set(st, 2, 0, 1)
+    E.load_library().tt_graph_replay(0)
+    try:
+        st.prefill(cond, text)
+        got, n = st.generate(B, steps, seed=11)
+    finally:
+        E.load_library().tt_graph_replay(1)
+    assert n == n0 and torch.equal(got, base), "eager launches over two row ranges changed the codes"
+    assert st.stat(1) == 0, f"the launch loop fell back to {st.stat(1)} queue drain(s): the progress words did not arrive in time"
+    # teacher-forced steps (tt_ar_decode_step) go through the same fork / join: logits of a row do not depend on the ranges
+    toks = base[:, :3].int()
+    lg = {}
+    for nsub in (1, 4):
+        _set(st, nsub, 0, 0)
+        st.prefill(cond, text)
+        st.begin(B)
+        for j in range(3):
+            st.decode_step(toks[:, j])
+        lg[nsub] = st.logits(B).clone()
+    assert torch.equal(lg[1], lg[4]), "logits of a teacher-forced step depend on the row ranges"
+    st.close()
+
+
+@torch.no_grad()
+def test_ar_step_graph_key_excludes_seed_row_offset_and_code_buffer():
+    """One capture serves calls that differ in seed, row_offset (the candidate range of a rank / of a batch of the reference's
+    autoregressive_batch_size loop) and receiving buffer; eager launches agree call by call."""
+    cfg = ARConfig(**G.AR_CFG)
+    sd = W.suppress_stop_token(quantize_sd(W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.AR_SEED), torch.bfloat16), cfg)
+    cond, text = G.ar_inputs(cfg)
+    st = stages.ArStage(sd, cfg, dtype=E.TT_BF16, max_batch=8, max_text=40, max_new_tokens=32, max_latent_candidates=1)
+    calls = [(5, 0), (5, 8), (6, 8), (5, 0), (7, 16)]
+    got = []
+    for seed, off in calls:
+        st.prefill(cond, text)
+        got.append(st.generate(8, 12, seed=seed, row_offset=off)[0].clone())
+    assert st.stat(0) == 1, f"{st.stat(0)} captures for calls that differ in seed / row_offset / receiving buffer only"
+    assert torch.equal(got[0], got[3]) and not torch.equal(got[0], got[1]) and not torch.equal(got[1], got[2])
+    E.load_library().tt_graph_replay(0)
+    try:
+        for (seed, off), g in zip(calls, got):
+            st.prefill(cond, text)
+            assert torch.equal(st.generate(8, 12, seed=seed, row_offset=off)[0], g), f"kept graph differs from eager launches (seed {seed}, row_offset {off})"
+    finally:
+        E.load_library().tt_graph_replay(1)
+    # rows [8, 16) of a 16-row call == an 8-row call at row_offset 8 (Philox streams are keyed by the global candidate index)
+    st16 = stages.ArStage(sd, cfg, dtype=E.TT_BF16, max_batch=16, max_text=40, max_new_tokens=32, max_latent_candidates=1)
+    st16.prefill(cond, text)
+    both = st16.generate(16, 12, seed=5)[0]
+    assert torch.equal(both[8:], got[1]) and torch.equal(both[:8], got[0])
+    st16.close()
+    st.close()
+
+
+@torch.no_grad()
+def test_diffusion_step_graph_is_kept_between_calls():
+    """The sampler step is captured once per geometry: later calls with other noise / output tensors (other addresses) replay it through
+    the handle's pointer table and equal eager launches bit for bit; another length re-captures."""
+    cfg = DiffusionConfig(**G.DIFF_CFG)
+    sd = quantize_sd(W.synthetic_state_dict(W.diffusion_manifest(cfg), seed=G.DIFF_SEED), torch.float16)
+    S, latents, cond, x, step_noise = G.diff_inputs(cfg)
+    st = stages.DiffusionStage(sd, cfg, dtype=E.TT_F16, max_seq=128, max_codes=64, max_steps=16)
+    sched = Schedule(G.DIFF_STEPS, 4000, True, 2.0)
+    g = torch.Generator().manual_seed(77)
+    noises = [step_noise, torch.randn(step_noise.shape, generator=g), torch.randn(step_noise.shape, generator=g)]
+    mels = []
+    keep = []  # hold the earlier tensors so that the allocator hands out new addresses
+    for nz in noises:
+        st.condition(latents, cond, S)
+        mel = st.sample(sched, x, nz)
+        keep.append(mel)
+        mels.append(mel.clone())
+    assert st.stat(0) == 1, f"{st.stat(0)} captures for three calls of one geometry"
+    assert not torch.equal(mels[0], mels[1])
+    E.load_library().tt_graph_replay(0)
+    try:
+        for nz, m in zip(noises, mels):
+            st.condition(latents, cond, S)
+            assert torch.equal(st.sample(sched, x, nz), m), "the kept sampler-step graph differs from eager launches"
+    finally:
+        E.load_library().tt_graph_replay(1)
+    S2 = S - 8
+    st.condition(latents, cond, S2)
+    mel_s = st.sample(sched, x[..., :S2].contiguous(), step_noise[..., :S2].contiguous())
+    assert st.stat(0) == 2 and mel_s.shape[-1] == S2 and torch.isfinite(mel_s).all()
+    st.condition(latents, cond, S)
+    assert torch.equal(st.sample(sched, x, noises[0]), mels[0]) and st.stat(0) == 3
+    assert st.guard() == 0
+    st.close()
+
+
+@torch.no_grad()
+def test_overflow_guards_trip_on_fp16_overflow_only():
+    """fp16 operands saturate at 65504.  Weights scaled so that an intermediate exceeds that: the stage's guard counts it with fp16
+    operands and stays at zero with bf16 operands (and with the unscaled weights in fp16)."""
+    cfg = ARConfig(**G.AR_CFG)
+    sd = W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.AR_SEED), cfg)
+    hot = dict(sd)
+    for k in list(hot):
+        if k.endswith("mlp.c_fc.weight") or k.endswith("mlp.c_fc.bias"):
+            hot[k] = hot[k] * 1.0e5   # gelu(c_fc(h)) ~ 4e5: beyond the fp16 range, nothing for bf16
+        if k.endswith("mlp.c_proj.weight"):
+            hot[k] = hot[k] * 1.0e-5  # (keeps the residual stream tame in bf16)
+    cond, text = G.ar_inputs(cfg)
+    for weights, dt, want_trip in ((sd, E.TT_F16, False), (hot, E.TT_F16, True), (hot, E.TT_BF16, False)):
+        st = stages.ArStage(weights, cfg, dtype=dt, max_batch=8, max_text=40, max_new_tokens=16, max_latent_candidates=1)
+        st.prefill(cond, text)
+        st.generate(8, 8, seed=1)
+        n = st.guard()
+        print(f"[guard] AR dtype={E.DTYPE_NAMES[dt]} scaled={weights is hot}: {n}")
+        assert (n > 0) == want_trip, f"AR guard count {n} with dtype {E.DTYPE_NAMES[dt]} (scaled weights: {weights is hot})"
+        assert st.guard() == 0, "guard(reset=True) did not clear the counter"
+        st.close()
+    dcfg = DiffusionConfig(**G.DIFF_CFG)
+    dsd = W.synthetic_state_dict(W.diffusion_manifest(dcfg), seed=G.DIFF_SEED)
+    dhot = dict(dsd)
+    k_in = [k for k in dhot if k.endswith("in_layers.2.weight")][-1]  # a ResBlock's 1x1 convolution: its output feeds a GroupNorm
+    dhot[k_in] = dhot[k_in] * 1.0e6
+    S, latents, cond_d, x, step_noise = G.diff_inputs(dcfg)
+    sched = Schedule(G.DIFF_STEPS, 4000, True, 2.0)
+    for weights, dt, want_trip in ((dsd, E.TT_F16, False), (dhot, E.TT_BF16, False)):
+        st = stages.DiffusionStage(weights, dcfg, dtype=dt, max_seq=128, max_codes=64, max_steps=16)
+        st.condition(latents, cond_d, S)
+        mel = st.sample(sched, x, step_noise)
+        assert torch.isfinite(mel).all()
+        n = st.guard()
+        print(f"[guard] diffusion dtype={E.DTYPE_NAMES[dt]} scaled={weights is dhot}: {n}")
+        assert (n > 0) == want_trip
+        st.close()
+
+
+@torch.no_grad()
+def test_tts_demotes_an_overflowing_fp16_stage_to_bf16():
+    """TextToSpeech with per-stage operand types: the diffusion stage (fp16 by default) is given weights whose x-path overflows fp16;
+    the guard trips, the stage is rebuilt with bf16 operands and the utterance rendered again - finite audio, one demotion on record."""
+    from tortoise_tts_amd.api import TextToSpeech, resolve_stage_dtypes
+    assert resolve_stage_dtypes(None, False) == {"ar": E.TT_BF16, "clvp": E.TT_BF16, "diffusion": E.TT_F16, "vocoder": E.TT_F16}
+    ar, clvp, diff = ARConfig(**G.AR_CFG), CLVPConfig(**G.CLVP_CFG), DiffusionConfig(**G.DIFF_CFG)
+    dsd = dict(W.synthetic_state_dict(W.diffusion_manifest(diff), seed=G.DIFF_SEED))
+    # inp_block scaled so that the integrating conv's operand inp_block(x) ~ 1e6 overflows fp16 while bf16 holds it
+    dsd["inp_block.weight"] = dsd["inp_block.weight"] * 3.0e5
+    dsd["integrating_conv.weight"] = dsd["integrating_conv.weight"] * 1.0e-5
+    sds = {"autoregressive": W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(ar), seed=G.AR_SEED), ar),
+           "clvp": W.synthetic_state_dict(W.clvp_manifest(clvp), seed=G.CLVP_SEED),
+           "diffusion": dsd,
+           "vocoder": W.fold_weight_norm(W.synthetic_state_dict(W.vocoder_manifest(VocoderConfig()), seed=G.VOC_SEED))}
+    tts = TextToSpeech(state_dicts=sds, configs={"ar": ar, "clvp": clvp, "diffusion": diff}, max_candidates=8, max_mel_tokens=32)
+    assert tts.dtype_names() == {"ar": "bf16", "clvp": "bf16", "diffusion": "fp16", "vocoder": "fp16"}
+    g = torch.Generator().manual_seed(2)
+    lat = (torch.randn(1, ar.model_dim, generator=g) * 0.5, torch.randn(1, 2 * diff.model_channels, generator=g) * 0.5)
+    with pytest.warns(UserWarning, match="diffusion stage overflowed fp16"):
+        wav = tts.tts(list(range(10, 25)), conditioning_latents=lat, num_autoregressive_samples=8, diffusion_iterations=4, max_mel_tokens=24,
+                      use_deterministic_seed=3, verbose=False)
+    assert tts.demotions == ["diffusion"] and tts.dtype_names()["diffusion"] == "bf16"
+    assert torch.isfinite(wav).all() and wav.abs().max() <= 1.0
+    # the next utterance runs on the rebuilt stage without another demotion
+    wav2 = tts.tts(list(range(10, 25)), conditioning_latents=lat, num_autoregressive_samples=8, diffusion_iterations=4, max_mel_tokens=24,
+                   use_deterministic_seed=3, verbose=False)
+    assert tts.demotions == ["diffusion"] and torch.equal(wav, wav2)
+    for st in (tts.ar, tts.clvp, tts.diffusion, tts.vocoder):
+        st.close()

@@ -112,11 +112,41 @@ def utterance_batch_bytes(utterance_batch, max_candidates, max_mel_tokens, ar_cf
     return kv + integ
 
 
+STAGE_NAMES = ("ar", "clvp", "diffusion", "vocoder")
+
+
+def resolve_stage_dtypes(dtype, half):
+    """MFMA operand type per stage -> {'ar' | 'clvp' | 'diffusion' | 'vocoder': engine dtype code}.
+
+    The reference autocasts ONLY the autoregressive + CLVP stages to fp16, and only under half=True (api.py:413-414, 460-463); its
+    diffusion decoder and vocoder always run in fp32 (api.py:225 use_fp16=False, 540-560 no autocast).  Defaults here:
+      ar, clvp           bf16 (half=True: fp16, the reference's autocast type) - the residual stream of a GPT-2 trunk is where outlier
+                         channels live, and bf16 keeps the fp32 exponent range at no cost in speed;
+      diffusion, vocoder fp16 - the closest MFMA operand type to the reference's fp32 (3 more mantissa bits than bf16: 8-10x tighter
+                         against the reference's own p_sample_loop at the same speed); GroupNorm and the x0 clamp
+                         bound the activations, and an overflow guard (tt_diff_guard) watches for the case they do not: a tripped
+                         stage is rebuilt with bf16 operands and the utterance re-rendered (TextToSpeech._demote).
+    `dtype` may be None (defaults), one name for every stage, or a dict overriding some stages."""
+    base = "fp16" if half else "bf16"
+    out = {"ar": base, "clvp": base, "diffusion": "fp16", "vocoder": "fp16"}
+    if isinstance(dtype, dict):
+        unknown = set(dtype) - set(STAGE_NAMES)
+        if unknown:
+            raise ValueError(f"dtype: unknown stage(s) {sorted(unknown)}; stages are {STAGE_NAMES}")
+        out.update(dtype)
+    elif dtype is not None:
+        out = {k: dtype for k in STAGE_NAMES}
+    if half and any(E.dtype_code(out[k]) != E.TT_F16 for k in ("ar", "clvp")):
+        raise ValueError(f"half=True asks for fp16 operands in the autoregressive / CLVP stages but dtype={dtype!r} was also given")
+    return {k: E.dtype_code(v) for k, v in out.items()}
+
+
 class TextToSpeech:
     """Main entry point; see the module docstring.  Engine-only keyword arguments (all optional, after
     the reference's): `state_dicts` (dict of reference-layout state_dicts instead of files in
-    models_dir), `dtype` ('bf16' | 'fp16' MFMA operand type), `max_candidates` (per-GPU decode batch
-    capacity), `configs` (ARConfig/CLVPConfig/DiffusionConfig/VocoderConfig overrides for tests)."""
+    models_dir), `dtype` (MFMA operand type: 'bf16' | 'fp16' for every stage, or a dict per stage
+    {'ar', 'clvp', 'diffusion', 'vocoder'}; see resolve_stage_dtypes for the defaults), `max_candidates`
+    (per-GPU decode batch capacity), `configs` (ARConfig/CLVPConfig/DiffusionConfig/VocoderConfig overrides for tests)."""
 
     def __init__(self, autoregressive_batch_size=None, models_dir=MODELS_DIR, enable_redaction=True, kv_cache=False,
                  use_deepspeed=False, half=False, device=None, tokenizer_vocab_file=None, tokenizer_basic=False, *,
@@ -140,11 +170,9 @@ class TextToSpeech:
         if self.split_diffusion:
             tdist.pair_group()  # collective over all ranks: create it once, here, where every rank passes
         self.device = E.require_gpu(device)
-        if dtype is None:
-            dtype = "fp16" if half else "bf16"  # half=True is the reference's fp16 autocast (api.py:180, autoregressive.py:561)
-        elif half and dtype not in ("fp16", "f16"):
-            raise ValueError(f"half=True asks for fp16 operands but dtype={dtype!r} was also given")
-        self.dtype = {"bf16": E.TT_BF16, "fp16": E.TT_F16, "f16": E.TT_F16}[dtype]
+        self.dtypes = resolve_stage_dtypes(dtype, half)  # half=True is the reference's fp16 autocast (api.py:180, autoregressive.py:561)
+        self.dtype = self.dtypes["ar"]  # (conditioning encoders / random-latent MLPs follow the autoregressive stage)
+        self.demotions = []             # stages whose overflow guard tripped and that were rebuilt with bf16 operands
         cfgs = configs or {}
         self.ar_cfg = cfgs.get("ar", ARConfig())
         self.clvp_cfg = cfgs.get("clvp", CLVPConfig())
@@ -175,22 +203,15 @@ class TextToSpeech:
                 raise ValueError(f"utterance_batch={self.utterance_batch} x max_candidates={cap} x max_mel_tokens={max_mel_tokens} needs "
                                  f"{need / 2 ** 30:.0f} GiB of KV cache + integrator slices, the device has {total / 2 ** 30:.0f} GiB: "
                                  f"lower utterance_batch or max_mel_tokens")
-        self.ar = stages.ArStage(sd("autoregressive"), self.ar_cfg, self.device, self.dtype, max_batch=cap * self.utterance_batch,
-                                 max_text=max_text_tokens, max_new_tokens=max_mel_tokens, max_latent_candidates=4, kv_cache=self.kv_cache,
-                                 max_groups=self.utterance_batch)
-        self.clvp = stages.ClvpStage(sd("clvp"), self.clvp_cfg, self.device, self.dtype, max_rows=max(cap, 8) * max_mel_tokens)
+        self._caps = dict(cap=cap, max_text_tokens=max_text_tokens, max_mel_tokens=max_mel_tokens, max_S=max_S)
+        self._state_dicts = sds
         # tts_many also pushes utterance_batch utterances through ONE denoiser pass per diffusion step (padded to the longest)
         self.batch_diffusion = self.utterance_batch > 1
         # (Decoding batch i + 1 on a second stream while batch i's denoiser passes run was built and measured: both phases slow down by
         # what the other takes - decode 3.1 -> 4.35 s, rendering 2.85 -> 3.93 s for 15 chunks at 8 per batch, 6.4 -> 6.19 s in total, and
         # one batch of 16 is faster still, 6.06 s: profiles/r03_bench_read_overlap.txt - and removed again.)
-        self.diffusion = stages.DiffusionStage(sd("diffusion"), self.diff_cfg, self.device, self.dtype, max_seq=max_S,
-                                               max_codes=max_mel_tokens + 8, max_steps=512, max_batch=self.utterance_batch)
-        voc_sd = sd("vocoder")
-        if any(k.endswith("weight_v") for k in voc_sd):
-            voc_sd = W.fold_weight_norm(voc_sd)  # UnivNetGenerator.eval(inference=True), vocoder.py:284-298
-        self.vocoder = stages.VocoderStage(voc_sd, self.voc_cfg, self.device, self.dtype, max_frames=max_S)
-        self._state_dicts = sds
+        for name in STAGE_NAMES:
+            self._build_stage(name)
         self.rlg = None         # random-voice latent MLPs, built lazily like the reference (api.py:301-309)
         self.conditioning = None  # conditioning encoders (voice_samples path), built lazily
         self.mel_front_end = None
@@ -198,6 +219,53 @@ class TextToSpeech:
         self.stop_mel_token = self.ar_cfg.stop_mel_token
         self.mel_length_compression = self.ar_cfg.mel_length_compression
         self.timings = {}
+
+    def _build_stage(self, name):
+        """(Re)build one stage engine with self.dtypes[name] operands."""
+        c, dt = self._caps, self.dtypes[name]
+        old = getattr(self, {"ar": "ar", "clvp": "clvp", "diffusion": "diffusion", "vocoder": "vocoder"}[name], None)
+        if old is not None:
+            old.close()
+        if name == "ar":
+            self.ar = stages.ArStage(self._sd("autoregressive"), self.ar_cfg, self.device, dt, max_batch=c["cap"] * self.utterance_batch,
+                                     max_text=c["max_text_tokens"], max_new_tokens=c["max_mel_tokens"], max_latent_candidates=4,
+                                     kv_cache=self.kv_cache, max_groups=self.utterance_batch)
+        elif name == "clvp":
+            self.clvp = stages.ClvpStage(self._sd("clvp"), self.clvp_cfg, self.device, dt, max_rows=max(c["cap"], 8) * c["max_mel_tokens"])
+        elif name == "diffusion":
+            self.diffusion = stages.DiffusionStage(self._sd("diffusion"), self.diff_cfg, self.device, dt, max_seq=c["max_S"],
+                                                   max_codes=c["max_mel_tokens"] + 8, max_steps=512, max_batch=self.utterance_batch)
+        elif name == "vocoder":
+            voc_sd = self._sd("vocoder")
+            if any(k.endswith("weight_v") for k in voc_sd):
+                voc_sd = W.fold_weight_norm(voc_sd)  # UnivNetGenerator.eval(inference=True), vocoder.py:284-298
+            self.vocoder = stages.VocoderStage(voc_sd, self.voc_cfg, self.device, dt, max_frames=c["max_S"])
+        else:
+            raise ValueError(name)
+
+    def _tripped_stages(self, wav_ok=True):
+        """Stages whose operand-overflow guard counted non-finite values during the utterance that just finished (the caller has
+        synchronised); agreed over the ranks so that every rank takes the same decision.  Resets the counters."""
+        flags = []
+        for name in ("ar", "clvp", "diffusion"):
+            g = getattr(getattr(self, name), "guard", None)
+            flags.append(bool(g()) if g is not None else False)
+        flags.append(not wav_ok)
+        if self.world > 1:
+            flags = tdist.any_over_ranks(flags)
+        return [n for n, f in zip(STAGE_NAMES, flags) if f]
+
+    def _demote(self, tripped):
+        """fp16 stages among `tripped` are rebuilt with bf16 operands (same weights, fp32 exponent range); a stage that overflows
+        in bf16 has non-finite weights or inputs: that is an error, not a precision choice."""
+        import warnings
+        for name in tripped:
+            if self.dtypes[name] != E.TT_F16:
+                raise E.OperandOverflow(f"the {name} stage produced non-finite values with bf16 operands (non-finite weights or inputs?)")
+            warnings.warn(f"tortoise_tts_amd: the {name} stage overflowed fp16 operands; rebuilding it with bf16 operands and re-rendering")
+            self.dtypes[name] = E.TT_BF16
+            self.demotions.append(name)
+            self._build_stage(name)
 
     # ------------------------------------------------------------------ reference helpers
     @property
@@ -248,6 +316,10 @@ class TextToSpeech:
             self.rlg = stages.RandomLatentStage(self._sd("rlg_auto"), self._sd("rlg_diffuser"), self.device, self.dtype)
         ca, cd = self.rlg.channels  # 1024 / 2048 for the released rlg_auto.pth / rlg_diffuser.pth
         return self.rlg.latents(torch.randn(1, ca), torch.randn(1, cd))
+
+    def dtype_names(self):
+        """{'ar': 'bf16', ...}: the operand type every stage currently runs with (after any overflow demotion)."""
+        return {k: E.DTYPE_NAMES[v] for k, v in self.dtypes.items()}
 
     def deterministic_state(self, seed=None):
         """api.py:598-609."""
@@ -348,6 +420,7 @@ class TextToSpeech:
         # conditioning_free is rendered by ranks 0 and 1 together: rank r evaluates denoiser row r of every step.
         split = self.split_diffusion and k == 1 and bool(sched.cond_free)
         wavs = {}
+        wav_ok = True
         for i in range(k):
             if split:
                 if self.rank > 1:
@@ -375,11 +448,24 @@ class TextToSpeech:
             ev.mark(4)
             z = noise.get("z")
             z = torch.randn(1, self.voc_cfg.noise_dim, S + 10, device=dev, generator=gen) if z is None else z.to(dev)
-            wavs[i] = self.vocoder.inference(mel, z).cpu()
+            audio = self.vocoder.inference(mel, z)
+            finite = torch.isfinite(audio).all()  # (a NaN survives the final clamp: the vocoder stage's overflow check)
+            wavs[i] = audio.cpu()
+            wav_ok = wav_ok and bool(finite)
         if not wavs:  # this rank had no winner to render
             ev.mark(4)
         ev.mark(5)
         ev.synchronize()
+        # operand-overflow guards (fp16 stages): counters the stages' own kernels kept, read after the synchronisation above
+        tripped = self._tripped_stages(wav_ok)
+        if tripped:
+            self._demote(tripped)
+            return self.tts(text, voice_samples=voice_samples, conditioning_latents=conditioning_latents, k=k, verbose=verbose,
+                            use_deterministic_seed=seed, return_deterministic_state=return_deterministic_state,
+                            num_autoregressive_samples=num_autoregressive_samples, temperature=temperature, length_penalty=length_penalty,
+                            repetition_penalty=repetition_penalty, top_p=top_p, max_mel_tokens=max_mel_tokens, cvvp_amount=cvvp_amount,
+                            diffusion_iterations=diffusion_iterations, cond_free=cond_free, cond_free_k=cond_free_k,
+                            diffusion_temperature=diffusion_temperature, top_k=top_k, **({"noise_override": noise} if noise else {}))
         self.timings = {"ar_s": ev.seconds(0, 1), "clvp_s": ev.seconds(1, 2), "latents_s": ev.seconds(2, 3),
                         "diffusion_s": ev.seconds(3, 4), "vocoder_s": ev.seconds(4, 5), "total_s": ev.seconds(0, 5)}
         # Rendered winners go to rank 0 only (the reference returns the audio to ONE caller); other ranks get None entries.
@@ -528,6 +614,10 @@ class TextToSpeech:
             t_host["render_s"] += _time.perf_counter() - t0
         if on_gpu:
             torch.cuda.synchronize()
+        tripped = self._tripped_stages(all(bool(torch.isfinite(o).all()) for o in out))
+        if tripped:  # an fp16 stage overflowed: rebuild it with bf16 operands and render the texts again (same seed)
+            self._demote(tripped)
+            return self.tts_many(texts, conditioning_latents=conditioning_latents, use_deterministic_seed=seed, verbose=verbose, **kwargs)
         # host-clock stage sums
         acc = {"ar_s": t_host["ar_s"], "clvp_s": t_host["rank_s"], "latents_s": 0.0, "diffusion_s": t_host["render_s"], "vocoder_s": 0.0,
                "total_s": _time.perf_counter() - t_all}

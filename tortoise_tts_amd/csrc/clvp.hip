@@ -24,6 +24,8 @@ struct tt_clvp {
   float* enc = nullptr; float* pooled = nullptr; void* pooled_t = nullptr;
   float* text_latent = nullptr; float* speech_latent = nullptr;
   int max_batch = 0;
+  int* guard = nullptr;       // operand-overflow guard (see tt_ar_guard): bumped by the row norms
+  int* guard_host = nullptr;  // pinned copy, refreshed at the end of tt_clvp_score
 };
 
 static int clvp_tower_run(tt_clvp* e, const ClvpTower& t, const int* tokens, int B, int n, float* latent_out, hipStream_t s) {
@@ -36,6 +38,7 @@ static int clvp_tower_run(tt_clvp* e, const ClvpTower& t, const int* tokens, int
     memset(&a, 0, sizeof(a));
     a.x = e->x; a.ldx = D; a.M = M; a.D = D; a.mode = NORM_RMS; a.g1 = w.attn_norm_g; a.eps1 = 1e-8f;
     a.out_t = e->h; a.ldot = D;
+    a.guard = e->guard;
     TT_TRY(rownorm_launch(dt, a, s));
     GemmArgs g = gemm_args(e->h, D, w.w_qkv, D, M, 3 * D, D);
     g.seq_len = n; g.dmodel = D; g.heads = H; g.q = e->q; g.k = e->k; g.vt = e->vt; g.seq_pad = n_pad; g.q_scale = 0.125f;
@@ -62,6 +65,7 @@ static int clvp_tower_run(tt_clvp* e, const ClvpTower& t, const int* tokens, int
   memset(&a, 0, sizeof(a));
   a.x = e->x; a.ldx = D; a.M = M; a.D = D; a.mode = NORM_LAYER; a.g1 = t.w.norm_g; a.b1 = t.w.norm_b; a.eps1 = 1e-5f;
   a.out_f32 = e->enc; a.ldo32 = D;
+  a.guard = e->guard;
   TT_TRY(rownorm_launch(dt, a, s));
   TT_TRY(mean_rows_launch(e->enc, e->pooled, B, n, D, s));
   TT_TRY(cast_pad_launch(dt, e->pooled, D, e->pooled_t, D, B, D, D, s));
@@ -99,6 +103,9 @@ int tt_clvp_create(const tt_clvp_config* cfg, const tt_clvp_tower* text, const t
   if (!rc) rc = e->arena.alloc(&e->pooled_t, (rows * D / 8 + D) * 2);
   if (!rc) rc = e->arena.alloc_t(&e->text_latent, cfg->latent_dim);
   if (!rc) rc = e->arena.alloc_t(&e->speech_latent, (rows / 8 + 8) * cfg->latent_dim);
+  if (!rc) rc = e->arena.alloc_t(&e->guard, 4);
+  if (!rc && hipHostMalloc((void**)&e->guard_host, 4 * sizeof(int)) != hipSuccess) { set_error("tt_clvp_create: hipHostMalloc failed"); rc = -2; }
+  if (!rc) e->guard_host[0] = 0;
   if (rc) {
     tt_clvp_destroy(e);
     return rc;
@@ -110,6 +117,7 @@ int tt_clvp_create(const tt_clvp_config* cfg, const tt_clvp_tower* text, const t
 void tt_clvp_destroy(tt_clvp* e) {
   if (!e) return;
   (void)hipDeviceSynchronize();
+  if (e->guard_host) (void)hipHostFree(e->guard_host);
   e->arena.release();
   e->sb.destroy();
   delete e;
@@ -124,7 +132,20 @@ int tt_clvp_score(tt_clvp* e, const int* text, int T, const int* codes, int B, i
   TT_TRY(clvp_tower_run(e, e->text, text, 1, T, e->text_latent, s));
   TT_TRY(clvp_tower_run(e, e->speech, codes, B, n, e->speech_latent, s));
   TT_TRY(clvp_score_launch(e->text_latent, 1, e->speech_latent, e->temperature, scores, B, e->cfg.latent_dim, s));
+  TT_CHECK_HIP(hipMemcpyAsync(e->guard_host, e->guard, sizeof(int), hipMemcpyDeviceToHost, s));
   return e->sb.leave(us);
+}
+
+// Operand-overflow guard of this stage (see tt_ar_guard), as of the last finished tt_clvp_score (after the caller synchronised).
+int tt_clvp_guard(tt_clvp* e, int reset) {
+  if (!e) { set_error("tt_clvp_guard: null handle"); return -1; }
+  const int n = e->guard_host[0];
+  if (n > 0) set_error("CLVP stage: %d kernel(s) met non-finite values (operand overflow in %s)", n, e->cfg.dtype == DT_F16 ? "fp16: use bf16 operands for this stage" : "bf16");
+  if (reset && n > 0) {  // (a clean counter needs no device work: this sits at the end of every utterance)
+    if (hipMemsetAsync(e->guard, 0, 4 * sizeof(int), e->sb.own) != hipSuccess || hipStreamSynchronize(e->sb.own) != hipSuccess) { set_error("tt_clvp_guard: reset failed"); return -2; }
+    e->guard_host[0] = 0;
+  }
+  return n;
 }
 
 }  // extern "C"

@@ -66,6 +66,19 @@ struct tt_diff {
   float* x = nullptr;          // [S][in]
   void* x_t = nullptr;         // [2][S][in_pad] T
   float* out = nullptr;        // [2][S][out]
+  // operand-overflow guard: device counter bumped by the GroupNorm / sampler kernels when they meet a non-finite value; every
+  // sampling run ends with a copy into the pinned word tt_diff_guard reads
+  int* guard = nullptr;
+  int* guard_host = nullptr;
+  // The captured sampler step stays on the handle between calls: the caller's noise / output pointers reach the sampler kernel
+  // through a device-side table (io_dev, refreshed per call), so the key is the geometry alone (utterances, lengths, guidance rows,
+  // steps).  Replaces the per-call capture + instantiate of round 3 (and the destroy-right-after-the-last-launch that went with it).
+  const void** io_dev = nullptr;    // [16][2]: {step_noise, mel_out} per utterance
+  const void** io_host = nullptr;   // pinned staging
+  hipGraph_t step_graph = nullptr;
+  hipGraphExec_t step_exec = nullptr;
+  std::vector<int> step_key;
+  int captures = 0;  // sampler-step captures so far (tt_diff_stat)
   // split sampling: this handle evaluates one denoiser row per step
   hipGraph_t split_graph = nullptr;
   hipGraphExec_t split_exec = nullptr;
@@ -82,6 +95,7 @@ static int run_gn(tt_diff* e, const float* x, int B, int S, const float* g, cons
   // per-step scale / shift rows are staged at a fixed address (e->ss_cur): no step-dependent addressing in the kernel
   a.out_t = out_t; a.ldot = ldot; a.out_f32 = out_f32; a.ldo32 = e->C;
   a.partial = e->gn_partial;
+  a.guard = e->guard;
   if (e->masked) {
     a.vperiod = e->U;
     for (int u = 0; u < e->U; ++u) a.vlen[u] = e->Su[u];
@@ -247,6 +261,14 @@ static int diff_prepare_timesteps(tt_diff* e, int n, hipStream_t s) {
   return 0;
 }
 
+static void diff_drop_step_graph(tt_diff* e) {
+  if (e->step_exec) (void)hipGraphExecDestroy(e->step_exec);
+  if (e->step_graph) (void)hipGraphDestroy(e->step_graph);
+  e->step_exec = nullptr;
+  e->step_graph = nullptr;
+  e->step_key.clear();
+}
+
 static void split_release(tt_diff* e) {
   if (e->split_exec) (void)hipGraphExecDestroy(e->split_exec);
   if (e->split_graph) (void)hipGraphDestroy(e->split_graph);
@@ -306,6 +328,13 @@ int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff*
   if (!rc) rc = e->arena.alloc_t(&e->x, (size_t)e->UB * cfg->max_seq * cfg->in_channels);
   if (!rc) rc = e->arena.alloc(&e->x_t, (B2 * cfg->max_seq + 8) * cfg->in_pad * 2);
   if (!rc) rc = e->arena.alloc_t(&e->out, B2 * cfg->max_seq * cfg->out_channels);
+  if (!rc) rc = e->arena.alloc_t(&e->guard, 4);
+  if (!rc) rc = e->arena.alloc_t(&e->io_dev, 32);
+  if (!rc && (hipHostMalloc((void**)&e->guard_host, 4 * sizeof(int)) != hipSuccess || hipHostMalloc((void**)&e->io_host, 32 * sizeof(void*)) != hipSuccess)) {
+    set_error("tt_diff_create: hipHostMalloc failed");
+    rc = -2;
+  }
+  if (!rc) e->guard_host[0] = 0;
   if (rc) {
     tt_diff_destroy(e);
     return rc;
@@ -318,6 +347,9 @@ void tt_diff_destroy(tt_diff* e) {
   if (!e) return;
   (void)hipDeviceSynchronize();
   split_release(e);
+  diff_drop_step_graph(e);
+  if (e->guard_host) (void)hipHostFree(e->guard_host);
+  if (e->io_host) (void)hipHostFree((void*)e->io_host);
   e->arena.release();
   e->sb.destroy();
   delete e;
@@ -391,6 +423,7 @@ int tt_diff_condition_slot(tt_diff* e, int u, const float* latents, int M, const
 
 int tt_diff_get_code_emb(tt_diff* e, float* dst, void* stream) {
   TT_REQUIRE(e && dst && e->S > 0, "tt_diff_get_code_emb: no conditioning");
+  TT_REQUIRE(e->U == 1 && e->conditioned == 1u, "tt_diff_get_code_emb: the handle holds a batch of %d utterances (tt_diff_batch_begin); call tt_diff_condition first", e->U);
   hipStream_t us = (hipStream_t)stream;
   TT_TRY(e->sb.enter(us));
   TT_CHECK_HIP(hipMemcpyAsync(dst, e->code_emb, (size_t)e->S * e->C * sizeof(float), hipMemcpyDeviceToDevice, e->sb.own));
@@ -399,6 +432,7 @@ int tt_diff_get_code_emb(tt_diff* e, float* dst, void* stream) {
 
 int tt_diff_forward(tt_diff* e, const float* x, int timestep, int cond_free, float* out, void* stream) {
   TT_REQUIRE(e && x && out && e->S > 0, "tt_diff_forward: call tt_diff_condition first");
+  TT_REQUIRE(e->U == 1 && e->conditioned == 1u, "tt_diff_forward: the handle holds a batch of %d utterances (tt_diff_batch_begin); call tt_diff_condition first", e->U);
   hipStream_t us = (hipStream_t)stream, s = e->sb.own;
   TT_TRY(e->sb.enter(us));
   const int S = e->S, IC = e->cfg.in_channels, IP = e->cfg.in_pad;
@@ -424,7 +458,12 @@ static int diff_sample_run(tt_diff* e, const float* const* x_T, const float* con
   for (int i = 0; i < n_steps; ++i) ts[i] = steps_host[i].timestep;
   TT_CHECK_HIP(hipMemcpyAsync(e->ts_dev, ts.data(), n_steps * sizeof(int), hipMemcpyHostToDevice, s));
   TT_CHECK_HIP(hipMemcpyAsync(e->steps_dev, steps_host, n_steps * sizeof(tt_diff_step), hipMemcpyHostToDevice, s));
-  TT_CHECK_HIP(hipStreamSynchronize(s));  // host staging buffers may go away
+  for (int u = 0; u < U; ++u) {  // this call's noise / output pointers: data for the kept sampler-step graph
+    e->io_host[2 * u] = step_noise[u];
+    e->io_host[2 * u + 1] = mel_out[u];
+  }
+  TT_CHECK_HIP(hipMemcpyAsync(e->io_dev, e->io_host, 32 * sizeof(void*), hipMemcpyHostToDevice, s));
+  TT_CHECK_HIP(hipStreamSynchronize(s));  // host staging buffers may go away (and io_host may be rewritten by the next call)
   TT_CHECK_HIP(hipMemsetAsync(e->slot, 0, sizeof(int), s));
   TT_TRY(diff_prepare_timesteps(e, n_steps, s));
   const int R = cond_free ? 2 : 1, B = R * U;
@@ -441,9 +480,10 @@ static int diff_sample_run(tt_diff* e, const float* const* x_T, const float* con
     memset(&p, 0, sizeof(p));
     p.steps = e->steps_dev; p.slot = e->slot; p.x = e->x + (size_t)u * S * IC; p.x_t = offset_t(e->x_t, (size_t)u * S * IP); p.cpad = IP;
     p.out = e->out + (size_t)u * S * e->cfg.out_channels;
-    p.has_uncond = cond_free ? 1 : 0; p.noise = step_noise[u]; p.S = e->Su[u]; p.C = IC;
+    p.has_uncond = cond_free ? 1 : 0; p.S = e->Su[u]; p.C = IC;
+    p.io = e->io_dev + 2 * u;  // {step_noise[u], mel_out[u]}: data of this call, not of the captured step
+    p.guard = e->guard;
     p.ld_rows = U * S;
-    p.mel_out = mel_out[u];
     p.mel_scale = 2.3143386840820312f - (-11.512925148010254f);
     p.mel_shift = -11.512925148010254f;
   }
@@ -453,28 +493,46 @@ static int diff_sample_run(tt_diff* e, const float* const* x_T, const float* con
     return slot_advance_launch(e->slot, e->ss_all, e->ss_cur, e->NR * 2 * e->C, e->n_steps_cur - 1, s);
   };
   if (!rc && graphs_enabled() && n_steps > 2) {
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-    if (ce != hipSuccess) { set_error("tt_diff_sample: capture failed: %s", hipGetErrorString(ce)); rc = -2; }
-    if (!rc) {
-      rc = one_step();
-      ce = hipStreamEndCapture(s, &graph);
-      if (!rc && ce != hipSuccess) { set_error("tt_diff_sample: capture failed: %s", hipGetErrorString(ce)); rc = -2; }
-    }
-    if (!rc) {
-      ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      if (ce != hipSuccess) { set_error("tt_diff_sample: instantiate failed: %s", hipGetErrorString(ce)); rc = -2; }
+    // everything the captured step bakes in that a later call could change
+    std::vector<int> key = {U, S, R, n_steps, dt, g_prof_on ? 1 : 0};
+    for (int u = 0; u < 16; ++u) key.push_back(u < U ? e->Su[u] : 0);
+    if (!e->step_exec || key != e->step_key) {
+      diff_drop_step_graph(e);
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+      if (ce != hipSuccess) { set_error("tt_diff_sample: capture failed: %s", hipGetErrorString(ce)); rc = -2; }
+      if (!rc) {
+        rc = one_step();
+        ce = hipStreamEndCapture(s, &graph);
+        if (!rc && ce != hipSuccess) { set_error("tt_diff_sample: capture failed: %s", hipGetErrorString(ce)); rc = -2; }
+      }
+      if (!rc) {
+        ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (ce != hipSuccess) { set_error("tt_diff_sample: instantiate failed: %s", hipGetErrorString(ce)); rc = -2; }
+      }
+      if (rc) {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+      } else {
+        e->step_graph = graph;
+        e->step_exec = exec;
+        e->step_key.swap(key);
+        e->captures += 1;
+      }
     }
     for (int i = 0; i < n_steps && !rc; ++i) {
-      ce = hipGraphLaunch(exec, s);
+      hipError_t ce = hipGraphLaunch(e->step_exec, s);
       if (ce != hipSuccess) { set_error("tt_diff_sample: hipGraphLaunch: %s", hipGetErrorString(ce)); rc = -2; }
     }
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
+    if (rc) {
+      (void)hipStreamSynchronize(s);
+      diff_drop_step_graph(e);
+    }
   } else {
     for (int i = 0; i < n_steps && !rc; ++i) rc = one_step();
   }
+  if (!rc && hipMemcpyAsync(e->guard_host, e->guard, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) { set_error("tt_diff_sample: reading the guard failed"); rc = -2; }
   e->masked = false;
   return rc;
 }
@@ -506,6 +564,7 @@ int tt_diff_split_begin(tt_diff* e, const float* x_T, const tt_diff_step* steps_
   TT_REQUIRE(e && x_T && steps_host && e->S > 0, "tt_diff_split_begin: call tt_diff_condition first");
   TT_REQUIRE(n_steps >= 1 && n_steps <= e->cfg.max_steps, "tt_diff_split_begin: %d steps exceed capacity %d", n_steps, e->cfg.max_steps);
   TT_REQUIRE(row == 0 || row == 1, "tt_diff_split_begin: row must be 0 (conditioned) or 1 (conditioning-free)");
+  TT_REQUIRE(e->U == 1 && e->conditioned == 1u, "tt_diff_split_begin: the handle holds a batch of %d utterances (tt_diff_batch_begin); call tt_diff_condition first", e->U);
   split_release(e);
   hipStream_t us = (hipStream_t)stream, s = e->sb.own;
   TT_TRY(e->sb.enter(us));
@@ -565,6 +624,7 @@ int tt_diff_split_update(tt_diff* e, const float* rows, const float* step_noise,
   pa.steps = e->steps_dev; pa.slot = e->slot; pa.x = e->x; pa.x_t = e->x_t; pa.cpad = e->cfg.in_pad; pa.out = rows;
   pa.has_uncond = 1; pa.noise = step_noise; pa.S = e->S; pa.C = e->cfg.in_channels;
   pa.mel_out = mel_out;
+  pa.guard = e->guard;
   pa.mel_scale = 2.3143386840820312f - (-11.512925148010254f);
   pa.mel_shift = -11.512925148010254f;
   TT_TRY(psample_launch(e->cfg.dtype, pa, s));
@@ -575,9 +635,28 @@ int tt_diff_split_update(tt_diff* e, const float* rows, const float* step_noise,
 
 int tt_diff_split_end(tt_diff* e) {
   TT_REQUIRE(e != nullptr, "tt_diff_split_end: null handle");
+  TT_CHECK_HIP(hipMemcpyAsync(e->guard_host, e->guard, sizeof(int), hipMemcpyDeviceToHost, e->sb.own));
   TT_CHECK_HIP(hipStreamSynchronize(e->sb.own));
   split_release(e);
   return 0;
+}
+
+int tt_diff_stat(tt_diff* e, int which) {  // 0: sampler-step graph captures so far (tests: the kept graph is reused)
+  if (!e) { set_error("tt_diff_stat: null handle"); return -1; }
+  return which == 0 ? e->captures : -1;
+}
+
+// Operand-overflow guard (fp16 operands saturate at 65504): non-finite values met by the GroupNorm statistics / the sampler since
+// the last reset, as of the end of the last finished tt_diff_sample / tt_diff_sample_batch / tt_diff_split_end.  reset != 0 clears it.
+int tt_diff_guard(tt_diff* e, int reset) {
+  if (!e) { set_error("tt_diff_guard: null handle"); return -1; }
+  const int n = e->guard_host[0];
+  if (n > 0) set_error("diffusion stage: %d kernel(s) met non-finite values (operand overflow in %s)", n, e->cfg.dtype == DT_F16 ? "fp16: re-run this stage with bf16 operands" : "bf16");
+  if (reset && n > 0) {  // (a clean counter needs no device work: this sits at the end of every utterance)
+    if (hipMemsetAsync(e->guard, 0, 4 * sizeof(int), e->sb.own) != hipSuccess || hipStreamSynchronize(e->sb.own) != hipSuccess) { set_error("tt_diff_guard: reset failed"); return -2; }
+    e->guard_host[0] = 0;
+  }
+  return n;
 }
 
 }  // extern "C"

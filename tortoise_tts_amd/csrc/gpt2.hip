@@ -7,9 +7,16 @@
 //                (deterministic, no atomics); sampling on device; whole step replayed from one hipGraph.
 //   * latents:   teacher-forced full pass for the CLVP winners (autoregressive.py:454-506).
 #include "runtime.h"
+#include <unistd.h>
 #include "../../include/tortoise_mi355x.h"
 
 using namespace tt;
+
+struct ArParams {
+  unsigned long long keys[16];
+  int row_offset;
+  int pad[3];
+};
 
 struct tt_ar {
   tt_ar_config cfg;
@@ -38,7 +45,8 @@ struct tt_ar {
   float* logits = nullptr; // [max_batch][V]
   int* state = nullptr; unsigned* seen = nullptr; int* unfinished = nullptr; int* unfinished_count = nullptr;
   int* next_tok = nullptr;
-  int* count_host = nullptr;  // pinned
+  int* guard = nullptr;    // [4] device counters: [0] rows with a non-finite value seen by the row norms / the sampler (tt_ar_guard)
+  int* guard_host = nullptr;  // pinned copy, refreshed at the end of every generation / latent pass
   int max_rows = 0;
   int P1 = 0;      // current prefix length (incl. start token); with several groups the longest one
   int G = 1;       // utterances (groups) of the current batch, each with its own prefix: kp / vp are [group][layer][H][max_prefix][64]
@@ -57,11 +65,36 @@ struct tt_ar {
   // The captured decode step is kept between calls: everything a call can change is either device data (token / slot counters, the
   // Philox keys below, the prefix caches) or part of step_key - the bytes of the sampler's argument block plus the batch / group /
   // prefix-length values the launchers bake into the graph.  A call with the same key replays step_exec; any other key re-captures.
-  unsigned long long* keys_dev = nullptr;   // [16] Philox key per utterance group (group 0 alone without groups)
-  unsigned long long* keys_host = nullptr;  // pinned staging of the same
+  ArParams* par_dev = nullptr;    // Philox key per utterance group (group 0 alone without groups) + row_offset of the call
+  ArParams* par_host = nullptr;   // pinned staging of the same
   hipGraph_t step_graph = nullptr;
   hipGraphExec_t step_exec = nullptr;
   std::vector<unsigned char> step_key;
+  // The sampler writes into a code buffer the HANDLE owns ([max_batch][tmax], stop-filled at the start of a generation) and the
+  // finished columns are copied to the caller's buffer at the end of a call: the caller's pointer is not part of the kept graph.
+  int* codes_own = nullptr;
+  // Progress words in pinned host memory, written by the step's last kernel (system-scope stores): [0] tokens sampled so far,
+  // [1] index of the first token after which every row had stopped (-1: none yet).  The host launches steps at most `lookahead`
+  // ahead of [0] and stops launching when [1] turns >= 0: no queue drain inside the loop (round 3: a D2H copy + stream
+  // synchronisation every 8 steps), at most `lookahead` surplus steps after the last row stopped.
+  int* progress_host = nullptr;
+  int* progress_dev = nullptr;
+  int lookahead = 6;
+  // Decode step cut into `nsub` independent row ranges (candidates are independent until the sampler): each range runs its 30
+  // layers on its own stream, so the HBM-bound attention of one range overlaps the latency-bound GEMM / norm chain of another.
+  // Every kernel is row-local (GEMM tiles, one-workgroup-per-row norms, per-sequence attention), so the logits and therefore the
+  // codes are bit-identical for any nsub.  graph_mode 0: one captured graph with nsub parallel branches; 1: one linear graph per
+  // range + one for the tail (lm_head, sampler), forked / joined by the host with events every step.  stagger: range i starts
+  // after range i - 1 has issued its first attention launch (phase shift between the chains).
+  int nsub = 1, stagger = 0, graph_mode = 0;
+  hipStream_t sub_stream[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_tail = nullptr;
+  hipEvent_t ev_join[3] = {nullptr, nullptr, nullptr}, ev_stag[3] = {nullptr, nullptr, nullptr};
+  hipGraph_t part_graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // graph_mode 1: ranges 0 .. 3, [4] = tail
+  hipGraphExec_t part_exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int step_nsub = 1;  // ranges of the kept graph(s)
+  int captures = 0;   // decode-step captures so far (tt_ar_stat: tests assert the kept graph is reused)
+  int drains = 0;     // host-side queue drains the launch loop fell back to (0 when the progress words arrive)
 };
 
 static void ar_drop_step_graph(tt_ar* e) {
@@ -69,6 +102,12 @@ static void ar_drop_step_graph(tt_ar* e) {
   if (e->step_graph) (void)hipGraphDestroy(e->step_graph);
   e->step_exec = nullptr;
   e->step_graph = nullptr;
+  for (int i = 0; i < 5; ++i) {
+    if (e->part_exec[i]) (void)hipGraphExecDestroy(e->part_exec[i]);
+    if (e->part_graph[i]) (void)hipGraphDestroy(e->part_graph[i]);
+    e->part_exec[i] = nullptr;
+    e->part_graph[i] = nullptr;
+  }
   e->step_key.clear();
 }
 
@@ -78,21 +117,27 @@ static inline GemmArgs ar_gemm(const tt_ar* e, const void* A, int lda, const voi
   return gemm_args(A, lda, W, ldw, M, N, K);
 }
 
-static int ar_rownorm(tt_ar* e, float* x, int M, const float* g1, const float* b1, const float* g2, const float* b2,
-                      const float* add_bias, int nslab, int slab_rows, hipStream_t s) {
+// x [M][D] rows (+ pending bias / split-K slabs of the GEMM before) -> LayerNorm -> h_out [M][D] T.  slabs: [nslab][slab_rows][D]
+static int ar_rownorm_rows(tt_ar* e, float* x, void* h_out, int M, const float* g1, const float* b1, const float* add_bias, const float* slabs,
+                           int nslab, int slab_rows, hipStream_t s) {
   RowNormArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.ldx = e->D; a.M = M; a.D = e->D;
   a.add_bias = add_bias;
-  a.add_slabs = nslab ? e->slabs : nullptr;
+  a.add_slabs = nslab ? slabs : nullptr;
   a.nslab = nslab; a.slab_stride = (size_t)slab_rows * e->D; a.ldslab = e->D;
   a.write_x = (add_bias || nslab) ? 1 : 0;
   a.mode = NORM_LAYER;
   a.g1 = g1; a.b1 = b1; a.eps1 = 1e-5f;
-  a.g2 = g2; a.b2 = b2; a.eps2 = 1e-5f;
-  a.out_t = e->h; a.ldot = e->D;
+  a.out_t = h_out; a.ldot = e->D;
   a.row_blocks = 1;
+  a.guard = e->guard;
   return rownorm_launch(e->cfg.dtype, a, s);
+}
+static int ar_rownorm(tt_ar* e, float* x, int M, const float* g1, const float* b1, const float* g2, const float* b2,
+                      const float* add_bias, int nslab, int slab_rows, hipStream_t s) {
+  (void)g2; (void)b2;
+  return ar_rownorm_rows(e, x, e->h, M, g1, b1, add_bias, e->slabs, nslab, slab_rows, s);
 }
 
 // GPT2Model.forward over full sequences (causal), in place on e->x [B*n][D].
@@ -148,98 +193,169 @@ static int pick_split(int B, int N, int K) {
 // lm_head = Sequential(final_norm, mel_head) applied to ln_f(x) (autoregressive.py:42, 174)
 // lat_index: >= 0 files the normalised row(s) as that latent (prefill: 0); -1: under the device-side step counter (decode step
 // feeding token i - 1 produces latent i); -2: no capture
-static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, hipStream_t s, int lat_index = -2, int logits_row0 = 0) {
-  {
-    RowNormArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x = x; a.ldx = e->D; a.M = M; a.D = e->D;
-    a.add_bias = add_bias;
-    a.add_slabs = nslab ? e->slabs : nullptr;
-    a.nslab = nslab; a.slab_stride = (size_t)e->B * e->D; a.ldslab = e->D;
-    a.write_x = (add_bias || nslab) ? 1 : 0;
-    a.mode = NORM_LAYER;
-    a.g1 = e->w.lnf_g; a.b1 = e->w.lnf_b; a.eps1 = 1e-5f;
-    a.g2 = e->w.final_norm_g; a.b2 = e->w.final_norm_b; a.eps2 = 1e-5f;
-    a.out_t = e->h; a.ldot = e->D;
-    a.row_blocks = 1;
-    if (e->lat && lat_index != -2 && M <= e->lat_batch) {
-      a.out_f32 = e->lat; a.ldo32 = e->D;
-      a.f32_slot_stride = (size_t)e->lat_batch * e->D;
-      if (lat_index >= 0) a.out_f32 += (size_t)lat_index * a.f32_slot_stride;
-      else { a.f32_slot = e->state + 1; a.f32_slot_base = 1; }
-    }
-    TT_TRY(rownorm_launch(e->cfg.dtype, a, s));
+static int ar_head_norm(tt_ar* e, float* x, void* h_out, int M, const float* add_bias, const float* slabs, int nslab, int slab_rows,
+                        hipStream_t s, int lat_index = -2) {
+  RowNormArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.ldx = e->D; a.M = M; a.D = e->D;
+  a.add_bias = add_bias;
+  a.add_slabs = nslab ? slabs : nullptr;
+  a.nslab = nslab; a.slab_stride = (size_t)slab_rows * e->D; a.ldslab = e->D;
+  a.write_x = (add_bias || nslab) ? 1 : 0;
+  a.mode = NORM_LAYER;
+  a.g1 = e->w.lnf_g; a.b1 = e->w.lnf_b; a.eps1 = 1e-5f;
+  a.g2 = e->w.final_norm_g; a.b2 = e->w.final_norm_b; a.eps2 = 1e-5f;
+  a.out_t = h_out; a.ldot = e->D;
+  a.row_blocks = 1;
+  a.guard = e->guard;
+  if (e->lat && lat_index != -2 && M <= e->lat_batch) {
+    a.out_f32 = e->lat; a.ldo32 = e->D;
+    a.f32_slot_stride = (size_t)e->lat_batch * e->D;
+    if (lat_index >= 0) a.out_f32 += (size_t)lat_index * a.f32_slot_stride;
+    else { a.f32_slot = e->state + 1; a.f32_slot_base = 1; }
   }
+  return rownorm_launch(e->cfg.dtype, a, s);
+}
+static int ar_head_gemm(tt_ar* e, int M, hipStream_t s, int logits_row0 = 0) {
   GemmArgs g = ar_gemm(e, e->h, e->D, e->w_head_p, e->D, M, e->Vp, e->D);
   g.bias = e->b_head_p; g.out_f32 = e->logits + (size_t)logits_row0 * e->Vp; g.ldo32 = e->Vp;
   TT_TRY(gemm_launch(e->cfg.dtype, EPI_STD, g, s));
   e->logits_rows = logits_row0 + M;
   return 0;
 }
+static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, hipStream_t s, int lat_index = -2, int logits_row0 = 0) {
+  TT_TRY(ar_head_norm(e, x, e->h, M, add_bias, e->slabs, nslab, e->B, s, lat_index));
+  return ar_head_gemm(e, M, s, logits_row0);
+}
 
-// One KV-cached decode step for e->B sequences; the fed tokens are in e->next_tok.
-static int decode_step_enqueue(tt_ar* e, hipStream_t s, bool embedded = false) {
-  const int D = e->D, H = e->H, B = e->B, dt = e->cfg.dtype;
-  // `embedded`: the sampler already wrote this step's input rows into e->x (tt_ar_generate)
-  if (!embedded) TT_TRY(ar_embed_launch(e->next_tok, e->state, e->w.mel_emb, e->w.mel_pos, e->x, B, D, e->cfg.mel_pos_offset, s));
+// The 30 layers of one KV-cached decode step for the sequences [row0, row0 + nb) + the input norm of lm_head, all on stream s.
+// `slabs`: this range's private split-K slab region ([MAX_SPLIT][nb][D]).  ev_attn0: recorded behind the first attention launch.
+static int decode_layers_enqueue(tt_ar* e, hipStream_t s, int row0, int nb, float* slabs, hipEvent_t ev_attn0) {
+  const int D = e->D, H = e->H, dt = e->cfg.dtype;
+  float* x = e->x + (size_t)row0 * D;
+  void* h = offset_t(e->h, (size_t)row0 * D);
+  void* ff = offset_t(e->ff, (size_t)row0 * 4 * D);
+  void* attn = offset_t(e->attn, (size_t)row0 * D);
+  void* q = offset_t(e->q, (size_t)row0 * D);
+  const size_t seq_elems = (size_t)H * e->tmax * 64;   // per-sequence K (or V) elements of one layer
   const float* pend_bias = nullptr;
   int pend_slabs = 0;
   for (int l = 0; l < e->cfg.layers; ++l) {
     const tt_gpt_layer& w = e->L[l];
-    TT_TRY(ar_rownorm(e, e->x, B, w.ln1_g, w.ln1_b, nullptr, nullptr, pend_bias, pend_slabs, B, s));
-    GemmArgs g = ar_gemm(e, e->h, D, w.w_qkv, D, B, 3 * D, D);
+    TT_TRY(ar_rownorm_rows(e, x, h, nb, w.ln1_g, w.ln1_b, pend_bias, slabs, pend_slabs, nb, s));
+    GemmArgs g = ar_gemm(e, h, D, w.w_qkv, D, nb, 3 * D, D);
     g.bias = w.b_qkv; g.dmodel = D; g.heads = H; g.q_scale = 0.125f;
-    g.step = e->state + 1; g.qbuf = e->q;
-    g.kc = offset_t(e->kc, (size_t)l * e->gen_layer_elems);
-    g.vc = offset_t(e->vc, (size_t)l * e->gen_layer_elems);
+    g.step = e->state + 1; g.qbuf = q;
+    g.kc = offset_t(e->kc, (size_t)l * e->gen_layer_elems + (size_t)row0 * seq_elems);
+    g.vc = offset_t(e->vc, (size_t)l * e->gen_layer_elems + (size_t)row0 * seq_elems);
     g.tmax = e->tmax;
     TT_TRY(gemm_launch(dt, EPI_QKV_DECODE, g, s));
     DecodeAttnArgs a;
     memset(&a, 0, sizeof(a));
-    a.q = e->q;
+    a.q = q;
     a.kp = offset_t(e->kp, (size_t)l * e->prefix_layer_elems);
     a.vp = offset_t(e->vp, (size_t)l * e->prefix_layer_elems);
-    if (e->G > 1) {
-      a.ngroups = e->G; a.group_size = B / e->G;
+    if (e->G > 1) {  // (utterance groups: always one range, row0 == 0)
+      a.ngroups = e->G; a.group_size = nb / e->G;
       a.prefix_group_stride = (size_t)e->cfg.layers * e->prefix_layer_elems;
       for (int gi = 0; gi < e->G; ++gi) a.p1_tab[gi] = e->P1g[gi];
     }
     a.P1 = e->P1; a.kc = g.kc; a.vc = g.vc; a.tmax = e->tmax; a.step = e->state + 1;
-    a.out = e->attn; a.B = B; a.heads = H; a.host_tgen = e->host_slot + 1;
+    a.out = attn; a.B = nb; a.heads = H; a.host_tgen = e->host_slot + 1;
     TT_TRY(decode_attention_launch(dt, a, s));
+    if (l == 0 && ev_attn0) TT_CHECK_HIP(hipEventRecord(ev_attn0, s));
     // >= 1024 sequences (several utterances per batch): one block per output tile fills the chip, so the split-K partial sums are
     // folded inside the launch in slab order (gemm.h serial_k: the same bits as slabs + row norm, without 2 x 4 x B x D x 4 bytes of slab traffic)
-    const bool serial = B >= 1024;
-    int sk = pick_split(B, D, D);
-    g = ar_gemm(e, e->attn, D, w.w_proj, D, B, D, D);
+    const bool serial = nb >= 1024;
+    int sk = pick_split(nb, D, D);
+    g = ar_gemm(e, attn, D, w.w_proj, D, nb, D, D);
     if (serial && sk > 1) {
-      g.serial_k = sk; g.bias = w.b_proj; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
+      g.serial_k = sk; g.bias = w.b_proj; g.res = x; g.ldres = D; g.out_f32 = x; g.ldo32 = D;
       TT_TRY(gemm_launch(dt, EPI_STD, g, s));
-      TT_TRY(ar_rownorm(e, e->x, B, w.ln2_g, w.ln2_b, nullptr, nullptr, nullptr, 0, B, s));
+      TT_TRY(ar_rownorm_rows(e, x, h, nb, w.ln2_g, w.ln2_b, nullptr, slabs, 0, nb, s));
     } else {
-      g.splitk = sk; g.out_f32 = e->slabs; g.ldo32 = D;
+      g.splitk = sk; g.out_f32 = slabs; g.ldo32 = D;
       if (sk == 1) { g.bias = nullptr; }
       TT_TRY(gemm_launch(dt, EPI_STD, g, s));
-      TT_TRY(ar_rownorm(e, e->x, B, w.ln2_g, w.ln2_b, nullptr, nullptr, w.b_proj, sk, B, s));
+      TT_TRY(ar_rownorm_rows(e, x, h, nb, w.ln2_g, w.ln2_b, w.b_proj, slabs, sk, nb, s));
     }
-    g = ar_gemm(e, e->h, D, w.w_fc, D, B, 4 * D, D);
-    g.bias = w.b_fc; g.act = ACT_GELU_TANH; g.out_t = e->ff; g.ldot = 4 * D;
+    g = ar_gemm(e, h, D, w.w_fc, D, nb, 4 * D, D);
+    g.bias = w.b_fc; g.act = ACT_GELU_TANH; g.out_t = ff; g.ldot = 4 * D;
     TT_TRY(gemm_launch(dt, EPI_STD, g, s));
-    sk = pick_split(B, D, 4 * D);
-    g = ar_gemm(e, e->ff, 4 * D, w.w_proj2, 4 * D, B, D, 4 * D);
+    sk = pick_split(nb, D, 4 * D);
+    g = ar_gemm(e, ff, 4 * D, w.w_proj2, 4 * D, nb, D, 4 * D);
     if (serial && sk > 1) {
-      g.serial_k = sk; g.bias = w.b_proj2; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
+      g.serial_k = sk; g.bias = w.b_proj2; g.res = x; g.ldres = D; g.out_f32 = x; g.ldo32 = D;
       TT_TRY(gemm_launch(dt, EPI_STD, g, s));
       pend_bias = nullptr;
       pend_slabs = 0;
     } else {
-      g.splitk = sk; g.out_f32 = e->slabs; g.ldo32 = D;
+      g.splitk = sk; g.out_f32 = slabs; g.ldo32 = D;
       TT_TRY(gemm_launch(dt, EPI_STD, g, s));
       pend_bias = w.b_proj2;
       pend_slabs = sk;
     }
   }
-  return ar_head(e, e->x, B, pend_bias, pend_slabs, s, -1);
+  return ar_head_norm(e, x, h, nb, pend_bias, slabs, pend_slabs, nb, s, row0 == 0 && nb == e->B ? -1 : -2);
+}
+
+// Row ranges of the current decode batch: e->nsub of them when the batch divides into ranges of a multiple of 4 sequences
+// (the attention kernel's workgroup) and nothing ties the rows together (utterance groups, per-step latent capture).
+static int ar_ranges(const tt_ar* e) {
+  const int n = e->nsub;
+  if (n <= 1 || e->G > 1 || e->lat != nullptr) return 1;
+  if (e->B % (4 * n) != 0 || e->B / n < 16) return 1;
+  return n;
+}
+static inline float* ar_range_slabs(tt_ar* e, int i, int nb) { return e->slabs + (size_t)i * MAX_SPLIT * nb * e->D; }
+
+// One KV-cached decode step for e->B sequences up to the logits; the fed tokens are in e->next_tok (or, `embedded`, the sampler
+// already wrote this step's input rows into e->x: tt_ar_generate).  With several row ranges: fork on `s`, one stream per range,
+// join on `s` in front of lm_head (the same calls capture into one graph with parallel branches or run eagerly).
+static int decode_step_enqueue(tt_ar* e, hipStream_t s, bool embedded = false) {
+  const int B = e->B;
+  if (!embedded) TT_TRY(ar_embed_launch(e->next_tok, e->state, e->w.mel_emb, e->w.mel_pos, e->x, B, e->D, e->cfg.mel_pos_offset, s));
+  const int ns = ar_ranges(e);
+  if (ns == 1) {
+    TT_TRY(decode_layers_enqueue(e, s, 0, B, e->slabs, nullptr));
+    return ar_head_gemm(e, B, s);
+  }
+  const int nb = B / ns;
+  TT_CHECK_HIP(hipEventRecord(e->ev_fork, s));
+  for (int i = 0; i < ns; ++i) {
+    hipStream_t si = i == 0 ? s : e->sub_stream[i - 1];
+    if (i > 0) {
+      TT_CHECK_HIP(hipStreamWaitEvent(si, e->ev_fork, 0));
+      if (e->stagger) TT_CHECK_HIP(hipStreamWaitEvent(si, e->ev_stag[i - 1], 0));
+    }
+    TT_TRY(decode_layers_enqueue(e, si, i * nb, nb, ar_range_slabs(e, i, nb), (e->stagger && i < ns - 1) ? e->ev_stag[i] : nullptr));
+    if (i > 0) TT_CHECK_HIP(hipEventRecord(e->ev_join[i - 1], si));
+  }
+  for (int i = 1; i < ns; ++i) TT_CHECK_HIP(hipStreamWaitEvent(s, e->ev_join[i - 1], 0));
+  return ar_head_gemm(e, B, s);
+}
+
+// Capture fn() on stream s into a new graph + executable.
+template <typename F>
+static int ar_capture(hipStream_t s, F&& fn, hipGraph_t* graph_out, hipGraphExec_t* exec_out) {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  TT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  const int rc = fn();
+  hipError_t ce = hipStreamEndCapture(s, &graph);
+  if (rc) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  if (ce == hipSuccess) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (ce != hipSuccess) {
+    if (graph) (void)hipGraphDestroy(graph);
+    set_error("tt_ar_generate: graph capture / instantiate failed: %s", hipGetErrorString(ce));
+    return -2;
+  }
+  *graph_out = graph;
+  *exec_out = exec;
+  return 0;
 }
 
 extern "C" {
@@ -294,11 +410,27 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
     e->lat_batch = cfg->max_batch;
     rc = e->arena.alloc_t(&e->lat, (size_t)(e->tmax + 1) * e->lat_batch * D);
   }
-  if (!rc) rc = e->arena.alloc_t(&e->keys_dev, 16);
-  if (!rc && (hipHostMalloc((void**)&e->count_host, (e->tmax + 8) * sizeof(int)) != hipSuccess ||
-              hipHostMalloc((void**)&e->keys_host, 16 * sizeof(unsigned long long)) != hipSuccess)) {
+  if (!rc) rc = e->arena.alloc_t(&e->par_dev, 1);
+  if (!rc) rc = e->arena.alloc_t(&e->codes_own, (size_t)cfg->max_batch * e->tmax);
+  if (!rc) rc = e->arena.alloc_t(&e->guard, 4);
+  if (!rc && (hipHostMalloc((void**)&e->par_host, sizeof(ArParams)) != hipSuccess ||
+              hipHostMalloc((void**)&e->progress_host, 4 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+              hipHostMalloc((void**)&e->guard_host, 4 * sizeof(int)) != hipSuccess ||
+              hipHostGetDevicePointer((void**)&e->progress_dev, e->progress_host, 0) != hipSuccess)) {
     set_error("tt_ar_create: hipHostMalloc failed");
     rc = -2;
+  }
+  if (!rc) {
+    e->guard_host[0] = 0;
+    e->progress_host[0] = 0; e->progress_host[1] = -1; e->progress_host[2] = e->progress_host[3] = 0;
+    hipError_t he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming);
+    for (int i = 0; i < 3 && he == hipSuccess; ++i) {
+      he = hipStreamCreateWithFlags(&e->sub_stream[i], hipStreamNonBlocking);
+      if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming);
+      if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_stag[i], hipEventDisableTiming);
+    }
+    if (he != hipSuccess) { set_error("tt_ar_create: stream / event creation failed: %s", hipGetErrorString(he)); rc = -2; }
   }
   if (rc) {
     tt_ar_destroy(e);
@@ -312,8 +444,16 @@ void tt_ar_destroy(tt_ar* e) {
   if (!e) return;
   (void)hipDeviceSynchronize();
   ar_drop_step_graph(e);
-  if (e->count_host) (void)hipHostFree(e->count_host);
-  if (e->keys_host) (void)hipHostFree(e->keys_host);
+  if (e->par_host) (void)hipHostFree(e->par_host);
+  if (e->progress_host) (void)hipHostFree(e->progress_host);
+  if (e->guard_host) (void)hipHostFree(e->guard_host);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_tail) (void)hipEventDestroy(e->ev_tail);
+  for (int i = 0; i < 3; ++i) {
+    if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
+    if (e->ev_stag[i]) (void)hipEventDestroy(e->ev_stag[i]);
+    if (e->sub_stream[i]) (void)hipStreamDestroy(e->sub_stream[i]);
+  }
   e->arena.release();
   e->sb.destroy();
   delete e;
@@ -388,7 +528,7 @@ int tt_ar_decode_step(tt_ar* e, const int* tokens, void* stream) {
   hipStream_t us = (hipStream_t)stream, s = e->sb.own;
   TT_TRY(e->sb.enter(us));
   TT_CHECK_HIP(hipMemcpyAsync(e->next_tok, tokens, (size_t)e->B * sizeof(int), hipMemcpyDeviceToDevice, s));
-  TT_TRY(ar_state_advance_launch(e->state, s));  // state[1] = slot of the token being fed
+  TT_TRY(ar_state_advance_launch(e->state, nullptr, nullptr, s));  // state[1] = slot of the token being fed
   e->host_slot += 1;
   e->logits_from_prefill = false;
   TT_TRY(decode_step_enqueue(e, s));
@@ -397,42 +537,53 @@ int tt_ar_decode_step(tt_ar* e, const int* tokens, void* stream) {
 
 // Sampling loop shared by tt_ar_generate (fresh = true: the whole utterance) and tt_ar_generate_chunk (streaming: the loop
 // is resumed where the previous chunk stopped; every per-step quantity lives in device-side state, so resuming is just
-// replaying the step graph again).  Tokens [e->gen_done, target) are produced; codes is [B][ldcodes].
+// replaying the step graph again).  Tokens [e->gen_done, target) are produced; codes is the caller's [B][ldcodes] buffer.
 static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes, const tt_sampling* sp, int* codes, int* n_steps_host,
                            int* finished_host, hipStream_t s) {
   SampleArgs sa;
   memset(&sa, 0, sizeof(sa));
   sa.B = B; sa.V = e->V; sa.seen = e->seen;
   sa.rep_penalty = sp->repetition_penalty; sa.temperature = sp->temperature; sa.top_p = sp->top_p; sa.top_k = sp->top_k;
-  sa.exp_noise = sp->exp_noise; sa.row_offset = sp->row_offset;
+  sa.exp_noise = sp->exp_noise;
   sa.state = e->state; sa.unfinished = e->unfinished; sa.stop_token = e->cfg.stop_mel_token;
-  sa.codes = codes; sa.ldcodes = ldcodes; sa.next_tok = e->next_tok; sa.unfinished_count = e->unfinished_count;
+  sa.codes = e->codes_own; sa.ldcodes = e->tmax; sa.next_tok = e->next_tok; sa.unfinished_count = e->unfinished_count;
   sa.embed_x = e->x; sa.tok_emb = e->w.mel_emb; sa.pos_emb = e->w.mel_pos; sa.D = e->D; sa.pos_offset = e->cfg.mel_pos_offset;
   sa.pos_len = e->cfg.mel_pos_len;
-  // the Philox keys go through device memory (sa.seed / sa.group_seeds stay zero): the seed of a call is not part of the step graph
+  sa.guard = e->guard;
+  // the Philox keys and the row offset go through device memory (sa.seed / sa.group_seeds / sa.row_offset stay zero): neither the
+  // seed nor the candidate range of a call is part of the step graph
   sa.seed = 0;
-  sa.keys_dev = e->keys_dev;
-  for (int gi = 0; gi < 16; ++gi) e->keys_host[gi] = sp->seed;
+  sa.row_offset = 0;
+  sa.keys_dev = e->par_dev->keys;
+  sa.row_offset_dev = &e->par_dev->row_offset;
+  for (int gi = 0; gi < 16; ++gi) e->par_host->keys[gi] = sp->seed;
+  e->par_host->row_offset = sp->row_offset;
   if (e->G > 1) {
     TT_REQUIRE(B % e->G == 0 && (B / e->G) % 4 == 0, "tt_ar_generate: %d sequences do not split into %d groups of a multiple of 4", B, e->G);
     sa.ngroups = e->G; sa.group_size = B / e->G;
-    for (int gi = 0; gi < e->G; ++gi) e->keys_host[gi] = sp->group_seeds ? sp->group_seeds[gi] : sp->seed;
+    for (int gi = 0; gi < e->G; ++gi) e->par_host->keys[gi] = sp->group_seeds ? sp->group_seeds[gi] : sp->seed;
   }
-  // (keys_host is free again: every earlier generation ended with a stream synchronisation)
-  TT_CHECK_HIP(hipMemcpyAsync(e->keys_dev, e->keys_host, 16 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+  // (par_host and the progress words are free again: every earlier generation ended with a stream synchronisation)
+  TT_CHECK_HIP(hipMemcpyAsync(e->par_dev, e->par_host, sizeof(ArParams), hipMemcpyHostToDevice, s));
+  volatile int* prog = e->progress_host;
   if (fresh) {
     e->B = B;
     e->gen_done = 0;
     e->gen_finished = false;
+    prog[0] = 0;
+    prog[1] = -1;
     TT_TRY(ar_begin_launch(e->state, e->seen, e->unfinished, e->unfinished_count, B, e->V, e->tmax + 8, e->cfg.start_mel_token, s));
     TT_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)codes, e->cfg.stop_mel_token, (size_t)B * ldcodes, s));
+    TT_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)e->codes_own, e->cfg.stop_mel_token, (size_t)B * e->tmax, s));
     // token 0: every row samples from the shared prefill logits
     sa.logits = e->logits; sa.ldl = 0; sa.ldg = e->Vp;
     TT_REQUIRE(e->logits_from_prefill, "tt_ar_generate: the logits buffer does not hold the prefill logits of all %d group(s); call tt_ar_prefill / tt_ar_prefill_group first", e->G);
     e->logits_from_prefill = false;
     TT_TRY(sample_launch(sa, s));
-    TT_TRY(ar_state_advance_launch(e->state, s));
+    TT_TRY(ar_state_advance_launch(e->state, e->unfinished_count, e->progress_dev, s));
     e->gen_done = 1;
+  } else {
+    prog[0] = e->gen_done;
   }
   sa.logits = e->logits; sa.ldl = e->Vp; sa.ldg = e->Vp;  // (ldg is unused with per-row logits; set so that fresh and resumed runs share one step key)
   if (!fresh) {
@@ -443,73 +594,109 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
   }
 
   const bool use_graph = graphs_enabled() && target - e->gen_done > 1;
+  const int ns = ar_ranges(e);
+  const bool parts = use_graph && ns > 1 && e->graph_mode == 1;
   int rc = 0;
+  auto tail_enqueue = [&](hipStream_t st) -> int {
+    TT_TRY(sample_launch(sa, st));
+    return ar_state_advance_launch(e->state, e->unfinished_count, e->progress_dev, st);
+  };
   if (use_graph) {
-    // what the captured step bakes in besides device pointers owned by the handle: the sampler's argument block (scalars, the caller's
-    // code buffer, the optional injected-noise pointer) and the batch geometry the launchers read from the handle
-    std::vector<unsigned char> key(sizeof(sa) + 20 * sizeof(int));
+    // what the captured step bakes in besides device pointers owned by the handle: the sampler's argument block (scalars, the optional
+    // injected-noise pointer) and the batch geometry / range structure the launchers read from the handle
+    std::vector<unsigned char> key(sizeof(sa) + 24 * sizeof(int));
     memcpy(key.data(), &sa, sizeof(sa));
-    int geo[20] = {B, e->G, e->P1, g_prof_on ? 1 : 0};
+    int geo[24] = {B, e->G, e->P1, g_prof_on ? 1 : 0};
     for (int gi = 0; gi < 16; ++gi) geo[4 + gi] = gi < e->G ? e->P1g[gi] : 0;
+    geo[20] = ns; geo[21] = e->stagger; geo[22] = parts ? 1 : 0;
     memcpy(key.data() + sizeof(sa), geo, sizeof(geo));
-    if (!e->step_exec || key != e->step_key) {
+    const bool have = parts ? e->part_exec[4] != nullptr : e->step_exec != nullptr;
+    if (!have || key != e->step_key) {
       ar_drop_step_graph(e);
-      hipGraph_t graph = nullptr;
-      hipGraphExec_t exec = nullptr;
-      TT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      rc = decode_step_enqueue(e, s, true);
-      if (!rc) rc = sample_launch(sa, s);
-      if (!rc) rc = ar_state_advance_launch(e->state, s);
-      hipError_t ce = hipStreamEndCapture(s, &graph);
+      if (!parts) {
+        rc = ar_capture(s, [&]() -> int {
+          TT_TRY(decode_step_enqueue(e, s, true));
+          return tail_enqueue(s);
+        }, &e->step_graph, &e->step_exec);
+      } else {
+        const int nb = B / ns;
+        for (int i = 0; i < ns && !rc; ++i) {
+          hipStream_t si = i == 0 ? s : e->sub_stream[i - 1];
+          rc = ar_capture(si, [&]() -> int { return decode_layers_enqueue(e, si, i * nb, nb, ar_range_slabs(e, i, nb), nullptr); },
+                          &e->part_graph[i], &e->part_exec[i]);
+        }
+        if (!rc) rc = ar_capture(s, [&]() -> int {
+          TT_TRY(ar_head_gemm(e, B, s));
+          return tail_enqueue(s);
+        }, &e->part_graph[4], &e->part_exec[4]);
+      }
       if (rc) {
-        if (graph) (void)hipGraphDestroy(graph);
+        ar_drop_step_graph(e);
         return rc;
       }
-      if (ce == hipSuccess) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      if (ce != hipSuccess) {
-        if (graph) (void)hipGraphDestroy(graph);
-        set_error("tt_ar_generate: graph capture / instantiate failed: %s", hipGetErrorString(ce));
-        return -2;
-      }
-      e->step_graph = graph;
-      e->step_exec = exec;
       e->step_key.swap(key);
+      e->step_nsub = ns;
+      e->captures += 1;
     }
   }
   const int first_step = e->gen_done;
   int steps_done = e->gen_done;
-  bool finished = e->gen_finished;
-  int first_zero = -1;
-  for (int step = first_step; step < target && !finished; ++step) {
-    if (use_graph) {
-      hipError_t le = hipGraphLaunch(e->step_exec, s);
-      if (le != hipSuccess) { set_error("hipGraphLaunch: %s", hipGetErrorString(le)); rc = -2; break; }
+  bool stop_seen = false;
+  if (parts) TT_CHECK_HIP(hipEventRecord(e->ev_tail, s));
+  for (int step = first_step; step < target; ++step) {
+    // stay at most `lookahead` steps ahead of the device; the words are written by the last kernel of every step
+    int spins = 0;
+    while (step - prog[0] >= e->lookahead && prog[1] < 0) {
+      if (++spins > 4000) {  // >= 200 ms without the expected progress: fall back to a queue drain (always correct, only slower)
+        hipError_t ce = hipStreamSynchronize(s);
+        if (ce != hipSuccess) { set_error("tt_ar_generate: %s", hipGetErrorString(ce)); rc = -2; }
+        e->drains += 1;
+        break;
+      }
+      usleep(50);
+    }
+    if (rc) break;
+    if (prog[1] >= 0) { stop_seen = true; break; }
+    hipError_t le = hipSuccess;
+    if (use_graph && !parts) {
+      le = hipGraphLaunch(e->step_exec, s);
+    } else if (parts) {
+      for (int i = 1; i < ns && le == hipSuccess; ++i) le = hipStreamWaitEvent(e->sub_stream[i - 1], e->ev_tail, 0);
+      if (le == hipSuccess) le = hipGraphLaunch(e->part_exec[0], s);
+      for (int i = 1; i < ns && le == hipSuccess; ++i) {
+        le = hipGraphLaunch(e->part_exec[i], e->sub_stream[i - 1]);
+        if (le == hipSuccess) le = hipEventRecord(e->ev_join[i - 1], e->sub_stream[i - 1]);
+      }
+      for (int i = 1; i < ns && le == hipSuccess; ++i) le = hipStreamWaitEvent(s, e->ev_join[i - 1], 0);
+      if (le == hipSuccess) le = hipGraphLaunch(e->part_exec[4], s);
+      if (le == hipSuccess) le = hipEventRecord(e->ev_tail, s);
     } else {
       e->host_slot = step - 1;
       rc = decode_step_enqueue(e, s, true);
-      if (!rc) rc = sample_launch(sa, s);
-      if (!rc) rc = ar_state_advance_launch(e->state, s);
+      if (!rc) rc = tail_enqueue(s);
       if (rc) break;
     }
+    if (le != hipSuccess) { set_error("tt_ar_generate: step launch: %s", hipGetErrorString(le)); rc = -2; break; }
     steps_done = step + 1;
-    if (((step - first_step) & 7) == 7 || step == target - 1) {
-      hipError_t ce = hipMemcpyAsync(e->count_host, e->unfinished_count, (size_t)steps_done * sizeof(int), hipMemcpyDeviceToHost, s);
-      if (ce == hipSuccess) ce = hipStreamSynchronize(s);
-      if (ce != hipSuccess) { set_error("tt_ar_generate: %s", hipGetErrorString(ce)); rc = -2; break; }
-      for (int i = 0; i < steps_done; ++i)
-        if (e->count_host[i] == 0) { first_zero = i; finished = true; break; }
-    }
   }
-  if (steps_done == first_step && !rc) {  // nothing to replay (one-token request): still a host-visible completion point
-    hipError_t ce = hipMemcpyAsync(e->count_host, e->unfinished_count, (size_t)steps_done * sizeof(int), hipMemcpyDeviceToHost, s);
+  (void)stop_seen;
+  if (!rc) {
+    // the finished columns go to the caller's buffer; one host-visible completion point per call
+    hipError_t ce = hipMemcpy2DAsync(codes, (size_t)ldcodes * sizeof(int), e->codes_own, (size_t)e->tmax * sizeof(int),
+                                     (size_t)steps_done * sizeof(int), (size_t)B, hipMemcpyDeviceToDevice, s);
+    if (ce == hipSuccess) ce = hipMemcpyAsync(e->guard_host, e->guard, sizeof(int), hipMemcpyDeviceToHost, s);
     if (ce == hipSuccess) ce = hipStreamSynchronize(s);
     if (ce != hipSuccess) { set_error("tt_ar_generate: %s", hipGetErrorString(ce)); rc = -2; }
-    for (int i = 0; i < steps_done && !rc; ++i)
-      if (e->count_host[i] == 0) { first_zero = i; finished = true; break; }
   }
-  if (rc) ar_drop_step_graph(e);  // a failed replay leaves nothing to trust
+  if (rc) {
+    (void)hipStreamSynchronize(s);
+    for (int i = 0; i < 3; ++i) (void)hipStreamSynchronize(e->sub_stream[i]);
+    ar_drop_step_graph(e);  // a failed replay leaves nothing to trust
+  }
   TT_TRY(rc);
-  e->gen_done = first_zero >= 0 ? first_zero + 1 : steps_done;
+  const int first_zero = prog[1];
+  const bool finished = first_zero >= 0;
+  e->gen_done = finished ? (first_zero + 1 < steps_done ? first_zero + 1 : steps_done) : steps_done;
   e->gen_finished = finished;
   e->host_slot = e->gen_done - 1;
   if (n_steps_host) *n_steps_host = e->gen_done;
@@ -582,8 +769,57 @@ int tt_ar_latents(tt_ar* e, const float* emb, int k, int n, float* out, void* st
   a.g1 = e->w.lnf_g; a.b1 = e->w.lnf_b; a.eps1 = 1e-5f;
   a.g2 = e->w.final_norm_g; a.b2 = e->w.final_norm_b; a.eps2 = 1e-5f;
   a.out_f32 = out; a.ldo32 = D;
+  a.guard = e->guard;
   TT_TRY(rownorm_launch(e->cfg.dtype, a, s));
+  TT_CHECK_HIP(hipMemcpyAsync(e->guard_host, e->guard, sizeof(int), hipMemcpyDeviceToHost, s));
   return e->sb.leave(us);
+}
+
+// Operand-overflow guard (fp16 operands saturate at 65504): row norms / sampler launches that met a non-finite value since the
+// last reset, as of the end of the last finished tt_ar_generate[_chunk] (which synchronise) or tt_ar_latents (after the caller
+// synchronised its stream).  reset != 0 clears the counter.  Returns the count (>= 0) or a negative error.
+int tt_ar_guard(tt_ar* e, int reset) {
+  if (!e) { set_error("tt_ar_guard: null handle"); return -1; }
+  const int n = e->guard_host[0];
+  if (n > 0) set_error("autoregressive stage: %d kernel(s) met non-finite values (operand overflow in %s)", n, e->cfg.dtype == DT_F16 ? "fp16: use bf16 operands for this stage" : "bf16");
+  if (reset && n > 0) {  // (a clean counter needs no device work: this sits at the end of every utterance)
+    if (hipMemsetAsync(e->guard, 0, 4 * sizeof(int), e->sb.own) != hipSuccess || hipStreamSynchronize(e->sb.own) != hipSuccess) { set_error("tt_ar_guard: reset failed"); return -2; }
+    e->guard_host[0] = 0;
+  }
+  return n;
+}
+
+// Counters for tests / diagnostics: 0 = decode-step graph captures so far, 1 = queue drains of the launch loop (expected 0),
+// 2 = row ranges of the kept step graph.
+int tt_ar_stat(tt_ar* e, int which) {
+  if (!e) { set_error("tt_ar_stat: null handle"); return -1; }
+  return which == 0 ? e->captures : which == 1 ? e->drains : which == 2 ? e->step_nsub : -1;
+}
+
+// Engine options of a handle (defaults in brackets):
+//   TT_AR_OPT_SUBBATCHES  [1]  row ranges the decode step is cut into (1, 2 or 4), each on its own stream; codes are bit-identical
+//   TT_AR_OPT_STAGGER     [0]  range i starts after range i - 1 has issued its first attention launch
+//   TT_AR_OPT_GRAPH_MODE  [0]  0: one graph with parallel branches; 1: one linear graph per range + one for the tail
+//   TT_AR_OPT_LOOKAHEAD   [6]  decode steps the host may run ahead of the device (>= 1)
+int tt_ar_set_option(tt_ar* e, int option, int value) {
+  TT_REQUIRE(e != nullptr, "tt_ar_set_option: null handle");
+  switch (option) {
+    case TT_AR_OPT_SUBBATCHES:
+      TT_REQUIRE(value == 1 || value == 2 || value == 4, "tt_ar_set_option: %d row ranges (1, 2 or 4)", value);
+      e->nsub = value;
+      break;
+    case TT_AR_OPT_STAGGER: e->stagger = value != 0; break;
+    case TT_AR_OPT_GRAPH_MODE:
+      TT_REQUIRE(value == 0 || value == 1, "tt_ar_set_option: graph mode %d (0 or 1)", value);
+      e->graph_mode = value;
+      break;
+    case TT_AR_OPT_LOOKAHEAD:
+      TT_REQUIRE(value >= 1 && value <= 64, "tt_ar_set_option: lookahead %d outside 1 .. 64", value);
+      e->lookahead = value;
+      break;
+    default: TT_REQUIRE(false, "tt_ar_set_option: unknown option %d", option);
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -213,7 +213,10 @@ __global__ void psample_kernel(PSampleArgs a) {
   const float* ou = a.out + (size_t)ld * 2 * C;
   const int slot = *a.slot;
   const PSampleStep st = a.steps[slot];
-  const float* noise = a.noise ? a.noise + (size_t)slot * C * S : nullptr;
+  const float* noise_base = a.io ? (const float*)a.io[0] : a.noise;
+  float* mel_out = a.io ? (float*)a.io[1] : a.mel_out;
+  const float* noise = noise_base ? noise_base + (size_t)slot * C * S : nullptr;
+  bool bad = false;
   for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
     const int s = (int)(f / a.cpad), c = (int)(f % a.cpad);
     T xt = (T)0.f;
@@ -221,15 +224,20 @@ __global__ void psample_kernel(PSampleArgs a) {
       const float x = a.x[(size_t)s * C + c];
       float eps = oc[(size_t)s * 2 * C + c];
       const float var = oc[(size_t)s * 2 * C + C + c];
+      bad = bad || !(fabsf(eps) < INFINITY) || !(fabsf(var) < INFINITY);
       const float frac = (var + 1.f) * 0.5f;
       const float log_var = frac * st.max_log + (1.f - frac) * st.min_log;
-      if (a.has_uncond) eps = (1.f + st.cfk) * eps - st.cfk * ou[(size_t)s * 2 * C + c];
+      if (a.has_uncond) {
+        const float eu = ou[(size_t)s * 2 * C + c];
+        bad = bad || !(fabsf(eu) < INFINITY);
+        eps = (1.f + st.cfk) * eps - st.cfk * eu;
+      }
       float x0 = st.sqrt_recip * x - st.sqrt_recipm1 * eps;
       x0 = fminf(1.f, fmaxf(-1.f, x0));
       float xn = st.coef1 * x0 + st.coef2 * x;
       if (st.nonzero != 0.f && noise) xn += st.nonzero * expf(0.5f * log_var) * noise[(size_t)c * S + s];
       a.x[(size_t)s * C + c] = xn;
-      if (a.mel_out) a.mel_out[(size_t)c * S + s] = (xn + 1.f) * 0.5f * a.mel_scale + a.mel_shift;
+      if (mel_out) mel_out[(size_t)c * S + s] = (xn + 1.f) * 0.5f * a.mel_scale + a.mel_shift;
       xt = (T)xn;
     }
     if (a.x_t) {
@@ -238,6 +246,8 @@ __global__ void psample_kernel(PSampleArgs a) {
       if (a.has_uncond) d[((size_t)ld + s) * a.cpad + c] = xt;  // the conditioning-free batch row reads the same state
     }
   }
+  // the x0 clamp (fminf / fmaxf drop a NaN) would hide a non-finite model output: count it here
+  if (a.guard && __ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(a.guard, 1);
 }
 // End of a sampler step: advance the device-side step counter and stage the NEXT step's scale / shift rows at a fixed
 // address (ss_cur), so that every GroupNorm of the next step reads them with plain up-front loads instead of a dependent

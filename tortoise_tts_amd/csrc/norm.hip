@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
 #pragma unroll
     for (int j = 0; j < J; ++j) sq += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
     sq = block_sum_256(sq, red);
+    if (a.guard && tid == 0 && !(sq < INFINITY)) atomicAdd(a.guard, 1);  // NaN / inf in the row: an operand overflowed upstream
     const float nrm = sqrtf(sq) * rsqrtf((float)a.D);
     const float inv = 1.0f / fmaxf(nrm, a.eps1);
 #pragma unroll
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(RowNormArgs a) {
       }
     }
     const float var = block_sum_256(sq, red) / (float)a.D;
+    if (a.guard && l == 0 && tid == 0 && !(var < INFINITY)) atomicAdd(a.guard, 1);  // NaN / inf in the row: an operand overflowed upstream
     const float rstd = rsqrtf(var + epss[l]);
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(256) void rownorm_narrow_kernel(RowNormArgs a) {
   float4 y;
   if constexpr (RMS) {
     const float sq = block_sum_256_fresh(t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w, red);
+    if (a.guard && tid == 0 && !(sq < INFINITY)) atomicAdd(a.guard, 1);
     const float nrm = sqrtf(sq) * rsqrtf((float)a.D);
     const float inv = 1.0f / fmaxf(nrm, a.eps1);
     y = make_float4(t.x * inv * g.x, t.y * inv * g.y, t.z * inv * g.z, t.w * inv * g.w);
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(256) void rownorm_narrow_kernel(RowNormArgs a) {
     const float mean = block_sum_256_fresh(t.x + t.y + t.z + t.w, red) / (float)a.D;
     const float dx = t.x - mean, dy = t.y - mean, dz = t.z - mean, dw = t.w - mean;
     const float var = block_sum_256_fresh(live ? dx * dx + dy * dy + dz * dz + dw * dw : 0.f, red + 4) / (float)a.D;
+    if (a.guard && tid == 0 && !(var < INFINITY)) atomicAdd(a.guard, 1);  // NaN / inf in the row: an operand overflowed upstream
     const float rstd = rsqrtf(var + a.eps1);
     y = make_float4(dx * rstd * g.x + b.x, dy * rstd * g.y + b.y, dz * rstd * g.z + b.z, dw * rstd * g.w + b.w);
   }
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(256) void rownorm_wave_kernel(RowNormArgs a) {
 #pragma unroll
     for (int j = 0; j < J; ++j) sq += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
     sq = wave_sum(sq);
+    if (a.guard && lane == 0 && !(sq < INFINITY)) atomicAdd(a.guard, 1);
     const float nrm = sqrtf(sq) * rsqrtf((float)a.D);
     const float inv = 1.0f / fmaxf(nrm, a.eps1);
 #pragma unroll
@@ -266,7 +271,9 @@ __global__ __launch_bounds__(256) void rownorm_wave_kernel(RowNormArgs a) {
           sq += dx * dx + dy * dy + dz * dz + dw * dw;
         }
       }
-      const float rstd = rsqrtf(wave_sum(sq) / (float)a.D + epss[l]);
+      const float var = wave_sum(sq) / (float)a.D;
+      if (a.guard && l == 0 && lane == 0 && !(var < INFINITY)) atomicAdd(a.guard, 1);
+      const float rstd = rsqrtf(var + epss[l]);
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const int c = (lane + 64 * j) * 4;
@@ -447,6 +454,7 @@ __device__ __forceinline__ void gn_finalize(const GroupNormArgs& a, int b, int t
     const double inv_n = a.vperiod > 0 ? 1.0 / ((double)a.vlen[b % a.vperiod] * (double)(a.C / 32)) : a.inv_count;
     const double m = ss * inv_n;
     double var = qq * inv_n - m * m;
+    if (a.guard && !(var < 1.0e300)) atomicAdd(a.guard, 1);  // NaN / inf statistics: an operand overflowed upstream
     if (var < 0.0) var = 0.0;
     mean_s[tid] = (float)m;
     rstd_s[tid] = rsqrtf((float)var + a.eps);

@@ -37,6 +37,7 @@ struct RowNormArgs {
   int f32_slot_base;
   size_t f32_slot_stride;
   int row_blocks;      // 1: always one workgroup per row (the decode step: a row's arithmetic order must not depend on how many rows the batch has)
+  int* guard;          // optional device counter: += 1 per workgroup / wave that saw a non-finite input value (operand-overflow guard)
 };
 int rownorm_launch(int dtype, const RowNormArgs& a, hipStream_t stream);
 
@@ -65,6 +66,7 @@ struct GroupNormArgs {
   // convolution sees past the end of a shorter sequence).  vperiod == 0: every sample has S rows.
   int vperiod;
   int vlen[32];
+  int* guard;  // optional device counter: += 1 per (workgroup, group) whose statistics came out non-finite (operand-overflow guard)
 };
 int groupnorm_launch(int dtype, const GroupNormArgs& a, hipStream_t stream);
 size_t groupnorm_partial_floats(int B, int S);
@@ -139,9 +141,13 @@ struct SampleArgs {
   // keys_dev != null: the Philox keys are read from device memory instead (keys_dev[group], keys_dev[0] without groups), so that a
   // captured step graph does not bake the seed of one call in and can be replayed by the next (tt_ar_generate)
   const unsigned long long* keys_dev;
+  const int* row_offset_dev;  // != null: row_offset is read from device memory as well (same reason)
+  int* guard;                 // optional device counter: += 1 per wave that read a NaN / +inf logit
 };
 int sample_launch(const SampleArgs& a, hipStream_t stream);
-int ar_state_advance_launch(int* state, hipStream_t stream);
+// state[0] += 1, state[1] = newest token's index; with `progress` (host-mapped int[2]) also publishes {tokens so far, first step
+// after which unfinished_count was 0} for the host's launch loop (state[2] mirrors the latter on the device)
+int ar_state_advance_launch(int* state, const int* unfinished_count, int* progress, hipStream_t stream);
 int ar_begin_launch(int* state, unsigned* seen, int* unfinished, int* unfinished_count, int B, int V, int max_steps,
                     int start_token, hipStream_t stream);
 
@@ -191,6 +197,10 @@ struct PSampleArgs {
   float* mel_out;       // optional [C][S] channels-first denormalised mel written on the last step
   float mel_scale, mel_shift;
   int ld_rows;          // rows between the two batch rows of `out` / `x_t` (0: S; padded batches: the common padded length)
+  // optional indirection (a sampler-step graph kept between calls must not bake caller pointers in): when `io` is set, noise and
+  // mel_out are read from io[0] / io[1] of this utterance's device-side pointer pair instead of the two fields above
+  const void* const* io;
+  int* guard;           // optional device counter: += 1 per wave that read a non-finite model output (the x0 clamp would hide it)
 };
 int psample_launch(int dtype, const PSampleArgs& a, hipStream_t stream);
 int slot_advance_launch(int* slot, const float* ss_all, float* ss_cur, int row_floats, int last_slot, hipStream_t stream);

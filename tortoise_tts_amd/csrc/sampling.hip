@@ -39,6 +39,9 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 
 // one thread: finished rows emit the stop token (stream_generator.py:980-996), bookkeeping of the sampled token; returns it
 __device__ __forceinline__ int sample_commit(const SampleArgs& a, int b, int step, int best_i, unsigned* seen) {
+  // a row of non-finite logits (an overflowed operand upstream: the guard has counted it) never beats the initial candidate: such a
+  // row ends here with the stop token instead of indexing the tables with the sentinel
+  if ((unsigned)best_i >= (unsigned)a.V) best_i = a.stop_token;
   const int unf = a.unfinished[b];
   const int tok = unf ? best_i : a.stop_token;
   const int still = unf && tok != a.stop_token;
@@ -85,21 +88,25 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   // Philox key of this row's utterance: from device memory when the caller replays a cached step graph (the seed of a call is then
   // data, not a baked-in kernel argument), else from the argument block; block-uniform, read once
   const unsigned long long philox_key = a.keys_dev ? a.keys_dev[grp] : (a.ngroups > 1 ? a.group_seeds[grp] : a.seed);
+  const int row_offset = a.row_offset_dev ? *a.row_offset_dev : a.row_offset;  // (block-uniform scalar load)
   const float* lg = a.logits + (a.ldl ? (size_t)b * a.ldl : (size_t)grp * (a.ldg ? a.ldg : V));
   unsigned* seen = a.seen + (size_t)b * ((V + 31) / 32);
   constexpr int PER = 40;  // supports V <= 10240
   float val[PER];
+  bool bad = false;  // NaN / +inf logits: an operand overflowed somewhere upstream (-inf is legitimate: a suppressed token)
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int t = tid + 256 * j;
     float s = -INFINITY;
     if (t < V) {
       s = lg[t];
+      bad = bad || s != s || s == INFINITY;
       if (a.rep_penalty != 1.0f && ((seen[t >> 5] >> (t & 31)) & 1u)) s = s < 0.f ? s * a.rep_penalty : s / a.rep_penalty;
       if (a.temperature != 1.0f) s = s / a.temperature;
     }
     val[j] = s;
   }
+  if (a.guard && __ballot(bad) != 0ull && (tid & 63) == 0) atomicAdd(a.guard, 1);
 
   // ---- top-k threshold: radix-select the k-th largest key (4 passes of 8 bits)
   const int k = a.top_k < V ? a.top_k : V;
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       unsigned r[4];
       const unsigned long long key = philox_key;
       const int cand = a.ngroups > 1 ? b - grp * a.group_size : b;  // index within the utterance: the draw does not depend on the batching
-      philox4x32_10((unsigned)id, (unsigned)step, (unsigned)(a.row_offset + cand), 0u, (unsigned)key, (unsigned)(key >> 32), r);
+      philox4x32_10((unsigned)id, (unsigned)step, (unsigned)(row_offset + cand), 0u, (unsigned)key, (unsigned)(key >> 32), r);
       const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
       q = -__logf(u);
     }
@@ -326,6 +333,7 @@ __global__ __launch_bounds__(1024) void sample_wide_kernel(SampleArgs a) {
   // Philox key of this row's utterance: from device memory when the caller replays a cached step graph (the seed of a call is then
   // data, not a baked-in kernel argument), else from the argument block; block-uniform, read once
   const unsigned long long philox_key = a.keys_dev ? a.keys_dev[grp] : (a.ngroups > 1 ? a.group_seeds[grp] : a.seed);
+  const int row_offset = a.row_offset_dev ? *a.row_offset_dev : a.row_offset;
   const float* lg = a.logits + (a.ldl ? (size_t)b * a.ldl : (size_t)grp * (a.ldg ? a.ldg : V));
   unsigned* seen = a.seen + (size_t)b * ((V + 31) / 32);
   for (int t = tid; t < WIDE_N; t += 1024) {
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(1024) void sample_wide_kernel(SampleArgs a) {
       unsigned r[4];
       const unsigned long long pk = philox_key;
       const int cand = a.ngroups > 1 ? b - grp * a.group_size : b;
-      philox4x32_10((unsigned)id, (unsigned)step, (unsigned)(a.row_offset + cand), 0u, (unsigned)pk, (unsigned)(pk >> 32), r);
+      philox4x32_10((unsigned)id, (unsigned)step, (unsigned)(row_offset + cand), 0u, (unsigned)pk, (unsigned)(pk >> 32), r);
       const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
       q = -__logf(u);
     }
@@ -457,14 +465,26 @@ int sample_launch(const SampleArgs& a, hipStream_t stream) {
   return 0;
 }
 
-__global__ void ar_advance_kernel(int* state) {
+// Last kernel of a step.  state[0] = tokens sampled so far, state[1] = slot / index of the newest token (the one the next decode
+// step feeds), state[2] = index of the first token after which every row had stopped (-1: none yet).  With `progress` (pinned
+// host memory) the two host-visible words are published with system-scope stores: the host paces and ends its launch loop on
+// them without draining the queue (tt_ar_generate).
+__global__ void ar_advance_kernel(int* state, const int* unfinished_count, int* progress) {
   if (threadIdx.x == 0) {
-    state[0] += 1;         // tokens sampled so far
-    state[1] = state[0] - 1;  // slot / index of the newest token (the one the next decode step feeds)
+    const int step = state[0];  // index of the token the sampler just produced
+    state[0] = step + 1;
+    state[1] = step;
+    if (progress) {
+      if (unfinished_count && unfinished_count[step] == 0 && state[2] < 0) {
+        state[2] = step;
+        __hip_atomic_store(progress + 1, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __hip_atomic_store(progress, step + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
-int ar_state_advance_launch(int* state, hipStream_t stream) {
-  ar_advance_kernel<<<1, 64, 0, stream>>>(state);
+int ar_state_advance_launch(int* state, const int* unfinished_count, int* progress, hipStream_t stream) {
+  ar_advance_kernel<<<1, 64, 0, stream>>>(state, unfinished_count, progress);
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -486,6 +506,7 @@ __global__ void ar_begin_kernel(int* state, unsigned* seen, int* unfinished, int
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     state[0] = 0;
     state[1] = -1;
+    state[2] = -1;
   }
 }
 int ar_begin_launch(int* state, unsigned* seen, int* unfinished, int* unfinished_count, int B, int V, int max_steps,

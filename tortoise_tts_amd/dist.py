@@ -48,14 +48,25 @@ def init_from_env(device_index=None):
             # render the whole utterance again as an independent "rank 0".  This covers the failure that hits every rank
             # (driver / IPC / topology).  A PARTIAL failure - some ranks inside the forced all_reduce, some out - is not
             # recoverable here: the survivors block in the collective until the launcher's timeout tears the job down.
+            # The other ranks leave with exit status 0 (CollectiveInitFailed is a SystemExit): under torch.distributed.run a worker
+            # that FAILS makes the elastic agent terminate the whole group, rank 0 included - an idle rank that exits cleanly does not.
             if rank != 0:
-                raise CollectiveInitFailed(f"rank {rank}: {backend} initialisation failed; rank 0 continues alone")
+                raise CollectiveInitFailed(rank, backend)
             return 0, 1, local
     return rank, world, local
 
 
-class CollectiveInitFailed(RuntimeError):
-    """Raised on ranks != 0 when the multi-rank launch could not initialise its collectives (rank 0 falls back to one GPU)."""
+class CollectiveInitFailed(SystemExit):
+    """Raised on ranks != 0 when the multi-rank launch could not initialise its collectives (rank 0 falls back to one GPU).
+    A SystemExit with status 0: uncaught, the idle rank ends cleanly and the launcher keeps rank 0 alive; callers that want to keep
+    the process (tests, a server that parks the worker) can catch it."""
+
+    def __init__(self, rank, backend):
+        super().__init__(0)
+        self.rank, self.backend = rank, backend
+
+    def __str__(self):
+        return f"rank {self.rank}: {self.backend} initialisation failed; rank 0 continues alone"
 
 
 FALLBACK_SINGLE = False  # set when a multi-rank launch could not initialise its collectives
@@ -183,6 +194,18 @@ def broadcast_int(value, src=0):
     t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
     dist.broadcast(t, src=src)
     return int(t.item())
+
+
+def any_over_ranks(flags):
+    """Element-wise OR of a short list of host booleans over all ranks (control plane: e.g. "a stage's overflow guard tripped
+    somewhere, every rank re-runs the utterance")."""
+    flags = [bool(f) for f in flags]
+    if _single():
+        return flags
+    dev = "cpu" if _host_staged() or not torch.cuda.is_available() else "cuda"
+    t = torch.tensor([int(f) for f in flags], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [bool(v) for v in t.tolist()]
 
 
 def max_over_ranks(value):

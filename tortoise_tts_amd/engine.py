@@ -10,6 +10,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TORTOISE_MI355X_LIB") or os.path.join(HERE, "lib", "libtortoise_mi355x.so")  # env: an alternative build of the same ABI
 
 TT_BF16, TT_F16 = 0, 1
+DTYPE_NAMES = {TT_BF16: "bf16", TT_F16: "fp16"}
+TT_AR_OPT_SUBBATCHES, TT_AR_OPT_STAGGER, TT_AR_OPT_GRAPH_MODE, TT_AR_OPT_LOOKAHEAD = 1, 2, 3, 4
+
+
+def dtype_code(name):
+    """'bf16' | 'fp16' | 'f16' (or an engine code) -> engine dtype code."""
+    if isinstance(name, int):
+        return name
+    try:
+        return {"bf16": TT_BF16, "fp16": TT_F16, "f16": TT_F16}[name]
+    except KeyError:
+        raise ValueError(f"unknown operand type {name!r} (bf16 | fp16)") from None
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3, 4, 5
 
 vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers are passed as integers
@@ -142,6 +154,12 @@ _PROTOS = {
     "tt_ar_decode_step": (_i, [vp, vp, vp]),
     "tt_ar_latents": (_i, [vp, vp, _i, _i, vp, vp]),
     "tt_ar_stream_latents": (_i, [vp, _i, _i, vp, vp]),
+    "tt_ar_set_option": (_i, [vp, _i, _i]),
+    "tt_ar_guard": (_i, [vp, _i]),
+    "tt_ar_stat": (_i, [vp, _i]),
+    "tt_diff_stat": (_i, [vp, _i]),
+    "tt_clvp_guard": (_i, [vp, _i]),
+    "tt_diff_guard": (_i, [vp, _i]),
     "tt_clvp_create": (_i, [C.POINTER(ClvpConfig), C.POINTER(ClvpTower), C.POINTER(ClvpTower), vp, C.POINTER(vp)]),
     "tt_clvp_destroy": (None, [vp]),
     "tt_clvp_score": (_i, [vp, vp, _i, vp, _i, _i, vp, vp]),
@@ -231,6 +249,17 @@ def require_gpu(device=None):
     if device is None or torch.device(device).type != "cuda":
         raise EngineError("TextToSpeech needs an MI355X (gfx950) device; the engine has no CPU path")
     return torch.device(device)
+
+
+class OperandOverflow(EngineError):
+    """A stage's overflow guard tripped: non-finite values downstream of an MFMA operand cast (fp16 saturates at 65504)."""
+
+
+def guard_count(rc):
+    """Return value of a tt_*_guard call: >= 0 is the count, negative an error."""
+    if rc < 0:
+        check(rc)
+    return rc
 
 
 def check(rc):

@@ -4,6 +4,7 @@ call on the caller's current torch stream.  No model arithmetic happens here bey
 gathers for the once-per-utterance prefix (plumbing).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -69,6 +70,23 @@ class ArStage:
         self.ccfg = c
         self.h = E.vp()
         E.check(self.lib.tt_ar_create(C.byref(c), C.byref(self.w.weights), C.byref(self.h)))
+        # A/B switches of the measurement scripts (scripts/ab_stage.py); the product default is what tt_ar_create sets
+        for env, opt in (("TT_AR_SUBBATCHES", E.TT_AR_OPT_SUBBATCHES), ("TT_AR_STAGGER", E.TT_AR_OPT_STAGGER),
+                         ("TT_AR_GRAPH_MODE", E.TT_AR_OPT_GRAPH_MODE), ("TT_AR_LOOKAHEAD", E.TT_AR_OPT_LOOKAHEAD)):
+            if os.environ.get(env):
+                self.set_option(opt, int(os.environ[env]))
+
+    def set_option(self, option, value):
+        """tt_ar_set_option: row ranges of the decode step / stagger / graph form / host lookahead (codes do not depend on them)."""
+        E.check(self.lib.tt_ar_set_option(self.h, int(option), int(value)))
+
+    def stat(self, which):
+        """tt_ar_stat: 0 decode-step graph captures, 1 queue drains of the launch loop, 2 row ranges of the kept graph."""
+        return self.lib.tt_ar_stat(self.h, int(which))
+
+    def guard(self, reset=True):
+        """Non-finite values met by this stage's norms / sampler since the last reset (operand-overflow guard)."""
+        return E.guard_count(self.lib.tt_ar_guard(self.h, int(reset)))
 
     def close(self):
         if self.h:
@@ -115,13 +133,9 @@ class ArStage:
         E.check(self.lib.tt_ar_decode_step(self.h, E.ptr(t), E.stream_ptr()))
 
     def _codes_buffer(self, B, max_new):
-        """The int32 [B, max_new] buffer the sampler writes: kept per shape, because its address is part of the key under which the
-        engine keeps the captured decode step (csrc/gpt2.hip step_key) - a fresh tensor per call would re-capture the graph per call.
-        Callers receive copies (`.long()`)."""
-        buf = getattr(self, "_codes", None)
-        if buf is None or buf.shape != (B, max_new):
-            buf = self._codes = torch.empty(B, max_new, device=self.device, dtype=torch.int32)
-        return buf
+        """int32 [B, max_new] receiving buffer of one call (the sampler itself writes a buffer the handle owns, so this address is
+        not part of the kept decode-step graph's key)."""
+        return torch.empty(B, max_new, device=self.device, dtype=torch.int32)
 
     def generate(self, B, max_new, temperature=0.8, top_p=0.8, repetition_penalty=2.0, top_k=50, seed=0, row_offset=0,
                  exp_noise=None, group_seeds=None):
@@ -218,6 +232,9 @@ class ClvpStage:
         except Exception:
             pass
 
+    def guard(self, reset=True):
+        return E.guard_count(self.lib.tt_clvp_guard(self.h, int(reset)))
+
     def score(self, text_tokens, codes):
         """text_tokens int [1 or B, T] (rows identical), codes int [B, n] -> f32 [B]."""
         text = _i32(text_tokens[0], self.device)
@@ -270,6 +287,14 @@ class DiffusionStage:
         except Exception:
             pass
 
+    def stat(self, which):
+        return self.lib.tt_diff_stat(self.h, int(which))
+
+    def guard(self, reset=True):
+        """Non-finite GroupNorm statistics / sampler inputs since the last reset, as of the last finished sampling run (the caller
+        has synchronised, e.g. by reading the result)."""
+        return E.guard_count(self.lib.tt_diff_guard(self.h, int(reset)))
+
     def condition(self, latents, cond_latent, S):
         """latents f32 [1, M, latent]; cond_latent f32 [1, 2C] (diffusion_decoder.py:232-260)."""
         lat = latents[0].to(self.device).float().contiguous()
@@ -285,6 +310,8 @@ class DiffusionStage:
 
     def forward(self, x, timestep, cond_free=True):
         """x f32 [1, 100, S] -> raw model outputs [B, 200, S] (B = 2 with cond_free: row 0 cond, row 1 uncond)."""
+        if self.S <= 0:
+            raise ValueError("forward() needs condition() first (after sample_many the handle holds a batch)")
         xt = x[0].to(self.device).float().t().contiguous()
         B = 2 if cond_free else 1
         out = torch.empty(B, self.S, self.cfg.out_channels, device=self.device, dtype=torch.float32)
