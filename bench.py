@@ -44,11 +44,22 @@ def synthetic_weights(seed=1234):
 
 
 def synthetic_prompt(seed=0, text_tokens=54):
+    """Seeded stand-in prompt of the benchmark's SHAPE (the full-width goldens of tests/golden/full_*.npz were generated on it:
+    oracle/make_golden_full.py).  bench.py itself times bench_prompt()."""
     g = torch.Generator().manual_seed(seed)
     text = torch.randint(1, 255, (text_tokens,), generator=g)  # do_tts.py default sentence -> 54 BPE ids (SURVEY §8)
     auto = torch.randn(1, 1024, generator=g) * 0.5             # stands in for voices/cond_latent_example/pat.pth
     diff = torch.randn(1, 2048, generator=g) * 0.5
     return text, (auto, diff)
+
+
+def bench_prompt():
+    """The prompt SURVEY.md 8(d) prescribes: the default sentence of tortoise/do_tts.py:12 as 54 BPE ids (the reference's tokenizer.json,
+    basic cleaners) and the reference's example voice latents voices/cond_latent_example/pat.pth - committed as
+    tests/golden/bench_prompt.npz by oracle/make_bench_prompt.py (the GPU box has no /root/reference)."""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "bench_prompt.npz"))
+    return torch.from_numpy(z["ids"]).long(), (torch.from_numpy(z["auto"]).float(), torch.from_numpy(z["diffusion"]).float())
 
 
 def cpu_baseline(sds, text, latents, preset_kw, M, cores):
@@ -254,7 +265,7 @@ def stream_bench(args):
     M = args.mel_tokens
     tts = TextToSpeech(state_dicts=sds, dtype=args.dtype or "bf16", max_mel_tokens=max(M, 64), kv_cache=True)
     t_build = time.perf_counter() - t_build
-    text, (auto, _) = synthetic_prompt()
+    text, (auto, _) = bench_prompt()
 
     def run(i):
         torch.cuda.synchronize()
@@ -340,7 +351,7 @@ def main():
     M = args.mel_tokens
     t_build = time.perf_counter()
     sds = synthetic_weights()
-    text, latents = synthetic_prompt()
+    text, latents = bench_prompt()
     read_mode = args.workload == "read"
     # read: every rank holds a complete engine with the full candidate batch and renders whole chunks (no candidate sharding)
     ubatch = (args.utterance_batch or 16) if read_mode else 1
@@ -406,7 +417,8 @@ def main():
             "config": {"workload": ("read.py long-form: 15 chunks per step, each = " if read_mode else "") +
                                    f"tts_with_preset('{args.preset}'): {N} AR candidates x {M} mel tokens (EOS suppressed, fixed length), "
                                    f"CLVP top-1, {preset_kw['diffusion_iterations']} diffusion iterations cond_free={preset_kw.get('cond_free', True)}, "
-                                   f"UnivNet; 55 text tokens; {audio_s:.2f} s of 24 kHz audio per step",
+                                   f"UnivNet; prompt = do_tts.py default sentence (54 BPE ids + pad = 55 text tokens) with the reference's pat.pth "
+                                   f"voice latents (tests/golden/bench_prompt.npz); {audio_s:.2f} s of 24 kHz audio per step",
                        "weights": "seeded synthetic at the reference hyper-parameters (no checkpoints offline)",
                        "parallelism": (f"chunk j on rank j % {world} (replicas, complete pipeline per rank), clips sent to rank 0" if read_mode else
                                        f"candidates sharded {N // world}/GPU, 1 all_gather of scores+codes, "

@@ -126,17 +126,14 @@ int tt_ar_generate_chunk(tt_ar* h, int B, int first, int n_more, int ldcodes, co
  * filed by the decode steps themselves (no extra pass); handles with max_batch <= 8 only; n <= tokens generated so far. */
 int tt_ar_stream_latents(tt_ar* h, int B, int n, float* out, void* stream);
 
-/* Engine options of a handle (not part of the reference's surface; defaults in brackets).  The decode step of B candidates can be
- * cut into row ranges that run their 30 layers concurrently on separate streams - candidates are independent until the sampler, every
- * kernel is row-local, so the sampled codes are bit-identical for any setting:
- *   TT_AR_OPT_SUBBATCHES [1]  1, 2 or 4 ranges (used when B divides into ranges of >= 16 sequences, a multiple of 4)
- *   TT_AR_OPT_STAGGER    [0]  range i starts after range i - 1 has issued its first attention launch
- *   TT_AR_OPT_GRAPH_MODE [0]  0: one hipGraph with parallel branches; 1: one linear graph per range + one for lm_head / sampler
+/* Engine options of a handle (not part of the reference's surface; defaults in brackets):
+ *   TT_AR_OPT_SUBBATCHES [1]  the decode step of B candidates cut into 1, 2 or 4 row ranges that run their 30 layers concurrently on
+ *                             separate streams (used when B divides into ranges of >= 16 sequences, a multiple of 4).  Candidates are
+ *                             independent until the sampler and every kernel is row-local, so the sampled codes are bit-identical
+ *                             for any setting.  An experiment kept as an option: measured slower than one range
  *   TT_AR_OPT_LOOKAHEAD  [6]  decode steps the host may launch ahead of the device (the loop is paced by progress words the
  *                             last kernel of a step publishes to pinned memory; no queue drain inside the loop) */
 #define TT_AR_OPT_SUBBATCHES 1
-#define TT_AR_OPT_STAGGER 2
-#define TT_AR_OPT_GRAPH_MODE 3
 #define TT_AR_OPT_LOOKAHEAD 4
 int tt_ar_set_option(tt_ar* h, int option, int value);
 /* Operand-overflow guard: the row norms and the sampler count launches that met a non-finite value (an fp16 operand beyond 65504

@@ -29,16 +29,16 @@ def main():
     ap.add_argument("--mel-tokens", type=int, default=200)
     ap.add_argument("--iterations", type=int, default=200)
     ap.add_argument("--ar-variants", default="",
-                    help="';'-separated 'ranges,graph_form,stagger[,lookahead]' settings of tt_ar_set_option to time one after the other on ONE "
-                         "handle (same weights, same box, same process), e.g. '1,0,0;2,0,0;2,1,0;2,0,1;4,0,0'")
+                    help="';'-separated 'ranges[,lookahead]' settings of tt_ar_set_option to time one after the other on ONE "
+                         "handle (same weights, same box, same process), e.g. '1;2;4;1,1;1'")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     args = ap.parse_args()
-    from bench import synthetic_prompt
+    from bench import bench_prompt
     from tortoise_tts_amd import stages, weights as W
     from tortoise_tts_amd.config import ARConfig, DiffusionConfig
     from tortoise_tts_amd.schedule import Schedule
     import torch.nn.functional as F
-    text, (auto, diffc) = synthetic_prompt()
+    text, (auto, diffc) = bench_prompt()
     dev = "cuda"
     with torch.no_grad():
         if "ar" in args.stages:
@@ -53,11 +53,8 @@ def main():
                 tag = args.tag
                 if var is not None:
                     ar.set_option(E.TT_AR_OPT_SUBBATCHES, var[0])
-                    ar.set_option(E.TT_AR_OPT_GRAPH_MODE, var[1])
-                    ar.set_option(E.TT_AR_OPT_STAGGER, var[2])
-                    if len(var) > 3:
-                        ar.set_option(E.TT_AR_OPT_LOOKAHEAD, var[3])
-                    tag = "r%d/g%d/s%d%s" % (var[0], var[1], var[2], "/l%d" % var[3] if len(var) > 3 else "")
+                    ar.set_option(E.TT_AR_OPT_LOOKAHEAD, var[1] if len(var) > 1 else 6)
+                    tag = "ranges=%d%s" % (var[0], " look=%d" % var[1] if len(var) > 1 else "")
                 times = []
                 codes = None
                 for r in range(args.reps + 1):

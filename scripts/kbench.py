@@ -69,9 +69,23 @@ EXTRA = {200: "128x64 4w ring3 2 blocks/CU", 500: "64x64 4w ring3 2 blocks/CU", 
          2400: "128x256 8w(2x4) ring3"}
 
 
+def concurrency(M, chain=30, tgen=100, reps=20):
+    out = (D * 8)()
+    chk(lib.tt_kb_concurrency(M, chain, tgen, reps, out))
+    return list(out)[:7]
+
+
 def main():
     which = sys.argv[1:] or ["bw", "gemm2", "gemm_decode", "attn"]
     lib.tt_init()
+    if "streams" in which:
+        # two launch chains on two streams: do kernels of different queues share the chip?  (row ranges of the decode step)
+        print("two-stream concurrency probe (us per replay of a 30-launch chain; G = decode projection GEMM N = K = 1024 split-K 4, A = decode attention 16 heads x 100 own keys)")
+        for M in (64, 128, 256):
+            g, gg, a, ag, aa, gg1, ag1 = concurrency(M)
+            print("  M=%3d: G alone %7.1f | G||G two streams %7.1f (x%.2f of one; 1.0 = full overlap, 2.0 = serialised) | A alone %7.1f | A||G %7.1f "
+                  "(sum %.1f, max %.1f) | A||A %7.1f (x%.2f) | one graph, two branches: G||G %7.1f, A||G %7.1f" %
+                  (M, g, gg, gg / g, a, ag, a + g, max(a, g), aa, aa / a, gg1, ag1), flush=True)
     if "bw" in which:
         for fp, tag in ((2 << 20, "2 MiB (one L2)"), (24 << 20, "24 MiB (all L2s)"), (160 << 20, "160 MiB (Infinity Cache)"), (2 << 30, "2 GiB (HBM)")):
             for mode, mtag in ((0, "global_load_lds 16B"), (1, "global_load_dwordx4 -> VGPR, full lines"), (2, "global_load_dwordx4 -> VGPR, fragment shaped")):

@@ -1,7 +1,7 @@
 """-m gpu, round 4: what changed in the engines' control structure, each asserted as an EQUALITY (these are scheduling changes, the
 arithmetic of a row must not move):
-  * the decode step cut into row ranges on parallel streams (tt_ar_set_option): codes bit-identical for 1 / 2 / 4 ranges, both graph
-    forms, with and without the stagger, with ragged stop tokens, eager or replayed;
+  * the decode step cut into row ranges on parallel streams (tt_ar_set_option): codes bit-identical for 1 / 2 / 4 ranges, with ragged
+    stop tokens, eager or replayed, whatever the host's lookahead - repeated, because what this guards against was intermittent;
   * the launch loop paced by progress words in pinned memory (no queue drain inside the loop): same codes, same early exit;
   * seeds, row_offset and the caller's code buffer are DATA of the kept decode-step graph (one capture for all of them);
   * the sampler-step graph of the diffusion stage stays on the handle (one capture for several calls with fresh tensors);
@@ -20,13 +20,8 @@ from tests.gpu_util import quantize_sd
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [(2, 0, 0), (2, 0, 1), (2, 1, 0), (4, 0, 0), (4, 0, 1), (4, 1, 0)]  # (row ranges, graph form, stagger)
-
-
-def _set(st, nsub, mode, stagger, lookahead=None):
+def _set(st, nsub, lookahead=None):
     st.set_option(E.TT_AR_OPT_SUBBATCHES, nsub)
-    st.set_option(E.TT_AR_OPT_GRAPH_MODE, mode)
-    st.set_option(E.TT_AR_OPT_STAGGER, stagger)
     if lookahead is not None:
         st.set_option(E.TT_AR_OPT_LOOKAHEAD, lookahead)
 
@@ -35,8 +30,9 @@ def _set(st, nsub, mode, stagger, lookahead=None):
 @torch.no_grad()
 def test_ar_row_ranges_sample_identical_codes(eos_boost):
     """64 candidates in 1 / 2 / 4 row ranges on parallel streams: the sampled codes are the same bits (every kernel of the step is
-    row-local), whatever the graph form, the stagger or the host's lookahead; with a reachable stop token the rows end raggedly and
-    the loop leaves at the same step."""
+    row-local), whatever the host's lookahead; with a reachable stop token the rows end raggedly and the loop leaves at the same
+    step.  Each setting is repeated: round 4 found an INTERMITTENT difference here (1 - 8 rows in ~5 % of the generations) whose cause
+    was the write-through split-K slab stores of round 3, not the ranges (csrc/gemm_impl.h EpiStd::store)."""
     cfg = ARConfig(**G.AR_CFG)
     sd = G.sampling_state_dict(cfg, eos_boost) if eos_boost else W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.AR_SEED), cfg)
     cond, text = G.ar_inputs(cfg)
@@ -50,28 +46,31 @@ def test_ar_row_ranges_sample_identical_codes(eos_boost):
         stop = cfg.stop_mel_token
         ends = [(int((r == stop).nonzero()[0]) if (r == stop).any() else steps) for r in base.cpu()]
         assert min(ends) < max(ends), "rows did not finish at different steps: the test lost its point"
-    for nsub, mode, stagger in VARIANTS:
-        for look in (1, 6):
-            _set(st, nsub, mode, stagger, look)
-            st.prefill(cond, text)
-            got, n = st.generate(B, steps, seed=11)
-            assert st.stat(2) == nsub, f"the kept step graph has {st.stat(2)} ranges, asked for {nsub}"
-            assert n == n0 and torch.equal(got, base), f"{nsub} row ranges (graph form {mode}, stagger {stagger}, lookahead {look}) changed the codes"
+    for nsub in (2, 4):
+        for look in (1, 2, 6):
+            _set(st, nsub, look)
+            for rep in range(12):
+                st.prefill(cond, text)
+                got, n = st.generate(B, steps, seed=11)
+                assert st.stat(2) == nsub, f"the kept step graph has {st.stat(2)} ranges, asked for {nsub}"
+                assert n == n0 and torch.equal(got, base), f"{nsub} row ranges (lookahead {look}, repetition {rep}) changed the codes"
     # eager launches take the same fork / join on real streams
-    _set(st, 2, 0, 1)
     E.load_library().tt_graph_replay(0)
     try:
-        st.prefill(cond, text)
-        got, n = st.generate(B, steps, seed=11)
+        for nsub in (2, 4):
+            _set(st, nsub, 6)
+            for rep in range(6):
+                st.prefill(cond, text)
+                got, n = st.generate(B, steps, seed=11)
+                assert n == n0 and torch.equal(got, base), f"eager launches over {nsub} row ranges changed the codes (repetition {rep})"
     finally:
         E.load_library().tt_graph_replay(1)
-    assert n == n0 and torch.equal(got, base), "eager launches over two row ranges changed the codes"
     assert st.stat(1) == 0, f"the launch loop fell back to {st.stat(1)} queue drain(s): the progress words did not arrive in time"
     # teacher-forced steps (tt_ar_decode_step) go through the same fork / join: logits of a row do not depend on the ranges
     toks = base[:, :3].int()
     lg = {}
     for nsub in (1, 4):
-        _set(st, nsub, 0, 0)
+        _set(st, nsub)
         st.prefill(cond, text)
         st.begin(B)
         for j in range(3):
@@ -219,3 +218,62 @@ def test_tts_demotes_an_overflowing_fp16_stage_to_bf16():
     assert tts.demotions == ["diffusion"] and torch.equal(wav, wav2)
     for st in (tts.ar, tts.clvp, tts.diffusion, tts.vocoder):
         st.close()
+
+
+@torch.no_grad()
+def test_two_engines_on_two_threads_render_what_they_render_alone():
+    """Round 3 removed a decode / render overlap because two engines working from two threads showed "an intermittent clip difference".
+    Root cause (round 4): the write-through split-K slab stores of the decode projections are not ordered by the kernel boundary
+    while another queue keeps the memory system busy - the row norm behind them summed stale slab values now and then.  With plain
+    slab stores two handles on two threads / streams produce, run after run, exactly what each produces alone."""
+    import threading
+    cfg = ARConfig(**G.AR_CFG)
+    sd = W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(cfg), seed=G.AR_SEED), cfg)
+    cond, text = G.ar_inputs(cfg)
+    dcfg = DiffusionConfig(**G.DIFF_CFG)
+    dsd = W.synthetic_state_dict(W.diffusion_manifest(dcfg), seed=G.DIFF_SEED)
+    S, latents, dcond, x, step_noise = G.diff_inputs(dcfg)
+    sched = Schedule(G.DIFF_STEPS, 4000, True, 2.0)
+    B, steps, runs = 64, 40, 50
+    ars = [stages.ArStage(sd, cfg, dtype=E.TT_BF16, max_batch=B, max_text=40, max_new_tokens=48, max_latent_candidates=1) for _ in range(2)]
+    df = stages.DiffusionStage(dsd, dcfg, dtype=E.TT_F16, max_seq=128, max_codes=64, max_steps=16)
+    ars[0].prefill(cond, text)
+    want_codes = ars[0].generate(B, steps, seed=21)[0].clone()
+    df.condition(latents, dcond, S)
+    want_mel = df.sample(sched, x, step_noise).clone()
+    errors = []
+
+    def decode(st, seed_runs):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for r in range(seed_runs):
+                    st.prefill(cond, text)
+                    got = st.generate(B, steps, seed=21)[0]
+                    if not torch.equal(got, want_codes):
+                        errors.append(f"decode run {r}: {int((got != want_codes).any(dim=1).sum())} rows differ")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def render(seed_runs):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for r in range(seed_runs):
+                    df.condition(latents, dcond, S)
+                    got = df.sample(sched, x, step_noise)
+                    torch.cuda.current_stream().synchronize()
+                    if not torch.equal(got, want_mel):
+                        errors.append(f"render run {r}: mel differs")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=decode, args=(ars[0], runs)), threading.Thread(target=decode, args=(ars[1], runs)),
+               threading.Thread(target=render, args=(runs,))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors[:5]
+    for st in ars:
+        st.close()
+    df.close()

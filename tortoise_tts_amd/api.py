@@ -253,7 +253,9 @@ class TextToSpeech:
         flags.append(not wav_ok)
         if self.world > 1:
             flags = tdist.any_over_ranks(flags)
-        return [n for n, f in zip(STAGE_NAMES, flags) if f]
+        # only the FIRST tripped stage in pipeline order is at fault for certain: the later ones may merely have been fed its
+        # non-finite output (an overflowed denoiser hands the vocoder a NaN mel); they get their own turn after the re-render
+        return [n for n, f in zip(STAGE_NAMES, flags) if f][:1]
 
     def _demote(self, tripped):
         """fp16 stages among `tripped` are rebuilt with bf16 operands (same weights, fp32 exponent range); a stage that overflows

@@ -197,9 +197,13 @@ struct EpiStd {
     if (slab(e)) {
       float* o = e.out_f32 + (size_t)z * c.M * e.ldo32 + (size_t)m * e.ldo32 + n;
       if (AL || (nvalid == 4 && (e.ldo32 & 3) == 0)) {
-        // write-through (sc1): the slab is read next by another kernel on other XCDs, so a plain store only parks 4 MB of dirty
-        // lines in the L2 for the kernel boundary to flush (in-situ A/B: -0.7 % on the decode step)
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(v) : "memory");
+        // PLAIN stores.  Round 3 wrote the slabs through (`global_store_dwordx4 ... sc1`, -0.7 % on the decode step: no dirty lines
+        // for the kernel boundary to flush).  Round 4 measured that this is only safe while the engine has the chip to itself: with a
+        // second queue keeping the memory system busy (another handle on another stream, or the row ranges of tt_ar_set_option) the
+        // row norm of the NEXT launch intermittently summed stale slab values - 7 of 160 generations differed in 1 - 8 rows with
+        // write-through stores, 0 of 80 with plain ones, same binary otherwise (profiles/r04_concurrency_bisect.txt).  The kernel
+        // boundary's release covers dirty L2 lines; it evidently does not wait for write-through traffic still on its way.
+        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
       } else {
         for (int i = 0; i < nvalid; ++i) o[i] = v[i];
       }

@@ -81,16 +81,22 @@ struct tt_ar {
   int* progress_dev = nullptr;
   int lookahead = 6;
   // Decode step cut into `nsub` independent row ranges (candidates are independent until the sampler): each range runs its 30
-  // layers on its own stream, so the HBM-bound attention of one range overlaps the latency-bound GEMM / norm chain of another.
+  // layers on its own stream, so the HBM-bound attention of one range can overlap the latency-bound GEMM / norm chain of another.
   // Every kernel is row-local (GEMM tiles, one-workgroup-per-row norms, per-sequence attention), so the logits and therefore the
-  // codes are bit-identical for any nsub.  graph_mode 0: one captured graph with nsub parallel branches; 1: one linear graph per
-  // range + one for the tail (lm_head, sampler), forked / joined by the host with events every step.  stagger: range i starts
-  // after range i - 1 has issued its first attention launch (phase shift between the chains).
-  int nsub = 1, stagger = 0, graph_mode = 0;
+  // codes are bit-identical for any nsub.  Replayed as one LINEAR hipGraph per range + one for the tail (lm_head, sampler), forked
+  // and joined by the host with events every step: a single graph with parallel branches is executed one branch after the other
+  // by this runtime (scripts/kbench.py streams: G || G 2.0 x of one chain as branches, 1.2 - 1.3 x on two streams).
+  // Measured (profiles/r04_ab_ar_subbatches.txt): no gain - a range's GEMM / norm chain does not get shorter with fewer rows (it is
+  // latency-bound), so n ranges run n chains per layer and can at best hide the attention time behind them.  Default 1.
+  int nsub = 1;
   hipStream_t sub_stream[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_tail = nullptr;
-  hipEvent_t ev_join[3] = {nullptr, nullptr, nullptr}, ev_stag[3] = {nullptr, nullptr, nullptr};
-  hipGraph_t part_graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // graph_mode 1: ranges 0 .. 3, [4] = tail
+  // fork / join / tail events of the range streams: a ring, one slot per step the host may be ahead (lookahead <= 64), so that no
+  // event is re-recorded while a wait on its previous record may still be queued
+  static constexpr int EV_RING = 80;
+  std::vector<hipEvent_t> ev_ring;  // [EV_RING][8]: 0 fork, 1 tail, 2 .. 4 join
+  unsigned ev_seq = 0;
+  hipEvent_t ev(int slot, int which) const { return ev_ring[(size_t)slot * 8 + which]; }
+  hipGraph_t part_graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // one linear graph per range 0 .. 3, [4] = tail (lm_head + sampler)
   hipGraphExec_t part_exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int step_nsub = 1;  // ranges of the kept graph(s)
   int captures = 0;   // decode-step captures so far (tt_ar_stat: tests assert the kept graph is reused)
@@ -229,8 +235,8 @@ static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, 
 }
 
 // The 30 layers of one KV-cached decode step for the sequences [row0, row0 + nb) + the input norm of lm_head, all on stream s.
-// `slabs`: this range's private split-K slab region ([MAX_SPLIT][nb][D]).  ev_attn0: recorded behind the first attention launch.
-static int decode_layers_enqueue(tt_ar* e, hipStream_t s, int row0, int nb, float* slabs, hipEvent_t ev_attn0) {
+// `slabs`: this range's private split-K slab region ([MAX_SPLIT][nb][D]).
+static int decode_layers_enqueue(tt_ar* e, hipStream_t s, int row0, int nb, float* slabs) {
   const int D = e->D, H = e->H, dt = e->cfg.dtype;
   float* x = e->x + (size_t)row0 * D;
   void* h = offset_t(e->h, (size_t)row0 * D);
@@ -263,7 +269,6 @@ static int decode_layers_enqueue(tt_ar* e, hipStream_t s, int row0, int nb, floa
     a.P1 = e->P1; a.kc = g.kc; a.vc = g.vc; a.tmax = e->tmax; a.step = e->state + 1;
     a.out = attn; a.B = nb; a.heads = H; a.host_tgen = e->host_slot + 1;
     TT_TRY(decode_attention_launch(dt, a, s));
-    if (l == 0 && ev_attn0) TT_CHECK_HIP(hipEventRecord(ev_attn0, s));
     // >= 1024 sequences (several utterances per batch): one block per output tile fills the chip, so the split-K partial sums are
     // folded inside the launch in slab order (gemm.h serial_k: the same bits as slabs + row norm, without 2 x 4 x B x D x 4 bytes of slab traffic)
     const bool serial = nb >= 1024;
@@ -311,27 +316,25 @@ static inline float* ar_range_slabs(tt_ar* e, int i, int nb) { return e->slabs +
 
 // One KV-cached decode step for e->B sequences up to the logits; the fed tokens are in e->next_tok (or, `embedded`, the sampler
 // already wrote this step's input rows into e->x: tt_ar_generate).  With several row ranges: fork on `s`, one stream per range,
-// join on `s` in front of lm_head (the same calls capture into one graph with parallel branches or run eagerly).
+// join on `s` in front of lm_head (eager launches: tt_ar_decode_step, tt_graph_replay(0); replay uses one graph per range).
 static int decode_step_enqueue(tt_ar* e, hipStream_t s, bool embedded = false) {
   const int B = e->B;
   if (!embedded) TT_TRY(ar_embed_launch(e->next_tok, e->state, e->w.mel_emb, e->w.mel_pos, e->x, B, e->D, e->cfg.mel_pos_offset, s));
   const int ns = ar_ranges(e);
   if (ns == 1) {
-    TT_TRY(decode_layers_enqueue(e, s, 0, B, e->slabs, nullptr));
+    TT_TRY(decode_layers_enqueue(e, s, 0, B, e->slabs));
     return ar_head_gemm(e, B, s);
   }
   const int nb = B / ns;
-  TT_CHECK_HIP(hipEventRecord(e->ev_fork, s));
+  const int slot = (int)(e->ev_seq++ % tt_ar::EV_RING);
+  TT_CHECK_HIP(hipEventRecord(e->ev(slot, 0), s));
   for (int i = 0; i < ns; ++i) {
     hipStream_t si = i == 0 ? s : e->sub_stream[i - 1];
-    if (i > 0) {
-      TT_CHECK_HIP(hipStreamWaitEvent(si, e->ev_fork, 0));
-      if (e->stagger) TT_CHECK_HIP(hipStreamWaitEvent(si, e->ev_stag[i - 1], 0));
-    }
-    TT_TRY(decode_layers_enqueue(e, si, i * nb, nb, ar_range_slabs(e, i, nb), (e->stagger && i < ns - 1) ? e->ev_stag[i] : nullptr));
-    if (i > 0) TT_CHECK_HIP(hipEventRecord(e->ev_join[i - 1], si));
+    if (i > 0) TT_CHECK_HIP(hipStreamWaitEvent(si, e->ev(slot, 0), 0));
+    TT_TRY(decode_layers_enqueue(e, si, i * nb, nb, ar_range_slabs(e, i, nb)));
+    if (i > 0) TT_CHECK_HIP(hipEventRecord(e->ev(slot, 2 + i - 1), si));
   }
-  for (int i = 1; i < ns; ++i) TT_CHECK_HIP(hipStreamWaitEvent(s, e->ev_join[i - 1], 0));
+  for (int i = 1; i < ns; ++i) TT_CHECK_HIP(hipStreamWaitEvent(s, e->ev(slot, 2 + i - 1), 0));
   return ar_head_gemm(e, B, s);
 }
 
@@ -423,13 +426,10 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
   if (!rc) {
     e->guard_host[0] = 0;
     e->progress_host[0] = 0; e->progress_host[1] = -1; e->progress_host[2] = e->progress_host[3] = 0;
-    hipError_t he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming);
-    for (int i = 0; i < 3 && he == hipSuccess; ++i) {
-      he = hipStreamCreateWithFlags(&e->sub_stream[i], hipStreamNonBlocking);
-      if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming);
-      if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_stag[i], hipEventDisableTiming);
-    }
+    hipError_t he = hipSuccess;
+    for (int i = 0; i < 3 && he == hipSuccess; ++i) he = hipStreamCreateWithFlags(&e->sub_stream[i], hipStreamNonBlocking);
+    e->ev_ring.assign((size_t)tt_ar::EV_RING * 8, nullptr);
+    for (size_t i = 0; i < e->ev_ring.size() && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&e->ev_ring[i], hipEventDisableTiming);
     if (he != hipSuccess) { set_error("tt_ar_create: stream / event creation failed: %s", hipGetErrorString(he)); rc = -2; }
   }
   if (rc) {
@@ -447,13 +447,10 @@ void tt_ar_destroy(tt_ar* e) {
   if (e->par_host) (void)hipHostFree(e->par_host);
   if (e->progress_host) (void)hipHostFree(e->progress_host);
   if (e->guard_host) (void)hipHostFree(e->guard_host);
-  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-  if (e->ev_tail) (void)hipEventDestroy(e->ev_tail);
-  for (int i = 0; i < 3; ++i) {
-    if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
-    if (e->ev_stag[i]) (void)hipEventDestroy(e->ev_stag[i]);
+  for (hipEvent_t ev : e->ev_ring)
+    if (ev) (void)hipEventDestroy(ev);
+  for (int i = 0; i < 3; ++i)
     if (e->sub_stream[i]) (void)hipStreamDestroy(e->sub_stream[i]);
-  }
   e->arena.release();
   e->sb.destroy();
   delete e;
@@ -595,7 +592,7 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
 
   const bool use_graph = graphs_enabled() && target - e->gen_done > 1;
   const int ns = ar_ranges(e);
-  const bool parts = use_graph && ns > 1 && e->graph_mode == 1;
+  const bool parts = use_graph && ns > 1;
   int rc = 0;
   auto tail_enqueue = [&](hipStream_t st) -> int {
     TT_TRY(sample_launch(sa, st));
@@ -608,7 +605,7 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
     memcpy(key.data(), &sa, sizeof(sa));
     int geo[24] = {B, e->G, e->P1, g_prof_on ? 1 : 0};
     for (int gi = 0; gi < 16; ++gi) geo[4 + gi] = gi < e->G ? e->P1g[gi] : 0;
-    geo[20] = ns; geo[21] = e->stagger; geo[22] = parts ? 1 : 0;
+    geo[20] = ns;
     memcpy(key.data() + sizeof(sa), geo, sizeof(geo));
     const bool have = parts ? e->part_exec[4] != nullptr : e->step_exec != nullptr;
     if (!have || key != e->step_key) {
@@ -622,7 +619,7 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
         const int nb = B / ns;
         for (int i = 0; i < ns && !rc; ++i) {
           hipStream_t si = i == 0 ? s : e->sub_stream[i - 1];
-          rc = ar_capture(si, [&]() -> int { return decode_layers_enqueue(e, si, i * nb, nb, ar_range_slabs(e, i, nb), nullptr); },
+          rc = ar_capture(si, [&]() -> int { return decode_layers_enqueue(e, si, i * nb, nb, ar_range_slabs(e, i, nb)); },
                           &e->part_graph[i], &e->part_exec[i]);
         }
         if (!rc) rc = ar_capture(s, [&]() -> int {
@@ -642,7 +639,8 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
   const int first_step = e->gen_done;
   int steps_done = e->gen_done;
   bool stop_seen = false;
-  if (parts) TT_CHECK_HIP(hipEventRecord(e->ev_tail, s));
+  int tail_slot = (int)(e->ev_seq++ % tt_ar::EV_RING);  // slot whose tail event marks "everything before this step is done" on s
+  if (parts) TT_CHECK_HIP(hipEventRecord(e->ev(tail_slot, 1), s));
   for (int step = first_step; step < target; ++step) {
     // stay at most `lookahead` steps ahead of the device; the words are written by the last kernel of every step
     int spins = 0;
@@ -661,15 +659,17 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
     if (use_graph && !parts) {
       le = hipGraphLaunch(e->step_exec, s);
     } else if (parts) {
-      for (int i = 1; i < ns && le == hipSuccess; ++i) le = hipStreamWaitEvent(e->sub_stream[i - 1], e->ev_tail, 0);
+      const int slot = (int)(e->ev_seq++ % tt_ar::EV_RING);
+      for (int i = 1; i < ns && le == hipSuccess; ++i) le = hipStreamWaitEvent(e->sub_stream[i - 1], e->ev(tail_slot, 1), 0);
       if (le == hipSuccess) le = hipGraphLaunch(e->part_exec[0], s);
       for (int i = 1; i < ns && le == hipSuccess; ++i) {
         le = hipGraphLaunch(e->part_exec[i], e->sub_stream[i - 1]);
-        if (le == hipSuccess) le = hipEventRecord(e->ev_join[i - 1], e->sub_stream[i - 1]);
+        if (le == hipSuccess) le = hipEventRecord(e->ev(slot, 2 + i - 1), e->sub_stream[i - 1]);
       }
-      for (int i = 1; i < ns && le == hipSuccess; ++i) le = hipStreamWaitEvent(s, e->ev_join[i - 1], 0);
+      for (int i = 1; i < ns && le == hipSuccess; ++i) le = hipStreamWaitEvent(s, e->ev(slot, 2 + i - 1), 0);
       if (le == hipSuccess) le = hipGraphLaunch(e->part_exec[4], s);
-      if (le == hipSuccess) le = hipEventRecord(e->ev_tail, s);
+      if (le == hipSuccess) le = hipEventRecord(e->ev(slot, 1), s);
+      tail_slot = slot;
     } else {
       e->host_slot = step - 1;
       rc = decode_step_enqueue(e, s, true);
@@ -798,8 +798,6 @@ int tt_ar_stat(tt_ar* e, int which) {
 
 // Engine options of a handle (defaults in brackets):
 //   TT_AR_OPT_SUBBATCHES  [1]  row ranges the decode step is cut into (1, 2 or 4), each on its own stream; codes are bit-identical
-//   TT_AR_OPT_STAGGER     [0]  range i starts after range i - 1 has issued its first attention launch
-//   TT_AR_OPT_GRAPH_MODE  [0]  0: one graph with parallel branches; 1: one linear graph per range + one for the tail
 //   TT_AR_OPT_LOOKAHEAD   [6]  decode steps the host may run ahead of the device (>= 1)
 int tt_ar_set_option(tt_ar* e, int option, int value) {
   TT_REQUIRE(e != nullptr, "tt_ar_set_option: null handle");
@@ -807,11 +805,6 @@ int tt_ar_set_option(tt_ar* e, int option, int value) {
     case TT_AR_OPT_SUBBATCHES:
       TT_REQUIRE(value == 1 || value == 2 || value == 4, "tt_ar_set_option: %d row ranges (1, 2 or 4)", value);
       e->nsub = value;
-      break;
-    case TT_AR_OPT_STAGGER: e->stagger = value != 0; break;
-    case TT_AR_OPT_GRAPH_MODE:
-      TT_REQUIRE(value == 0 || value == 1, "tt_ar_set_option: graph mode %d (0 or 1)", value);
-      e->graph_mode = value;
       break;
     case TT_AR_OPT_LOOKAHEAD:
       TT_REQUIRE(value >= 1 && value <= 64, "tt_ar_set_option: lookahead %d outside 1 .. 64", value);

@@ -679,3 +679,124 @@ extern "C" int tt_kb_flash(int B, int H, int n, int causal, int relpos, int chai
   ar.release();
   return rc;
 }
+
+// --------------------------------------------------------------------------------------------------------------------
+// Do two launch chains on two streams overlap on this device?  The decode step alternates an HBM-bound kernel (attention)
+// with latency-bound ones (64 x 64 GEMMs at one wave per SIMD, row norms); cutting the candidates into row ranges on
+// separate streams only pays if kernels of different queues actually share the chip.  Chains (each `chain` launches long):
+//   G = the decode projection GEMM (M rows, N = K = 1024, 4 split-K slabs), A = decode attention over M sequences x 16 heads.
+// out[0] G alone, [1] G || G on two streams (own activations, shared weights), [2] A alone, [3] A || G, [4] A || A,
+// [5] G || G as ONE hipGraph with two parallel branches, [6] A || G as one graph with two branches: microseconds per
+// replay of the whole chain(s).  Perfect overlap: [1] == [0], [3] == max([0], [2]); serialised: [1] == 2 x [0], [3] == [0] + [2].
+extern "C" int tt_kb_concurrency(int M, int chain, int tgen, int reps, double* out) {
+  Arena ar;
+  hipStream_t s0 = nullptr, s1 = nullptr;
+  hipEvent_t ea = nullptr, eb = nullptr, ef = nullptr, ej = nullptr;
+  TT_CHECK_HIP(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+  TT_CHECK_HIP(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+  TT_CHECK_HIP(hipEventCreate(&ea));
+  TT_CHECK_HIP(hipEventCreate(&eb));
+  TT_CHECK_HIP(hipEventCreateWithFlags(&ef, hipEventDisableTiming));
+  TT_CHECK_HIP(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+  const int D = 1024, H = 16, P1 = 59, tmax = tgen + 8, NW = 8, NL = 4;
+  void* A[2]; float* slab[2]; void* W[NW];
+  void* q[2]; void* o[2]; void* kp = nullptr; void* vp = nullptr; void* kc[2][NL]; void* vc[2][NL]; int* step = nullptr;
+  int rc = 0;
+  for (int i = 0; i < 2 && !rc; ++i) {
+    rc = dev_bf16(ar, &A[i], (size_t)(M + 8) * D, 11u + i);
+    if (!rc) rc = ar.alloc_t(&slab[i], (size_t)4 * M * D);
+    if (!rc) rc = dev_bf16(ar, &q[i], (size_t)M * D, 21u + i);
+    if (!rc) rc = ar.alloc(&o[i], (size_t)M * D * 2);
+    for (int l = 0; l < NL && !rc; ++l) {
+      rc = dev_bf16(ar, &kc[i][l], (size_t)M * H * tmax * 64 + 64, 100u + 8 * i + l);
+      if (!rc) rc = dev_bf16(ar, &vc[i][l], (size_t)M * H * tmax * 64 + 64, 200u + 8 * i + l);
+    }
+  }
+  for (int i = 0; i < NW && !rc; ++i) rc = dev_bf16(ar, &W[i], (size_t)D * D, 77u + i);
+  if (!rc) rc = dev_bf16(ar, &kp, (size_t)H * P1 * 64 + 64, 4u);
+  if (!rc) rc = dev_bf16(ar, &vp, (size_t)H * P1 * 64 + 64, 5u);
+  if (!rc) rc = ar.alloc_t(&step, 4);
+  const int st = tgen - 1;
+  if (!rc && hipMemcpy(step, &st, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) rc = -2;
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
+  auto chain_g = [&](int i, hipStream_t s) -> int {
+    for (int c = 0; c < chain; ++c) {
+      GemmArgs g = gemm_args(A[i], D, W[c % NW], D, M, D, D);
+      g.splitk = 4; g.out_f32 = slab[i]; g.ldo32 = D;
+      TT_TRY(gemm_launch(DT_BF16, EPI_STD, g, s));
+    }
+    return 0;
+  };
+  auto chain_a = [&](int i, hipStream_t s) -> int {
+    for (int c = 0; c < chain; ++c) {
+      DecodeAttnArgs a;
+      memset(&a, 0, sizeof(a));
+      a.q = q[i]; a.kp = kp; a.vp = vp; a.P1 = P1; a.kc = kc[i][c % NL]; a.vc = vc[i][c % NL]; a.tmax = tmax; a.step = step; a.host_tgen = tgen;
+      a.out = o[i]; a.B = M; a.heads = H;
+      TT_TRY(decode_attention_launch(DT_BF16, a, s));
+    }
+    return 0;
+  };
+  auto capture = [&](hipStream_t s, auto&& fn, hipGraphExec_t* ex) -> int {
+    hipGraph_t g = nullptr;
+    TT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int r = fn();
+    hipError_t ce = hipStreamEndCapture(s, &g);
+    if (r) return r;
+    TT_CHECK_HIP(ce);
+    TT_CHECK_HIP(hipGraphInstantiate(ex, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    return 0;
+  };
+  // x: graph for stream 0 (or null), y: graph for stream 1 (or null): `reps` replays of each, concurrently; wall time on s0's clock
+  auto time_pair = [&](hipGraphExec_t x, hipGraphExec_t y, double* us) -> int {
+    for (int warm = 0; warm < 2; ++warm) {
+      TT_CHECK_HIP(hipEventRecord(ea, s0));
+      TT_CHECK_HIP(hipEventRecord(ef, s0));
+      TT_CHECK_HIP(hipStreamWaitEvent(s1, ef, 0));
+      const int n = warm ? reps : 2;
+      for (int r = 0; r < n; ++r) {
+        if (x) TT_CHECK_HIP(hipGraphLaunch(x, s0));
+        if (y) TT_CHECK_HIP(hipGraphLaunch(y, s1));
+      }
+      TT_CHECK_HIP(hipEventRecord(ej, s1));
+      TT_CHECK_HIP(hipStreamWaitEvent(s0, ej, 0));
+      TT_CHECK_HIP(hipEventRecord(eb, s0));
+      TT_CHECK_HIP(hipStreamSynchronize(s0));
+      TT_CHECK_HIP(hipStreamSynchronize(s1));
+    }
+    float ms = 0.f;
+    TT_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb));
+    *us = 1e3 * ms / reps;
+    return 0;
+  };
+  hipGraphExec_t g0 = nullptr, g1 = nullptr, a0 = nullptr, a1 = nullptr, gg = nullptr, ag = nullptr;
+  if (!rc) rc = capture(s0, [&]() { return chain_g(0, s0); }, &g0);
+  if (!rc) rc = capture(s1, [&]() { return chain_g(1, s1); }, &g1);
+  if (!rc) rc = capture(s0, [&]() { return chain_a(0, s0); }, &a0);
+  if (!rc) rc = capture(s1, [&]() { return chain_a(1, s1); }, &a1);
+  auto forked = [&](auto&& f0, auto&& f1) -> int {  // one graph, two parallel branches
+    TT_CHECK_HIP(hipEventRecord(ef, s0));
+    TT_CHECK_HIP(hipStreamWaitEvent(s1, ef, 0));
+    TT_TRY(f0());
+    TT_TRY(f1());
+    TT_CHECK_HIP(hipEventRecord(ej, s1));
+    TT_CHECK_HIP(hipStreamWaitEvent(s0, ej, 0));
+    return 0;
+  };
+  if (!rc) rc = capture(s0, [&]() { return forked([&]() { return chain_g(0, s0); }, [&]() { return chain_g(1, s1); }); }, &gg);
+  if (!rc) rc = capture(s0, [&]() { return forked([&]() { return chain_a(0, s0); }, [&]() { return chain_g(1, s1); }); }, &ag);
+  if (!rc) rc = time_pair(g0, nullptr, &out[0]);
+  if (!rc) rc = time_pair(g0, g1, &out[1]);
+  if (!rc) rc = time_pair(a0, nullptr, &out[2]);
+  if (!rc) rc = time_pair(a0, g1, &out[3]);
+  if (!rc) rc = time_pair(a0, a1, &out[4]);
+  if (!rc) rc = time_pair(gg, nullptr, &out[5]);
+  if (!rc) rc = time_pair(ag, nullptr, &out[6]);
+  for (hipGraphExec_t ex : {g0, g1, a0, a1, gg, ag})
+    if (ex) (void)hipGraphExecDestroy(ex);
+  (void)hipEventDestroy(ea); (void)hipEventDestroy(eb); (void)hipEventDestroy(ef); (void)hipEventDestroy(ej);
+  (void)hipStreamDestroy(s0); (void)hipStreamDestroy(s1);
+  ar.release();
+  return rc;
+}

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("TORTOISE_MI355X_LIB") or os.path.join(HERE, "lib", "l
 
 TT_BF16, TT_F16 = 0, 1
 DTYPE_NAMES = {TT_BF16: "bf16", TT_F16: "fp16"}
-TT_AR_OPT_SUBBATCHES, TT_AR_OPT_STAGGER, TT_AR_OPT_GRAPH_MODE, TT_AR_OPT_LOOKAHEAD = 1, 2, 3, 4
+TT_AR_OPT_SUBBATCHES, TT_AR_OPT_LOOKAHEAD = 1, 4
 
 
 def dtype_code(name):

@@ -71,13 +71,12 @@ class ArStage:
         self.h = E.vp()
         E.check(self.lib.tt_ar_create(C.byref(c), C.byref(self.w.weights), C.byref(self.h)))
         # A/B switches of the measurement scripts (scripts/ab_stage.py); the product default is what tt_ar_create sets
-        for env, opt in (("TT_AR_SUBBATCHES", E.TT_AR_OPT_SUBBATCHES), ("TT_AR_STAGGER", E.TT_AR_OPT_STAGGER),
-                         ("TT_AR_GRAPH_MODE", E.TT_AR_OPT_GRAPH_MODE), ("TT_AR_LOOKAHEAD", E.TT_AR_OPT_LOOKAHEAD)):
+        for env, opt in (("TT_AR_SUBBATCHES", E.TT_AR_OPT_SUBBATCHES), ("TT_AR_LOOKAHEAD", E.TT_AR_OPT_LOOKAHEAD)):
             if os.environ.get(env):
                 self.set_option(opt, int(os.environ[env]))
 
     def set_option(self, option, value):
-        """tt_ar_set_option: row ranges of the decode step / stagger / graph form / host lookahead (codes do not depend on them)."""
+        """tt_ar_set_option: row ranges of the decode step / host lookahead (the sampled codes do not depend on them)."""
         E.check(self.lib.tt_ar_set_option(self.h, int(option), int(value)))
 
     def stat(self, which):
