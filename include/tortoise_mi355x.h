@@ -13,7 +13,7 @@
  *     it does not copy weights).
  *   - `stream` is a hipStream_t (0 = default stream).  Calls are asynchronous on that stream unless
  *     stated otherwise; no call allocates device memory after *_create / *_reserve.
- *   - dtype: TT_BF16 or TT_F16 selects the MFMA operand type (weights + GEMM activations);
+ *   - dtype: TT_BF16 or TT_F16 selects the MFMA operand type (weights + GEMM activations; TT_F32: see below);
  *     residual streams, norms, softmax and accumulators are always f32.
  *   - "T" below means that operand type.  Weight matrices are [out_features][in_features]
  *     (K contiguous); conv kernels are [out][tap][in_padded].  tortoise_tts_amd/pack.py produces
@@ -30,6 +30,11 @@ extern "C" {
 
 #define TT_BF16 0
 #define TT_F16 1
+/* Verification mode: fp32 GEMM / attention operands and fp32 KV caches in the autoregressive, CLVP, diffusion and vocoder stages
+ * (v_mfma_f32_16x16x4_f32 + plain VALU attention, untuned - an order of magnitude slower).  It exists so that tests can hold the
+ * engines against the reference's fp32 modules at fp32 tolerances instead of inside bf16 / fp16 operand noise; weight
+ * matrices are then f32 in the layouts documented below ("T" = float).  Other stage handles refuse it. */
+#define TT_F32 2
 
 const char* tt_last_error(void);
 int tt_init(void);     /* once per process, after the HIP device is selected */
@@ -295,7 +300,12 @@ int tt_diff_split_end(tt_diff* h);
 /* Operand-overflow guard of this stage (see tt_ar_guard): GroupNorm statistics / sampler inputs that came out non-finite, as of the
  * last finished sampling run (after the caller synchronised its stream).  The reference runs this stage in fp32 (api.py:540-560). */
 int tt_diff_guard(tt_diff* h, int reset);
-int tt_diff_stat(tt_diff* h, int which);  /* which = 0: sampler-step graph captures so far (the step graph stays on the handle) */
+int tt_diff_stat(tt_diff* h, int which);
+/* TT_DIFF_OPT_OVERLAP_PREPASS [1]: the conditioning_timestep_integrator of every step (diffusion_decoder.py:292-293; it depends on the
+ * timestep and the conditioning, not on x_t) is evaluated in chunks of the schedule on a second stream WHILE the sampler loop walks
+ * the steps whose chunks are complete; 0 = whole pre-pass first (one stream).  Same results either way. */
+#define TT_DIFF_OPT_OVERLAP_PREPASS 1
+int tt_diff_set_option(tt_diff* h, int option, int value);  /* which = 0: sampler-step graph captures so far (the step graph stays on the handle) */
 
 /* ============================================================================================
  * Stage 3 — UnivNetGenerator.inference   (reference: tortoise/models/vocoder.py:300-312, api.py:559)

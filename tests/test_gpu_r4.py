@@ -277,3 +277,37 @@ def test_two_engines_on_two_threads_render_what_they_render_alone():
     for st in ars:
         st.close()
     df.close()
+
+
+@torch.no_grad()
+def test_overlapped_integrator_prepass_is_scheduling_only():
+    """Full-width denoiser, S = 870, 40 iterations = 3 chunks of the conditioning-integrator pre-pass: with the chunks on their own
+    stream next to the sampler loop (the default) the mel is bit-identical to the whole pre-pass running first on the one stream,
+    replayed or eager, run after run."""
+    cfg = DiffusionConfig()
+    sd = W.synthetic_state_dict(W.diffusion_manifest(cfg), 1236)
+    M, iters = 200, 40
+    S = M * 4 * 24000 // 22050
+    st = stages.DiffusionStage(sd, cfg, dtype=E.TT_F16, max_seq=S + 8, max_codes=M + 8, max_steps=64)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(1, M, 1024, generator=g)
+    dcond = torch.randn(1, 2048, generator=g) * 0.5
+    sched = Schedule(iters, cfg.trained_steps, True, 2)
+    x = torch.randn(1, 100, S, generator=g)
+    noise = torch.randn(iters, 1, 100, S, generator=g)
+    st.set_option(E.TT_DIFF_OPT_OVERLAP_PREPASS, 0)
+    st.condition(lat, dcond, S)
+    want = st.sample(sched, x, noise).clone()
+    assert torch.isfinite(want).all() and st.guard() == 0
+    st.set_option(E.TT_DIFF_OPT_OVERLAP_PREPASS, 1)
+    for rep in range(4):
+        st.condition(lat, dcond, S)
+        assert torch.equal(st.sample(sched, x, noise), want), f"the overlapped pre-pass changed the mel (repetition {rep})"
+    E.load_library().tt_graph_replay(0)
+    try:
+        st.condition(lat, dcond, S)
+        assert torch.equal(st.sample(sched, x, noise), want), "eager launches with the overlapped pre-pass changed the mel"
+    finally:
+        E.load_library().tt_graph_replay(1)
+    assert st.stat(0) == 1
+    st.close()

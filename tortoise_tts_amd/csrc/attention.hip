@@ -547,6 +547,7 @@ static int launch_flash_lds(const ProfScope& ps, const FlashArgs& a, hipStream_t
 }
 
 int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
+  if (dtype == DT_F32) return flash_f32_launch(a, stream);  // verification mode (attention_f32.hip)
   TT_REQUIRE(a.BH > 0 && a.n > 0 && a.heads > 0 && a.BH % a.heads == 0, "flash: bad shape BH=%d n=%d heads=%d", a.BH, a.n, a.heads);
   TT_REQUIRE(a.n_pad % 32 == 0 && a.n_pad >= ((a.n + 31) / 32) * 32, "flash: n_pad=%d must be a multiple of 32 covering n=%d", a.n_pad, a.n);
   TT_REQUIRE(a.ldo % 4 == 0, "flash: ldo must be a multiple of 4");
@@ -931,6 +932,7 @@ __global__ __launch_bounds__(NSEQ * 64, 4) void decode_attn_lds_kernel(DecodeAtt
 }
 
 int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stream) {
+  if (dtype == DT_F32) return decode_attn_f32_launch(a, stream);  // verification mode (attention_f32.hip)
   TT_REQUIRE(a.B > 0 && a.heads > 0 && a.P1 >= 0 && a.tmax > 0, "decode_attention: bad shape");
   const int ctx_cap = a.P1 + a.tmax;
   // algorithmic bytes: every sequence reads its own generated K and V rows once (host_tgen keys) + the shared prefix once

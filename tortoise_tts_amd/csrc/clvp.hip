@@ -87,20 +87,21 @@ int tt_clvp_create(const tt_clvp_config* cfg, const tt_clvp_tower* text, const t
   e->temperature = temperature;
   const size_t rows = (size_t)cfg->max_rows + 64;
   const int D = cfg->dim;
+  const size_t es = dtype_bytes(cfg->dtype);
   e->max_batch = cfg->max_rows;  // every row could be its own sequence in the worst case
   int rc = e->sb.init();
   if (!rc) rc = e->arena.alloc_t(&e->x, rows * D);
-  if (!rc) rc = e->arena.alloc(&e->h, rows * D * 2);
-  if (!rc) rc = e->arena.alloc(&e->u, rows * 2 * cfg->ff_inner * 2);
-  if (!rc) rc = e->arena.alloc(&e->gg, rows * cfg->ff_inner * 2);
-  if (!rc) rc = e->arena.alloc(&e->attn, rows * D * 2);
-  if (!rc) rc = e->arena.alloc(&e->q, rows * D * 2);
-  if (!rc) rc = e->arena.alloc(&e->k, rows * D * 2);
+  if (!rc) rc = e->arena.alloc(&e->h, rows * D * es);
+  if (!rc) rc = e->arena.alloc(&e->u, rows * 2 * cfg->ff_inner * es);
+  if (!rc) rc = e->arena.alloc(&e->gg, rows * cfg->ff_inner * es);
+  if (!rc) rc = e->arena.alloc(&e->attn, rows * D * es);
+  if (!rc) rc = e->arena.alloc(&e->q, rows * D * es);
+  if (!rc) rc = e->arena.alloc(&e->k, rows * D * es);
   // V^T: [B*H][64][n_pad]; n_pad <= n + 31 and B*n <= max_rows, B <= max_rows / 1
-  if (!rc) rc = e->arena.alloc(&e->vt, (size_t)D * (rows + 32 * (size_t)(cfg->max_rows / 8 + 8)) * 2);
+  if (!rc) rc = e->arena.alloc(&e->vt, (size_t)D * (rows + 32 * (size_t)(cfg->max_rows / 8 + 8)) * es);
   if (!rc) rc = e->arena.alloc_t(&e->enc, rows * D);
   if (!rc) rc = e->arena.alloc_t(&e->pooled, rows * D / 8 + D);
-  if (!rc) rc = e->arena.alloc(&e->pooled_t, (rows * D / 8 + D) * 2);
+  if (!rc) rc = e->arena.alloc(&e->pooled_t, (rows * D / 8 + D) * es);
   if (!rc) rc = e->arena.alloc_t(&e->text_latent, cfg->latent_dim);
   if (!rc) rc = e->arena.alloc_t(&e->speech_latent, (rows / 8 + 8) * cfg->latent_dim);
   if (!rc) rc = e->arena.alloc_t(&e->guard, 4);

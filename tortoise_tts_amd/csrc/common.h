@@ -25,6 +25,14 @@ template <> struct Vec<f16> {
   typedef __attribute__((ext_vector_type(2))) _Float16 x2;
 };
 
+// float "operands": the verification mode (DT_F32) - every GEMM / attention operand stays fp32, so the engine can be held against the
+// reference's fp32 modules at fp32 tolerances (slow kernels, tests only)
+template <> struct Vec<float> {
+  typedef __attribute__((ext_vector_type(8))) float x8;
+  typedef __attribute__((ext_vector_type(4))) float x4;
+  typedef __attribute__((ext_vector_type(2))) float x2;
+};
+
 // D(16x16 f32) += A(16x32) * B(32x16).  Lane l holds A[row = l&15][k = (l>>4)*8 .. +7],
 // B[k = (l>>4)*8 .. +7][col = l&15]; D lane l reg r = D[row = (l>>4)*4 + r][col = l&15].
 __device__ __forceinline__ f32x4 mfma16(Vec<bf16>::x8 a, Vec<bf16>::x8 b, f32x4 c) {
@@ -162,7 +170,15 @@ const char* last_error();
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-enum DType { DT_BF16 = 0, DT_F16 = 1 };
+enum DType { DT_BF16 = 0, DT_F16 = 1, DT_F32 = 2 };
+static inline int dtype_bytes(int dtype) { return dtype == DT_F32 ? 4 : 2; }
+// f(tag) with tag.v of the operand type: TT_DISPATCH_T(dtype, T, stmt) runs stmt with T = bf16 / f16 / float
+#define TT_DISPATCH_T(dtype, T, ...)                                   \
+  do {                                                                 \
+    if ((dtype) == tt::DT_BF16) { typedef tt::bf16 T; __VA_ARGS__; }   \
+    else if ((dtype) == tt::DT_F16) { typedef tt::f16 T; __VA_ARGS__; } \
+    else { typedef float T; __VA_ARGS__; }                             \
+  } while (0)
 
 }  // namespace tt
 

@@ -139,6 +139,7 @@ static int cond_attn_block(tt_cond* e, const tt_attn_block& w, const float* in, 
 extern "C" {
 
 int tt_cond_create(const tt_cond_config* cfg, const tt_cond_weights* w, tt_cond** out) {
+  TT_REQUIRE(cfg && (cfg->dtype == DT_BF16 || cfg->dtype == DT_F16), "tt_cond_create: dtype must be TT_BF16 or TT_F16 (the fp32 verification mode covers the AR / CLVP / diffusion / vocoder stages)");
   TT_REQUIRE(cfg && w && out, "tt_cond_create: null argument");
   TT_REQUIRE(cfg->ar_dim % 64 == 0 && cfg->diff_channels % 64 == 0 && cfg->ar_mel_pad % 64 == 0 && cfg->diff_mel_pad % 64 == 0 &&
              cfg->ar_mel_pad >= cfg->ar_mel && cfg->diff_mel_pad >= cfg->diff_mel, "tt_cond_create: widths must be multiples of 64 (mel widths padded)");

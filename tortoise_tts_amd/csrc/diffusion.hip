@@ -21,12 +21,30 @@ using namespace tt;
 
 static_assert(sizeof(PSampleStep) == sizeof(tt_diff_step), "PSampleStep must mirror tt_diff_step");
 
+// Work buffers of one pass over the denoiser's layers.  Two sets: [0] the sampler loop / conditioning (rows of ONE step), [1] the
+// conditioning-integrator pre-pass, which runs over whole chunks of the schedule on its own stream WHILE the sampler loop walks the
+// steps whose integrator outputs are already there (diff_sample_run).
+struct DiffWork {
+  float* tmp_a = nullptr;      // [rows][C] f32 scratch
+  float* tmp_b = nullptr;
+  float* tmp_c = nullptr;
+  void* act = nullptr;         // [rows][C] T   GN/SiLU output (GEMM operand)
+  void* q = nullptr; void* k = nullptr; void* vt = nullptr; void* att = nullptr;
+  float* gn_partial = nullptr;
+  float* gn_gemm_part = nullptr;    // statistics emitted by GEMM epilogues: [row_tile][2][C/16][2]
+  const float* stats_ptr = nullptr; // tensor those statistics describe (the last such GEMM's f32 output)
+  int stats_rows = 0;               // its row-tile height
+  int stats_seq = 0;
+  int rows = 0;
+};
+
 struct tt_diff {
   tt_diff_config cfg;
   tt_diff_weights w;
   std::vector<tt_attn_block> latent_attn, attn;
   std::vector<tt_res_block> res;
   int C, H, NR;  // NR = number of ResBlocks (3 + L + 3)
+  int es = 2;    // bytes per operand element (4: the fp32 verification mode)
   Arena arena;
   StreamBridge sb;
   int S = 0;        // rows per sample of the current pass (a padded batch: the common padded length)
@@ -37,21 +55,16 @@ struct tt_diff {
   bool masked = false;       // the kernels of the current pass take per-sample valid lengths (Su) - off while one utterance is conditioned
   int rows_max = 0;
   float* code_emb = nullptr;   // [2][S][C]: row 0 conditioned, row 1 unconditioned embedding broadcast
-  float* tmp_a = nullptr;      // [rows][C] f32 scratch
-  float* tmp_b = nullptr;
-  float* tmp_c = nullptr;
-  void* act = nullptr;         // [rows][C] T   GN/SiLU output (GEMM operand)
+  DiffWork wk[2];
+  hipStream_t pre_stream = nullptr;          // the pre-pass's stream
+  hipEvent_t ev_pre_start = nullptr;
+  std::vector<hipEvent_t> ev_chunk;          // chunk c of the pre-pass is complete
+  int overlap_prepass = 1;                   // 0: pre-pass on the main stream in front of the loop (round 3 behaviour; A/B switch)
   void* cat = nullptr;         // [2S][C] T     inp_block(x) of the current step (left half of the integrating conv's K)
   void* integ_all = nullptr;   // [steps][B][S][C] T  conditioning_timestep_integrator output of every step (right half of K)
   float* rep_in = nullptr;     // [chunk samples][S][C] f32: code_emb rows repeated per timestep (batched integrator input)
   int chunk_rows = 0;          // row capacity of one batched-integrator chunk
   int integ_B = 0, integ_n = 0; // rows per step / steps currently held by integ_all
-  void* q = nullptr; void* k = nullptr; void* vt = nullptr; void* att = nullptr;
-  float* gn_partial = nullptr;
-  float* gn_gemm_part = nullptr;   // statistics emitted by GEMM epilogues: [row_tile][2][C/16][2]
-  const float* stats_ptr = nullptr; // tensor those statistics describe (the last such GEMM's f32 output)
-  int stats_rows = 0;              // its row-tile height
-  int stats_seq = 0;
   void* lat_t = nullptr;       // [M][latent] T
   int* ts_dev = nullptr;       // [steps]
   float* temb_sin = nullptr;   // [steps][C]
@@ -86,7 +99,7 @@ struct tt_diff {
 };
 
 // ss: scale / shift rows [2C]; batch row b reads ss + (b / ss_div) * ss_stride (ss_stride 0: one row for the whole batch)
-static int run_gn(tt_diff* e, const float* x, int B, int S, const float* g, const float* b, const float* ss, size_t ss_stride, int ss_div,
+static int run_gn(tt_diff* e, DiffWork& w_, const float* x, int B, int S, const float* g, const float* b, const float* ss, size_t ss_stride, int ss_div,
                   int act, void* out_t, int ldot, float* out_f32, hipStream_t s) {
   GroupNormArgs a;
   memset(&a, 0, sizeof(a));
@@ -94,24 +107,24 @@ static int run_gn(tt_diff* e, const float* x, int B, int S, const float* g, cons
   a.scale_shift = ss; a.ss_batch_stride = ss_stride; a.ss_batch_div = ss_div; a.act = act;
   // per-step scale / shift rows are staged at a fixed address (e->ss_cur): no step-dependent addressing in the kernel
   a.out_t = out_t; a.ldot = ldot; a.out_f32 = out_f32; a.ldo32 = e->C;
-  a.partial = e->gn_partial;
+  a.partial = w_.gn_partial;
   a.guard = e->guard;
   if (e->masked) {
     a.vperiod = e->U;
     for (int u = 0; u < e->U; ++u) a.vlen[u] = e->Su[u];
   }
-  if (x == e->stats_ptr && e->stats_seq == S && S >= e->stats_rows) {
-    a.gemm_part = e->gn_gemm_part;
-    a.part_rows = e->stats_rows;
+  if (x == w_.stats_ptr && w_.stats_seq == S && S >= w_.stats_rows) {
+    a.gemm_part = w_.gn_gemm_part;
+    a.part_rows = w_.stats_rows;
   }
   return groupnorm_launch(e->cfg.dtype, a, s);
 }
 
 // EPI_STD GEMM whose f32 output will be group-normalised next: let its epilogue emit the statistics.
-static int gemm_with_stats(tt_diff* e, GemmArgs& g, int S, hipStream_t s) {
+static int gemm_with_stats(tt_diff* e, DiffWork& w_, GemmArgs& g, int S, hipStream_t s) {
   const bool fused = (e->C / 32) % 16 == 0 && g.out_f32 != nullptr && g.N == e->C && g.splitk <= 1;
   if (fused) {
-    g.gn_part = e->gn_gemm_part;
+    g.gn_part = w_.gn_gemm_part;
     g.gn_seq = S;
     if (e->masked) {
       g.gn_vperiod = e->U;
@@ -120,78 +133,85 @@ static int gemm_with_stats(tt_diff* e, GemmArgs& g, int S, hipStream_t s) {
   }
   TT_TRY(gemm_launch(e->cfg.dtype, EPI_STD, g, s));
   if (fused) {
-    e->stats_ptr = g.out_f32;
-    e->stats_rows = gemm_stat_rows(g);
-    e->stats_seq = S;
-  } else if (g.out_f32 == e->stats_ptr) {
-    e->stats_ptr = nullptr;  // tensor overwritten without fresh statistics
+    w_.stats_ptr = g.out_f32;
+    w_.stats_rows = gemm_stat_rows(g, e->cfg.dtype);
+    w_.stats_seq = S;
+  } else if (g.out_f32 == w_.stats_ptr) {
+    w_.stats_ptr = nullptr;  // tensor overwritten without fresh statistics
   }
   return 0;
 }
 
 // AttentionBlock (arch_util.py:80-123): out = in + proj(attn(qkv(GN(in))))
-static int run_attn_block(tt_diff* e, const tt_attn_block& w, const float* in, int B, int S, float* out_f32, void* out_t, int ldot,
+static int run_attn_block(tt_diff* e, DiffWork& w_, const tt_attn_block& w, const float* in, int B, int S, float* out_f32, void* out_t, int ldot,
                           hipStream_t s) {
   const int C = e->C, H = e->H, dt = e->cfg.dtype, M = B * S, n_pad = round_up(S, 32);
-  TT_TRY(run_gn(e, in, B, S, w.norm_g, w.norm_b, nullptr, 0, 1, ACT_NONE, e->act, C, nullptr, s));
-  GemmArgs g = gemm_args(e->act, C, w.w_qkv, C, M, 3 * C, C);
-  g.bias = w.b_qkv; g.seq_len = S; g.dmodel = C; g.heads = H; g.q = e->q; g.k = e->k; g.vt = e->vt; g.seq_pad = n_pad;
+  TT_TRY(run_gn(e, w_, in, B, S, w.norm_g, w.norm_b, nullptr, 0, 1, ACT_NONE, w_.act, C, nullptr, s));
+  GemmArgs g = gemm_args(w_.act, C, w.w_qkv, C, M, 3 * C, C);
+  g.bias = w.b_qkv; g.seq_len = S; g.dmodel = C; g.heads = H; g.q = w_.q; g.k = w_.k; g.vt = w_.vt; g.seq_pad = n_pad;
   g.q_scale = 0.125f;  // (q * 64^-1/4) . (k * 64^-1/4)  ==  (q/8) . k   (arch_util.py:64-67)
   TT_TRY(gemm_launch(dt, EPI_QKV_HEADS, g, s));
   FlashArgs f;
   memset(&f, 0, sizeof(f));
-  f.q = e->q; f.k = e->k; f.vt = e->vt; f.out = e->att; f.ldo = C; f.BH = B * H; f.heads = H; f.n = S; f.n_pad = n_pad;
+  f.q = w_.q; f.k = w_.k; f.vt = w_.vt; f.out = w_.att; f.ldo = C; f.BH = B * H; f.heads = H; f.n = S; f.n_pad = n_pad;
   f.relpos = w.relpos;
   if (e->masked) {
     f.nv_period = e->U;
     for (int u = 0; u < e->U; ++u) f.nv[u] = e->Su[u];
   }
   TT_TRY(flash_attention_launch(dt, f, s));
-  g = gemm_args(e->att, C, w.w_proj, C, M, C, C);
+  g = gemm_args(w_.att, C, w.w_proj, C, M, C, C);
   g.bias = w.b_proj; g.res = in; g.ldres = C; g.out_f32 = out_f32; g.ldo32 = C; g.out_t = out_t; g.ldot = ldot;
-  return gemm_with_stats(e, g, S, s);
+  return gemm_with_stats(e, w_, g, S, s);
 }
 
 // ResBlock (diffusion_decoder.py:60-120, use_scale_shift_norm, efficient_config, kernel 3).
-static int run_res_block(tt_diff* e, const tt_res_block& w, const float* ss, size_t ss_stride, int ss_div, const float* in, int B, int S,
+static int run_res_block(tt_diff* e, DiffWork& w_, const tt_res_block& w, const float* ss, size_t ss_stride, int ss_div, const float* in, int B, int S,
                          float* out_f32, hipStream_t s) {
   const int C = e->C, dt = e->cfg.dtype, M = B * S;
-  TT_TRY(run_gn(e, in, B, S, w.gn1_g, w.gn1_b, nullptr, 0, 1, ACT_SILU, e->act, C, nullptr, s));
-  GemmArgs g = gemm_args(e->act, C, w.w_in, C, M, C, C);
-  g.bias = w.b_in; g.out_f32 = e->tmp_c; g.ldo32 = C;
-  TT_TRY(gemm_with_stats(e, g, S, s));
-  TT_TRY(run_gn(e, e->tmp_c, B, S, w.gn2_g, w.gn2_b, ss, ss_stride, ss_div, ACT_SILU, e->act, C, nullptr, s));
-  g = gemm_args(e->act, C, w.w_out, 3 * C, M, C, 3 * C);
+  (void)dt;
+  TT_TRY(run_gn(e, w_, in, B, S, w.gn1_g, w.gn1_b, nullptr, 0, 1, ACT_SILU, w_.act, C, nullptr, s));
+  GemmArgs g = gemm_args(w_.act, C, w.w_in, C, M, C, C);
+  g.bias = w.b_in; g.out_f32 = w_.tmp_c; g.ldo32 = C;
+  TT_TRY(gemm_with_stats(e, w_, g, S, s));
+  TT_TRY(run_gn(e, w_, w_.tmp_c, B, S, w.gn2_g, w.gn2_b, ss, ss_stride, ss_div, ACT_SILU, w_.act, C, nullptr, s));
+  g = gemm_args(w_.act, C, w.w_out, 3 * C, M, C, 3 * C);
   g.taps = 3; g.seq_len = S; g.bias = w.b_out; g.res = in; g.ldres = C; g.out_f32 = out_f32; g.ldo32 = C;
-  return gemm_with_stats(e, g, S, s);
+  return gemm_with_stats(e, w_, g, S, s);
 }
 
-// conditioning_timestep_integrator for steps [0, n) x B guidance rows starting at conditioning row `row0`, batched over the
+// conditioning_timestep_integrator for steps [c0, c0 + ns) x B guidance rows starting at conditioning row `row0`, batched over the
 // timesteps: sample (j, r) = (step j, row r) is one batch row of the three DiffusionLayers, with its own scale / shift rows
 // ss_all[j] (GroupNorm and attention are per sample, so this is exactly the per-step evaluation, reordered).  Result ->
-// integ_all[j][r] in the operand type.  Chunked so the f32 work buffers stay within e->chunk_rows rows.
-static int diff_integrator_all(tt_diff* e, int n, int B, int row0, hipStream_t s) {
+// integ_all[j][r] in the operand type.  One chunk = at most w_.rows rows of f32 work buffers.
+static int diff_integrator_chunk(tt_diff* e, DiffWork& w_, int c0, int ns, int B, int row0, hipStream_t s) {
   const int C = e->C, S = e->S;
   const size_t ss_row = (size_t)e->NR * 2 * C;
-  const int per = std::max(1, e->chunk_rows / (B * S));  // steps per chunk
-  for (int c0 = 0; c0 < n; c0 += per) {
-    const int ns = std::min(per, n - c0), nb = ns * B;
-    e->stats_ptr = nullptr;
-    TT_TRY(repeat_rows_launch(e->code_emb + (size_t)row0 * S * C, e->rep_in, B * S, ns, C, s));
-    const float* cur = e->rep_in;
-    for (int i = 0; i < 3; ++i) {
-      TT_TRY(run_res_block(e, e->res[i], e->ss_all + (size_t)c0 * ss_row + (size_t)i * 2 * C, ss_row, B, cur, nb, S, e->tmp_a, s));
-      if (i < 2) {
-        TT_TRY(run_attn_block(e, e->attn[i], e->tmp_a, nb, S, e->tmp_b, nullptr, 0, s));
-        cur = e->tmp_b;
-      } else {  // the last layer's output is only ever a GEMM operand: store it in the operand type, per step
-        TT_TRY(run_attn_block(e, e->attn[i], e->tmp_a, nb, S, nullptr, offset_t(e->integ_all, (size_t)c0 * B * S * C), C, s));
-      }
+  const int nb = ns * B;
+  w_.stats_ptr = nullptr;
+  TT_TRY(repeat_rows_launch(e->code_emb + (size_t)row0 * S * C, e->rep_in, B * S, ns, C, s));
+  const float* cur = e->rep_in;
+  for (int i = 0; i < 3; ++i) {
+    TT_TRY(run_res_block(e, w_, e->res[i], e->ss_all + (size_t)c0 * ss_row + (size_t)i * 2 * C, ss_row, B, cur, nb, S, w_.tmp_a, s));
+    if (i < 2) {
+      TT_TRY(run_attn_block(e, w_, e->attn[i], w_.tmp_a, nb, S, w_.tmp_b, nullptr, 0, s));
+      cur = w_.tmp_b;
+    } else {  // the last layer's output is only ever a GEMM operand: store it in the operand type, per step
+      TT_TRY(run_attn_block(e, w_, e->attn[i], w_.tmp_a, nb, S, nullptr, offset_t(e->integ_all, (size_t)c0 * B * S * C, e->es), C, s));
     }
   }
+  w_.stats_ptr = nullptr;
+  return 0;
+}
+static inline int diff_steps_per_chunk(const tt_diff* e, int B) { return std::max(1, e->chunk_rows / (B * e->S)); }
+
+// The whole schedule's integrator outputs, chunk after chunk, on stream s (callers that need them all before they go on:
+// tt_diff_forward, the split tail).
+static int diff_integrator_all(tt_diff* e, int n, int B, int row0, hipStream_t s) {
+  const int per = diff_steps_per_chunk(e, B);
+  for (int c0 = 0; c0 < n; c0 += per) TT_TRY(diff_integrator_chunk(e, e->wk[1], c0, std::min(per, n - c0), B, row0, s));
   e->integ_B = B;
   e->integ_n = n;
-  e->stats_ptr = nullptr;
   return 0;
 }
 
@@ -201,7 +221,8 @@ static int diff_forward(tt_diff* e, int B, hipStream_t s) {
   const int C = e->C, S = e->S, dt = e->cfg.dtype, M = B * S, L = e->cfg.num_layers;
   TT_REQUIRE(e->integ_B == B, "diffusion: the integrator pre-pass holds %d rows per step, this step evaluates %d", e->integ_B, B);
   const float* ss = e->ss_cur;  // the current step's [NR][2C] rows (staged by slot_advance_launch / diff_prepare_timesteps)
-  e->stats_ptr = nullptr;       // no epilogue statistics are valid at the start of a pass
+  DiffWork& w_ = e->wk[0];
+  w_.stats_ptr = nullptr;       // no epilogue statistics are valid at the start of a pass
   // inp_block (k3, in_pad -> C): left half of the integrating conv's K
   GemmArgs g = gemm_args(e->x_t, e->cfg.in_pad, e->w.w_inp, 3 * e->cfg.in_pad, M, C, 3 * e->cfg.in_pad);
   g.taps = 3; g.seq_len = S; g.bias = e->w.b_inp; g.out_t = e->cat; g.ldot = C;
@@ -209,20 +230,20 @@ static int diff_forward(tt_diff* e, int B, hipStream_t s) {
   // integrating_conv over [inp_block(x) | integrator(code_emb, t)]: the right half comes straight from this slot's slice
   g = gemm_args(e->cat, C, e->w.w_integ, 2 * C, M, C, 2 * C);
   g.A2 = e->integ_all; g.lda2 = C; g.k_split = C; g.a2_slot = e->slot; g.a2_slot_stride = (size_t)B * S * C;
-  g.bias = e->w.b_integ; g.out_f32 = e->tmp_a; g.ldo32 = C;
-  TT_TRY(gemm_with_stats(e, g, S, s));
-  float* hcur = e->tmp_a;
-  float* hoth = e->tmp_b;
+  g.bias = e->w.b_integ; g.out_f32 = w_.tmp_a; g.ldo32 = C;
+  TT_TRY(gemm_with_stats(e, w_, g, S, s));
+  float* hcur = w_.tmp_a;
+  float* hoth = w_.tmp_b;
   for (int i = 0; i < L; ++i) {
-    TT_TRY(run_res_block(e, e->res[3 + i], ss + (size_t)(3 + i) * 2 * C, 0, 1, hcur, B, S, hoth, s));
-    TT_TRY(run_attn_block(e, e->attn[3 + i], hoth, B, S, hcur, nullptr, 0, s));
+    TT_TRY(run_res_block(e, w_, e->res[3 + i], ss + (size_t)(3 + i) * 2 * C, 0, 1, hcur, B, S, hoth, s));
+    TT_TRY(run_attn_block(e, w_, e->attn[3 + i], hoth, B, S, hcur, nullptr, 0, s));
   }
   for (int i = 0; i < 3; ++i) {
-    TT_TRY(run_res_block(e, e->res[3 + L + i], ss + (size_t)(3 + L + i) * 2 * C, 0, 1, hcur, B, S, hoth, s));
+    TT_TRY(run_res_block(e, w_, e->res[3 + L + i], ss + (size_t)(3 + L + i) * 2 * C, 0, 1, hcur, B, S, hoth, s));
     float* t = hcur; hcur = hoth; hoth = t;
   }
-  TT_TRY(run_gn(e, hcur, B, S, e->w.out_gn_g, e->w.out_gn_b, nullptr, 0, 1, ACT_SILU, e->act, C, nullptr, s));
-  g = gemm_args(e->act, C, e->w.w_final, 3 * C, M, e->cfg.out_channels, 3 * C);
+  TT_TRY(run_gn(e, w_, hcur, B, S, e->w.out_gn_g, e->w.out_gn_b, nullptr, 0, 1, ACT_SILU, w_.act, C, nullptr, s));
+  g = gemm_args(w_.act, C, e->w.w_final, 3 * C, M, e->cfg.out_channels, 3 * C);
   g.taps = 3; g.seq_len = S; g.bias = e->w.b_final; g.out_f32 = e->out; g.ldo32 = e->cfg.out_channels;
   return gemm_launch(dt, EPI_STD, g, s);
 }
@@ -291,6 +312,8 @@ int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff*
   e->UB = cfg->max_batch > 1 ? cfg->max_batch : 1;
   e->w = *w;
   e->C = cfg->channels; e->H = cfg->heads; e->NR = 3 + cfg->num_layers + 3;
+  e->es = dtype_bytes(cfg->dtype);
+  const size_t es = e->es;
   e->latent_attn.assign(w->latent_attn_host, w->latent_attn_host + 4);
   e->attn.assign(w->attn_host, w->attn_host + 3 + cfg->num_layers);
   e->res.assign(w->res_host, w->res_host + e->NR);
@@ -300,33 +323,42 @@ int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff*
   e->rows_max = std::max(e->chunk_rows, cfg->max_codes);
   const size_t rows = (size_t)e->rows_max + 64;
   int rc = e->sb.init();
+  if (!rc && (hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking) != hipSuccess ||
+              hipEventCreateWithFlags(&e->ev_pre_start, hipEventDisableTiming) != hipSuccess)) { set_error("tt_diff_create: stream / event creation failed"); rc = -2; }
   const size_t B2 = (size_t)2 * e->UB;  // samples of one denoiser pass: (conditioned, conditioning-free) x utterances
   if (!rc) rc = e->arena.alloc_t(&e->code_emb, B2 * cfg->max_seq * C);
-  if (!rc) rc = e->arena.alloc_t(&e->tmp_a, rows * C);
-  if (!rc) rc = e->arena.alloc_t(&e->tmp_b, rows * C);
-  if (!rc) rc = e->arena.alloc_t(&e->tmp_c, rows * C);
+  // work set 0: one step's rows (guidance rows x utterances x max_seq) or one conditioning pass (max_codes rows); set 1: a chunk of the pre-pass
+  const size_t rows_of[2] = {(size_t)std::max((int)(B2 * cfg->max_seq), cfg->max_codes) + 64, rows};
+  for (int i = 0; i < 2 && !rc; ++i) {
+    DiffWork& w_ = e->wk[i];
+    const size_t r = rows_of[i];
+    w_.rows = (int)r;
+    rc = e->arena.alloc_t(&w_.tmp_a, r * C);
+    if (!rc) rc = e->arena.alloc_t(&w_.tmp_b, r * C);
+    if (!rc) rc = e->arena.alloc_t(&w_.tmp_c, r * C);
+    if (!rc) rc = e->arena.alloc(&w_.act, r * C * es);
+    if (!rc) rc = e->arena.alloc(&w_.q, r * C * es);
+    if (!rc) rc = e->arena.alloc(&w_.k, r * C * es);
+    if (!rc) rc = e->arena.alloc(&w_.vt, (size_t)C * (2 * r + 64) * es);  // per sample C x round_up(S, 32) keys: <= 2x the rows for short sequences
+    if (!rc) rc = e->arena.alloc(&w_.att, r * C * es);
+    if (!rc) rc = e->arena.alloc_t(&w_.gn_partial, (r / 16 + r + 64) * 64);  // [samples][row chunks >= 16 rows][32][2], worst case one-row samples
+    if (!rc) rc = e->arena.alloc_t(&w_.gn_gemm_part, (r / 32 + 2) * 2 * (C / 16) * 2 + 64);
+  }
   if (!rc) rc = e->arena.alloc_t(&e->rep_in, rows * C);
-  if (!rc) rc = e->arena.alloc(&e->act, rows * C * 2);
-  if (!rc) rc = e->arena.alloc(&e->cat, (B2 * cfg->max_seq + 64) * C * 2);
-  if (!rc) rc = e->arena.alloc(&e->integ_all, ((size_t)cfg->max_steps * B2 * cfg->max_seq + 64) * C * 2, false);
-  if (!rc) rc = e->arena.alloc(&e->q, rows * C * 2);
-  if (!rc) rc = e->arena.alloc(&e->k, rows * C * 2);
-  if (!rc) rc = e->arena.alloc(&e->vt, (size_t)C * (2 * rows + 64) * 2);  // per sample C x round_up(S, 32) keys: <= 2x the rows for short sequences
-  if (!rc) rc = e->arena.alloc(&e->att, rows * C * 2);
-  if (!rc) rc = e->arena.alloc_t(&e->gn_partial, ((size_t)e->rows_max / 16 + e->rows_max + 64) * 64);  // [samples][row chunks >= 16 rows][32][2], worst case one-row samples
-  if (!rc) rc = e->arena.alloc_t(&e->gn_gemm_part, ((size_t)e->rows_max / 32 + 2) * 2 * (C / 16) * 2 + 64);
-  if (!rc) rc = e->arena.alloc(&e->lat_t, ((size_t)cfg->max_codes + 8) * cfg->latent_channels * 2);
+  if (!rc) rc = e->arena.alloc(&e->cat, (B2 * cfg->max_seq + 64) * C * es);
+  if (!rc) rc = e->arena.alloc(&e->integ_all, ((size_t)cfg->max_steps * B2 * cfg->max_seq + 64) * C * es, false);
+  if (!rc) rc = e->arena.alloc(&e->lat_t, ((size_t)cfg->max_codes + 8) * cfg->latent_channels * es);
   if (!rc) rc = e->arena.alloc_t(&e->ts_dev, cfg->max_steps);
   if (!rc) rc = e->arena.alloc_t(&e->temb_sin, (size_t)cfg->max_steps * C);
-  if (!rc) rc = e->arena.alloc(&e->temb_t, (size_t)cfg->max_steps * C * 2);
-  if (!rc) rc = e->arena.alloc(&e->temb_t2, (size_t)cfg->max_steps * C * 2);
+  if (!rc) rc = e->arena.alloc(&e->temb_t, (size_t)cfg->max_steps * C * es);
+  if (!rc) rc = e->arena.alloc(&e->temb_t2, (size_t)cfg->max_steps * C * es);
   if (!rc) rc = e->arena.alloc_t(&e->temb_mid, (size_t)cfg->max_steps * C);
   if (!rc) rc = e->arena.alloc_t(&e->ss_all, (size_t)cfg->max_steps * e->NR * 2 * C);
   if (!rc) rc = e->arena.alloc_t(&e->ss_cur, (size_t)e->NR * 2 * C);
   if (!rc) rc = e->arena.alloc_t(&e->steps_dev, cfg->max_steps);
   if (!rc) rc = e->arena.alloc_t(&e->slot, 4);
   if (!rc) rc = e->arena.alloc_t(&e->x, (size_t)e->UB * cfg->max_seq * cfg->in_channels);
-  if (!rc) rc = e->arena.alloc(&e->x_t, (B2 * cfg->max_seq + 8) * cfg->in_pad * 2);
+  if (!rc) rc = e->arena.alloc(&e->x_t, (B2 * cfg->max_seq + 8) * cfg->in_pad * es);
   if (!rc) rc = e->arena.alloc_t(&e->out, B2 * cfg->max_seq * cfg->out_channels);
   if (!rc) rc = e->arena.alloc_t(&e->guard, 4);
   if (!rc) rc = e->arena.alloc_t(&e->io_dev, 32);
@@ -350,6 +382,10 @@ void tt_diff_destroy(tt_diff* e) {
   diff_drop_step_graph(e);
   if (e->guard_host) (void)hipHostFree(e->guard_host);
   if (e->io_host) (void)hipHostFree((void*)e->io_host);
+  for (hipEvent_t ev : e->ev_chunk)
+    if (ev) (void)hipEventDestroy(ev);
+  if (e->ev_pre_start) (void)hipEventDestroy(e->ev_pre_start);
+  if (e->pre_stream) (void)hipStreamDestroy(e->pre_stream);
   e->arena.release();
   e->sb.destroy();
   delete e;
@@ -361,23 +397,24 @@ static int diff_condition_into(tt_diff* e, const float* latents, int M, const fl
                                float* dst_uncond, hipStream_t s) {
   const int C = e->C, dt = e->cfg.dtype, LC = e->cfg.latent_channels;
   const bool masked = e->masked;
+  DiffWork& w_ = e->wk[0];
   e->masked = false;
-  e->stats_ptr = nullptr;
+  w_.stats_ptr = nullptr;
   TT_TRY(cast_pad_launch(dt, latents, LC, e->lat_t, LC, M, LC, LC, s));
   GemmArgs g = gemm_args(e->lat_t, LC, e->w.w_latent_conv, 3 * LC, M, C, 3 * LC);
-  g.taps = 3; g.seq_len = M; g.bias = e->w.b_latent_conv; g.out_f32 = e->tmp_a; g.ldo32 = C;
-  TT_TRY(gemm_with_stats(e, g, M, s));
-  float* cur = e->tmp_a;
-  float* oth = e->tmp_b;
+  g.taps = 3; g.seq_len = M; g.bias = e->w.b_latent_conv; g.out_f32 = w_.tmp_a; g.ldo32 = C;
+  TT_TRY(gemm_with_stats(e, w_, g, M, s));
+  float* cur = w_.tmp_a;
+  float* oth = w_.tmp_b;
   for (int i = 0; i < 4; ++i) {
-    TT_TRY(run_attn_block(e, e->latent_attn[i], cur, 1, M, oth, nullptr, 0, s));
+    TT_TRY(run_attn_block(e, w_, e->latent_attn[i], cur, 1, M, oth, nullptr, 0, s));
     float* t = cur; cur = oth; oth = t;
   }
   // code_norm(h) * (1 + cond_scale) + cond_shift   (diffusion_decoder.py:249-250)
-  TT_TRY(run_gn(e, cur, 1, M, e->w.code_norm_g, e->w.code_norm_b, cond, 0, 1, ACT_NONE, nullptr, 0, oth, s));
+  TT_TRY(run_gn(e, w_, cur, 1, M, e->w.code_norm_g, e->w.code_norm_b, cond, 0, 1, ACT_NONE, nullptr, 0, oth, s));
   TT_TRY(gather_rows_launch(oth, interp_idx, dst_cond, S, C, s));        // F.interpolate(nearest)
   TT_TRY(broadcast_rows_launch(e->w.uncond_emb, dst_uncond, S, C, s));   // unconditioned_embedding.repeat
-  e->stats_ptr = nullptr;
+  w_.stats_ptr = nullptr;
   e->masked = masked;
   return 0;
 }
@@ -403,7 +440,7 @@ int tt_diff_batch_begin(tt_diff* e, int U, int S_pad, void* stream) {
   for (int u = 0; u < 16; ++u) e->Su[u] = 0;
   // rows past an utterance's own length stay zero for the whole run: they are the zero padding its convolutions read
   TT_CHECK_HIP(hipMemsetAsync(e->code_emb, 0, (size_t)2 * U * S_pad * e->C * sizeof(float), s));
-  TT_CHECK_HIP(hipMemsetAsync(e->x_t, 0, (size_t)2 * U * S_pad * e->cfg.in_pad * 2, s));
+  TT_CHECK_HIP(hipMemsetAsync(e->x_t, 0, (size_t)2 * U * S_pad * e->cfg.in_pad * e->es, s));
   TT_CHECK_HIP(hipMemsetAsync(e->x, 0, (size_t)U * S_pad * e->cfg.in_channels * sizeof(float), s));
   return e->sb.leave(us);
 }
@@ -441,7 +478,7 @@ int tt_diff_forward(tt_diff* e, const float* x, int timestep, int cond_free, flo
   TT_CHECK_HIP(hipMemsetAsync(e->slot, 0, sizeof(int), s));
   TT_TRY(diff_prepare_timesteps(e, 1, s));
   TT_TRY(cast_pad_launch(e->cfg.dtype, x, IC, e->x_t, IP, S, IC, IP, s));
-  TT_TRY(cast_pad_launch(e->cfg.dtype, x, IC, offset_t(e->x_t, (size_t)S * IP), IP, S, IC, IP, s));
+  TT_TRY(cast_pad_launch(e->cfg.dtype, x, IC, offset_t(e->x_t, (size_t)S * IP, e->es), IP, S, IC, IP, s));
   const int B = cond_free ? 2 : 1;
   TT_TRY(diff_integrator_all(e, 1, B, 0, s));
   TT_TRY(diff_forward(e, B, s));
@@ -470,15 +507,40 @@ static int diff_sample_run(tt_diff* e, const float* const* x_T, const float* con
   for (int u = 0; u < U; ++u) {
     float* xu = e->x + (size_t)u * S * IC;
     TT_TRY(transpose_launch(x_T[u], xu, IC, e->Su[u], s));  // [C][S_u] -> [S_u][C]
-    for (int r = 0; r < R; ++r) TT_TRY(cast_pad_launch(dt, xu, IC, offset_t(e->x_t, (size_t)(r * U + u) * S * IP), IP, e->Su[u], IC, IP, s));
+    for (int r = 0; r < R; ++r) TT_TRY(cast_pad_launch(dt, xu, IC, offset_t(e->x_t, (size_t)(r * U + u) * S * IP, e->es), IP, e->Su[u], IC, IP, s));
   }
   e->masked = U > 1;
-  int rc = diff_integrator_all(e, n_steps, B, 0, s);  // every step's conditioning integrator, batched over the schedule
+  // Every step's conditioning integrator, batched over the schedule in chunks of `per` steps.  The chunks run on the pre-pass stream
+  // with their own work buffers; the sampler loop below starts as soon as chunk 0 is there and waits, in front of the first step of
+  // every later chunk, for that chunk's event: the large MFMA-bound GEMMs of the pre-pass (M = chunk rows) fill the CUs the loop's
+  // latency-bound launches (M = 2 S rows) leave idle.  overlap_prepass == 0: the round-3 order (whole pre-pass first, one stream).
+  const int per = diff_steps_per_chunk(e, B), nchunks = cdiv(n_steps, per);
+  const bool overlap = e->overlap_prepass != 0 && nchunks > 1;
+  int rc = 0;
+  hipStream_t ps = overlap ? e->pre_stream : s;
+  while (!rc && (int)e->ev_chunk.size() < nchunks) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_error("tt_diff_sample: event creation failed"); rc = -2; }
+    else e->ev_chunk.push_back(ev);
+  }
+  if (!rc && overlap) {
+    if (hipEventRecord(e->ev_pre_start, s) != hipSuccess || hipStreamWaitEvent(ps, e->ev_pre_start, 0) != hipSuccess) { set_error("tt_diff_sample: fork failed"); rc = -2; }
+  }
+  for (int c = 0; c < nchunks && !rc; ++c) {
+    rc = diff_integrator_chunk(e, e->wk[1], c * per, std::min(per, n_steps - c * per), B, 0, ps);
+    if (!rc && overlap && hipEventRecord(e->ev_chunk[c], ps) != hipSuccess) { set_error("tt_diff_sample: event record failed"); rc = -2; }
+  }
+  e->integ_B = B;
+  e->integ_n = n_steps;
+  auto chunk_gate = [&](int step) -> int {  // in front of step `step`: its integrator slice must be there
+    if (overlap && step % per == 0) TT_CHECK_HIP(hipStreamWaitEvent(s, e->ev_chunk[step / per], 0));
+    return 0;
+  };
   std::vector<PSampleArgs> pa(U);
   for (int u = 0; u < U && !rc; ++u) {
     PSampleArgs& p = pa[u];
     memset(&p, 0, sizeof(p));
-    p.steps = e->steps_dev; p.slot = e->slot; p.x = e->x + (size_t)u * S * IC; p.x_t = offset_t(e->x_t, (size_t)u * S * IP); p.cpad = IP;
+    p.steps = e->steps_dev; p.slot = e->slot; p.x = e->x + (size_t)u * S * IC; p.x_t = offset_t(e->x_t, (size_t)u * S * IP, e->es); p.cpad = IP;
     p.out = e->out + (size_t)u * S * e->cfg.out_channels;
     p.has_uncond = cond_free ? 1 : 0; p.S = e->Su[u]; p.C = IC;
     p.io = e->io_dev + 2 * u;  // {step_noise[u], mel_out[u]}: data of this call, not of the captured step
@@ -522,6 +584,8 @@ static int diff_sample_run(tt_diff* e, const float* const* x_T, const float* con
       }
     }
     for (int i = 0; i < n_steps && !rc; ++i) {
+      rc = chunk_gate(i);
+      if (rc) break;
       hipError_t ce = hipGraphLaunch(e->step_exec, s);
       if (ce != hipSuccess) { set_error("tt_diff_sample: hipGraphLaunch: %s", hipGetErrorString(ce)); rc = -2; }
     }
@@ -530,8 +594,12 @@ static int diff_sample_run(tt_diff* e, const float* const* x_T, const float* con
       diff_drop_step_graph(e);
     }
   } else {
-    for (int i = 0; i < n_steps && !rc; ++i) rc = one_step();
+    for (int i = 0; i < n_steps && !rc; ++i) {
+      rc = chunk_gate(i);
+      if (!rc) rc = one_step();
+    }
   }
+  if (rc && overlap) (void)hipStreamSynchronize(ps);  // nothing of this run may still be in flight when the caller sees the error
   if (!rc && hipMemcpyAsync(e->guard_host, e->guard, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) { set_error("tt_diff_sample: reading the guard failed"); rc = -2; }
   e->masked = false;
   return rc;
@@ -578,7 +646,7 @@ int tt_diff_split_begin(tt_diff* e, const float* x_T, const tt_diff_step* steps_
   TT_TRY(diff_prepare_timesteps(e, n_steps, s));
   TT_TRY(transpose_launch(x_T, e->x, IC, S, s));  // [C][S] -> [S][C]
   TT_TRY(cast_pad_launch(dt, e->x, IC, e->x_t, IP, S, IC, IP, s));
-  TT_TRY(cast_pad_launch(dt, e->x, IC, offset_t(e->x_t, (size_t)S * IP), IP, S, IC, IP, s));
+  TT_TRY(cast_pad_launch(dt, e->x, IC, offset_t(e->x_t, (size_t)S * IP, e->es), IP, S, IC, IP, s));
   TT_TRY(diff_integrator_all(e, n_steps, 1, row, s));
   int rc = 0;
   if (graphs_enabled()) {
@@ -644,6 +712,15 @@ int tt_diff_split_end(tt_diff* e) {
 int tt_diff_stat(tt_diff* e, int which) {  // 0: sampler-step graph captures so far (tests: the kept graph is reused)
   if (!e) { set_error("tt_diff_stat: null handle"); return -1; }
   return which == 0 ? e->captures : -1;
+}
+
+// TT_DIFF_OPT_OVERLAP_PREPASS [1]: the conditioning-integrator pre-pass runs chunk by chunk on its own stream while the sampler loop
+// walks the steps whose chunks are done (0: the whole pre-pass first, on the one stream - the round-3 order; same results either way).
+int tt_diff_set_option(tt_diff* e, int option, int value) {
+  TT_REQUIRE(e != nullptr, "tt_diff_set_option: null handle");
+  TT_REQUIRE(option == TT_DIFF_OPT_OVERLAP_PREPASS, "tt_diff_set_option: unknown option %d", option);
+  e->overlap_prepass = value != 0;
+  return 0;
 }
 
 // Operand-overflow guard (fp16 operands saturate at 65504): non-finite values met by the GroupNorm statistics / the sampler since

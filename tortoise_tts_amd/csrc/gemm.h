@@ -69,9 +69,9 @@ struct GemmArgs {
   int tmax;
 };
 
-// dtype: DT_BF16 / DT_F16.  Returns 0 or a negative error (message via tt::last_error()).
+// dtype: DT_BF16 / DT_F16 (DT_F32: the slow fp32-operand verification kernel, gemm_f32.hip).  Returns 0 or a negative error (message via tt::last_error()).
 int gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t stream);
 int gemm_init();  // sets dynamic-LDS attributes; called once per process
-int gemm_stat_rows(const GemmArgs& a);  // rows per statistics tile of the kernel gemm_launch would pick for `a`
+int gemm_stat_rows(const GemmArgs& a, int dtype = DT_BF16);  // rows per statistics tile of the kernel gemm_launch would pick for `a`
 
 }  // namespace tt

@@ -10,6 +10,8 @@ extern template int gemm_launch_typed<bf16>(int, const GemmArgs&, const GemmPlan
 extern template int gemm_launch_typed<f16>(int, const GemmArgs&, const GemmPlan&, hipStream_t);
 extern template int gemm_init_typed<bf16>();
 extern template int gemm_init_typed<f16>();
+template <> int gemm_launch_typed<float>(int, const GemmArgs&, const GemmPlan&, hipStream_t);  // gemm_f32.hip (verification mode)
+template <> int gemm_init_typed<float>();
 
 // Tile choice from the problem shape only (measured on MI355X, scripts/kbench.py):
 //   >= 256 tiles of 256x256 : 256x256, 16 waves of 64x64, 2 stages of 64 KB (twice the flops per byte through the per-CU load
@@ -47,8 +49,8 @@ static int prof_class(int tile, int epi, bool conv, bool stats = false) {
 
 // Device argument core: tile grid, XCD row bands (minimise the bytes one XCD pulls over the fabric, A / bands + W * bands / 8),
 // split-K ranges and the reciprocals the kernel divides by.
-static void plan_core(const GemmArgs& a, int epi, GemmPlan& p) {
-  const int tile = pick_tile(a);
+static void plan_core(const GemmArgs& a, int epi, GemmPlan& p, int force_tile = -1) {
+  const int tile = force_tile >= 0 ? force_tile : pick_tile(a);
   const int bm = tile == TILE_64x64 ? 64 : tile == TILE_256x256 ? 256 : 128, bn = tile == TILE_256x256 ? 256 : tile == TILE_128x128 ? 128 : 64;
   GemmCore& c = p.core;
   memset(&c, 0, sizeof(c));
@@ -106,10 +108,10 @@ static void normalise(GemmArgs& a) {
   a.cin = a.K / a.taps;
 }
 
-int gemm_stat_rows(const GemmArgs& a0) {
+int gemm_stat_rows(const GemmArgs& a0, int dtype) {
   GemmArgs a = a0;
   normalise(a);
-  return tile_stat_rows(pick_tile(a));
+  return tile_stat_rows(dtype == DT_F32 ? TILE_64x64 : pick_tile(a));  // (the fp32 verification GEMM has one tile)
 }
 
 int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
@@ -117,7 +119,7 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   normalise(a);
   TT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   TT_REQUIRE(a.K % 64 == 0 && a.cin % 64 == 0, "gemm: K=%d (taps=%d) must be a multiple of 64 per tap", a.K, a.taps);
-  TT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda=%d / ldw=%d must be multiples of 8 elements", a.lda, a.ldw);
+  TT_REQUIRE((a.lda % 8 == 0 && a.ldw % 8 == 0) || (dtype == DT_F32 && a.lda % 4 == 0 && a.ldw % 4 == 0), "gemm: lda=%d / ldw=%d must be multiples of 8 elements", a.lda, a.ldw);
   TT_REQUIRE(a.splitk == 1 || (epi == EPI_STD && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
   TT_REQUIRE(a.splitk <= a.K / 64, "gemm: splitk=%d exceeds the %d k-tiles", a.splitk, a.K / 64);
   if (a.serial_k > 1)
@@ -139,6 +141,11 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   }
   if (a.taps > 1 || epi == EPI_QKV_HEADS) TT_REQUIRE(a.seq_len > 0 && a.M % a.seq_len == 0, "gemm: M=%d is not a whole number of sequences of %d", a.M, a.seq_len);
   GemmPlan plan;
+  if (dtype == DT_F32) {
+    plan_core(a, epi, plan, TILE_64x64);
+    plan.conv3s = false;
+    return gemm_launch_typed<float>(epi, a, plan, stream);
+  }
   plan_core(a, epi, plan);
   if (dtype == DT_BF16) return gemm_launch_typed<bf16>(epi, a, plan, stream);
   if (dtype == DT_F16) return gemm_launch_typed<f16>(epi, a, plan, stream);

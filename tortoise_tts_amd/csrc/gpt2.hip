@@ -23,6 +23,7 @@ struct tt_ar {
   tt_ar_weights w;
   std::vector<tt_gpt_layer> L;
   int D, H, V;
+  int es = 2;               // bytes per operand element (2: bf16 / fp16, 4: the fp32 verification mode)
   int Vp = 0;               // vocabulary padded to a multiple of 4: row stride of the logits and rows of the padded head copy
   void* w_head_p = nullptr; // [Vp][D] T  lm_head weight with zero rows appended (8194 -> 8196: every epilogue access of the head GEMM
   float* b_head_p = nullptr;//            is a whole aligned quad - the run-time-ragged generic kernel cost 24 us per step instead of ~12)
@@ -157,8 +158,8 @@ static int gpt_trunk_full(tt_ar* e, int B, int n, bool to_prefix, hipStream_t s,
     g.bias = w.b_qkv; g.seq_len = n; g.dmodel = D; g.heads = H;
     g.q = e->q;
     const size_t pl = ((size_t)group * e->cfg.layers + l) * e->prefix_layer_elems;
-    g.k = to_prefix ? offset_t(e->kp, pl) : e->kfull;
-    g.v = to_prefix ? offset_t(e->vp, pl) : nullptr;
+    g.k = to_prefix ? offset_t(e->kp, pl, e->es) : e->kfull;
+    g.v = to_prefix ? offset_t(e->vp, pl, e->es) : nullptr;
     g.vt = e->vt; g.seq_pad = n_pad; g.q_scale = 0.125f;
     TT_TRY(gemm_launch(dt, EPI_QKV_HEADS, g, s));
     FlashArgs f;
@@ -239,10 +240,10 @@ static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, 
 static int decode_layers_enqueue(tt_ar* e, hipStream_t s, int row0, int nb, float* slabs) {
   const int D = e->D, H = e->H, dt = e->cfg.dtype;
   float* x = e->x + (size_t)row0 * D;
-  void* h = offset_t(e->h, (size_t)row0 * D);
-  void* ff = offset_t(e->ff, (size_t)row0 * 4 * D);
-  void* attn = offset_t(e->attn, (size_t)row0 * D);
-  void* q = offset_t(e->q, (size_t)row0 * D);
+  void* h = offset_t(e->h, (size_t)row0 * D, e->es);
+  void* ff = offset_t(e->ff, (size_t)row0 * 4 * D, e->es);
+  void* attn = offset_t(e->attn, (size_t)row0 * D, e->es);
+  void* q = offset_t(e->q, (size_t)row0 * D, e->es);
   const size_t seq_elems = (size_t)H * e->tmax * 64;   // per-sequence K (or V) elements of one layer
   const float* pend_bias = nullptr;
   int pend_slabs = 0;
@@ -252,15 +253,15 @@ static int decode_layers_enqueue(tt_ar* e, hipStream_t s, int row0, int nb, floa
     GemmArgs g = ar_gemm(e, h, D, w.w_qkv, D, nb, 3 * D, D);
     g.bias = w.b_qkv; g.dmodel = D; g.heads = H; g.q_scale = 0.125f;
     g.step = e->state + 1; g.qbuf = q;
-    g.kc = offset_t(e->kc, (size_t)l * e->gen_layer_elems + (size_t)row0 * seq_elems);
-    g.vc = offset_t(e->vc, (size_t)l * e->gen_layer_elems + (size_t)row0 * seq_elems);
+    g.kc = offset_t(e->kc, (size_t)l * e->gen_layer_elems + (size_t)row0 * seq_elems, e->es);
+    g.vc = offset_t(e->vc, (size_t)l * e->gen_layer_elems + (size_t)row0 * seq_elems, e->es);
     g.tmax = e->tmax;
     TT_TRY(gemm_launch(dt, EPI_QKV_DECODE, g, s));
     DecodeAttnArgs a;
     memset(&a, 0, sizeof(a));
     a.q = q;
-    a.kp = offset_t(e->kp, (size_t)l * e->prefix_layer_elems);
-    a.vp = offset_t(e->vp, (size_t)l * e->prefix_layer_elems);
+    a.kp = offset_t(e->kp, (size_t)l * e->prefix_layer_elems, e->es);
+    a.vp = offset_t(e->vp, (size_t)l * e->prefix_layer_elems, e->es);
     if (e->G > 1) {  // (utterance groups: always one range, row0 == 0)
       a.ngroups = e->G; a.group_size = nb / e->G;
       a.prefix_group_stride = (size_t)e->cfg.layers * e->prefix_layer_elems;
@@ -371,12 +372,16 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
   TT_REQUIRE(cfg->vocab <= 10240, "tt_ar_create: vocab %d exceeds the sampler's 10240 limit", cfg->vocab);
   TT_REQUIRE(cfg->mel_pos_offset == 1 || cfg->mel_pos_offset == 2, "tt_ar_create: mel_pos_offset must be 2 (kv_cache=True rule) or 1 (kv_cache=False rule), got %d", cfg->mel_pos_offset);
   TT_REQUIRE(cfg->max_groups >= 0 && cfg->max_groups <= 16, "tt_ar_create: max_groups %d outside 0 .. 16", cfg->max_groups);
+  TT_REQUIRE(cfg->dtype == DT_BF16 || cfg->dtype == DT_F16 || cfg->dtype == DT_F32, "tt_ar_create: unknown dtype %d", cfg->dtype);
+  TT_REQUIRE(cfg->dtype != DT_F32 || cfg->max_groups <= 1, "tt_ar_create: the fp32 verification mode decodes one utterance per batch");
   tt_ar* e = new tt_ar();
   e->cfg = *cfg;
   if (e->cfg.max_groups < 1) e->cfg.max_groups = 1;
   e->w = *w;
   e->L.assign(w->layers_host, w->layers_host + cfg->layers);
   e->D = cfg->model_dim; e->H = cfg->heads; e->V = cfg->vocab;
+  e->es = dtype_bytes(cfg->dtype);
+  const size_t es = e->es;
   e->tmax = cfg->max_new_tokens;
   const int D = e->D, H = e->H;
   int rc = e->sb.init();
@@ -385,24 +390,24 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
   e->prefix_layer_elems = (size_t)H * cfg->max_prefix * 64;
   e->gen_layer_elems = (size_t)cfg->max_batch * H * e->tmax * 64;
   const int npad_max = round_up(e->max_rows, 32) + 32;
-  if (!rc) rc = e->arena.alloc(&e->kp, (e->prefix_layer_elems * cfg->layers * e->cfg.max_groups + 4096) * 2);
-  if (!rc) rc = e->arena.alloc(&e->vp, (e->prefix_layer_elems * cfg->layers * e->cfg.max_groups + 4096) * 2);
-  if (!rc) rc = e->arena.alloc(&e->kc, (e->gen_layer_elems * cfg->layers + 4096) * 2);
-  if (!rc) rc = e->arena.alloc(&e->vc, (e->gen_layer_elems * cfg->layers + 4096) * 2);
+  if (!rc) rc = e->arena.alloc(&e->kp, (e->prefix_layer_elems * cfg->layers * e->cfg.max_groups + 4096) * es);
+  if (!rc) rc = e->arena.alloc(&e->vp, (e->prefix_layer_elems * cfg->layers * e->cfg.max_groups + 4096) * es);
+  if (!rc) rc = e->arena.alloc(&e->kc, (e->gen_layer_elems * cfg->layers + 4096) * es);
+  if (!rc) rc = e->arena.alloc(&e->vc, (e->gen_layer_elems * cfg->layers + 4096) * es);
   if (!rc) rc = e->arena.alloc_t(&e->x, rows * D);
-  if (!rc) rc = e->arena.alloc(&e->h, rows * D * 2);
-  if (!rc) rc = e->arena.alloc(&e->ff, rows * 4 * D * 2);
-  if (!rc) rc = e->arena.alloc(&e->attn, rows * D * 2);
-  if (!rc) rc = e->arena.alloc(&e->q, rows * D * 2);
-  if (!rc) rc = e->arena.alloc(&e->kfull, rows * D * 2);
+  if (!rc) rc = e->arena.alloc(&e->h, rows * D * es);
+  if (!rc) rc = e->arena.alloc(&e->ff, rows * 4 * D * es);
+  if (!rc) rc = e->arena.alloc(&e->attn, rows * D * es);
+  if (!rc) rc = e->arena.alloc(&e->q, rows * D * es);
+  if (!rc) rc = e->arena.alloc(&e->kfull, rows * D * es);
   // V^T scratch: per (batch, head) 64 rows of n_pad keys; total keys <= max_rows (+ padding per sequence)
-  if (!rc) rc = e->arena.alloc(&e->vt, ((size_t)H * 64 * ((size_t)npad_max + 32 * (size_t)cfg->max_batch)) * 2);
+  if (!rc) rc = e->arena.alloc(&e->vt, ((size_t)H * 64 * ((size_t)npad_max + 32 * (size_t)cfg->max_batch)) * es);
   if (!rc) rc = e->arena.alloc_t(&e->slabs, (size_t)MAX_SPLIT * cfg->max_batch * D);
   e->Vp = round_up(e->V, 4);
   if (!rc) rc = e->arena.alloc_t(&e->logits, (size_t)cfg->max_batch * e->Vp);
-  if (!rc) rc = e->arena.alloc(&e->w_head_p, (size_t)e->Vp * D * 2);   // (arena memory is zeroed: the padding rows / bias entries are 0)
+  if (!rc) rc = e->arena.alloc(&e->w_head_p, (size_t)e->Vp * D * es);   // (arena memory is zeroed: the padding rows / bias entries are 0)
   if (!rc) rc = e->arena.alloc_t(&e->b_head_p, e->Vp);
-  if (!rc && hipMemcpy(e->w_head_p, w->w_mel_head, (size_t)e->V * D * 2, hipMemcpyDeviceToDevice) != hipSuccess) { set_error("tt_ar_create: copying the head weight failed"); rc = -2; }
+  if (!rc && hipMemcpy(e->w_head_p, w->w_mel_head, (size_t)e->V * D * es, hipMemcpyDeviceToDevice) != hipSuccess) { set_error("tt_ar_create: copying the head weight failed"); rc = -2; }
   if (!rc && hipMemcpy(e->b_head_p, w->b_mel_head, (size_t)e->V * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) { set_error("tt_ar_create: copying the head bias failed"); rc = -2; }
   if (!rc) rc = e->arena.alloc_t(&e->state, 4);
   if (!rc) rc = e->arena.alloc_t(&e->seen, (size_t)cfg->max_batch * ((e->V + 31) / 32));

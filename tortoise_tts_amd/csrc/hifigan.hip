@@ -89,6 +89,7 @@ int tt_hifi_output_frames(int n_latents) {  // F.interpolate output lengths (hif
 }
 
 int tt_hifi_create(const tt_hifi_config* cfg, const tt_hifi_weights* w, tt_hifi** out) {
+  TT_REQUIRE(cfg && (cfg->dtype == DT_BF16 || cfg->dtype == DT_F16), "tt_hifi_create: dtype must be TT_BF16 or TT_F16 (the fp32 verification mode covers the AR / CLVP / diffusion / vocoder stages)");
   TT_REQUIRE(cfg && w && out, "tt_hifi_create: null argument");
   TT_REQUIRE(cfg->num_stages >= 1 && cfg->num_stages <= TT_HIFI_MAX_STAGES && cfg->num_kernels >= 1 && cfg->num_kernels <= 3 &&
              cfg->num_dilations >= 1 && cfg->num_dilations <= 3, "tt_hifi_create: %d stages / %d kernels / %d dilations unsupported", cfg->num_stages, cfg->num_kernels, cfg->num_dilations);

@@ -23,8 +23,7 @@ int geglu_launch(int dtype, const void* in, int ldin, void* out, int ldout, int 
   TT_REQUIRE(inner % 4 == 0 && ldin % 4 == 0 && ldout % 4 == 0, "geglu: dims must be multiples of 4");
   const long total = (long)M * (inner / 4);
   const int blocks = (int)std::min<long>(cdiv64(total, 256), 4096);
-  if (dtype == DT_BF16) geglu_kernel<bf16><<<blocks, 256, 0, stream>>>((const bf16*)in, ldin, (bf16*)out, ldout, M, inner);
-  else geglu_kernel<f16><<<blocks, 256, 0, stream>>>((const f16*)in, ldin, (f16*)out, ldout, M, inner);
+  TT_DISPATCH_T(dtype, T, geglu_kernel<T><<<blocks, 256, 0, stream>>>((const T*)in, ldin, (T*)out, ldout, M, inner));
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -61,8 +60,7 @@ int rotary_launch(int dtype, void* q, void* k, void* vt, const float* inv_freq, 
   TT_REQUIRE(rot > 0 && rot <= 64 && rot % 2 == 0, "rotary: bad rot=%d", rot);
   const long total = (long)BH * n * (rot / 2);
   const int blocks = (int)std::min<long>(cdiv64(total, 256), 8192);
-  if (dtype == DT_BF16) rotary_kernel<bf16><<<blocks, 256, 0, stream>>>((bf16*)q, (bf16*)k, (bf16*)vt, inv_freq, BH, n, n_pad, rot);
-  else rotary_kernel<f16><<<blocks, 256, 0, stream>>>((f16*)q, (f16*)k, (f16*)vt, inv_freq, BH, n, n_pad, rot);
+  TT_DISPATCH_T(dtype, T, rotary_kernel<T><<<blocks, 256, 0, stream>>>((T*)q, (T*)k, (T*)vt, inv_freq, BH, n, n_pad, rot));
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -137,8 +135,7 @@ __global__ void cast_pad_kernel(const float* src, int lds, T* dst, int ldd, int 
 }
 int cast_pad_launch(int dtype, const float* src, int lds, void* dst, int ldd, int rows, int c, int cpad, hipStream_t stream) {
   const int blocks = (int)std::min<long>(cdiv64((long)rows * cpad, 256), 4096);
-  if (dtype == DT_BF16) cast_pad_kernel<bf16><<<blocks, 256, 0, stream>>>(src, lds, (bf16*)dst, ldd, rows, c, cpad);
-  else cast_pad_kernel<f16><<<blocks, 256, 0, stream>>>(src, lds, (f16*)dst, ldd, rows, c, cpad);
+  TT_DISPATCH_T(dtype, T, cast_pad_kernel<T><<<blocks, 256, 0, stream>>>(src, lds, (T*)dst, ldd, rows, c, cpad));
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -196,8 +193,7 @@ __global__ void silu_cast_kernel(const float* src, T* dst, int n) {
 }
 int silu_cast_launch(int dtype, const float* src, void* dst, int n, hipStream_t stream) {
   const int blocks = std::min(cdiv(n, 256), 4096);
-  if (dtype == DT_BF16) silu_cast_kernel<bf16><<<blocks, 256, 0, stream>>>(src, (bf16*)dst, n);
-  else silu_cast_kernel<f16><<<blocks, 256, 0, stream>>>(src, (f16*)dst, n);
+  TT_DISPATCH_T(dtype, T, silu_cast_kernel<T><<<blocks, 256, 0, stream>>>(src, (T*)dst, n));
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -271,8 +267,7 @@ int slot_advance_launch(int* slot, const float* ss_all, float* ss_cur, int row_f
 }
 int psample_launch(int dtype, const PSampleArgs& a, hipStream_t stream) {
   const int blocks = (int)std::min<long>(cdiv64((long)a.S * a.cpad, 256), 4096);
-  if (dtype == DT_BF16) psample_kernel<bf16><<<blocks, 256, 0, stream>>>(a);
-  else psample_kernel<f16><<<blocks, 256, 0, stream>>>(a);
+  TT_DISPATCH_T(dtype, T, psample_kernel<T><<<blocks, 256, 0, stream>>>(a));
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }

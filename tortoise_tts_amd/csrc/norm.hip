@@ -302,14 +302,11 @@ int rownorm_launch(int dtype, const RowNormArgs& a, hipStream_t stream) {
   ProfScope ps(PROF_ROWNORM, stream, 0.0, (double)a.M * a.D * (4.0 * (1 + a.nslab + (a.write_x ? 1 : 0)) + (a.out_t ? 2.0 : 0.0) + (a.out_f32 ? 4.0 : 0.0)), true);
   // few rows (decode): one block per row keeps 4x more loads in flight; many rows: wave per row, no barriers
   if (a.D <= 1024 && a.M >= 1024 && !a.row_blocks) {
-    if (dtype == DT_BF16) launch_timed(ps, rownorm_wave_kernel<bf16>, dim3(cdiv(a.M, 4)), dim3(256), 0, stream, a);
-    else launch_timed(ps, rownorm_wave_kernel<f16>, dim3(cdiv(a.M, 4)), dim3(256), 0, stream, a);
+    TT_DISPATCH_T(dtype, T, launch_timed(ps, rownorm_wave_kernel<T>, dim3(cdiv(a.M, 4)), dim3(256), 0, stream, a));
   } else {
-    const bool narrow = dtype == DT_BF16 ? rownorm_narrow_launch<bf16>(ps, a, stream) : rownorm_narrow_launch<f16>(ps, a, stream);
-    if (!narrow) {
-      if (dtype == DT_BF16) launch_timed(ps, rownorm_kernel<bf16, -1>, dim3(a.M), dim3(256), 0, stream, a);
-      else launch_timed(ps, rownorm_kernel<f16, -1>, dim3(a.M), dim3(256), 0, stream, a);
-    }
+    bool narrow = false;
+    TT_DISPATCH_T(dtype, T, narrow = rownorm_narrow_launch<T>(ps, a, stream));
+    if (!narrow) TT_DISPATCH_T(dtype, T, launch_timed(ps, (rownorm_kernel<T, -1>), dim3(a.M), dim3(256), 0, stream, a));
   }
   TT_CHECK_HIP(hipGetLastError());
   return 0;
@@ -593,7 +590,7 @@ int groupnorm_launch(int dtype, const GroupNormArgs& a0, hipStream_t stream) {
   const int rpb = few ? 2 : GN_APPLY_ROWS;  // apply is pure streaming: many small blocks
   dim3 grid2(cdiv(a.S, rpb), a.B);
   if (a.C == 1024) {
-    const int variant = (dtype == DT_BF16 ? 0 : 4) + (a.gemm_part ? 2 : 0) + (a.scale_shift ? 1 : 0);
+    const int variant = (dtype == DT_BF16 ? 0 : dtype == DT_F16 ? 4 : 8) + (a.gemm_part ? 2 : 0) + (a.scale_shift ? 1 : 0);
 #define TT_GN(T, F, SSV)                                                                                              \
     do {                                                                                                                \
       if (few) launch_timed(ps, gn_apply_c1024_kernel<T, F, SSV, 2>, grid2, dim3(256), 0, stream, a, nchunk);          \
@@ -607,12 +604,15 @@ int groupnorm_launch(int dtype, const GroupNormArgs& a0, hipStream_t stream) {
       case 4: TT_GN(f16, false, false); break;
       case 5: TT_GN(f16, false, true); break;
       case 6: TT_GN(f16, true, false); break;
-      default: TT_GN(f16, true, true); break;
+      case 7: TT_GN(f16, true, true); break;
+      case 8: TT_GN(float, false, false); break;   // (the fp32 verification mode)
+      case 9: TT_GN(float, false, true); break;
+      case 10: TT_GN(float, true, false); break;
+      default: TT_GN(float, true, true); break;
     }
 #undef TT_GN
   } else {
-    if (dtype == DT_BF16) launch_timed(ps, gn_apply_kernel<bf16>, grid2, dim3(256), 0, stream, a, nchunk, rpc, rpb);
-    else launch_timed(ps, gn_apply_kernel<f16>, grid2, dim3(256), 0, stream, a, nchunk, rpc, rpb);
+    TT_DISPATCH_T(dtype, T, launch_timed(ps, gn_apply_kernel<T>, grid2, dim3(256), 0, stream, a, nchunk, rpc, rpb));
   }
   TT_CHECK_HIP(hipGetLastError());
   return 0;

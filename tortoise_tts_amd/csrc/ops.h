@@ -88,6 +88,7 @@ struct FlashArgs {
   int variant;  // 0: chosen from the shape; 1: never the key-split form (microbenchmarks / A-B runs)
 };
 int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream);
+int flash_f32_launch(const FlashArgs& a, hipStream_t stream);  // fp32 verification mode (attention_f32.hip)
 
 struct DecodeAttnArgs {
   const void* q;    // [B][heads*64], pre-scaled
@@ -109,6 +110,7 @@ struct DecodeAttnArgs {
   int p1_tab[16];
 };
 int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stream);
+int decode_attn_f32_launch(const DecodeAttnArgs& a, hipStream_t stream);  // fp32 verification mode (attention_f32.hip)
 
 // ------------------------------------------------------------------------------ AR sampling
 struct SampleArgs {

@@ -83,9 +83,10 @@ static inline GemmArgs gemm_args(const void* A, int lda, const void* W, int ldw,
   return g;
 }
 
-static inline int elem_size(int dtype) { return 2; }
-static inline void* offset_t(void* p, size_t elems) { return (void*)((char*)p + elems * 2); }
-static inline const void* offset_t(const void* p, size_t elems) { return (const void*)((const char*)p + elems * 2); }
+static inline int elem_size(int dtype) { return dtype_bytes(dtype); }
+// p + elems operand elements of `es` bytes (2: bf16 / fp16, 4: the fp32 verification mode)
+static inline void* offset_t(void* p, size_t elems, int es = 2) { return (void*)((char*)p + elems * es); }
+static inline const void* offset_t(const void* p, size_t elems, int es = 2) { return (const void*)((const char*)p + elems * es); }
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace tt

@@ -49,12 +49,13 @@ int tt_voc_create(const tt_voc_config* cfg, const tt_voc_weights* w, tt_voc** ou
   for (int i = 0; i < 3; ++i) hop *= e->blocks[i].stride;
   const size_t T = L * hop;
   int rc = e->sb.init();
+  const size_t es = dtype_bytes(cfg->dtype);  // (4: the fp32 verification mode)
   if (!rc) rc = e->arena.alloc_t(&e->c_cf, L * cfg->mel_channels);
   if (!rc) rc = e->arena.alloc_t(&e->c_tm, L * cfg->mel_channels);
-  if (!rc) rc = e->arena.alloc(&e->c_t, (L + 8) * cfg->mel_pad * 2);
+  if (!rc) rc = e->arena.alloc(&e->c_t, (L + 8) * cfg->mel_pad * es);
   if (!rc) rc = e->arena.alloc_t(&e->kp_h, (L + 8) * 64);
-  if (!rc) rc = e->arena.alloc(&e->kp_ht, (L + 8) * 64 * 2);
-  if (!rc) rc = e->arena.alloc(&e->kp_t1, (L + 8) * 64 * 2);
+  if (!rc) rc = e->arena.alloc(&e->kp_ht, (L + 8) * 64 * es);
+  if (!rc) rc = e->arena.alloc(&e->kp_t1, (L + 8) * 64 * es);
   if (!rc) rc = e->arena.alloc_t(&e->kernels, L * 24576);
   if (!rc) rc = e->arena.alloc_t(&e->kbias, L * 256);
   if (!rc) rc = e->arena.alloc_t(&e->xa, 32 * T);

@@ -9,9 +9,10 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TORTOISE_MI355X_LIB") or os.path.join(HERE, "lib", "libtortoise_mi355x.so")  # env: an alternative build of the same ABI
 
-TT_BF16, TT_F16 = 0, 1
-DTYPE_NAMES = {TT_BF16: "bf16", TT_F16: "fp16"}
+TT_BF16, TT_F16, TT_F32 = 0, 1, 2  # TT_F32: the slow fp32-operand VERIFICATION mode of the AR / CLVP / diffusion / vocoder stages (tests)
+DTYPE_NAMES = {TT_BF16: "bf16", TT_F16: "fp16", TT_F32: "fp32"}
 TT_AR_OPT_SUBBATCHES, TT_AR_OPT_LOOKAHEAD = 1, 4
+TT_DIFF_OPT_OVERLAP_PREPASS = 1
 
 
 def dtype_code(name):
@@ -19,9 +20,9 @@ def dtype_code(name):
     if isinstance(name, int):
         return name
     try:
-        return {"bf16": TT_BF16, "fp16": TT_F16, "f16": TT_F16}[name]
+        return {"bf16": TT_BF16, "fp16": TT_F16, "f16": TT_F16, "fp32": TT_F32, "f32": TT_F32}[name]
     except KeyError:
-        raise ValueError(f"unknown operand type {name!r} (bf16 | fp16)") from None
+        raise ValueError(f"unknown operand type {name!r} (bf16 | fp16; fp32 = the slow verification mode)") from None
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3, 4, 5
 
 vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers are passed as integers
@@ -158,6 +159,7 @@ _PROTOS = {
     "tt_ar_guard": (_i, [vp, _i]),
     "tt_ar_stat": (_i, [vp, _i]),
     "tt_diff_stat": (_i, [vp, _i]),
+    "tt_diff_set_option": (_i, [vp, _i, _i]),
     "tt_clvp_guard": (_i, [vp, _i]),
     "tt_diff_guard": (_i, [vp, _i]),
     "tt_clvp_create": (_i, [C.POINTER(ClvpConfig), C.POINTER(ClvpTower), C.POINTER(ClvpTower), vp, C.POINTER(vp)]),

@@ -16,7 +16,7 @@ from .config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
 
 
 def torch_dtype(dtype):
-    return torch.bfloat16 if dtype == E.TT_BF16 else torch.float16
+    return {E.TT_BF16: torch.bfloat16, E.TT_F16: torch.float16, E.TT_F32: torch.float32}[dtype]
 
 
 class Holder:

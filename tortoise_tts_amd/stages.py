@@ -274,6 +274,11 @@ class DiffusionStage:
         self.h = E.vp()
         E.check(self.lib.tt_diff_create(C.byref(c), C.byref(self.w.weights), C.byref(self.h)))
         self.S = 0
+        if os.environ.get("TT_DIFF_OVERLAP_PREPASS"):  # A/B switch of the measurement scripts
+            self.set_option(E.TT_DIFF_OPT_OVERLAP_PREPASS, int(os.environ["TT_DIFF_OVERLAP_PREPASS"]))
+
+    def set_option(self, option, value):
+        E.check(self.lib.tt_diff_set_option(self.h, int(option), int(value)))
 
     def close(self):
         if self.h:
