@@ -65,7 +65,11 @@ def _worker(rank, world, port, out_dir):
 
 
 def test_tts_control_flow_on_eight_ranks_equals_one_process(tmp_path):
-    _worker(0, 1, 0, str(tmp_path))
+    prev = torch.get_num_threads()  # (the workers run single-threaded: so does the in-process reference, and the setting is put back)
+    try:
+        _worker(0, 1, 0, str(tmp_path))
+    finally:
+        torch.set_num_threads(prev)
     mp.spawn(_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
     a = torch.load(tmp_path / "tts_w1.pt")
     b = torch.load(tmp_path / "tts_w8.pt")

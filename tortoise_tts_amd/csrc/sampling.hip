@@ -37,6 +37,19 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// Strictly sequential (left to right) sum of x[0 .. n) in LDS, computed redundantly by every lane of ONE wave: the values are read 64
+// at a time into a register per lane and handed out with v_readlane (a few cycles each) instead of one dependent LDS round trip
+// (~100 cycles at one wave per SIMD) per element.  Same additions in the same order as `for (i) acc += x[i]`.
+__device__ __forceinline__ float seq_sum_lds(const float* x, int n, int lane) {
+  float acc = 0.f;
+  for (int base = 0; base < n; base += 64) {
+    const float v = base + lane < n ? x[base + lane] : 0.f;
+    const int cnt = min(64, n - base);
+    for (int j = 0; j < cnt; ++j) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+  }
+  return acc;
+}
+
 // one thread: finished rows emit the stop token (stream_generator.py:980-996), bookkeeping of the sampled token; returns it
 __device__ __forceinline__ int sample_commit(const SampleArgs& a, int b, int step, int best_i, unsigned* seen) {
   // a row of non-finite logits (an overflowed operand upstream: the guard has counted it) never beats the initial candidate: such a
@@ -68,10 +81,10 @@ __device__ __forceinline__ void sample_embed(const SampleArgs& a, int b, int ste
 }
 
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
-  __shared__ unsigned hist[256];
-  __shared__ unsigned sel_prefix, sel_remaining;
+  __shared__ float cnt_s[2][3][4];
   __shared__ unsigned wtot[4];
-  __shared__ int nsurv;
+  __shared__ int nsurv, ncand;
+  __shared__ unsigned kth_s;
   __shared__ float sv[SURV_CAP];
   __shared__ int si[SURV_CAP];
   __shared__ float sorted_v[SURV_CAP];
@@ -94,162 +107,260 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   constexpr int PER = 40;  // supports V <= 10240
   float val[PER];
   bool bad = false;  // NaN / +inf logits: an operand overflowed somewhere upstream (-inf is legitimate: a suppressed token)
+  {
+    // every load unconditional (index clamped) and requested before the first use: a `t < V` branch around the loads made the
+    // compiler issue them one round trip at a time - 33 dependent global-memory latencies, 20 us of the 48 us this kernel took
+    float raw[PER];
+    unsigned sw[PER];
 #pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const int t = tid + 256 * j;
-    float s = -INFINITY;
-    if (t < V) {
-      s = lg[t];
-      bad = bad || s != s || s == INFINITY;
-      if (a.rep_penalty != 1.0f && ((seen[t >> 5] >> (t & 31)) & 1u)) s = s < 0.f ? s * a.rep_penalty : s / a.rep_penalty;
-      if (a.temperature != 1.0f) s = s / a.temperature;
+    for (int j = 0; j < PER; ++j) {
+      const int tc = min(tid + 256 * j, V - 1);
+      raw[j] = lg[tc];
+      sw[j] = seen[tc >> 5];
     }
-    val[j] = s;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int t = tid + 256 * j;
+      float s = raw[j];
+      const bool live = t < V;
+      bad = bad || (live && (s != s || s == INFINITY));
+      if (a.rep_penalty != 1.0f && ((sw[j] >> (t & 31)) & 1u)) s = s < 0.f ? s * a.rep_penalty : s / a.rep_penalty;
+      if (a.temperature != 1.0f) s = s / a.temperature;
+      val[j] = live ? s : -INFINITY;
+    }
   }
   if (a.guard && __ballot(bad) != 0ull && (tid & 63) == 0) atomicAdd(a.guard, 1);
 
-  // ---- top-k threshold: radix-select the k-th largest key (4 passes of 8 bits)
+  // ---- top-k (ties kept) + order.  k (<= 256) is tiny against the vocabulary, so the work runs on a small candidate set:
+  //   1. a lower bound L of the k-th largest key: the k-th largest of the 256 per-thread maxima, to 16 bits (k keys are >= it) -
+  //      "greatest t with count(max >= t) >= k", two bits per round by counting: one compare per thread, DPP wave sums, 8 rounds;
+  //   2. every (score, token) with key >= L is a candidate (typically 60 - 120 of 8194);
+  //   3. among the candidates, by counting over the LDS: the k-th largest key = the top-k threshold (scores below it drop out, ties at
+  //      it stay: TopKLogitsWarper), then each survivor's rank in (score descending, token ascending) order.
+  // A plateau of equal scores that overflows the candidate buffer, or k beyond the populated threads, takes the generic path: the
+  // same counting search over all register-resident keys, 16 rounds.  (Round 3's radix select put ~8 000 LDS atomicAdds on three or
+  // four bins in its first pass: logits share their sign / exponent byte.)
   const int k = a.top_k < V ? a.top_k : V;
-  if (tid == 0) {
-    sel_prefix = 0u;
-    sel_remaining = (unsigned)k;
-    nsurv = 0;
-  }
-  __syncthreads();
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    hist[tid] = 0u;
-    __syncthreads();
-    const unsigned prefix = sel_prefix, rem = sel_remaining;
-    const unsigned mask_hi = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int t = tid + 256 * j;
-      if (t < V) {
-        const unsigned key = f2key(val[j]);
-        if ((key & mask_hi) == (prefix & mask_hi)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-      }
-    }
-    __syncthreads();
-    // digit d of the k-th largest key: the one with  count(digits > d) < rem <= count(digits >= d).  Suffix sums of the
-    // 256 bins by wave shuffles (bin = thread), not a serial scan by one thread (256 dependent LDS reads per pass).
-    const unsigned c = hist[tid];
-    unsigned sfx = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned t = __shfl_down(sfx, o, 64);
-      if ((tid & 63) + o < 64) sfx += t;
-    }
-    if ((tid & 63) == 0) wtot[tid >> 6] = sfx;
-    __syncthreads();
-    unsigned above = 0u;
-    for (int w = (tid >> 6) + 1; w < 4; ++w) above += wtot[w];
-    const unsigned ge = sfx + above, gt = ge - c;
-    if (ge >= rem && gt < rem) {  // exactly one bin
-      sel_prefix = prefix | ((unsigned)tid << shift);
-      sel_remaining = rem - gt;
-    }
-    __syncthreads();
-  }
-  const unsigned kth = sel_prefix;  // key of the k-th largest score; everything >= kth survives (ties kept)
+  unsigned key[PER];
+  unsigned tmax = 0u;
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
-    const int t = tid + 256 * j;
-    if (t < V && f2key(val[j]) >= kth) {
-      const int slot = atomicAdd(&nsurv, 1);
-      if (slot < SURV_CAP) {
-        sv[slot] = val[j];
-        si[slot] = t;
+    key[j] = tid + 256 * j < V ? f2key(val[j]) : 0u;  // (real keys are > 0: f2key(-inf) = 0x007FFFFF)
+    tmax = max(tmax, key[j]);
+  }
+  if (tid == 0) {
+    nsurv = 0;
+    ncand = 0;
+  }
+  const float kf = (float)k;
+  int round = 0;
+  unsigned lower = 0u;
+#pragma unroll 1
+  for (int bit = 30; bit >= 16; bit -= 2, ++round) {
+    const unsigned c1 = lower | (1u << bit), c2 = lower | (2u << bit), c3 = lower | (3u << bit);
+    const float n1 = wave_sum(tmax >= c1 ? 1.f : 0.f), n2 = wave_sum(tmax >= c2 ? 1.f : 0.f), n3 = wave_sum(tmax >= c3 ? 1.f : 0.f);
+    float* cs = &cnt_s[round & 1][0][0];
+    if ((tid & 63) == 0) {
+      cs[0 * 4 + (tid >> 6)] = n1;
+      cs[1 * 4 + (tid >> 6)] = n2;
+      cs[2 * 4 + (tid >> 6)] = n3;
+    }
+    __syncthreads();  // (one barrier per round: the next round writes the other buffer)
+    const float t1 = cs[0] + cs[1] + cs[2] + cs[3], t2 = cs[4] + cs[5] + cs[6] + cs[7], t3 = cs[8] + cs[9] + cs[10] + cs[11];
+    lower = t3 >= kf ? c3 : t2 >= kf ? c2 : t1 >= kf ? c1 : lower;
+  }
+  if (lower > 0u) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      if (key[j] >= lower) {
+        const int slot = atomicAdd(&ncand, 1);
+        if (slot < SURV_CAP) {
+          sv[slot] = val[j];
+          si[slot] = tid + 256 * j;
+        }
       }
     }
   }
   __syncthreads();
-  if (nsurv > SURV_CAP) {
-    // Degenerate plateau: more than SURV_CAP scores tie at the k-th value (HF keeps them all).  The slots above were handed out in
-    // atomic order, i.e. run-dependent: redo the selection deterministically - everything strictly above the k-th value (< k
-    // entries), then the ties in ascending token order until the buffer is full.  (block-uniform branch: nsurv is shared)
-    __syncthreads();
-    if (tid == 0) nsurv = 0;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int t = tid + 256 * j;
-      if (t < V && f2key(val[j]) > kth) {
-        const int slot = atomicAdd(&nsurv, 1);
-        sv[slot] = val[j];
-        si[slot] = t;
+  const bool fast = lower > 0u && ncand <= SURV_CAP;  // (block-uniform)
+  if (fast) {
+    const int nc = ncand;
+    // the k-th largest candidate key and the number of candidates >= it
+    for (int i = tid; i < nc; i += 256) {
+      const unsigned ki = f2key(sv[i]);
+      int g = 0, ge = 0;
+#pragma unroll 8
+      for (int j = 0; j < nc; ++j) {
+        const unsigned kj = f2key(sv[j]);
+        g += kj > ki ? 1 : 0;
+        ge += kj >= ki ? 1 : 0;
+      }
+      if (g < k && k <= ge) {  // (every thread that qualifies writes the same pair)
+        kth_s = ki;
+        nsurv = ge;
       }
     }
     __syncthreads();
-    int base = nsurv;
-    // (fully unrolled although it is the rare path: a run-time index into val[] would move the whole array to scratch memory -
-    // 160 bytes per lane written and re-read five times by EVERY launch, 10.5 MB per decode step at 256 candidates)
+    const unsigned kth = kth_s;
+    for (int i = tid; i < nc; i += 256) {
+      const float v = sv[i];
+      if (f2key(v) < kth) continue;
+      const int id = si[i];
+      int rank = 0;
+#pragma unroll 8
+      for (int j = 0; j < nc; ++j) {
+        const float w = sv[j];
+        rank += (f2key(w) >= kth && ((w > v) || (w == v && si[j] < id))) ? 1 : 0;
+      }
+      sorted_v[rank] = v;
+      sorted_i[rank] = id;
+    }
+    __syncthreads();
+  } else {
+    __syncthreads();
+    if (tid == 0) nsurv = 0;
+    unsigned thr = 0u;
+#pragma unroll 1
+    for (int bit = 30; bit >= 0; bit -= 2, ++round) {
+      const unsigned c1 = thr | (1u << bit), c2 = thr | (2u << bit), c3 = thr | (3u << bit);
+      float n1 = 0.f, n2 = 0.f, n3 = 0.f;  // counts <= 10 240: exact in fp32
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {  // (fully unrolled: a run-time index into key[] would move the array to scratch memory)
+        n1 += key[j] >= c1 ? 1.f : 0.f;
+        n2 += key[j] >= c2 ? 1.f : 0.f;
+        n3 += key[j] >= c3 ? 1.f : 0.f;
+      }
+      n1 = wave_sum(n1); n2 = wave_sum(n2); n3 = wave_sum(n3);
+      float* cs = &cnt_s[round & 1][0][0];
+      if ((tid & 63) == 0) {
+        cs[0 * 4 + (tid >> 6)] = n1;
+        cs[1 * 4 + (tid >> 6)] = n2;
+        cs[2 * 4 + (tid >> 6)] = n3;
+      }
+      __syncthreads();
+      const float t1 = cs[0] + cs[1] + cs[2] + cs[3], t2 = cs[4] + cs[5] + cs[6] + cs[7], t3 = cs[8] + cs[9] + cs[10] + cs[11];
+      thr = t3 >= kf ? c3 : t2 >= kf ? c2 : t1 >= kf ? c1 : thr;
+    }
+    const unsigned kth = thr;  // key of the k-th largest score; everything >= kth survives (ties kept)
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-      if (base < SURV_CAP) {  // block-uniform
-        const int t = tid + 256 * j;
-        const bool tie = t < V && f2key(val[j]) == kth;
-        const unsigned long long m = __ballot(tie);
-        const int before = __popcll(m & ((1ull << (tid & 63)) - 1ull));
-        if ((tid & 63) == 0) wtot[tid >> 6] = (unsigned)__popcll(m);
-        __syncthreads();
-        int off = base, total = 0;
-        for (int w = 0; w < 4; ++w) {
-          if (w < (tid >> 6)) off += (int)wtot[w];
-          total += (int)wtot[w];
-        }
-        const int slot = off + before;
-        if (tie && slot < SURV_CAP) {
+      const int t = tid + 256 * j;
+      if (t < V && key[j] >= kth) {
+        const int slot = atomicAdd(&nsurv, 1);
+        if (slot < SURV_CAP) {
           sv[slot] = val[j];
           si[slot] = t;
         }
-        base += total;
-        __syncthreads();
       }
     }
-    if (tid == 0) nsurv = base;
+    __syncthreads();
+    if (nsurv > SURV_CAP) {
+      // Degenerate plateau: more than SURV_CAP scores tie at the k-th value (HF keeps them all).  The slots above were handed out in
+      // atomic order, i.e. run-dependent: redo the selection deterministically - everything strictly above the k-th value (< k
+      // entries), then the ties in ascending token order until the buffer is full.  (block-uniform branch: nsurv is shared)
+      __syncthreads();
+      if (tid == 0) nsurv = 0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int t = tid + 256 * j;
+        if (t < V && key[j] > kth) {
+          const int slot = atomicAdd(&nsurv, 1);
+          sv[slot] = val[j];
+          si[slot] = t;
+        }
+      }
+      __syncthreads();
+      int base = nsurv;
+      // (fully unrolled although it is the rare path: a run-time index into val[] would move the whole array to scratch memory)
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        if (base < SURV_CAP) {  // block-uniform
+          const int t = tid + 256 * j;
+          const bool tie = t < V && key[j] == kth;
+          const unsigned long long m = __ballot(tie);
+          const int before = __popcll(m & ((1ull << (tid & 63)) - 1ull));
+          if ((tid & 63) == 0) wtot[tid >> 6] = (unsigned)__popcll(m);
+          __syncthreads();
+          int off = base, total = 0;
+          for (int w = 0; w < 4; ++w) {
+            if (w < (tid >> 6)) off += (int)wtot[w];
+            total += (int)wtot[w];
+          }
+          const int slot = off + before;
+          if (tie && slot < SURV_CAP) {
+            sv[slot] = val[j];
+            si[slot] = t;
+          }
+          base += total;
+          __syncthreads();
+        }
+      }
+      if (tid == 0) nsurv = base;
+      __syncthreads();
+    }
+    const int ns = nsurv < SURV_CAP ? nsurv : SURV_CAP;
+    // rank sort: descending score, ascending index on ties (deterministic irrespective of slot order)
+    for (int i = tid; i < ns; i += 256) {
+      const float v = sv[i];
+      const int id = si[i];
+      int rank = 0;
+#pragma unroll 8
+      for (int j = 0; j < ns; ++j) {
+        const float w = sv[j];
+        rank += (w > v) || (w == v && si[j] < id);
+      }
+      sorted_v[rank] = v;
+      sorted_i[rank] = id;
+    }
     __syncthreads();
   }
   const int n = nsurv < SURV_CAP ? nsurv : SURV_CAP;
-  // ---- rank sort: descending score, ascending index on ties (deterministic irrespective of slot order)
-  for (int i = tid; i < n; i += 256) {
-    const float v = sv[i];
-    const int id = si[i];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) {
-      const float w = sv[j];
-      rank += (w > v) || (w == v && si[j] < id);
-    }
-    sorted_v[rank] = v;
-    sorted_i[rank] = id;
-  }
-  __syncthreads();
   // ---- top-p on the survivors (everything else already has probability 0).  The exponentials are evaluated by all
   // threads; the three sums stay sequential in index order (one thread, n <= a few dozen adds) so the kept set is decided
   // with exactly the arithmetic the oracle's cumulative sum uses.
   for (int i = tid; i < n; i += 256) sv[i] = __expf(sorted_v[i] - sorted_v[0]);  // sv is free after the rank sort
   __syncthreads();
-  if (tid == 0) {
-    float total = 0.f;
-    for (int i = 0; i < n; ++i) total += sv[i];
+  if (tid < 64) {  // (wave 0; every lane gets the same sum)
+    const float total = seq_sum_lds(sv, n, tid);
+    if (tid == 0) kept_total = total;  // (parked here for the parallel divisions below; overwritten with the kept sum afterwards)
+  }
+  __syncthreads();
+  {  // the probabilities sv[r] / total, by all threads (the same IEEE division one thread did serially in round 3); si is free
+    const float total = kept_total;
+    float* pr = (float*)si;
+    for (int i = tid; i < n; i += 256) pr[i] = sv[i] / total;
+  }
+  __syncthreads();
+  if (tid < 64) {  // wave 0, every lane redundantly: the same sequential arithmetic as one thread walking the arrays
+    const float* pr = (const float*)si;
     int keep = n;
     if (a.top_p < 1.0f) {
       float tail = 0.f;
       keep = 1;
       const float thr = 1.0f - a.top_p;
       // ascending cumulative probability of element r == sum of probabilities of elements r..n-1
-      for (int r = n - 1; r >= 1; --r) {
-        tail += sv[r] / total;
-        if (tail > thr) {
-          keep = r + 1;
-          break;
+      bool done = false;
+      for (int hi = n - 1; hi >= 1 && !done; hi -= 64) {  // elements hi, hi - 1, ... in chunks of 64 (lane j holds element hi - j)
+        const int r_l = hi - tid;
+        const float v = r_l >= 1 ? pr[r_l] : 0.f;
+        const int cnt = min(64, hi);
+        for (int j = 0; j < cnt; ++j) {
+          tail += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+          if (tail > thr) {
+            keep = hi - j + 1;
+            done = true;
+            break;
+          }
         }
       }
     }
-    float kt = 0.f;
-    for (int i = 0; i < keep; ++i) kt += sv[i];
-    kept = keep;
-    kept_total = kt;
+    const float kt = seq_sum_lds(sv, keep, tid);
+    if (tid == 0) {
+      kept = keep;
+      kept_total = kt;
+    }
   }
   __syncthreads();
   // ---- multinomial == argmax(p / q)
