@@ -59,7 +59,8 @@ struct tt_diff {
   hipStream_t pre_stream = nullptr;          // the pre-pass's stream
   hipEvent_t ev_pre_start = nullptr;
   std::vector<hipEvent_t> ev_chunk;          // chunk c of the pre-pass is complete
-  int overlap_prepass = 1;                   // 0: pre-pass on the main stream in front of the loop (round 3 behaviour; A/B switch)
+  int overlap_prepass = 1;                   // 0: pre-pass on the main stream in front of the loop (round 3); 1: chunks on their own stream, all enqueued up front;
+                                             // 2: chunk c + 1 enqueued right before the steps of chunk c (A/B: 297.6 / 294.9 / 296.3 ms, profiles/r04_ab_geometry.txt)
   void* cat = nullptr;         // [2S][C] T     inp_block(x) of the current step (left half of the integrating conv's K)
   void* integ_all = nullptr;   // [steps][B][S][C] T  conditioning_timestep_integrator output of every step (right half of K)
   float* rep_in = nullptr;     // [chunk samples][S][C] f32: code_emb rows repeated per timestep (batched integrator input)
@@ -526,14 +527,25 @@ static int diff_sample_run(tt_diff* e, const float* const* x_T, const float* con
   if (!rc && overlap) {
     if (hipEventRecord(e->ev_pre_start, s) != hipSuccess || hipStreamWaitEvent(ps, e->ev_pre_start, 0) != hipSuccess) { set_error("tt_diff_sample: fork failed"); rc = -2; }
   }
-  for (int c = 0; c < nchunks && !rc; ++c) {
-    rc = diff_integrator_chunk(e, e->wk[1], c * per, std::min(per, n_steps - c * per), B, 0, ps);
-    if (!rc && overlap && hipEventRecord(e->ev_chunk[c], ps) != hipSuccess) { set_error("tt_diff_sample: event record failed"); rc = -2; }
-  }
+  // chunk c is enqueued (on the pre-pass stream) right before the loop steps of chunk c - 1 are launched, so the main stream's first
+  // step is in the queue after ONE chunk's worth of host launches, not after all of them (eager launches: ~0.4 ms of host time per chunk)
+  int chunks_enqueued = 0;
+  auto enqueue_chunk = [&]() -> int {
+    const int c = chunks_enqueued++;
+    TT_TRY(diff_integrator_chunk(e, e->wk[1], c * per, std::min(per, n_steps - c * per), B, 0, ps));
+    if (overlap) TT_CHECK_HIP(hipEventRecord(e->ev_chunk[c], ps));
+    return 0;
+  };
+  if (!rc) rc = enqueue_chunk();
+  if (!overlap || e->overlap_prepass == 1)  // (1: every chunk goes out before the first step; 2: chunk c + 1 right before the steps of chunk c)
+    while (!rc && chunks_enqueued < nchunks) rc = enqueue_chunk();
   e->integ_B = B;
   e->integ_n = n_steps;
   auto chunk_gate = [&](int step) -> int {  // in front of step `step`: its integrator slice must be there
-    if (overlap && step % per == 0) TT_CHECK_HIP(hipStreamWaitEvent(s, e->ev_chunk[step / per], 0));
+    if (overlap && step % per == 0) {
+      if (chunks_enqueued < nchunks) TT_TRY(enqueue_chunk());  // the NEXT chunk goes out before this chunk's steps
+      TT_CHECK_HIP(hipStreamWaitEvent(s, e->ev_chunk[step / per], 0));
+    }
     return 0;
   };
   std::vector<PSampleArgs> pa(U);
@@ -719,7 +731,7 @@ int tt_diff_stat(tt_diff* e, int which) {  // 0: sampler-step graph captures so 
 int tt_diff_set_option(tt_diff* e, int option, int value) {
   TT_REQUIRE(e != nullptr, "tt_diff_set_option: null handle");
   TT_REQUIRE(option == TT_DIFF_OPT_OVERLAP_PREPASS, "tt_diff_set_option: unknown option %d", option);
-  e->overlap_prepass = value != 0;
+  e->overlap_prepass = value < 0 ? 0 : value > 2 ? 2 : value;
   return 0;
 }
 

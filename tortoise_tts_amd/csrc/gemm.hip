@@ -37,7 +37,7 @@ static int pick_tile(const GemmArgs& a) {
 }
 
 // rows per statistics tile (= the wave tile height TM of the kernel that pick_tile selects)
-static int tile_stat_rows(int tile) { return tile >= TILE_128x128 ? 64 : 32; }  // 256x256: 4 x 4 waves; 128x128: 2 x 4; 128x64: 4 x 2; 64x64: 2 x 2
+static int tile_stat_rows(int tile) { return (tile == TILE_128x128 || tile == TILE_256x256) ? 64 : 32; }  // 256x256: 4 x 4 waves; 128x128: 2 x 4; 128x64: 4 x 2; 64x64: 2 x 2
 
 // ProfScope classes: (tile, epilogue, conv?) -> one class per kernel that actually runs
 static int prof_class(int tile, int epi, bool conv, bool stats = false) {

@@ -952,6 +952,8 @@ static int visit_qkv(int tile, V&& v) {
   switch (tile) {
     case TILE_256x256: return v(KernelRef<T, 256, 256, 16, 4, 2, Epi, false, true, 0>{});
     case TILE_128x128: return v(KernelRef<T, 128, 128, 8, 2, 2, Epi, false, true, 0>{});
+    // (round 4: a 96 x 128 tile - 456 tiles = one round at two workgroups per CU instead of 336 tiles of 128 x 128 = 1.3 rounds - changed
+    //  nothing on the denoiser's QKV GEMM, 1.4795 / 1.4841 vs 1.4994 / 1.4893 ms per iteration: profiles/r04_ab_geometry.txt)
     case TILE_128x64: return v(KernelRef<T, 128, 64, 8, 4, 4, Epi, false, true, 0>{});
     default: return v(KernelRef<T, 64, 64, 4, 2, 4, Epi, false, true, 0>{});
   }
