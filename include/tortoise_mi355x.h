@@ -171,7 +171,8 @@ typedef struct tt_clvp_layer {   /* one attention + one feed-forward sublayer */
   const void* w_qkv;             /* T [3D][D] = [to_q; to_k; to_v] (no bias) */
   const void* w_out; const float* b_out;
   const float* ff_norm_g;
-  const void* w_ff1; const float* b_ff1;   /* T [2*inner][D]  (GEGLU proj) */
+  const void* w_ff1; const float* b_ff1;   /* T [2*inner][D]  GEGLU proj, value / gate rows INTERLEAVED in strips of 16:
+                                            * [value 0..15 | gate 0..15 | value 16..31 | ...] (pack.py geglu_interleave) */
   const void* w_ff2; const float* b_ff2;   /* T [D][inner] */
 } tt_clvp_layer;
 typedef struct tt_clvp_tower {

@@ -7,7 +7,7 @@ using namespace tt;
 extern "C" {
 
 const char* tt_last_error(void) { return tt::last_error(); }
-int tt_abi_version(void) { return 2; }
+int tt_abi_version(void) { return 3; }  // ABI changes
 
 int tt_init(void) {
   int dev = 0;

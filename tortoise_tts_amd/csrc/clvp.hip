@@ -19,7 +19,7 @@ struct tt_clvp {
   const float* temperature;
   Arena arena;
   StreamBridge sb;
-  float* x = nullptr; void* h = nullptr; void* u = nullptr; void* gg = nullptr; void* attn = nullptr;
+  float* x = nullptr; void* h = nullptr; void* gg = nullptr; void* attn = nullptr;
   void* q = nullptr; void* k = nullptr; void* vt = nullptr;
   float* enc = nullptr; float* pooled = nullptr; void* pooled_t = nullptr;
   float* text_latent = nullptr; float* speech_latent = nullptr;
@@ -53,10 +53,11 @@ static int clvp_tower_run(tt_clvp* e, const ClvpTower& t, const int* tokens, int
     TT_TRY(gemm_launch(dt, EPI_STD, g, s));
     a.g1 = w.ff_norm_g;
     TT_TRY(rownorm_launch(dt, a, s));
+    // GEGLU (xtransformers.py:429-437): value * gelu(gate) formed in the projection's epilogue (value / gate rows interleaved at pack
+    // time) - the [M][2 inner] projection (315 MB at 256 candidates x 200 codes) is never written or re-read
     g = gemm_args(e->h, D, w.w_ff1, D, M, 2 * inner, D);
-    g.bias = w.b_ff1; g.out_t = e->u; g.ldot = 2 * inner;
-    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
-    TT_TRY(geglu_launch(dt, e->u, 2 * inner, e->gg, inner, M, inner, s));
+    g.bias = w.b_ff1; g.out_t = e->gg; g.ldot = inner;
+    TT_TRY(gemm_launch(dt, EPI_GEGLU, g, s));
     g = gemm_args(e->gg, inner, w.w_ff2, inner, M, D, inner);
     g.bias = w.b_ff2; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
     TT_TRY(gemm_launch(dt, EPI_STD, g, s));
@@ -80,6 +81,7 @@ int tt_clvp_create(const tt_clvp_config* cfg, const tt_clvp_tower* text, const t
                    tt_clvp** out) {
   TT_REQUIRE(cfg && text && speech && temperature && out, "tt_clvp_create: null argument");
   TT_REQUIRE(cfg->heads * 64 == cfg->dim && cfg->dim % 64 == 0 && cfg->ff_inner % 64 == 0, "tt_clvp_create: unsupported dims");
+  TT_REQUIRE(cfg->dtype == DT_BF16 || cfg->dtype == DT_F16 || cfg->dtype == DT_F32, "tt_clvp_create: unknown dtype %d", cfg->dtype);
   tt_clvp* e = new tt_clvp();
   e->cfg = *cfg;
   e->text.w = *text; e->text.L.assign(text->layers_host, text->layers_host + cfg->depth);
@@ -92,7 +94,6 @@ int tt_clvp_create(const tt_clvp_config* cfg, const tt_clvp_tower* text, const t
   int rc = e->sb.init();
   if (!rc) rc = e->arena.alloc_t(&e->x, rows * D);
   if (!rc) rc = e->arena.alloc(&e->h, rows * D * es);
-  if (!rc) rc = e->arena.alloc(&e->u, rows * 2 * cfg->ff_inner * es);
   if (!rc) rc = e->arena.alloc(&e->gg, rows * cfg->ff_inner * es);
   if (!rc) rc = e->arena.alloc(&e->attn, rows * D * es);
   if (!rc) rc = e->arena.alloc(&e->q, rows * D * es);

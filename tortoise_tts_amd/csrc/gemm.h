@@ -10,7 +10,7 @@
 
 namespace tt {
 
-enum EpiKind { EPI_STD = 0, EPI_QKV_HEADS = 1, EPI_QKV_DECODE = 2 };
+enum EpiKind { EPI_STD = 0, EPI_QKV_HEADS = 1, EPI_QKV_DECODE = 2, EPI_GEGLU = 3 };
 
 struct GemmArgs {
   // operands
@@ -53,6 +53,9 @@ struct GemmArgs {
   int gn_ncol16;   // set by gemm_launch
   int gn_vperiod;  // padded batches: sequence b has gn_vlen[b % gn_vperiod] valid rows; the rest are left out of the statistics (0: all valid)
   int gn_vlen[32];
+  // EPI_GEGLU (x-transformers GEGLU, xtransformers.py:429-437): W rows (and bias) INTERLEAVED in strips of 16 - [value 0..15 | gate 0..15 |
+  //   value 16..31 | gate 16..31 | ...] (pack.py geglu_interleave) - so that a lane holds value and gate of the same output column in two
+  //   neighbouring fragments: out_t[m][j] = (value_j + b) * gelu_erf(gate_j + b), ldot = N / 2.  The [M][N] projection is never written.
   // EPI_QKV_HEADS: n -> (part = n / dmodel, head = (n % dmodel) / 64, d = n % 64), m -> (b, s)
   int dmodel, heads;
   void* q;        // [b*heads + h][seq_len][64]

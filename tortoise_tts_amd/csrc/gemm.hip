@@ -44,6 +44,7 @@ static int prof_class(int tile, int epi, bool conv, bool stats = false) {
   if (tile == TILE_64x64 && epi == EPI_STD && !conv && stats) return PROF_GEMM_64x64_STATS;
   const int base = tile == TILE_64x64 ? PROF_GEMM_64x64_STD : tile == TILE_128x64 ? PROF_GEMM_128x64_STD : tile == TILE_128x128 ? PROF_GEMM_128x128_STD : PROF_GEMM_256x256_STD;
   if (epi == EPI_STD) return base + (conv ? 1 : 0);
+  if (epi == EPI_GEGLU) return base;  // (reported with the plain 1x1 class of its tile)
   return base + (epi == EPI_QKV_HEADS ? 2 : 3);
 }
 
@@ -97,7 +98,7 @@ static void plan_core(const GemmArgs& a, int epi, GemmPlan& p, int force_tile = 
   // algorithmic work of this launch: 2*M*N*K flops; operands read once + ONE result written once (the extra split-K slabs
   // a launch writes are an implementation cost: they show up in the PMC traffic, not here)
   const bool std_epi = epi == EPI_STD;
-  const double out_bytes = (double)a.M * a.N * ((std_epi && a.out_f32 ? 4.0 : 0.0) + (a.out_t || !std_epi ? 2.0 : 0.0));
+  const double out_bytes = (double)a.M * (epi == EPI_GEGLU ? a.N / 2 : a.N) * ((std_epi && a.out_f32 ? 4.0 : 0.0) + (a.out_t || !std_epi ? 2.0 : 0.0));
   p.flops = 2.0 * a.M * a.N * a.K;
   p.bytes = ((double)a.N * a.K + (double)a.M * a.cin) * 2.0 + out_bytes + (a.res ? 4.0 * a.M * a.N : 0.0);
 }
@@ -133,7 +134,11 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
     TT_REQUIRE(epi == EPI_STD && a.splitk == 1 && a.out_f32 && a.gn_seq > 0 && a.N % 16 == 0, "gemm: GroupNorm statistics need the standard epilogue, an f32 output, no split-K and N %% 16 == 0");
     a.gn_ncol16 = a.N / 16;
   }
-  if (epi != EPI_STD) {
+  if (epi == EPI_GEGLU) {
+    TT_REQUIRE(a.taps == 1 && a.splitk == 1 && a.out_t && a.N % 32 == 0 && a.ldot >= a.N / 2 && (a.ldot & 3) == 0 && ((size_t)a.out_t & 15) == 0 &&
+                   (a.bias == nullptr || ((size_t)a.bias & 15) == 0) && !a.A2 && !a.gn_part && !a.res && !a.out_f32,
+               "gemm: the GEGLU epilogue takes a plain GEMM with N %% 32 == 0 (value / gate strips interleaved), an aligned T output of N / 2 columns and nothing else");
+  } else if (epi != EPI_STD) {
     TT_REQUIRE(epi == EPI_QKV_HEADS || epi == EPI_QKV_DECODE, "gemm: unknown epilogue %d", epi);
     TT_REQUIRE(a.taps == 1, "gemm: conv taps are only supported with the standard epilogue");
     TT_REQUIRE(a.dmodel % 64 == 0 && a.N == 3 * a.dmodel && a.heads * 64 == a.dmodel, "gemm: qkv epilogue needs N == 3*dmodel, head_dim 64");

@@ -120,6 +120,11 @@ int gemm_launch_typed<float>(int epi, const GemmArgs& a, const GemmPlan& plan, h
     d.e.q_scale = a.q_scale;
     d.e.dmodel = make_fastdiv(a.dmodel);
     launch_timed(ps, gemm_f32_kernel<EpiQkvDecode<float>, false>, grid, dim3(256), 0, stream, d);
+  } else if (epi == EPI_GEGLU) {
+    GemmDev<EpiGegluArgs> d;
+    d.c = plan.core;
+    d.e.bias = a.bias; d.e.out_t = a.out_t; d.e.ldot = a.ldot;
+    launch_timed(ps, gemm_f32_kernel<EpiGeglu<float>, false>, grid, dim3(256), 0, stream, d);
   } else {
     set_error("gemm: unknown epilogue %d", epi);
     return -1;

@@ -320,6 +320,41 @@ struct EpiQkvDecode {
   }
 };
 
+// GEGLU projection: value / gate strips interleaved (gemm.h EPI_GEGLU); the product value * gelu_erf(gate) is formed in registers.
+struct EpiGegluArgs {
+  const float* bias;
+  void* out_t;
+  int ldot;
+};
+template <typename T>
+struct EpiGeglu {
+  typedef EpiGegluArgs Args;
+  static constexpr int kId = 3;
+  static constexpr int kStats = 0;
+  static constexpr bool kSerial = false;
+  template <int FM, int FN> struct Ops { float4 bv[FN]; __device__ __forceinline__ int step() const { return 0; } };
+  template <int FM, int FN, bool AL>
+  static __device__ __forceinline__ void fetch(const GemmCore& c, const Args& e, Ops<FM, FN>& o, int, int n0w, int lane) {
+    const int fg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int nc = max(min(n0w + i * 16 + fg * 4, c.N - 4), 0);
+      o.bv[i] = e.bias ? *(const float4*)(e.bias + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  static __device__ __forceinline__ void apply(const Args&, f32x4& v, const float4& bv, const float4&) {
+    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+  }
+  // value fragment v (strip 2p), gate fragment g (strip 2p + 1), both with their bias added; n = first column of the VALUE quad
+  static __device__ __forceinline__ void store_pair(const Args& e, int m, int n, const f32x4& v, const f32x4& g) {
+    const int col = ((n >> 5) << 4) + (n & 15);  // strip pair p = n / 32 -> output columns 16 p ..
+    T* o = (T*)e.out_t + (size_t)m * e.ldot + col;
+    *(typename Vec<T>::x4*)o = pack4<T>(v[0] * gelu_erf(g[0]), v[1] * gelu_erf(g[1]), v[2] * gelu_erf(g[2]), v[3] * gelu_erf(g[3]));
+  }
+  template <bool AL>
+  static __device__ __forceinline__ void store(const GemmCore&, const Args&, int, int, int, const f32x4&, int, int) {}
+};
+
 // "Serial split-K": out = (((res + bias) + P0) + P1) + ... with P_q the partial product over the q-th of e.splitk equal K ranges,
 // each accumulated from zero in k order and folded into the running value in ONE launch.  That is bit for bit what the split-K
 // slab path computes in two kernels (slab z = P_z, then the LayerNorm kernel's x + bias + slab0 + slab1 + ...), without writing
@@ -339,6 +374,22 @@ template <typename Epi, int FM, int FN, int TM, int TN, bool AL, typename Ops>
 __device__ __forceinline__ void run_epilogue(const GemmCore& c, const typename Epi::Args& e, f32x4 (&acc)[FN][FM], const Ops& o, int step_t,
                                              int m0w, int n0w, int lane, int z) {
   const int fr = lane & 15, fg = lane >> 4;
+  if constexpr (Epi::kId == 3) {  // GEGLU: fragments come in (value, gate) pairs
+    static_assert(FN % 2 == 0, "GEGLU epilogue needs an even number of 16-column strips per wave");
+#pragma unroll
+    for (int i = 0; i < FN; i += 2) {
+      const int n = n0w + i * 16 + fg * 4;
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int m = m0w + j * 16 + fr;
+        Epi::apply(e, acc[i][j], o.bv[i], make_float4(0.f, 0.f, 0.f, 0.f));
+        Epi::apply(e, acc[i + 1][j], o.bv[i + 1], make_float4(0.f, 0.f, 0.f, 0.f));
+        if (m < c.M && n < c.N) Epi::store_pair(e, m, n, acc[i][j], acc[i + 1][j]);
+      }
+    }
+    (void)step_t; (void)z;
+    return;
+  }
   constexpr bool BIG = FM * FN > 8;
   bool stats = false;
   if constexpr (Epi::kId == 0) {
@@ -1046,6 +1097,14 @@ int gemm_launch_typed(int epi, const GemmArgs& a, const GemmPlan& plan, hipStrea
       decltype(kr)::launch(ps, grid, stream, d);
       return 0;
     });
+  } else if (epi == EPI_GEGLU) {
+    GemmDev<EpiGegluArgs> d;
+    d.c = plan.core;
+    d.e.bias = a.bias; d.e.out_t = a.out_t; d.e.ldot = a.ldot;
+    rc = visit_qkv<T, EpiGeglu<T>>(plan.tile, [&](auto kr) -> int {
+      decltype(kr)::launch(ps, grid, stream, d);
+      return 0;
+    });
   }
   if (rc == kNoKernel) {
     set_error("gemm: no kernel for epilogue %d tile %d", epi, plan.tile);
@@ -1069,6 +1128,7 @@ int gemm_init_typed() {
         for (int al = 0; al < 2; ++al) (void)visit_std<T>(tile, variant, conv != 0, al != 0, setattr);
     (void)visit_qkv<T, EpiQkvHeads<T>>(tile, setattr);
     (void)visit_qkv<T, EpiQkvDecode<T>>(tile, setattr);
+    (void)visit_qkv<T, EpiGeglu<T>>(tile, setattr);
   }
   if (hipFuncSetAttribute(conv3s_fn<T, EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_RES | EB_F32>>(), hipFuncAttributeMaxDynamicSharedMemorySize, kConv3sSmem) != hipSuccess) ++bad;
   if (hipFuncSetAttribute(conv3s_fn<T, EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_F32>>(), hipFuncAttributeMaxDynamicSharedMemorySize, kConv3sSmem) != hipSuccess) ++bad;

@@ -94,6 +94,15 @@ def pack_ar(sd, cfg: ARConfig, device, dtype):
 
 
 # ----------------------------------------------------------------------------------------- CLVP
+def geglu_interleave(inner):
+    """Row order of a GEGLU projection for the engine's fused epilogue (csrc/gemm.h EPI_GEGLU): the reference stores [value 0..inner) |
+    gate 0..inner) (xtransformers.py:429-437, `x, gate = proj(x).chunk(2)`); the engine wants them interleaved in strips of 16 -
+    [value 0..15 | gate 0..15 | value 16..31 | gate 16..31 | ...].  Returns idx with new[r] = old[idx[r]]."""
+    assert inner % 16 == 0
+    v = torch.arange(inner).reshape(-1, 16)
+    return torch.stack([v, v + inner], dim=1).reshape(-1)
+
+
 def _pack_clvp_tower(h, sd, cfg: CLVPConfig, tower, emb_key, latent_key):
     base = f"{tower}.transformer"
     layers = (E.ClvpLayer * cfg.depth)()
@@ -107,8 +116,9 @@ def _pack_clvp_tower(h, sd, cfg: CLVPConfig, tower, emb_key, latent_key):
         L.w_out = _p(h.op(sd[f"{pa}.1.wrap.to_out.weight"]))
         L.b_out = _p(h.f32(sd[f"{pa}.1.wrap.to_out.bias"]))
         L.ff_norm_g = _p(h.f32(sd[f"{pf}.0.0.g"]))
-        L.w_ff1 = _p(h.op(sd[f"{pf}.1.wrap.net.0.proj.weight"]))
-        L.b_ff1 = _p(h.f32(sd[f"{pf}.1.wrap.net.0.proj.bias"]))
+        gl = geglu_interleave(sd[f"{pf}.1.wrap.net.0.proj.weight"].shape[0] // 2)
+        L.w_ff1 = _p(h.op(sd[f"{pf}.1.wrap.net.0.proj.weight"][gl]))
+        L.b_ff1 = _p(h.f32(sd[f"{pf}.1.wrap.net.0.proj.bias"][gl]))
         L.w_ff2 = _p(h.op(sd[f"{pf}.1.wrap.net.3.weight"]))
         L.b_ff2 = _p(h.f32(sd[f"{pf}.1.wrap.net.3.bias"]))
     t = E.ClvpTower()
