@@ -127,6 +127,9 @@ def cpu_baseline(sds, text, latents, preset_kw, M, cores):
     total = ar_total + clvp_total + lat_total + diff_total + voc_total
     audio_s = S * 256 / 24000.0
     return {"value": audio_s / total, "unit": "audio-s/wall-s", "cores": best, "host_cores": cores, "kind": "port",
+            "what": "the CPU ORACLE (oracle/tortoise_oracle.py: fp32 restatement of the reference algorithm, pinned against the reference's modules), "
+                    "not the reference's own classes - /root/reference does not exist on the GPU box; bounded sample, extrapolated",
+            "context": "AR step timed at the MEAN decode context (prefix + M / 2 cached tokens); lines of rounds <= 2 timed it right after the prefill",
             "latency_s_extrapolated": total,
             "ar_step_s_by_threads": {str(k): round(v, 4) for k, v in sweep.items()},
             "sample": (f"oracle fp32 on {best} threads (best of {sorted(sweep)} on the AR step): AR prefill + 3 cached steps at the mean decode context (prefix + {ctx_extra + 1} tokens) at B={Bc} "

@@ -1,32 +1,9 @@
-// Small HBM-bound glue kernels: GEGLU, rotary, gathers, casts, the CLVP score tail and the fused
+// Small HBM-bound glue kernels: rotary, gathers, casts, the CLVP score tail and the fused
 // diffusion sampler epilogue (classifier-free guidance + learned-range variance + posterior mean +
 // noise + operand re-quantisation for the next step, one pass over the 100 x S state).
 #include "ops.h"
 
 namespace tt {
-
-template <typename T>
-__global__ void geglu_kernel(const T* in, int ldin, T* out, int ldout, int M, int inner) {
-  typedef typename Vec<T>::x4 x4;
-  const int per_row = inner >> 2;
-  const long total = (long)M * per_row;
-  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
-    const int m = (int)(f / per_row);
-    const int c = (int)(f % per_row) * 4;
-    const x4 a = *(const x4*)(in + (size_t)m * ldin + c);
-    const x4 g = *(const x4*)(in + (size_t)m * ldin + inner + c);
-    *(x4*)(out + (size_t)m * ldout + c) = pack4<T>((float)a[0] * gelu_erf((float)g[0]), (float)a[1] * gelu_erf((float)g[1]),
-                                                   (float)a[2] * gelu_erf((float)g[2]), (float)a[3] * gelu_erf((float)g[3]));
-  }
-}
-int geglu_launch(int dtype, const void* in, int ldin, void* out, int ldout, int M, int inner, hipStream_t stream) {
-  TT_REQUIRE(inner % 4 == 0 && ldin % 4 == 0 && ldout % 4 == 0, "geglu: dims must be multiples of 4");
-  const long total = (long)M * (inner / 4);
-  const int blocks = (int)std::min<long>(cdiv64(total, 256), 4096);
-  TT_DISPATCH_T(dtype, T, geglu_kernel<T><<<blocks, 256, 0, stream>>>((const T*)in, ldin, (T*)out, ldout, M, inner));
-  TT_CHECK_HIP(hipGetLastError());
-  return 0;
-}
 
 // x-transformers apply_rotary_pos_emb on the leading `rot` dims (xtransformers.py:277-286, 625-629):
 // t[d] = t[d]*cos(theta_d) - t[d+rot/2]*sin ; t[d+rot/2] = t[d+rot/2]*cos + t[d]*sin, theta = s * inv_freq[d]

@@ -158,8 +158,7 @@ int ar_embed_launch(const int* tok, const int* state, const float* tok_emb, cons
                     hipStream_t stream);
 
 // ------------------------------------------------------------------------------ small fused ops
-// out[m][j] = in[m][j] * gelu_erf(in[m][inner + j])
-int geglu_launch(int dtype, const void* in, int ldin, void* out, int ldout, int M, int inner, hipStream_t stream);
+// (GEGLU is formed in the projection GEMM's epilogue: gemm.h EPI_GEGLU)
 // x-transformers rotary on the first rot dims (rot = 32) of q, k ([BH][n][64]) and vt ([BH][64][n_pad])
 int rotary_launch(int dtype, void* q, void* k, void* vt, const float* inv_freq, int BH, int n, int n_pad, int rot,
                   hipStream_t stream);
