@@ -311,3 +311,39 @@ def test_overlapped_integrator_prepass_is_scheduling_only():
         E.load_library().tt_graph_replay(1)
     assert st.stat(0) == 1
     st.close()
+
+
+@pytest.mark.parametrize("dtype", [E.TT_F16, E.TT_BF16])
+@torch.no_grad()
+def test_fused_groupnorm_a_path_matches_the_standalone_apply(dtype):
+    """ResBlock in_layers as one launch (TT_DIFF_OPT_FUSED_GN: GroupNorm32 + SiLU applied on the 1x1 conv's A path, csrc/gemm_gna.h)
+    against the stand-alone apply launch, full-width denoiser at S = 870 (two samples: the tile at rows 832 .. 895 straddles them).
+    Not bit-identical by construction - the fused path folds mean / rstd / gamma / beta into one multiply-add and takes the
+    hardware reciprocal in the SiLU - but far inside the operand rounding: one eps evaluation and a 30-iteration mel, run twice."""
+    cfg = DiffusionConfig()
+    sd = W.synthetic_state_dict(W.diffusion_manifest(cfg), 1237)
+    M, iters = 200, 30
+    S = M * 4 * 24000 // 22050
+    st = stages.DiffusionStage(sd, cfg, dtype=dtype, max_seq=S + 8, max_codes=M + 8, max_steps=64)
+    g = torch.Generator().manual_seed(6)
+    lat = torch.randn(1, M, 1024, generator=g)
+    dcond = torch.randn(1, 2048, generator=g) * 0.5
+    sched = Schedule(iters, cfg.trained_steps, True, 2)
+    x = torch.randn(1, 100, S, generator=g)
+    noise = torch.randn(iters, 1, 100, S, generator=g)
+    st.set_option(E.TT_DIFF_OPT_FUSED_GN, 0)
+    st.condition(lat, dcond, S)
+    want = st.sample(sched, x, noise).clone()
+    assert torch.isfinite(want).all() and st.guard() == 0
+    st.set_option(E.TT_DIFF_OPT_FUSED_GN, 1)
+    got = []
+    for rep in range(2):
+        st.condition(lat, dcond, S)
+        got.append(st.sample(sched, x, noise).clone())
+        assert torch.isfinite(got[-1]).all() and st.guard() == 0
+    assert torch.equal(got[0], got[1]), "the fused path is not deterministic"
+    rel = float((got[0] - want).norm() / want.norm())
+    mx = float((got[0] - want).abs().max())
+    print(f"[parity] fused GroupNorm A path vs stand-alone apply ({E.DTYPE_NAMES[dtype]}, S={S}, {iters} iterations): rel-L2 {rel:.3e} max-abs {mx:.3e}")
+    assert rel < (4e-3 if dtype == E.TT_F16 else 3e-2), rel
+    st.close()

@@ -194,6 +194,7 @@ enum ProfId {  // one class per kernel instantiation that actually runs (names: 
   PROF_GEMM_256x256_STD, PROF_GEMM_256x256_CONV, PROF_GEMM_256x256_QKV, PROF_GEMM_256x256_QKVDEC,
   PROF_FLASH, PROF_DECODE_ATTN, PROF_ROWNORM, PROF_GROUPNORM, PROF_SAMPLE, PROF_GLUE, PROF_CONV1D, PROF_CONVT, PROF_LVC,
   PROF_GEMM_64x64_STATS,  // the denoiser's 1x1 GEMMs with the GroupNorm-statistics epilogue (M = 1740): kept apart from the decode GEMMs of the same tile
+  PROF_GEMM_GNA,          // GEMM with the GroupNorm apply on its A path (gemm_gna.h)
   PROF_COUNT
 };
 extern bool g_prof_on;

@@ -31,7 +31,9 @@ struct DiffWork {
   void* act = nullptr;         // [rows][C] T   GN/SiLU output (GEMM operand)
   void* q = nullptr; void* k = nullptr; void* vt = nullptr; void* att = nullptr;
   float* gn_partial = nullptr;
-  float* gn_gemm_part = nullptr;    // statistics emitted by GEMM epilogues: [row_tile][2][C/16][2]
+  float* gn_gemm_part = nullptr;    // statistics emitted by GEMM epilogues: [row_tile][2][C/16][2]; two buffers used in turn - a GEMM that
+  float* gn_gemm_part2 = nullptr;   //   normalises its own A rows (gemm_gna.h) READS its producer's partials while it WRITES its own
+  float* stats_part = nullptr;      // the buffer that holds the statistics of stats_ptr
   const float* stats_ptr = nullptr; // tensor those statistics describe (the last such GEMM's f32 output)
   int stats_rows = 0;               // its row-tile height
   int stats_seq = 0;
@@ -59,6 +61,7 @@ struct tt_diff {
   hipStream_t pre_stream = nullptr;          // the pre-pass's stream
   hipEvent_t ev_pre_start = nullptr;
   std::vector<hipEvent_t> ev_chunk;          // chunk c of the pre-pass is complete
+  int fuse_gn = 1;                           // TT_DIFF_OPT_FUSED_GN: the sampler step's ResBlock 1x1 GEMMs normalise their own A rows (gemm_gna.h)
   int overlap_prepass = 1;                   // 0: pre-pass on the main stream in front of the loop (round 3); 1: chunks on their own stream, all enqueued up front;
                                              // 2: chunk c + 1 enqueued right before the steps of chunk c (A/B: 297.6 / 294.9 / 296.3 ms, profiles/r04_ab_geometry.txt)
   void* cat = nullptr;         // [2S][C] T     inp_block(x) of the current step (left half of the integrating conv's K)
@@ -115,7 +118,7 @@ static int run_gn(tt_diff* e, DiffWork& w_, const float* x, int B, int S, const 
     for (int u = 0; u < e->U; ++u) a.vlen[u] = e->Su[u];
   }
   if (x == w_.stats_ptr && w_.stats_seq == S && S >= w_.stats_rows) {
-    a.gemm_part = w_.gn_gemm_part;
+    a.gemm_part = w_.stats_part;
     a.part_rows = w_.stats_rows;
   }
   return groupnorm_launch(e->cfg.dtype, a, s);
@@ -124,8 +127,9 @@ static int run_gn(tt_diff* e, DiffWork& w_, const float* x, int B, int S, const 
 // EPI_STD GEMM whose f32 output will be group-normalised next: let its epilogue emit the statistics.
 static int gemm_with_stats(tt_diff* e, DiffWork& w_, GemmArgs& g, int S, hipStream_t s) {
   const bool fused = (e->C / 32) % 16 == 0 && g.out_f32 != nullptr && g.N == e->C && g.splitk <= 1;
+  float* part = w_.stats_part == w_.gn_gemm_part ? w_.gn_gemm_part2 : w_.gn_gemm_part;  // never the buffer a pending reader holds
   if (fused) {
-    g.gn_part = w_.gn_gemm_part;
+    g.gn_part = part;
     g.gn_seq = S;
     if (e->masked) {
       g.gn_vperiod = e->U;
@@ -135,6 +139,7 @@ static int gemm_with_stats(tt_diff* e, DiffWork& w_, GemmArgs& g, int S, hipStre
   TT_TRY(gemm_launch(e->cfg.dtype, EPI_STD, g, s));
   if (fused) {
     w_.stats_ptr = g.out_f32;
+    w_.stats_part = part;
     w_.stats_rows = gemm_stat_rows(g, e->cfg.dtype);
     w_.stats_seq = S;
   } else if (g.out_f32 == w_.stats_ptr) {
@@ -170,11 +175,29 @@ static int run_attn_block(tt_diff* e, DiffWork& w_, const tt_attn_block& w, cons
 static int run_res_block(tt_diff* e, DiffWork& w_, const tt_res_block& w, const float* ss, size_t ss_stride, int ss_div, const float* in, int B, int S,
                          float* out_f32, hipStream_t s) {
   const int C = e->C, dt = e->cfg.dtype, M = B * S;
-  (void)dt;
-  TT_TRY(run_gn(e, w_, in, B, S, w.gn1_g, w.gn1_b, nullptr, 0, 1, ACT_SILU, w_.act, C, nullptr, s));
   GemmArgs g = gemm_args(w_.act, C, w.w_in, C, M, C, C);
   g.bias = w.b_in; g.out_f32 = w_.tmp_c; g.ldo32 = C;
-  TT_TRY(gemm_with_stats(e, w_, g, S, s));
+  bool fused_gn = false;
+  if (e->fuse_gn && !e->masked && in == w_.stats_ptr && w_.stats_seq == S && S >= w_.stats_rows) {
+    // in_layers as ONE launch: GroupNorm32 + SiLU applied on the 1x1 conv's A path (gemm_gna.h), statistics for out_layers' norm in its epilogue
+    GemmGnArgs n;
+    memset(&n, 0, sizeof(n));
+    n.gamma = w.gn1_g; n.beta = w.gn1_b; n.gemm_part = w_.stats_part; n.part_rows = w_.stats_rows; n.S = S; n.eps = 1e-5f; n.act = ACT_SILU;
+    n.guard = e->guard;
+    GemmArgs gf = g;
+    gf.A = in; gf.lda = C;
+    float* part = w_.stats_part == w_.gn_gemm_part ? w_.gn_gemm_part2 : w_.gn_gemm_part;
+    gf.gn_part = part; gf.gn_seq = S;
+    if (gemm_gna_supported(dt, EPI_STD, gf, n)) {
+      TT_TRY(gemm_gna_launch(dt, EPI_STD, gf, n, s));
+      w_.stats_ptr = gf.out_f32; w_.stats_part = part; w_.stats_rows = 32; w_.stats_seq = S;
+      fused_gn = true;
+    }
+  }
+  if (!fused_gn) {
+    TT_TRY(run_gn(e, w_, in, B, S, w.gn1_g, w.gn1_b, nullptr, 0, 1, ACT_SILU, w_.act, C, nullptr, s));
+    TT_TRY(gemm_with_stats(e, w_, g, S, s));
+  }
   TT_TRY(run_gn(e, w_, w_.tmp_c, B, S, w.gn2_g, w.gn2_b, ss, ss_stride, ss_div, ACT_SILU, w_.act, C, nullptr, s));
   g = gemm_args(w_.act, C, w.w_out, 3 * C, M, C, 3 * C);
   g.taps = 3; g.seq_len = S; g.bias = w.b_out; g.res = in; g.ldres = C; g.out_f32 = out_f32; g.ldo32 = C;
@@ -344,6 +367,7 @@ int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff*
     if (!rc) rc = e->arena.alloc(&w_.att, r * C * es);
     if (!rc) rc = e->arena.alloc_t(&w_.gn_partial, (r / 16 + r + 64) * 64);  // [samples][row chunks >= 16 rows][32][2], worst case one-row samples
     if (!rc) rc = e->arena.alloc_t(&w_.gn_gemm_part, (r / 32 + 2) * 2 * (C / 16) * 2 + 64);
+    if (!rc) rc = e->arena.alloc_t(&w_.gn_gemm_part2, (r / 32 + 2) * 2 * (C / 16) * 2 + 64);
   }
   if (!rc) rc = e->arena.alloc_t(&e->rep_in, rows * C);
   if (!rc) rc = e->arena.alloc(&e->cat, (B2 * cfg->max_seq + 64) * C * es);
@@ -730,7 +754,12 @@ int tt_diff_stat(tt_diff* e, int which) {  // 0: sampler-step graph captures so 
 // walks the steps whose chunks are done (0: the whole pre-pass first, on the one stream - the round-3 order; same results either way).
 int tt_diff_set_option(tt_diff* e, int option, int value) {
   TT_REQUIRE(e != nullptr, "tt_diff_set_option: null handle");
-  TT_REQUIRE(option == TT_DIFF_OPT_OVERLAP_PREPASS, "tt_diff_set_option: unknown option %d", option);
+  TT_REQUIRE(option == TT_DIFF_OPT_OVERLAP_PREPASS || option == TT_DIFF_OPT_FUSED_GN, "tt_diff_set_option: unknown option %d", option);
+  if (option == TT_DIFF_OPT_FUSED_GN) {
+    if ((value != 0) != (e->fuse_gn != 0)) diff_drop_step_graph(e);  // the kept sampler step was captured with the other launch sequence
+    e->fuse_gn = value != 0;
+    return 0;
+  }
   e->overlap_prepass = value < 0 ? 0 : value > 2 ? 2 : value;
   return 0;
 }

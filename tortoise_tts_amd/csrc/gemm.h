@@ -72,6 +72,26 @@ struct GemmArgs {
   int tmax;
 };
 
+// GroupNorm-apply on the A path (gemm_gna.h): `a.A` is the F32 tensor the GroupNorm reads ([M][1024], lda in floats), normalised with the
+// statistics partials `gemm_part` its producing GEMM left (tiles of part_rows rows), scale-shifted, activated and cast on the way into the
+// MFMA loop - out = epilogue(act(GN(A) * (1 + scale) + shift) @ W^T) without the stand-alone apply launch and its 16-bit tensor.
+struct GemmGnArgs {
+  const float* gamma;
+  const float* beta;
+  const float* ss;        // scale / shift rows [2 * 1024]: sample b reads ss + (b / ss_div) * ss_stride; nullptr: none
+  size_t ss_stride;
+  int ss_div;
+  const float* gemm_part;
+  int part_rows;
+  int S;                  // rows per sample (M = samples * S)
+  float eps;
+  int act;                // ACT_NONE / ACT_SILU
+  int* guard;             // optional operand-overflow counter (non-finite statistics)
+};
+// true when gemm_gna_launch has a kernel for this problem (else: groupnorm_launch + gemm_launch)
+bool gemm_gna_supported(int dtype, int epi, const GemmArgs& a, const GemmGnArgs& n);
+int gemm_gna_launch(int dtype, int epi, const GemmArgs& a, const GemmGnArgs& n, hipStream_t stream);
+
 // dtype: DT_BF16 / DT_F16 (DT_F32: the slow fp32-operand verification kernel, gemm_f32.hip).  Returns 0 or a negative error (message via tt::last_error()).
 int gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t stream);
 int gemm_init();  // sets dynamic-LDS attributes; called once per process

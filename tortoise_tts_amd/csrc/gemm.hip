@@ -9,6 +9,8 @@ namespace tt {
 extern template int gemm_launch_typed<bf16>(int, const GemmArgs&, const GemmPlan&, hipStream_t);
 extern template int gemm_launch_typed<f16>(int, const GemmArgs&, const GemmPlan&, hipStream_t);
 extern template int gemm_init_typed<bf16>();
+extern template int gemm_gna_launch_typed<bf16>(const GemmArgs&, const GemmPlan&, const GnaArgs&, hipStream_t);
+extern template int gemm_gna_launch_typed<f16>(const GemmArgs&, const GemmPlan&, const GnaArgs&, hipStream_t);
 extern template int gemm_init_typed<f16>();
 template <> int gemm_launch_typed<float>(int, const GemmArgs&, const GemmPlan&, hipStream_t);  // gemm_f32.hip (verification mode)
 template <> int gemm_init_typed<float>();
@@ -50,9 +52,10 @@ static int prof_class(int tile, int epi, bool conv, bool stats = false) {
 
 // Device argument core: tile grid, XCD row bands (minimise the bytes one XCD pulls over the fabric, A / bands + W * bands / 8),
 // split-K ranges and the reciprocals the kernel divides by.
-static void plan_core(const GemmArgs& a, int epi, GemmPlan& p, int force_tile = -1) {
+static void plan_core(const GemmArgs& a, int epi, GemmPlan& p, int force_tile = -1, int force_bm = 0, int force_bn = 0) {
   const int tile = force_tile >= 0 ? force_tile : pick_tile(a);
-  const int bm = tile == TILE_64x64 ? 64 : tile == TILE_256x256 ? 256 : 128, bn = tile == TILE_256x256 ? 256 : tile == TILE_128x128 ? 128 : 64;
+  const int bm = force_bm ? force_bm : tile == TILE_64x64 ? 64 : tile == TILE_256x256 ? 256 : 128;
+  const int bn = force_bn ? force_bn : tile == TILE_256x256 ? 256 : tile == TILE_128x128 ? 128 : 64;
   GemmCore& c = p.core;
   memset(&c, 0, sizeof(c));
   c.A = a.A; c.W = a.W; c.lda = a.lda; c.ldw = a.ldw; c.M = a.M; c.N = a.N;
@@ -156,6 +159,39 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   if (dtype == DT_F16) return gemm_launch_typed<f16>(epi, a, plan, stream);
   set_error("gemm: unknown dtype %d", dtype);
   return -1;
+}
+
+bool gemm_gna_supported(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs& n) {
+  GemmArgs a = a0;
+  normalise(a);
+  const bool al16 = ((size_t)a.A & 15) == 0 && (a.lda & 3) == 0 && ((size_t)n.gamma & 15) == 0 && ((size_t)n.beta & 15) == 0 &&
+                    (!n.ss || (((size_t)n.ss & 15) == 0 && (n.ss_stride & 3) == 0)) && a.bias && ((size_t)a.bias & 15) == 0 && a.out_f32 &&
+                    ((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0 && (a.ldw & 7) == 0;
+  return (dtype == DT_BF16 || dtype == DT_F16) && epi == EPI_STD && al16 && a.taps == 1 && a.splitk == 1 && a.serial_k <= 1 && a.K == kGnaC && !a.A2 &&
+         a.N % kGnaBN == 0 && a.M > 256 && a.M <= 4096 && n.S >= kGnaBM && a.M % n.S == 0 && n.gemm_part && n.part_rows > 0 &&
+         (n.part_rows & (n.part_rows - 1)) == 0 && n.S >= n.part_rows && a.gn_part != nullptr && !a.res && !a.out_t && a.act == ACT_NONE && a.gn_vperiod == 0 &&
+         n.act == ACT_SILU && !n.ss;
+}
+
+int gemm_gna_launch(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs& n, hipStream_t stream) {
+  GemmArgs a = a0;
+  normalise(a);
+  TT_REQUIRE(gemm_gna_supported(dtype, epi, a0, n), "gemm_gna: unsupported problem (M=%d N=%d K=%d S=%d)", a.M, a.N, a.K, n.S);
+  a.gn_ncol16 = a.N / 16;
+  a.seq_len = n.S;
+  GemmPlan plan;
+  plan_core(a, epi, plan, TILE_64x64, kGnaBM, kGnaBN);
+  plan.conv3s = false;
+  plan.prof_id = PROF_GEMM_GNA;
+  plan.bytes += (double)a.M * a.cin * 2.0;  // the activation rows are f32 here
+  GnaArgs d;
+  memset(&d, 0, sizeof(d));
+  d.gamma = n.gamma; d.beta = n.beta; d.ss = n.ss; d.ss_stride = n.ss_stride; d.ss_div = n.ss_div; d.gemm_part = n.gemm_part;
+  d.part_shift = 31 - __builtin_clz((unsigned)n.part_rows);
+  d.S = n.S; d.eps = n.eps; d.act = n.act; d.guard = n.guard;
+  d.inv_count = 1.0 / ((double)n.S * (double)(kGnaC / 32));
+  if (dtype == DT_BF16) return gemm_gna_launch_typed<bf16>(a, plan, d, stream);
+  return gemm_gna_launch_typed<f16>(a, plan, d, stream);
 }
 
 int gemm_init() {

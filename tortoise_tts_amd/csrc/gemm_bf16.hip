@@ -3,4 +3,5 @@
 namespace tt {
 template int gemm_launch_typed<bf16>(int, const GemmArgs&, const GemmPlan&, hipStream_t);
 template int gemm_init_typed<bf16>();
+template int gemm_gna_launch_typed<bf16>(const GemmArgs&, const GemmPlan&, const GnaArgs&, hipStream_t);
 }  // namespace tt

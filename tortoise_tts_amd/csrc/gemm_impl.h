@@ -915,6 +915,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv3s_kernel(const GemmDev<type
 }
 
 // ---------------------------------------------------------------------------------------------- host side (per operand type)
+}  // namespace tt
+#include "gemm_gna.h"
+namespace tt {
+
 enum Tile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x256 = 3, TILE_COUNT = 4 };
 // EPI_STD kernel variants: the generic one tests everything at run time, the others compile the unused features out
 enum StdVariant { V_GEN = 0, V_NONE = 1, V_SLAB = 2, V_GELU_T = 3, V_ST_F32 = 4, V_ST_RES = 5, V_ST_A2 = 6, V_BIAS_T = 7, V_SERIAL = 8, V_COUNT = 9 };
@@ -1112,6 +1116,43 @@ int gemm_launch_typed(int epi, const GemmArgs& a, const GemmPlan& plan, hipStrea
   }
   TT_CHECK_HIP(hipGetLastError());
   return rc;
+}
+
+// GroupNorm-apply on the A path (gemm_gna.h): 64 x 128 tile, 4 waves of 32 x 64, both operands four k-tiles ahead in registers.
+// 224 workgroups at the denoiser's 1740 rows x 1024 columns: one per CU, the same bytes per CU as two 64 x 64 workgroups of the 16-bit
+// path (W 256 KB + f32 A 256 KB), the apply redone by 8 column tiles instead of 16.
+#ifndef TT_GNA_NW
+#define TT_GNA_NW 8
+#endif
+#ifndef TT_GNA_PF
+#define TT_GNA_PF 4
+#endif
+#ifndef TT_GNA_BM
+#define TT_GNA_BM 64
+#define TT_GNA_BN 128
+#define TT_GNA_WM 2
+#endif
+constexpr int kGnaBM = TT_GNA_BM, kGnaBN = TT_GNA_BN, kGnaWM = TT_GNA_WM, kGnaST = TT_GNA_PF, kGnaNW = TT_GNA_NW;  // (kGnaST: prefetch depth in k-tiles)
+constexpr int kGnaSmem = 0;
+template <typename T, typename Epi, bool SS, bool SILU>
+static const void* gna_fn() { return (const void*)gemm_gna_kernel<T, kGnaBM, kGnaBN, kGnaNW, kGnaWM, kGnaST, Epi, SS, SILU>; }
+
+template <typename T>
+int gemm_gna_launch_typed(const GemmArgs& a, const GemmPlan& plan, const GnaArgs& n, hipStream_t stream) {
+  const dim3 grid(plan.core.gx * plan.core.gy, 1, 1);
+  ProfScope ps(plan.prof_id, stream, plan.flops, plan.bytes, true);
+  typedef EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_F32> EStF32;
+  GemmGnaDev<EpiStdArgs> d;
+  d.c = plan.core;
+  d.e = make_epi_std(a);
+  d.n = n;
+  if (n.act == ACT_SILU && !n.ss) launch_timed(ps, gemm_gna_kernel<T, kGnaBM, kGnaBN, kGnaNW, kGnaWM, kGnaST, EStF32, false, true>, grid, dim3(kGnaNW * 64), kGnaSmem, stream, d);
+  else {
+    set_error("gemm_gna: no kernel for act %d scale_shift %d", n.act, n.ss != nullptr);
+    return -1;
+  }
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 // dynamic-LDS attribute of every instantiation this type can launch

@@ -13,6 +13,7 @@ TT_BF16, TT_F16, TT_F32 = 0, 1, 2  # TT_F32: the slow fp32-operand VERIFICATION 
 DTYPE_NAMES = {TT_BF16: "bf16", TT_F16: "fp16", TT_F32: "fp32"}
 TT_AR_OPT_SUBBATCHES, TT_AR_OPT_LOOKAHEAD = 1, 4
 TT_DIFF_OPT_OVERLAP_PREPASS = 1
+TT_DIFF_OPT_FUSED_GN = 2
 
 
 def dtype_code(name):

@@ -276,6 +276,8 @@ class DiffusionStage:
         self.S = 0
         if os.environ.get("TT_DIFF_OVERLAP_PREPASS"):  # A/B switch of the measurement scripts
             self.set_option(E.TT_DIFF_OPT_OVERLAP_PREPASS, int(os.environ["TT_DIFF_OVERLAP_PREPASS"]))
+        if os.environ.get("TT_DIFF_FUSED_GN"):
+            self.set_option(E.TT_DIFF_OPT_FUSED_GN, int(os.environ["TT_DIFF_FUSED_GN"]))
 
     def set_option(self, option, value):
         E.check(self.lib.tt_diff_set_option(self.h, int(option), int(value)))
