@@ -48,8 +48,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_gna_kernel(const GemmGnaDev<type
   constexpr int FM = TM / 16, FN = TN / 16;
   constexpr int RP = NW * 8;        // rows of 64 elements that the workgroup's threads cover with one 8-element chunk each
   constexpr int PW = BN / RP;       // 16-byte chunks of W per thread per k-tile
-  constexpr int PA = BM / RP;       // 8-channel chunks of A per thread per k-tile
-  static_assert((NW == 4 || NW == 8) && PW >= 1 && PA >= 1, "gemm_gna: 256 or 512 threads");
+  constexpr bool QUAD = BM * 8 < NW * 64;  // fewer 8-channel chunks than threads: every thread takes ONE float4 (4 channels) of the A tile instead
+  constexpr int PA = QUAD ? 1 : BM / RP;   // 8-channel chunks (QUAD: 4-channel quads) of A per thread per k-tile
+  static_assert((NW == 4 || NW == 8) && PW >= 1 && (QUAD ? BM * 16 == NW * 64 : BM % RP == 0), "gemm_gna: 256 or 512 threads covering the A tile exactly");
   __shared__ __attribute__((aligned(16))) T Ws[2 * BN * BK];       // [2][BN][64]
   __shared__ __attribute__((aligned(16))) T As[2 * BM * BK];       // [2][BM][64]
   __shared__ __attribute__((aligned(16))) float2 tab[2 * kGnaC];   // [2][1024] (multiplier, offset)
@@ -92,11 +93,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_gna_kernel(const GemmGnaDev<type
   int a_dst[PA], a_slot[PA];
 #pragma unroll
   for (int p = 0; p < PA; ++p) {
-    const int row = (tid >> 3) + RP * p;
+    const int row = QUAD ? tid >> 4 : (tid >> 3) + RP * p;
+    const int q = tid & 15;                // QUAD: channels q * 4 .. + 3 = half (q & 1) of 16-byte chunk q >> 1
     const int m = min(m0 + row, c.M - 1);  // rows beyond M re-read the last row: never stored, left out of the statistics
-    a_ptr[p] = X + (size_t)m * c.lda + lc * 8;
-    a_dst[p] = row * BK + ((lc ^ ((row >> 1) & 7)) * 8);
-    a_slot[p] = (m >= next_start ? 1 : 0) * kGnaC + lc * 8;
+    a_ptr[p] = X + (size_t)m * c.lda + (QUAD ? q * 4 : lc * 8);
+    a_dst[p] = QUAD ? row * BK + (((q >> 1) ^ ((row >> 1) & 7)) * 8) + (q & 1) * 4 : row * BK + ((lc ^ ((row >> 1) & 7)) * 8);
+    a_slot[p] = (m >= next_start ? 1 : 0) * kGnaC + (QUAD ? q * 4 : lc * 8);
   }
   const T* w_ptr[PW];
   int w_dst[PW];
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_gna_kernel(const GemmGnaDev<type
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
       r[p][0] = *(const float4*)(a_ptr[p] + t * BK);
-      r[p][1] = *(const float4*)(a_ptr[p] + t * BK + 4);
+      if constexpr (!QUAD) r[p][1] = *(const float4*)(a_ptr[p] + t * BK + 4);
     }
   };
   auto transform = [&](int kt, const float4 (&r)[PA][2], const x8 (&w)[PW]) {  // registers -> LDS tiles of k-tile kt
@@ -127,11 +129,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_gna_kernel(const GemmGnaDev<type
     for (int p = 0; p < PW; ++p) *(x8*)(ws + w_dst[p]) = w[p];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      const float4* tb = (const float4*)(tab + a_slot[p] + t * BK);  // 8 (multiplier, offset) pairs
-      const float xs[8] = {r[p][0].x, r[p][0].y, r[p][0].z, r[p][0].w, r[p][1].x, r[p][1].y, r[p][1].z, r[p][1].w};
+      const float4* tb = (const float4*)(tab + a_slot[p] + t * BK);  // 8 (QUAD: 4) (multiplier, offset) pairs
+      float xs[8] = {r[p][0].x, r[p][0].y, r[p][0].z, r[p][0].w, 0.f, 0.f, 0.f, 0.f};
+      if constexpr (!QUAD) { xs[4] = r[p][1].x; xs[5] = r[p][1].y; xs[6] = r[p][1].z; xs[7] = r[p][1].w; }
       x8 o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < (QUAD ? 2 : 4); ++j) {
         const float4 mo = tb[j];
         float y0 = fmaf(xs[2 * j], mo.x, mo.y), y1 = fmaf(xs[2 * j + 1], mo.z, mo.w);
 #ifndef TT_GNA_NOSILU
@@ -143,7 +146,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_gna_kernel(const GemmGnaDev<type
         o[2 * j] = (T)y0;
         o[2 * j + 1] = (T)y1;
       }
-      *(x8*)(as + a_dst[p]) = o;
+      if constexpr (QUAD) {
+        typename Vec<T>::x4 o4;
+        o4[0] = o[0]; o4[1] = o[1]; o4[2] = o[2]; o4[3] = o[3];
+        *(typename Vec<T>::x4*)(as + a_dst[p]) = o4;
+      } else {
+        *(x8*)(as + a_dst[p]) = o;
+      }
     }
   };
 

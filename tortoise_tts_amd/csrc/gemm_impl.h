@@ -1118,19 +1118,21 @@ int gemm_launch_typed(int epi, const GemmArgs& a, const GemmPlan& plan, hipStrea
   return rc;
 }
 
-// GroupNorm-apply on the A path (gemm_gna.h): 64 x 128 tile, 4 waves of 32 x 64, both operands four k-tiles ahead in registers.
-// 224 workgroups at the denoiser's 1740 rows x 1024 columns: one per CU, the same bytes per CU as two 64 x 64 workgroups of the 16-bit
-// path (W 256 KB + f32 A 256 KB), the apply redone by 8 column tiles instead of 16.
+// GroupNorm-apply on the A path (gemm_gna.h): 32 x 256 tile, 8 waves of 32 x 32 (two per SIMD: one wave's SiLU transcendentals run under the
+// other's MFMA / LDS waits), both operands two k-tiles ahead in registers.  220 workgroups at the denoiser's 1740 rows x 1024 columns, the
+// apply redone by 4 column tiles.  In-situ A/Bs (profiles/r04_ab_fused_groupnorm.txt; sampler iteration, stand-alone apply = 100 %):
+// 64 x 128 / 4 waves +4 %, 64 x 128 / 8 waves -1 % (box-dependent), 32 x 256 / 8 waves -2.2 .. -2.7 %; prefetch 2 beats 1 (far) and 4, 8.
+// The TT_GNA_* macros are the knobs of those A/B builds (build.py --variant).
 #ifndef TT_GNA_NW
 #define TT_GNA_NW 8
 #endif
 #ifndef TT_GNA_PF
-#define TT_GNA_PF 4
+#define TT_GNA_PF 2
 #endif
 #ifndef TT_GNA_BM
-#define TT_GNA_BM 64
-#define TT_GNA_BN 128
-#define TT_GNA_WM 2
+#define TT_GNA_BM 32
+#define TT_GNA_BN 256
+#define TT_GNA_WM 1
 #endif
 constexpr int kGnaBM = TT_GNA_BM, kGnaBN = TT_GNA_BN, kGnaWM = TT_GNA_WM, kGnaST = TT_GNA_PF, kGnaNW = TT_GNA_NW;  // (kGnaST: prefetch depth in k-tiles)
 constexpr int kGnaSmem = 0;
