@@ -25,13 +25,17 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 
 def klass(k):
     """rocprofv3 kernel name -> the engine profiler's class name (tortoise_tts_amd/csrc/common.hip g_prof_names)."""
-    m = re.search(r"gemm_glds_kernelI\w+?Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ENS_\d+(EpiStd|EpiQkvHeads|EpiQkvDecode)(\w*?)EELb([01])ELb[01]E", k)
+    if "gemm_gna_kernel" in k:
+        return "gemm_gna<32,256,EpiStd,stats>"
+    m = re.search(r"gemm_glds_kernelI\w+?Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ENS_\d+(EpiStd|EpiQkvHeads|EpiQkvDecode|EpiGeglu)(\w*?)EELb([01])ELb[01]E", k)
     if m:
         bm, bn, epi, targs, conv = m.groups()
         # EpiStd<T, ACT, STATS, MODE>: the 64x64 1x1 GEMMs with the statistics epilogue (denoiser) are their own class in the engine's profiler
         st = re.match(r"IDF16[b_]Lin?\d+ELi1E", targs) is not None
         if epi == "EpiStd" and bm == "64" and bn == "64" and conv == "0" and st:
             return "gemm_glds<64,64,EpiStd,1x1,stats>"
+        if epi == "EpiGeglu":
+            return "gemm_glds<%s,%s,EpiStd,1x1>" % (bm, bn)  # (reported with the plain 1x1 class of its tile, as the engine's profiler does)
         return "gemm_glds<%s,%s,%s%s>" % (bm, bn, epi, (",conv" if conv == "1" else ",1x1") if epi == "EpiStd" else "")
     if "gemm_conv3s_kernel" in k:
         return "gemm_glds<128,64,EpiStd,conv>"  # the shared-halo 3-tap kernel reports under the conv class of its tile
