@@ -49,3 +49,14 @@ def test_fails_loudly_without_gpu(lib):
     assert b"hip" in lib.tt_last_error().lower() or b"device" in lib.tt_last_error().lower()
     with pytest.raises(E.EngineError):
         E.check(rc)
+
+
+def test_header_constants_match_the_host_mirror():
+    """Every integer `#define TT_*` of the header that the ctypes host names too has the header's value (dtype codes, option ids)."""
+    src = open(os.path.join(ROOT, "include", "tortoise_mi355x.h")).read()
+    defines = {k: int(v) for k, v in re.findall(r"^#define\s+(TT_[A-Z0-9_]+)\s+(-?\d+)\s*$", src, flags=re.M)}
+    assert {"TT_BF16", "TT_F16", "TT_F32", "TT_AR_OPT_SUBBATCHES", "TT_AR_OPT_LOOKAHEAD", "TT_DIFF_OPT_OVERLAP_PREPASS", "TT_DIFF_OPT_FUSED_GN"} <= set(defines)
+    mirrored = [k for k in defines if hasattr(E, k)]
+    assert len(mirrored) >= 7
+    for k in mirrored:
+        assert getattr(E, k) == defines[k], k
