@@ -425,6 +425,11 @@ int tt_op_layernorm(int dtype, const float* x, int M, int D, const float* g, con
 int tt_op_groupnorm(int dtype, const float* x, int B, int S, int C, const float* g, const float* b, const float* scale_shift,
                     int act, void* out_t, float* out_f32, float* workspace, void* stream);
 size_t tt_op_groupnorm_workspace(int B, int S);
+/* the fused ResBlock in_layers launch (TT_DIFF_OPT_FUSED_GN; diffusion_decoder.py:60-80): out_f32[B*S][N] = W . act(GroupNorm32(x)) + bias,
+ * x f32 [B][S][1024] token-major, act = 3 (SiLU); 256 < B*S <= 4096, S >= 32, N % 256 == 0, 16-bit operand types */
+int tt_op_gn_gemm(int dtype, const float* x, int B, int S, const float* gamma, const float* beta, int act, const void* W,
+                  const float* bias, int N, float* out_f32, float* workspace, void* stream);
+size_t tt_op_gn_gemm_workspace(int B, int S);
 int tt_op_flash_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int heads, int n, int n_pad,
                           int causal, const float* relpos, void* stream);
 int tt_op_sample(const float* logits, int ldl, int B, int V, unsigned* seen, const tt_sampling* s, int step, int* unfinished,

@@ -307,3 +307,30 @@ def test_univnet_kernels(lib):
         o = O.location_variable_convolution(xin[None].cpu(), kk, bb, hop)
         ref = xres.cpu() + (torch.sigmoid(o[:, :32]) * torch.tanh(o[:, 32:]))[0]
         report(f"lvc hop={hop}", xr, ref, 1e-5)
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("B,S,N", [(2, 870, 1024), (1, 870, 1024), (3, 333, 256), (8, 33, 512), (1, 4096, 1024), (2, 129, 1024)])
+def test_groupnorm_silu_on_the_gemm_a_path(lib, name, dt, tdt, tol, B, S, N):
+    """The fused ResBlock in_layers launch (csrc/gemm_gna.h, diffusion_decoder.py:60-80 GroupNorm32 -> SiLU -> 1x1 conv) against torch
+    fp32: samples whose boundary falls inside a 32-row tile (S = 870, 333, 33, 129), a row count that is no multiple of the tile
+    (2 x 129, 3 x 333), one sample, the largest row count the kernel takes; activations with a per-group offset and spread so that the
+    mean / rstd folding has something to cancel.  The reference rounds the normalised activations to the operand type as the kernel does."""
+    if dt == E.TT_F32:
+        pytest.skip("the fused launch is a 16-bit-operand kernel (the fp32 verification mode keeps the stand-alone apply)")
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    C = 1024
+    x = torch.randn(B, S, C, generator=g) * (0.5 + torch.rand(1, 1, C, generator=g) * 3.0) + torch.randn(1, 1, C, generator=g) * 2.0
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    W = (torch.randn(N, C, generator=g) / math.sqrt(C)).to(tdt)
+    bias = torch.randn(N, generator=g)
+    xd, gd, bd, Wd, biasd = dev(x), dev(gamma), dev(beta), dev(W), dev(bias)
+    out = torch.zeros(B * S, N, device="cuda")
+    ws = torch.zeros(lib.tt_op_gn_gemm_workspace(B, S) // 4, device="cuda")
+    E.check(lib.tt_op_gn_gemm(dt, E.ptr(xd), B, S, E.ptr(gd), E.ptr(bd), E.ACT_SILU, E.ptr(Wd), E.ptr(biasd), N, E.ptr(out), E.ptr(ws), None))
+    torch.cuda.synchronize()
+    h = F.silu(F.group_norm(xd.transpose(1, 2), 32, gd, bd, eps=1e-5)).transpose(1, 2).reshape(B * S, C)
+    ref = h.to(tdt).float() @ Wd.float().t() + biasd
+    report(f"groupnorm + silu on the GEMM A path {name} B={B} S={S} N={N}", out, ref, 2e-4)
+    assert torch.isfinite(out).all()

@@ -46,6 +46,44 @@ int tt_op_groupnorm(int dtype, const float* x, int B, int S, int C, const float*
   return groupnorm_launch(dtype, a, (hipStream_t)stream);
 }
 
+// Test entry of the fused in_layers launch (gemm_gna.h): out_f32[B*S][N] = Linear(act(GroupNorm32(x)))(W, bias) for x f32 [B][S][1024].
+// The statistics partials the kernel finalises are normally left by the producing GEMM's epilogue; here a helper kernel writes them in that
+// layout (tiles of 32 rows, slot 1 = the rows of a tile that belong to the next sample, strips of 16 channels).
+__global__ void gn_gemm_test_partials_kernel(const float* x, int M, int S, int C, float* part) {
+  const int t = blockIdx.x, strip = threadIdx.x;  // one block per 32-row tile, one thread per 16-channel strip
+  if (strip >= C / 16) return;
+  const int b_first = (t * 32) / S, next_start = (b_first + 1) * S;
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  for (int r = t * 32; r < min(t * 32 + 32, M); ++r)
+    for (int c = strip * 16; c < strip * 16 + 16; ++c) {
+      const float v = x[(size_t)r * C + c];
+      if (r < next_start) { s0 += v; q0 += v * v; } else { s1 += v; q1 += v * v; }
+    }
+  float* p = part + (((size_t)t * 2 + 0) * (C / 16) + strip) * 2;
+  p[0] = s0; p[1] = q0;
+  p = part + (((size_t)t * 2 + 1) * (C / 16) + strip) * 2;
+  p[0] = s1; p[1] = q1;
+}
+size_t tt_op_gn_gemm_workspace(int B, int S) { return ((size_t)(B * S / 32 + 2) * 2 * 64 * 2 + 64) * 2 * sizeof(float); }
+
+int tt_op_gn_gemm(int dtype, const float* x, int B, int S, const float* gamma, const float* beta, int act, const void* W, const float* bias, int N,
+                  float* out_f32, float* workspace, void* stream) {
+  TT_REQUIRE(x && gamma && beta && W && bias && out_f32 && workspace && B >= 1 && S >= 1, "tt_op_gn_gemm: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int C = 1024, M = B * S;
+  float* part_in = workspace;
+  float* part_out = workspace + ((size_t)(M / 32 + 2) * 2 * 64 * 2 + 64);
+  gn_gemm_test_partials_kernel<<<cdiv(M, 32), 64, 0, s>>>(x, M, S, C, part_in);
+  TT_CHECK_HIP(hipGetLastError());
+  GemmArgs g = gemm_args(x, C, W, C, M, N, C);
+  g.bias = bias; g.out_f32 = out_f32; g.ldo32 = N; g.gn_part = part_out; g.gn_seq = S;
+  GemmGnArgs n;
+  memset(&n, 0, sizeof(n));
+  n.gamma = gamma; n.beta = beta; n.gemm_part = part_in; n.part_rows = 32; n.S = S; n.eps = 1e-5f; n.act = act;
+  TT_REQUIRE(gemm_gna_supported(dtype, EPI_STD, g, n), "tt_op_gn_gemm: no fused kernel for B=%d S=%d N=%d act=%d dtype=%d (256 < B*S <= 4096, S >= 32, N %% 256 == 0, SiLU, 16-bit operands)", B, S, N, act, dtype);
+  return gemm_gna_launch(dtype, EPI_STD, g, n, s);
+}
+
 int tt_op_flash_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int heads, int n, int n_pad,
                           int causal, const float* relpos, void* stream) {
   FlashArgs f;
