@@ -168,6 +168,14 @@ def main():
                         per = 1 << 20
                         us = bw_probe(mode, waves, nb, fp, per)
                         print(f"bw2 {tag:24s} {mtag:40s} {wtag:20s} x {nb} blocks: {us:8.2f} us  {nb * per / us / 1e6:7.2f} TB/s  {per * (nb / 256) / us / 1e3:6.1f} GB/s per CU", flush=True)
+    if "kvpat" in which:  # the decode attention's K / V access pattern against contiguous streams of the same size and geometry (30 cold regions)
+        lib.tt_kb_kv_pattern.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(D)]
+        for tmax in (232, 128):
+            for mode, tag in ((0, "product layout: K chunk-major 8 x 2 KB runs + V 16 KB"), (2, "K 16 KB + V 16 KB contiguous, two arrays"), (1, "one 32 KB run per (sequence, head)")):
+                us = D(0)
+                chk(lib.tt_kb_kv_pattern(mode, 256, 16, tmax, 30, 10, C.byref(us)))
+                mb = 256 * 16 * 32768 / 1e6
+                print(f"kvpat tmax {tmax:3d} {tag:60s}: {us.value:7.2f} us per launch of {mb:.0f} MB = {mb / us.value:5.2f} TB/s", flush=True)
     if "bw3" in which:   # working-set series: what does a set resident in the Infinity Cache (256 MiB) stream at, against one that only HBM holds?
         for mib in (16, 64, 128, 192, 512, 2048, 8192):
             for nb in (512, 1024):

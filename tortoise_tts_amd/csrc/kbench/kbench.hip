@@ -652,6 +652,79 @@ extern "C" int tt_kb_bw_probe(int mode, int nw_waves, int nblocks, size_t footpr
 }
 
 
+// --------------------------------------------------------------------------------------------------------------------
+// What does the ACCESS PATTERN of the decode attention's per-sequence K / V stream cost against a contiguous stream of the same size and
+// launch geometry?  One wave per (sequence, head), `wpb` waves per workgroup, 16 loads of 16 B per lane in flight (as decode_attn_lds_kernel),
+// 32 KB per wave, `nwaves` waves per launch, a chain of launches over DIFFERENT regions (the 30 layers: nothing comes from the Infinity Cache).
+//   mode 0: the product layout at t = 128 keys - K chunk-major [8 chunks][tmax keys][8 dims] (eight runs of 2 KB, 3.7 KB apart), then V
+//           [128 keys][64 dims] (16 KB contiguous); K and V blocks of one (sequence, head) in two different arrays
+//   mode 1: the same 32 KB as ONE contiguous run per wave (a [key][K 64 | V 64] interleaved cache would stream like this)
+//   mode 2: K and V each one contiguous 16 KB run, in two arrays
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void kv_pattern_kernel(const char* kbuf, const char* vbuf, size_t region, int tmax, float* sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t w = (size_t)blockIdx.y * gridDim.x * 4 + (size_t)blockIdx.x * 4 + wave;  // (sequence group, head, sequence) as in the product grid
+  const size_t kblk = (size_t)8 * tmax * 16, vblk = (size_t)tmax * 128;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 v[16];
+  if (MODE == 0) {
+    const char* kb = kbuf + region + w * kblk;
+    const char* vb = vbuf + region + w * vblk;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v[2 * c] = *(const f32x4*)(kb + (size_t)c * tmax * 16 + lane * 16);
+      v[2 * c + 1] = *(const f32x4*)(kb + (size_t)c * tmax * 16 + 1024 + lane * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = *(const f32x4*)(vb + (size_t)u * 1024 + lane * 16);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+  } else {
+    const char* b0 = MODE == 1 ? kbuf + region + w * (kblk + vblk) : kbuf + region + w * kblk;
+    const char* b1 = MODE == 1 ? b0 + 16384 : vbuf + region + w * vblk;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = *(const f32x4*)(b0 + (size_t)u * 1024 + lane * 16);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = *(const f32x4*)(b1 + (size_t)u * 1024 + lane * 16);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = acc[0];
+}
+
+extern "C" int tt_kb_kv_pattern(int mode, int B, int heads, int tmax, int chain, int reps, double* us_out) {
+  Arena ar;
+  GraphTimer gt;
+  TT_TRY(gt.init());
+  const size_t nw = (size_t)B * heads;
+  const size_t kblk = (size_t)8 * tmax * 16, vblk = (size_t)tmax * 128;
+  const size_t region = nw * (kblk + vblk) + 65536;  // per launch of the chain (both arrays are sized for the interleaved mode)
+  void* kbuf = nullptr; void* vbuf = nullptr; float* sink = nullptr;
+  int rc = dev_bf16(ar, &kbuf, region * chain / 2 + 4096, 5u);
+  if (!rc) rc = dev_bf16(ar, &vbuf, region * chain / 2 + 4096, 6u);
+  if (!rc) rc = ar.alloc_t(&sink, 64);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
+  if (!rc) rc = gt.run([&](hipStream_t s) -> int {
+    for (int i = 0; i < chain; ++i) {
+      const dim3 grid(heads, B / 4);
+      const size_t off = (size_t)i * region;
+      if (mode == 0) kv_pattern_kernel<0><<<grid, 256, 0, s>>>((const char*)kbuf, (const char*)vbuf, off, tmax, sink);
+      else if (mode == 1) kv_pattern_kernel<1><<<grid, 256, 0, s>>>((const char*)kbuf, (const char*)vbuf, off, tmax, sink);
+      else kv_pattern_kernel<2><<<grid, 256, 0, s>>>((const char*)kbuf, (const char*)vbuf, off, tmax, sink);
+    }
+    TT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }, reps, us_out);
+  if (!rc) *us_out /= chain;
+  gt.destroy();
+  ar.release();
+  return rc;
+}
+
 extern "C" int tt_kb_flash(int B, int H, int n, int causal, int relpos, int chain, int reps, double* us_out) {
   Arena ar;
   GraphTimer gt;
