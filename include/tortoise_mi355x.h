@@ -51,6 +51,16 @@ typedef struct tt_gpt_layer {
   const float* ln2_g; const float* ln2_b;
   const void* w_fc;   const float* b_fc;      /* T [4D][D] */
   const void* w_proj2; const float* b_proj2;  /* T [D][4D] */
+  /* Optional (all six or none; needs 16-bit operands, D % 64 == 0, D <= 1024): the weights of the five-launch decode step, in which
+   * LayerNorm is folded into the QKV / c_fc GEMMs - LN(x) W^T + b = rstd (x Wg^T - mean colsum) + b' (transformers GPT2Block.forward:
+   * ln_1 -> attn.c_attn, ln_2 -> mlp.c_fc; tortoise/models/autoregressive.py:150-163 runs it per token).  Without them the decode
+   * step keeps a LayerNorm kernel in front of each of the two GEMMs. */
+  const void* w_qkv_ln;       /* T [3D][D]  w_qkv[n][k] * ln1_g[k], rounded to T once */
+  const float* c_qkv_ln;      /* f32 [3D]   sum_k of the ROUNDED w_qkv_ln[n][k] */
+  const float* b_qkv_ln;      /* f32 [3D]   b_qkv[n] + sum_k w_qkv[n][k] * ln1_b[k] */
+  const void* w_fc_ln;        /* T [4D][D]  w_fc * ln2_g */
+  const float* c_fc_ln;       /* f32 [4D] */
+  const float* b_fc_ln;       /* f32 [4D] */
 } tt_gpt_layer;
 
 typedef struct tt_ar_config {
@@ -132,13 +142,14 @@ int tt_ar_generate_chunk(tt_ar* h, int B, int first, int n_more, int ldcodes, co
 int tt_ar_stream_latents(tt_ar* h, int B, int n, float* out, void* stream);
 
 /* Engine options of a handle (not part of the reference's surface; defaults in brackets):
- *   TT_AR_OPT_SUBBATCHES [1]  the decode step of B candidates cut into 1, 2 or 4 row ranges that run their 30 layers concurrently on
- *                             separate streams (used when B divides into ranges of >= 16 sequences, a multiple of 4).  Candidates are
- *                             independent until the sampler and every kernel is row-local, so the sampled codes are bit-identical
- *                             for any setting.  An experiment kept as an option: measured slower than one range
+ *   TT_AR_OPT_FUSED_STEP [1]  five kernel launches per layer of the decode step (LayerNorm folded into the QKV / c_fc GEMMs, split-K
+ *                             partial sums folded inside the projection launches); 0 = seven launches (split-K slabs folded by a
+ *                             LayerNorm kernel) - the form handles without tt_gpt_layer's *_ln weights and the fp32 verification
+ *                             mode always use.  A measurement / bisecting switch: both forms are deterministic and independent of
+ *                             the batch size, but they are two different roundings of the same network
  *   TT_AR_OPT_LOOKAHEAD  [6]  decode steps the host may launch ahead of the device (the loop is paced by progress words the
  *                             last kernel of a step publishes to pinned memory; no queue drain inside the loop) */
-#define TT_AR_OPT_SUBBATCHES 1
+#define TT_AR_OPT_FUSED_STEP 2
 #define TT_AR_OPT_LOOKAHEAD 4
 int tt_ar_set_option(tt_ar* h, int option, int value);
 /* Operand-overflow guard: the row norms and the sampler count launches that met a non-finite value (an fp16 operand beyond 65504
@@ -147,7 +158,7 @@ int tt_ar_set_option(tt_ar* h, int option, int value);
  * (api.py:413-414); the host side re-runs a tripped stage with bf16 operands. */
 int tt_ar_guard(tt_ar* h, int reset);
 /* Counters for tests: which = 0 decode-step graph captures so far, 1 queue drains the launch loop fell back to (expected 0),
- * 2 row ranges of the kept step graph. */
+ * 2 kernel launches of one decode step in its current form, 3 = 1 when the five-launch form is in use. */
 int tt_ar_stat(tt_ar* h, int which);
 
 /* Teacher-forced single steps for parity tests: tt_ar_begin resets per-sequence state for B rows
@@ -430,6 +441,12 @@ size_t tt_op_groupnorm_workspace(int B, int S);
 int tt_op_gn_gemm(int dtype, const float* x, int B, int S, const float* gamma, const float* beta, int act, const void* W,
                   const float* bias, int N, float* out_f32, float* workspace, void* stream);
 size_t tt_op_gn_gemm_workspace(int B, int S);
+/* the decode step's fused pair (GPT2Block: attn.c_proj / mlp.c_proj + residual, then ln -> c_fc + gelu_new): x [M][D] += A [M][K] W[D][K]^T + bias
+ * with the split-K fold inside the launch (splitk > 1: arrival tickets; <= 1: -splitk K ranges folded by one workgroup), leaving xt (T copy of x)
+ * and stats f32 [M][D / 32][2] = per-32-column (sum, sum of squares); then, unless Wg is null, out_t [M][N2] = gelu_tanh(LN(x) W2^T + b2) from
+ * the folded operands Wg = W2 * gamma (T), colsum [N2], bias2 = b2 + W2 beta.  16-bit operand types, D % 64 == 0, D <= 1024. */
+int tt_op_resid_ln(int dtype, const void* A, int K, const void* W, const float* bias, float* x, int M, int D, int splitk, const void* Wg,
+                   const float* colsum, const float* bias2, int N2, void* out_t, void* xt, float* stats, void* stream);
 int tt_op_flash_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int heads, int n, int n_pad,
                           int causal, const float* relpos, void* stream);
 int tt_op_sample(const float* logits, int ldl, int B, int V, unsigned* seen, const tt_sampling* s, int step, int* unfinished,

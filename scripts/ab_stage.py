@@ -29,8 +29,8 @@ def main():
     ap.add_argument("--mel-tokens", type=int, default=200)
     ap.add_argument("--iterations", type=int, default=200)
     ap.add_argument("--ar-variants", default="",
-                    help="';'-separated 'ranges[,lookahead]' settings of tt_ar_set_option to time one after the other on ONE "
-                         "handle (same weights, same box, same process), e.g. '1;2;4;1,1;1'")
+                    help="';'-separated 'fused[,lookahead]' settings of tt_ar_set_option to time one after the other on ONE "
+                         "handle (same weights, same box, same process), e.g. '1;0;1;0' = five- / seven-launch decode step alternating")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     args = ap.parse_args()
     from bench import bench_prompt
@@ -52,9 +52,9 @@ def main():
             for var in variants:
                 tag = args.tag
                 if var is not None:
-                    ar.set_option(E.TT_AR_OPT_SUBBATCHES, var[0])
+                    ar.set_option(E.TT_AR_OPT_FUSED_STEP, var[0])
                     ar.set_option(E.TT_AR_OPT_LOOKAHEAD, var[1] if len(var) > 1 else 6)
-                    tag = "ranges=%d%s" % (var[0], " look=%d" % var[1] if len(var) > 1 else "")
+                    tag = "fused=%d%s" % (var[0], " look=%d" % var[1] if len(var) > 1 else "")
                 times = []
                 codes = None
                 for r in range(args.reps + 1):
@@ -65,9 +65,9 @@ def main():
                     torch.cuda.synchronize()
                     if r:
                         times.append((time.perf_counter() - t0) / n)
-                print("ab %-12s ar   B=%d n=%d: %.4f ms/step (min %.4f)  total %.1f ms  codes %s  drains %d" %
+                print("ab %-12s ar   B=%d n=%d: %.4f ms/step (min %.4f)  total %.1f ms  codes %s  drains %d  launches/step %d" %
                       (tag, args.candidates, n, 1e3 * sum(times) / len(times), 1e3 * min(times), 1e3 * n * sum(times) / len(times), digest(codes),
-                       ar.stat(1)), flush=True)
+                       ar.stat(1), ar.stat(2)), flush=True)
             ar.close()
             del ar
         if "diff" in args.stages:

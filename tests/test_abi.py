@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_mirrors_match(lib):
     for i, st in enumerate(E.BOUNDARY_STRUCTS):
         assert C.sizeof(st) == lib.tt_struct_size(i), st.__name__
-    assert lib.tt_abi_version() == 3
+    assert lib.tt_abi_version() == 4
 
 
 def test_fails_loudly_without_gpu(lib):
@@ -55,7 +55,7 @@ def test_header_constants_match_the_host_mirror():
     """Every integer `#define TT_*` of the header that the ctypes host names too has the header's value (dtype codes, option ids)."""
     src = open(os.path.join(ROOT, "include", "tortoise_mi355x.h")).read()
     defines = {k: int(v) for k, v in re.findall(r"^#define\s+(TT_[A-Z0-9_]+)\s+(-?\d+)\s*$", src, flags=re.M)}
-    assert {"TT_BF16", "TT_F16", "TT_F32", "TT_AR_OPT_SUBBATCHES", "TT_AR_OPT_LOOKAHEAD", "TT_DIFF_OPT_OVERLAP_PREPASS", "TT_DIFF_OPT_FUSED_GN"} <= set(defines)
+    assert {"TT_BF16", "TT_F16", "TT_F32", "TT_AR_OPT_FUSED_STEP", "TT_AR_OPT_LOOKAHEAD", "TT_DIFF_OPT_OVERLAP_PREPASS", "TT_DIFF_OPT_FUSED_GN"} <= set(defines)
     mirrored = [k for k in defines if hasattr(E, k)]
     assert len(mirrored) >= 7
     for k in mirrored:

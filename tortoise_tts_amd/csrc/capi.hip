@@ -7,7 +7,7 @@ using namespace tt;
 extern "C" {
 
 const char* tt_last_error(void) { return tt::last_error(); }
-int tt_abi_version(void) { return 3; }  // ABI changes
+int tt_abi_version(void) { return 4; }  // ABI changes
 
 int tt_init(void) {
   int dev = 0;
@@ -82,6 +82,39 @@ int tt_op_gn_gemm(int dtype, const float* x, int B, int S, const float* gamma, c
   n.gamma = gamma; n.beta = beta; n.gemm_part = part_in; n.part_rows = 32; n.S = S; n.eps = 1e-5f; n.act = act;
   TT_REQUIRE(gemm_gna_supported(dtype, EPI_STD, g, n), "tt_op_gn_gemm: no fused kernel for B=%d S=%d N=%d act=%d dtype=%d (256 < B*S <= 4096, S >= 32, N %% 256 == 0, SiLU, 16-bit operands)", B, S, N, act, dtype);
   return gemm_gna_launch(dtype, EPI_STD, g, n, s);
+}
+
+// Test entry of the decode step's fused pair (gemm.h EPI_RESID + a folded LayerNorm): the projection x += A W^T + bias with the split-K fold
+// inside the launch (splitk > 1: arrival tickets; splitk <= 1: -splitk K ranges folded by one workgroup, 0 / -1 = one range), which leaves x
+// (f32, in place), xt (T copy) and stats ([M][D / 32][2]); then out_t[M][N2] = gelu_tanh(LN(x) W2^T + b2) from the folded operands
+// (Wg = W2 * gamma, colsum, bias2 = b2 + W2 beta).  Wg == nullptr skips the second launch.  Scratch (slabs, counters) is allocated here.
+int tt_op_resid_ln(int dtype, const void* A, int K, const void* W, const float* bias, float* x, int M, int D, int splitk, const void* Wg,
+                   const float* colsum, const float* bias2, int N2, void* out_t, void* xt, float* stats, void* stream) {
+  TT_REQUIRE(A && W && bias && x && xt && stats && M >= 1, "tt_op_resid_ln: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  float* slabs = nullptr;
+  unsigned* count = nullptr;
+  const int sk = splitk > 1 ? splitk : 1;
+  TT_CHECK_HIP(hipMalloc((void**)&slabs, (size_t)sk * M * D * sizeof(float) + 256));
+  TT_CHECK_HIP(hipMalloc((void**)&count, ((size_t)cdiv(M, 64) * (D / 64) + 64) * sizeof(unsigned)));
+  TT_CHECK_HIP(hipMemsetAsync(count, 0, ((size_t)cdiv(M, 64) * (D / 64) + 64) * sizeof(unsigned), s));
+  GemmArgs g = gemm_args(A, K, W, K, M, D, K);
+  g.bias = bias; g.res = x; g.ldres = D; g.out_f32 = x; g.ldo32 = D; g.out_t = xt; g.ldot = D; g.rs_stats = stats;
+  if (splitk > 1) { g.splitk = splitk; g.rs_slabs = slabs; g.rs_count = count; }
+  else g.serial_k = splitk < -1 ? -splitk : 1;
+  int rc = gemm_launch(dtype, EPI_RESID, g, s);
+  if (!rc && Wg) {
+    g = gemm_args(xt, D, Wg, D, M, N2, D);
+    g.bias = bias2; g.act = ACT_GELU_TANH; g.out_t = out_t; g.ldot = N2;
+    g.ln_stats = stats; g.ln_colsum = colsum; g.ln_bands = D / 32; g.ln_eps = 1e-5f;
+    rc = gemm_launch(dtype, EPI_STD, g, s);
+  }
+  hipError_t e = hipStreamSynchronize(s);
+  (void)hipFree(slabs);
+  (void)hipFree(count);
+  TT_TRY(rc);
+  TT_CHECK_HIP(e);
+  return 0;
 }
 
 int tt_op_flash_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int heads, int n, int n_pad,

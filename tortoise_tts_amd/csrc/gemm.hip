@@ -53,7 +53,10 @@ static int prof_class(int tile, int epi, bool conv, bool stats = false) {
 // Device argument core: tile grid, XCD row bands (minimise the bytes one XCD pulls over the fabric, A / bands + W * bands / 8),
 // split-K ranges and the reciprocals the kernel divides by.
 static void plan_core(const GemmArgs& a, int epi, GemmPlan& p, int force_tile = -1, int force_bm = 0, int force_bn = 0) {
-  const int tile = force_tile >= 0 ? force_tile : pick_tile(a);
+  // EPI_RESID: the two tiles with 32-column wave tiles (one LayerNorm-statistics band per wave); both give a row the same bits
+  if (epi == EPI_RESID && force_tile < 0) force_tile = a.M > 1024 ? TILE_128x64 : TILE_64x64;
+  int tile = force_tile >= 0 ? force_tile : pick_tile(a);
+  if (a.ln_stats && tile == TILE_256x256) tile = TILE_128x128;  // (no folded-LayerNorm kernel on the 256 x 256 tile)
   const int bm = force_bm ? force_bm : tile == TILE_64x64 ? 64 : tile == TILE_256x256 ? 256 : 128;
   const int bn = force_bn ? force_bn : tile == TILE_256x256 ? 256 : tile == TILE_128x128 ? 128 : 64;
   GemmCore& c = p.core;
@@ -97,10 +100,11 @@ static void plan_core(const GemmArgs& a, int epi, GemmPlan& p, int force_tile = 
                     a.out_f32 && ((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0;
   p.conv3s = epi == EPI_STD && tile == TILE_128x64 && a.taps == 3 && a.dilation <= 1 && a.splitk == 1 && a.gn_part != nullptr && a.bias != nullptr &&
              a.out_t == nullptr && a.act == ACT_NONE && a.A2 == nullptr && al16 && a.cin >= 256;
-  p.prof_id = prof_class(tile, epi, a.taps > 1, a.gn_part != nullptr);
+  p.prof_id = epi == EPI_RESID ? PROF_GEMM_RESID : (a.ln_stats && epi == EPI_QKV_DECODE) ? PROF_GEMM_LN_QKVDEC : (a.ln_stats && epi == EPI_STD) ? PROF_GEMM_LN_FC
+              : prof_class(tile, epi, a.taps > 1, a.gn_part != nullptr);
   // algorithmic work of this launch: 2*M*N*K flops; operands read once + ONE result written once (the extra split-K slabs
   // a launch writes are an implementation cost: they show up in the PMC traffic, not here)
-  const bool std_epi = epi == EPI_STD;
+  const bool std_epi = epi == EPI_STD || epi == EPI_RESID;
   const double out_bytes = (double)a.M * (epi == EPI_GEGLU ? a.N / 2 : a.N) * ((std_epi && a.out_f32 ? 4.0 : 0.0) + (a.out_t || !std_epi ? 2.0 : 0.0));
   p.flops = 2.0 * a.M * a.N * a.K;
   p.bytes = ((double)a.N * a.K + (double)a.M * a.cin) * 2.0 + out_bytes + (a.res ? 4.0 * a.M * a.N : 0.0);
@@ -124,9 +128,27 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   TT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   TT_REQUIRE(a.K % 64 == 0 && a.cin % 64 == 0, "gemm: K=%d (taps=%d) must be a multiple of 64 per tap", a.K, a.taps);
   TT_REQUIRE((a.lda % 8 == 0 && a.ldw % 8 == 0) || (dtype == DT_F32 && a.lda % 4 == 0 && a.ldw % 4 == 0), "gemm: lda=%d / ldw=%d must be multiples of 8 elements", a.lda, a.ldw);
-  TT_REQUIRE(a.splitk == 1 || (epi == EPI_STD && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
+  TT_REQUIRE(a.splitk == 1 || ((epi == EPI_STD || epi == EPI_RESID) && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
+  if (epi == EPI_RESID) {
+    TT_REQUIRE(dtype != DT_F32, "gemm: EPI_RESID has no fp32 verification kernel (the decode step keeps the row-norm form there)");
+    TT_REQUIRE(a.taps == 1 && !a.A2 && !a.gn_part && a.act == ACT_NONE && a.bias && a.res && a.out_f32 && a.res == a.out_f32 && a.ldres == a.ldo32 && a.out_t && a.rs_stats &&
+                   a.N % 64 == 0 && ((size_t)a.bias & 15) == 0 && ((size_t)a.res & 15) == 0 && (a.ldres & 3) == 0 && ((size_t)a.out_t & 7) == 0 && (a.ldot & 3) == 0 &&
+                   ((size_t)a.rs_stats & 7) == 0,
+               "gemm: EPI_RESID needs bias, an in-place f32 residual (res == out_f32), a T copy, a statistics buffer, N %% 64 == 0 and aligned operands");
+    TT_REQUIRE(a.splitk == 1 || (a.serial_k <= 1 && a.rs_slabs && a.rs_count && ((size_t)a.rs_slabs & 15) == 0 && (size_t)a.splitk * a.M * a.N * sizeof(float) < (1ull << 31)),
+               "gemm: EPI_RESID with split-K needs a slab buffer (< 2 GiB) and arrival counters, and excludes serial_k");
+    TT_REQUIRE(a.serial_k <= 1 || (a.K / 64) % a.serial_k == 0, "gemm: K / 64 = %d is not divisible by serial_k = %d", a.K / 64, a.serial_k);
+  }
+  if (a.ln_stats) {
+    TT_REQUIRE(dtype != DT_F32 && a.taps == 1 && !a.A2 && a.splitk == 1 && a.serial_k <= 1 && a.ln_colsum && a.ln_bands * 32 == a.K && a.K <= 32 * 8 * 4 && (a.ln_bands & 1) == 0 &&
+                   ((size_t)a.ln_stats & 15) == 0 && ((size_t)a.ln_colsum & 15) == 0 && (a.N & 3) == 0,
+               "gemm: a folded LayerNorm needs K = 32 * ln_bands <= 1024 columns (an even band count), a column-sum vector and aligned statistics");
+    TT_REQUIRE(epi == EPI_QKV_DECODE || (epi == EPI_STD && a.act == ACT_GELU_TANH && a.bias && a.out_t && !a.out_f32 && !a.res && !a.gn_part && !a.act_t &&
+                                         ((size_t)a.bias & 15) == 0 && ((size_t)a.out_t & 7) == 0 && (a.ldot & 3) == 0),
+               "gemm: a folded LayerNorm is built for the decode QKV epilogue and for bias + tanh-GELU + T output (c_fc)");
+  }
   TT_REQUIRE(a.splitk <= a.K / 64, "gemm: splitk=%d exceeds the %d k-tiles", a.splitk, a.K / 64);
-  if (a.serial_k > 1)
+  if (a.serial_k > 1 && epi != EPI_RESID)
     TT_REQUIRE(epi == EPI_STD && a.splitk == 1 && a.bias && a.res && a.out_f32 && !a.out_t && !a.gn_part && a.taps == 1 && !a.A2 && a.act == ACT_NONE &&
                    (a.K / 64) % a.serial_k == 0 && (a.N & 3) == 0 && ((size_t)a.bias & 15) == 0 && ((size_t)a.res & 15) == 0 && (a.ldres & 3) == 0 &&
                    ((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0,
@@ -141,7 +163,7 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
     TT_REQUIRE(a.taps == 1 && a.splitk == 1 && a.out_t && a.N % 32 == 0 && a.ldot >= a.N / 2 && (a.ldot & 3) == 0 && ((size_t)a.out_t & 15) == 0 &&
                    (a.bias == nullptr || ((size_t)a.bias & 15) == 0) && !a.A2 && !a.gn_part && !a.res && !a.out_f32,
                "gemm: the GEGLU epilogue takes a plain GEMM with N %% 32 == 0 (value / gate strips interleaved), an aligned T output of N / 2 columns and nothing else");
-  } else if (epi != EPI_STD) {
+  } else if (epi != EPI_STD && epi != EPI_RESID) {
     TT_REQUIRE(epi == EPI_QKV_HEADS || epi == EPI_QKV_DECODE, "gemm: unknown epilogue %d", epi);
     TT_REQUIRE(a.taps == 1, "gemm: conv taps are only supported with the standard epilogue");
     TT_REQUIRE(a.dmodel % 64 == 0 && a.N == 3 * a.dmodel && a.heads * 64 == a.dmodel, "gemm: qkv epilogue needs N == 3*dmodel, head_dim 64");

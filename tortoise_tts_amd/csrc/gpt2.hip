@@ -2,9 +2,13 @@
 //   * prefill:   every candidate of an utterance shares the same [cond | text | start] prefix, so it is
 //                evaluated once (M = P+1 rows) and its K/V are shared by all sequences
 //                (the reference recomputes it B times: autoregressive.py:134-144 + repeat_interleave).
-//   * decode:    KV-cached step for B sequences; K/V appended by the QKV GEMM epilogue; projections
-//                use split-K slabs that the following LayerNorm kernel folds into the residual stream
-//                (deterministic, no atomics); sampling on device; whole step replayed from one hipGraph.
+//   * decode:    KV-cached step for B sequences, FIVE launches per layer: QKV GEMM with LayerNorm folded in (K / V appended by
+//                its epilogue), decode attention, attention projection, c_fc GEMM with LayerNorm folded in, MLP projection.
+//                The two projections fold their split-K partial sums INSIDE the launch (arrival ticket per tile, last arriver sums the
+//                slabs in slab order: deterministic, no float atomics), update the residual stream and leave the rows' LayerNorm
+//                statistics + a T copy of the raw rows for the next GEMM (gemm.h EPI_RESID / ln_stats).  Sampling on device; the
+//                whole step is replayed from one hipGraph.  (fp32 verification mode and handles without the folded weights: the
+//                seven-launch form - split-K slabs folded by a LayerNorm kernel in front of the QKV / c_fc GEMMs.)
 //   * latents:   teacher-forced full pass for the CLVP winners (autoregressive.py:454-506).
 #include "runtime.h"
 #include <unistd.h>
@@ -81,25 +85,11 @@ struct tt_ar {
   int* progress_host = nullptr;
   int* progress_dev = nullptr;
   int lookahead = 6;
-  // Decode step cut into `nsub` independent row ranges (candidates are independent until the sampler): each range runs its 30
-  // layers on its own stream, so the HBM-bound attention of one range can overlap the latency-bound GEMM / norm chain of another.
-  // Every kernel is row-local (GEMM tiles, one-workgroup-per-row norms, per-sequence attention), so the logits and therefore the
-  // codes are bit-identical for any nsub.  Replayed as one LINEAR hipGraph per range + one for the tail (lm_head, sampler), forked
-  // and joined by the host with events every step: a single graph with parallel branches is executed one branch after the other
-  // by this runtime (scripts/kbench.py streams: G || G 2.0 x of one chain as branches, 1.2 - 1.3 x on two streams).
-  // Measured (profiles/r04_ab_ar_subbatches.txt): no gain - a range's GEMM / norm chain does not get shorter with fewer rows (it is
-  // latency-bound), so n ranges run n chains per layer and can at best hide the attention time behind them.  Default 1.
-  int nsub = 1;
-  hipStream_t sub_stream[3] = {nullptr, nullptr, nullptr};
-  // fork / join / tail events of the range streams: a ring, one slot per step the host may be ahead (lookahead <= 64), so that no
-  // event is re-recorded while a wait on its previous record may still be queued
-  static constexpr int EV_RING = 80;
-  std::vector<hipEvent_t> ev_ring;  // [EV_RING][8]: 0 fork, 1 tail, 2 .. 4 join
-  unsigned ev_seq = 0;
-  hipEvent_t ev(int slot, int which) const { return ev_ring[(size_t)slot * 8 + which]; }
-  hipGraph_t part_graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // one linear graph per range 0 .. 3, [4] = tail (lm_head + sampler)
-  hipGraphExec_t part_exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int step_nsub = 1;  // ranges of the kept graph(s)
+  // five-launch decode step (see the header comment): needs the folded weights of every layer (tt_gpt_layer *_ln), D % 64 == 0, D <= 1024
+  bool can_fuse = false;
+  int fused = 1;               // tt_ar_set_option(TT_AR_OPT_FUSED_STEP): 0 keeps the seven-launch form (A/B runs, bisecting)
+  float* lnstats = nullptr;    // [max_batch][D / 32][2] row statistics left by the projections
+  unsigned* tickets = nullptr; // arrival counters of the projections' output tiles (zero between launches)
   int captures = 0;   // decode-step captures so far (tt_ar_stat: tests assert the kept graph is reused)
   int drains = 0;     // host-side queue drains the launch loop fell back to (0 when the progress words arrive)
 };
@@ -109,12 +99,6 @@ static void ar_drop_step_graph(tt_ar* e) {
   if (e->step_graph) (void)hipGraphDestroy(e->step_graph);
   e->step_exec = nullptr;
   e->step_graph = nullptr;
-  for (int i = 0; i < 5; ++i) {
-    if (e->part_exec[i]) (void)hipGraphExecDestroy(e->part_exec[i]);
-    if (e->part_graph[i]) (void)hipGraphDestroy(e->part_graph[i]);
-    e->part_exec[i] = nullptr;
-    e->part_graph[i] = nullptr;
-  }
   e->step_key.clear();
 }
 
@@ -235,61 +219,95 @@ static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, 
   return ar_head_gemm(e, M, s, logits_row0);
 }
 
-// The 30 layers of one KV-cached decode step for the sequences [row0, row0 + nb) + the input norm of lm_head, all on stream s.
-// `slabs`: this range's private split-K slab region ([MAX_SPLIT][nb][D]).
-static int decode_layers_enqueue(tt_ar* e, hipStream_t s, int row0, int nb, float* slabs) {
-  const int D = e->D, H = e->H, dt = e->cfg.dtype;
-  float* x = e->x + (size_t)row0 * D;
-  void* h = offset_t(e->h, (size_t)row0 * D, e->es);
-  void* ff = offset_t(e->ff, (size_t)row0 * 4 * D, e->es);
-  void* attn = offset_t(e->attn, (size_t)row0 * D, e->es);
-  void* q = offset_t(e->q, (size_t)row0 * D, e->es);
-  const size_t seq_elems = (size_t)H * e->tmax * 64;   // per-sequence K (or V) elements of one layer
+static inline bool ar_fused(const tt_ar* e) { return e->can_fuse && e->fused != 0; }
+
+// Attention / MLP projection of the five-launch decode step: x += A W^T + b with the split-K fold inside the launch; leaves the T copy
+// of the updated rows in e->h and their LayerNorm statistics in e->lnstats (gemm.h EPI_RESID).
+static int ar_proj_resid(tt_ar* e, const void* A, int K, const void* W, const float* bias, int nb, hipStream_t s) {
+  const int D = e->D;
+  GemmArgs g = ar_gemm(e, A, K, W, K, nb, D, K);
+  g.bias = bias; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
+  g.out_t = e->h; g.ldot = D; g.rs_stats = e->lnstats;
+  const int sk = pick_split(nb, D, K);
+  if (nb >= 1024 || sk == 1) {  // one workgroup per tile fills the chip (or there is one K range): the ranges are folded by that workgroup
+    g.serial_k = sk;
+  } else {
+    g.splitk = sk; g.rs_slabs = e->slabs; g.rs_count = e->tickets;
+  }
+  return gemm_launch(e->cfg.dtype, EPI_RESID, g, s);
+}
+static inline void ar_ln_fold(tt_ar* e, GemmArgs& g, const float* colsum) {
+  g.ln_stats = e->lnstats; g.ln_colsum = colsum; g.ln_bands = e->D / 32; g.ln_eps = 1e-5f; g.ln_guard = e->guard;
+}
+
+// The 30 layers of one KV-cached decode step for the e->B sequences + the input norm of lm_head, all on stream s.
+static int decode_layers_enqueue(tt_ar* e, hipStream_t s) {
+  const int D = e->D, H = e->H, dt = e->cfg.dtype, nb = e->B;
+  float* x = e->x;
+  float* slabs = e->slabs;
+  const bool fused = ar_fused(e);
   const float* pend_bias = nullptr;
   int pend_slabs = 0;
   for (int l = 0; l < e->cfg.layers; ++l) {
     const tt_gpt_layer& w = e->L[l];
-    TT_TRY(ar_rownorm_rows(e, x, h, nb, w.ln1_g, w.ln1_b, pend_bias, slabs, pend_slabs, nb, s));
-    GemmArgs g = ar_gemm(e, h, D, w.w_qkv, D, nb, 3 * D, D);
-    g.bias = w.b_qkv; g.dmodel = D; g.heads = H; g.q_scale = 0.125f;
-    g.step = e->state + 1; g.qbuf = q;
-    g.kc = offset_t(e->kc, (size_t)l * e->gen_layer_elems + (size_t)row0 * seq_elems, e->es);
-    g.vc = offset_t(e->vc, (size_t)l * e->gen_layer_elems + (size_t)row0 * seq_elems, e->es);
+    GemmArgs g;
+    if (fused && l > 0) {  // LayerNorm folded into the GEMM: A = T copy of the raw rows (left by the previous layer's MLP projection)
+      g = ar_gemm(e, e->h, D, w.w_qkv_ln, D, nb, 3 * D, D);
+      g.bias = w.b_qkv_ln;
+      ar_ln_fold(e, g, w.c_qkv_ln);
+    } else {               // (layer 0 of the five-launch form: the rows come from the embedding, nothing has left statistics yet)
+      TT_TRY(ar_rownorm_rows(e, x, e->h, nb, w.ln1_g, w.ln1_b, pend_bias, slabs, pend_slabs, nb, s));
+      g = ar_gemm(e, e->h, D, w.w_qkv, D, nb, 3 * D, D);
+      g.bias = w.b_qkv;
+    }
+    g.dmodel = D; g.heads = H; g.q_scale = 0.125f;
+    g.step = e->state + 1; g.qbuf = e->q;
+    g.kc = offset_t(e->kc, (size_t)l * e->gen_layer_elems, e->es);
+    g.vc = offset_t(e->vc, (size_t)l * e->gen_layer_elems, e->es);
     g.tmax = e->tmax;
     TT_TRY(gemm_launch(dt, EPI_QKV_DECODE, g, s));
     DecodeAttnArgs a;
     memset(&a, 0, sizeof(a));
-    a.q = q;
+    a.q = e->q;
     a.kp = offset_t(e->kp, (size_t)l * e->prefix_layer_elems, e->es);
     a.vp = offset_t(e->vp, (size_t)l * e->prefix_layer_elems, e->es);
-    if (e->G > 1) {  // (utterance groups: always one range, row0 == 0)
+    if (e->G > 1) {
       a.ngroups = e->G; a.group_size = nb / e->G;
       a.prefix_group_stride = (size_t)e->cfg.layers * e->prefix_layer_elems;
       for (int gi = 0; gi < e->G; ++gi) a.p1_tab[gi] = e->P1g[gi];
     }
     a.P1 = e->P1; a.kc = g.kc; a.vc = g.vc; a.tmax = e->tmax; a.step = e->state + 1;
-    a.out = attn; a.B = nb; a.heads = H; a.host_tgen = e->host_slot + 1;
+    a.out = e->attn; a.B = nb; a.heads = H; a.host_tgen = e->host_slot + 1;
     TT_TRY(decode_attention_launch(dt, a, s));
-    // >= 1024 sequences (several utterances per batch): one block per output tile fills the chip, so the split-K partial sums are
-    // folded inside the launch in slab order (gemm.h serial_k: the same bits as slabs + row norm, without 2 x 4 x B x D x 4 bytes of slab traffic)
+    if (fused) {
+      TT_TRY(ar_proj_resid(e, e->attn, D, w.w_proj, w.b_proj, nb, s));
+      g = ar_gemm(e, e->h, D, w.w_fc_ln, D, nb, 4 * D, D);
+      g.bias = w.b_fc_ln; g.act = ACT_GELU_TANH; g.out_t = e->ff; g.ldot = 4 * D;
+      ar_ln_fold(e, g, w.c_fc_ln);
+      TT_TRY(gemm_launch(dt, EPI_STD, g, s));
+      TT_TRY(ar_proj_resid(e, e->ff, 4 * D, w.w_proj2, w.b_proj2, nb, s));
+      continue;
+    }
+    // seven-launch form.  >= 1024 sequences (several utterances per batch): one block per output tile fills the chip, so the split-K partial
+    // sums are folded inside the launch in slab order (gemm.h serial_k: the same bits as slabs + row norm, without the slab traffic)
     const bool serial = nb >= 1024;
     int sk = pick_split(nb, D, D);
-    g = ar_gemm(e, attn, D, w.w_proj, D, nb, D, D);
+    g = ar_gemm(e, e->attn, D, w.w_proj, D, nb, D, D);
     if (serial && sk > 1) {
       g.serial_k = sk; g.bias = w.b_proj; g.res = x; g.ldres = D; g.out_f32 = x; g.ldo32 = D;
       TT_TRY(gemm_launch(dt, EPI_STD, g, s));
-      TT_TRY(ar_rownorm_rows(e, x, h, nb, w.ln2_g, w.ln2_b, nullptr, slabs, 0, nb, s));
+      TT_TRY(ar_rownorm_rows(e, x, e->h, nb, w.ln2_g, w.ln2_b, nullptr, slabs, 0, nb, s));
     } else {
       g.splitk = sk; g.out_f32 = slabs; g.ldo32 = D;
       if (sk == 1) { g.bias = nullptr; }
       TT_TRY(gemm_launch(dt, EPI_STD, g, s));
-      TT_TRY(ar_rownorm_rows(e, x, h, nb, w.ln2_g, w.ln2_b, w.b_proj, slabs, sk, nb, s));
+      TT_TRY(ar_rownorm_rows(e, x, e->h, nb, w.ln2_g, w.ln2_b, w.b_proj, slabs, sk, nb, s));
     }
-    g = ar_gemm(e, h, D, w.w_fc, D, nb, 4 * D, D);
-    g.bias = w.b_fc; g.act = ACT_GELU_TANH; g.out_t = ff; g.ldot = 4 * D;
+    g = ar_gemm(e, e->h, D, w.w_fc, D, nb, 4 * D, D);
+    g.bias = w.b_fc; g.act = ACT_GELU_TANH; g.out_t = e->ff; g.ldot = 4 * D;
     TT_TRY(gemm_launch(dt, EPI_STD, g, s));
     sk = pick_split(nb, D, 4 * D);
-    g = ar_gemm(e, ff, 4 * D, w.w_proj2, 4 * D, nb, D, 4 * D);
+    g = ar_gemm(e, e->ff, 4 * D, w.w_proj2, 4 * D, nb, D, 4 * D);
     if (serial && sk > 1) {
       g.serial_k = sk; g.bias = w.b_proj2; g.res = x; g.ldres = D; g.out_f32 = x; g.ldo32 = D;
       TT_TRY(gemm_launch(dt, EPI_STD, g, s));
@@ -302,40 +320,15 @@ static int decode_layers_enqueue(tt_ar* e, hipStream_t s, int row0, int nb, floa
       pend_slabs = sk;
     }
   }
-  return ar_head_norm(e, x, h, nb, pend_bias, slabs, pend_slabs, nb, s, row0 == 0 && nb == e->B ? -1 : -2);
+  return ar_head_norm(e, x, e->h, nb, pend_bias, slabs, pend_slabs, nb, s, -1);
 }
-
-// Row ranges of the current decode batch: e->nsub of them when the batch divides into ranges of a multiple of 4 sequences
-// (the attention kernel's workgroup) and nothing ties the rows together (utterance groups, per-step latent capture).
-static int ar_ranges(const tt_ar* e) {
-  const int n = e->nsub;
-  if (n <= 1 || e->G > 1 || e->lat != nullptr) return 1;
-  if (e->B % (4 * n) != 0 || e->B / n < 16) return 1;
-  return n;
-}
-static inline float* ar_range_slabs(tt_ar* e, int i, int nb) { return e->slabs + (size_t)i * MAX_SPLIT * nb * e->D; }
 
 // One KV-cached decode step for e->B sequences up to the logits; the fed tokens are in e->next_tok (or, `embedded`, the sampler
-// already wrote this step's input rows into e->x: tt_ar_generate).  With several row ranges: fork on `s`, one stream per range,
-// join on `s` in front of lm_head (eager launches: tt_ar_decode_step, tt_graph_replay(0); replay uses one graph per range).
+// already wrote this step's input rows into e->x: tt_ar_generate).
 static int decode_step_enqueue(tt_ar* e, hipStream_t s, bool embedded = false) {
   const int B = e->B;
   if (!embedded) TT_TRY(ar_embed_launch(e->next_tok, e->state, e->w.mel_emb, e->w.mel_pos, e->x, B, e->D, e->cfg.mel_pos_offset, s));
-  const int ns = ar_ranges(e);
-  if (ns == 1) {
-    TT_TRY(decode_layers_enqueue(e, s, 0, B, e->slabs));
-    return ar_head_gemm(e, B, s);
-  }
-  const int nb = B / ns;
-  const int slot = (int)(e->ev_seq++ % tt_ar::EV_RING);
-  TT_CHECK_HIP(hipEventRecord(e->ev(slot, 0), s));
-  for (int i = 0; i < ns; ++i) {
-    hipStream_t si = i == 0 ? s : e->sub_stream[i - 1];
-    if (i > 0) TT_CHECK_HIP(hipStreamWaitEvent(si, e->ev(slot, 0), 0));
-    TT_TRY(decode_layers_enqueue(e, si, i * nb, nb, ar_range_slabs(e, i, nb)));
-    if (i > 0) TT_CHECK_HIP(hipEventRecord(e->ev(slot, 2 + i - 1), si));
-  }
-  for (int i = 1; i < ns; ++i) TT_CHECK_HIP(hipStreamWaitEvent(s, e->ev(slot, 2 + i - 1), 0));
+  TT_TRY(decode_layers_enqueue(e, s));
   return ar_head_gemm(e, B, s);
 }
 
@@ -431,11 +424,14 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
   if (!rc) {
     e->guard_host[0] = 0;
     e->progress_host[0] = 0; e->progress_host[1] = -1; e->progress_host[2] = e->progress_host[3] = 0;
-    hipError_t he = hipSuccess;
-    for (int i = 0; i < 3 && he == hipSuccess; ++i) he = hipStreamCreateWithFlags(&e->sub_stream[i], hipStreamNonBlocking);
-    e->ev_ring.assign((size_t)tt_ar::EV_RING * 8, nullptr);
-    for (size_t i = 0; i < e->ev_ring.size() && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&e->ev_ring[i], hipEventDisableTiming);
-    if (he != hipSuccess) { set_error("tt_ar_create: stream / event creation failed: %s", hipGetErrorString(he)); rc = -2; }
+  }
+  // five-launch decode step: the folded weights of every layer, 16-bit operands, D a multiple of 64 and <= 1024 (4 x 4 band pairs per lane)
+  e->can_fuse = cfg->dtype != DT_F32 && D % 64 == 0 && D <= 1024;
+  for (const tt_gpt_layer& l : e->L)
+    if (!l.w_qkv_ln || !l.c_qkv_ln || !l.b_qkv_ln || !l.w_fc_ln || !l.c_fc_ln || !l.b_fc_ln) e->can_fuse = false;
+  if (!rc && e->can_fuse) {
+    rc = e->arena.alloc_t(&e->lnstats, (size_t)(cfg->max_batch + 64) * (D / 32) * 2);
+    if (!rc) rc = e->arena.alloc_t(&e->tickets, (size_t)cdiv(cfg->max_batch, 64) * (D / 64) + 64);
   }
   if (rc) {
     tt_ar_destroy(e);
@@ -452,10 +448,6 @@ void tt_ar_destroy(tt_ar* e) {
   if (e->par_host) (void)hipHostFree(e->par_host);
   if (e->progress_host) (void)hipHostFree(e->progress_host);
   if (e->guard_host) (void)hipHostFree(e->guard_host);
-  for (hipEvent_t ev : e->ev_ring)
-    if (ev) (void)hipEventDestroy(ev);
-  for (int i = 0; i < 3; ++i)
-    if (e->sub_stream[i]) (void)hipStreamDestroy(e->sub_stream[i]);
   e->arena.release();
   e->sb.destroy();
   delete e;
@@ -596,9 +588,10 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
   }
 
   const bool use_graph = graphs_enabled() && target - e->gen_done > 1;
-  const int ns = ar_ranges(e);
-  const bool parts = use_graph && ns > 1;
   int rc = 0;
+  // (the projections' arrival counters are zero between launches - the last arriver of a tile re-zeroes it; a generation starts from
+  //  a known state whatever an aborted launch may have left)
+  if (e->tickets) TT_CHECK_HIP(hipMemsetAsync(e->tickets, 0, ((size_t)cdiv(e->cfg.max_batch, 64) * (e->D / 64) + 64) * sizeof(unsigned), s));
   auto tail_enqueue = [&](hipStream_t st) -> int {
     TT_TRY(sample_launch(sa, st));
     return ar_state_advance_launch(e->state, e->unfinished_count, e->progress_dev, st);
@@ -610,42 +603,25 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
     memcpy(key.data(), &sa, sizeof(sa));
     int geo[24] = {B, e->G, e->P1, g_prof_on ? 1 : 0};
     for (int gi = 0; gi < 16; ++gi) geo[4 + gi] = gi < e->G ? e->P1g[gi] : 0;
-    geo[20] = ns;
+    geo[20] = ar_fused(e) ? 1 : 0;
     memcpy(key.data() + sizeof(sa), geo, sizeof(geo));
-    const bool have = parts ? e->part_exec[4] != nullptr : e->step_exec != nullptr;
-    if (!have || key != e->step_key) {
+    if (e->step_exec == nullptr || key != e->step_key) {
       ar_drop_step_graph(e);
-      if (!parts) {
-        rc = ar_capture(s, [&]() -> int {
-          TT_TRY(decode_step_enqueue(e, s, true));
-          return tail_enqueue(s);
-        }, &e->step_graph, &e->step_exec);
-      } else {
-        const int nb = B / ns;
-        for (int i = 0; i < ns && !rc; ++i) {
-          hipStream_t si = i == 0 ? s : e->sub_stream[i - 1];
-          rc = ar_capture(si, [&]() -> int { return decode_layers_enqueue(e, si, i * nb, nb, ar_range_slabs(e, i, nb)); },
-                          &e->part_graph[i], &e->part_exec[i]);
-        }
-        if (!rc) rc = ar_capture(s, [&]() -> int {
-          TT_TRY(ar_head_gemm(e, B, s));
-          return tail_enqueue(s);
-        }, &e->part_graph[4], &e->part_exec[4]);
-      }
+      rc = ar_capture(s, [&]() -> int {
+        TT_TRY(decode_step_enqueue(e, s, true));
+        return tail_enqueue(s);
+      }, &e->step_graph, &e->step_exec);
       if (rc) {
         ar_drop_step_graph(e);
         return rc;
       }
       e->step_key.swap(key);
-      e->step_nsub = ns;
       e->captures += 1;
     }
   }
   const int first_step = e->gen_done;
   int steps_done = e->gen_done;
   bool stop_seen = false;
-  int tail_slot = (int)(e->ev_seq++ % tt_ar::EV_RING);  // slot whose tail event marks "everything before this step is done" on s
-  if (parts) TT_CHECK_HIP(hipEventRecord(e->ev(tail_slot, 1), s));
   for (int step = first_step; step < target; ++step) {
     // stay at most `lookahead` steps ahead of the device; the words are written by the last kernel of every step
     int spins = 0;
@@ -661,20 +637,8 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
     if (rc) break;
     if (prog[1] >= 0) { stop_seen = true; break; }
     hipError_t le = hipSuccess;
-    if (use_graph && !parts) {
+    if (use_graph) {
       le = hipGraphLaunch(e->step_exec, s);
-    } else if (parts) {
-      const int slot = (int)(e->ev_seq++ % tt_ar::EV_RING);
-      for (int i = 1; i < ns && le == hipSuccess; ++i) le = hipStreamWaitEvent(e->sub_stream[i - 1], e->ev(tail_slot, 1), 0);
-      if (le == hipSuccess) le = hipGraphLaunch(e->part_exec[0], s);
-      for (int i = 1; i < ns && le == hipSuccess; ++i) {
-        le = hipGraphLaunch(e->part_exec[i], e->sub_stream[i - 1]);
-        if (le == hipSuccess) le = hipEventRecord(e->ev(slot, 2 + i - 1), e->sub_stream[i - 1]);
-      }
-      for (int i = 1; i < ns && le == hipSuccess; ++i) le = hipStreamWaitEvent(s, e->ev(slot, 2 + i - 1), 0);
-      if (le == hipSuccess) le = hipGraphLaunch(e->part_exec[4], s);
-      if (le == hipSuccess) le = hipEventRecord(e->ev(slot, 1), s);
-      tail_slot = slot;
     } else {
       e->host_slot = step - 1;
       rc = decode_step_enqueue(e, s, true);
@@ -695,7 +659,6 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
   }
   if (rc) {
     (void)hipStreamSynchronize(s);
-    for (int i = 0; i < 3; ++i) (void)hipStreamSynchronize(e->sub_stream[i]);
     ar_drop_step_graph(e);  // a failed replay leaves nothing to trust
   }
   TT_TRY(rc);
@@ -795,21 +758,22 @@ int tt_ar_guard(tt_ar* e, int reset) {
 }
 
 // Counters for tests / diagnostics: 0 = decode-step graph captures so far, 1 = queue drains of the launch loop (expected 0),
-// 2 = row ranges of the kept step graph.
+// 2 = kernel launches of one decode step in its current form (layers + head + sampler + step counter), 3 = 1 when the five-launch form runs.
 int tt_ar_stat(tt_ar* e, int which) {
   if (!e) { set_error("tt_ar_stat: null handle"); return -1; }
-  return which == 0 ? e->captures : which == 1 ? e->drains : which == 2 ? e->step_nsub : -1;
+  const int per_step = ar_fused(e) ? 5 * e->cfg.layers + 1 + 4 : 7 * e->cfg.layers + 4;
+  return which == 0 ? e->captures : which == 1 ? e->drains : which == 2 ? per_step : which == 3 ? (ar_fused(e) ? 1 : 0) : -1;
 }
 
 // Engine options of a handle (defaults in brackets):
-//   TT_AR_OPT_SUBBATCHES  [1]  row ranges the decode step is cut into (1, 2 or 4), each on its own stream; codes are bit-identical
+//   TT_AR_OPT_FUSED_STEP  [1]  five-launch decode step (LayerNorm folded into the QKV / c_fc GEMMs, in-launch split-K fold); 0: seven launches
 //   TT_AR_OPT_LOOKAHEAD   [6]  decode steps the host may run ahead of the device (>= 1)
 int tt_ar_set_option(tt_ar* e, int option, int value) {
   TT_REQUIRE(e != nullptr, "tt_ar_set_option: null handle");
   switch (option) {
-    case TT_AR_OPT_SUBBATCHES:
-      TT_REQUIRE(value == 1 || value == 2 || value == 4, "tt_ar_set_option: %d row ranges (1, 2 or 4)", value);
-      e->nsub = value;
+    case TT_AR_OPT_FUSED_STEP:
+      TT_REQUIRE(value == 0 || value == 1, "tt_ar_set_option: TT_AR_OPT_FUSED_STEP takes 0 or 1, got %d", value);
+      e->fused = value;
       break;
     case TT_AR_OPT_LOOKAHEAD:
       TT_REQUIRE(value >= 1 && value <= 64, "tt_ar_set_option: lookahead %d outside 1 .. 64", value);

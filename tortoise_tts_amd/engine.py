@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("TORTOISE_MI355X_LIB") or os.path.join(HERE, "lib", "l
 
 TT_BF16, TT_F16, TT_F32 = 0, 1, 2  # TT_F32: the slow fp32-operand VERIFICATION mode of the AR / CLVP / diffusion / vocoder stages (tests)
 DTYPE_NAMES = {TT_BF16: "bf16", TT_F16: "fp16", TT_F32: "fp32"}
-TT_AR_OPT_SUBBATCHES, TT_AR_OPT_LOOKAHEAD = 1, 4
+TT_AR_OPT_FUSED_STEP, TT_AR_OPT_LOOKAHEAD = 2, 4
 TT_DIFF_OPT_OVERLAP_PREPASS = 1
 TT_DIFF_OPT_FUSED_GN = 2
 
@@ -35,7 +35,8 @@ class EngineError(RuntimeError):
 
 class GptLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_proj", "b_proj", "ln2_g", "ln2_b",
-                                  "w_fc", "b_fc", "w_proj2", "b_proj2")]
+                                  "w_fc", "b_fc", "w_proj2", "b_proj2",
+                                  "w_qkv_ln", "c_qkv_ln", "b_qkv_ln", "w_fc_ln", "c_fc_ln", "b_fc_ln")]
 
 
 class ArConfig(C.Structure):
@@ -201,6 +202,7 @@ _PROTOS = {
     "tt_op_groupnorm_workspace": (_sz, [_i, _i]),
     "tt_op_gn_gemm": (_i, [_i, vp, _i, _i, vp, vp, _i, vp, vp, _i, vp, vp, vp]),
     "tt_op_gn_gemm_workspace": (_sz, [_i, _i]),
+    "tt_op_resid_ln": (_i, [_i, vp, _i, vp, vp, vp, _i, _i, _i, vp, vp, vp, _i, vp, vp, vp, vp]),
     "tt_op_flash_attention": (_i, [_i, vp, vp, vp, vp, _i, _i, _i, _i, _i, vp, vp]),
     "tt_op_sample": (_i, [vp, _i, _i, _i, vp, C.POINTER(Sampling), _i, vp, _i, vp, _i, vp]),
     "tt_op_conv1d": (_i, [vp, vp, vp, vp, _i, _i, _i, _i, _i, _i, _f, _i, _f, vp]),
