@@ -142,11 +142,11 @@ int tt_ar_generate_chunk(tt_ar* h, int B, int first, int n_more, int ldcodes, co
 int tt_ar_stream_latents(tt_ar* h, int B, int n, float* out, void* stream);
 
 /* Engine options of a handle (not part of the reference's surface; defaults in brackets):
- *   TT_AR_OPT_FUSED_STEP [1]  five kernel launches per layer of the decode step (LayerNorm folded into the QKV / c_fc GEMMs, split-K
- *                             partial sums folded inside the projection launches); 0 = seven launches (split-K slabs folded by a
- *                             LayerNorm kernel) - the form handles without tt_gpt_layer's *_ln weights and the fp32 verification
- *                             mode always use.  A measurement / bisecting switch: both forms are deterministic and independent of
- *                             the batch size, but they are two different roundings of the same network
+ *   TT_AR_OPT_FUSED_STEP [0]  1 = five kernel launches per layer of the decode step (LayerNorm folded into the QKV / c_fc GEMMs, split-K
+ *                             partial sums folded inside the projection launches by the last-arriving workgroup); 0 = seven launches
+ *                             (split-K slabs folded by a LayerNorm kernel).  Both forms are deterministic and independent of the batch
+ *                             size; they are two roundings of the same network.  Measured on MI355X the five-launch form is 7 % SLOWER
+ *                             (DESIGN.md 5.7), hence the default; it needs tt_gpt_layer's *_ln weights and 16-bit operands
  *   TT_AR_OPT_LOOKAHEAD  [6]  decode steps the host may launch ahead of the device (the loop is paced by progress words the
  *                             last kernel of a step publishes to pinned memory; no queue drain inside the loop) */
 #define TT_AR_OPT_FUSED_STEP 2
@@ -447,6 +447,9 @@ size_t tt_op_gn_gemm_workspace(int B, int S);
  * the folded operands Wg = W2 * gamma (T), colsum [N2], bias2 = b2 + W2 beta.  16-bit operand types, D % 64 == 0, D <= 1024. */
 int tt_op_resid_ln(int dtype, const void* A, int K, const void* W, const float* bias, float* x, int M, int D, int splitk, const void* Wg,
                    const float* colsum, const float* bias2, int N2, void* out_t, void* xt, float* stats, void* stream);
+/* process-wide A/B switch of the attention kernels (diagnostics, like tt_graph_replay): 1 (default) = 32-query waves on
+ * v_mfma_f32_32x32x16 for non-causal sequences of more than 128 rows, 0 = the 16-query-wave kernels everywhere; returns the previous value */
+int tt_flash_variant(int v);
 int tt_op_flash_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int heads, int n, int n_pad,
                           int causal, const float* relpos, void* stream);
 int tt_op_sample(const float* logits, int ldl, int B, int V, unsigned* seen, const tt_sampling* s, int step, int* unfinished,

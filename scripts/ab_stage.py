@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--ar-variants", default="",
                     help="';'-separated 'fused[,lookahead]' settings of tt_ar_set_option to time one after the other on ONE "
                          "handle (same weights, same box, same process), e.g. '1;0;1;0' = five- / seven-launch decode step alternating")
+    ap.add_argument("--flash-variants", default="",
+                    help="';'-separated tt_flash_variant settings (1 = 32-query-wave attention kernel, 0 = 16-query waves) to time the diffusion "
+                         "stage with, one fresh stage object each, e.g. '1;0;1;0'")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     args = ap.parse_args()
     from bench import bench_prompt
@@ -76,25 +79,33 @@ def main():
             M = args.mel_tokens
             S = M * 4 * 24000 // 22050
             from tortoise_tts_amd import engine as E
-            df = stages.DiffusionStage(sd, cfg, dtype=E.dtype_code(args.dtype), max_seq=max(S, 128), max_codes=max(M, 64), max_steps=args.iterations)
             g = torch.Generator().manual_seed(5)
             lat = torch.randn(1, M, 1024, generator=g).to(dev)
             sched = Schedule(args.iterations, cfg.trained_steps, True, 2)
             x = torch.randn(1, 100, S, generator=g).to(dev)
             noise = torch.randn(args.iterations, 1, 100, S, generator=g).to(dev)
-            times = []
-            mel = None
-            for r in range(args.reps + 1):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                df.condition(lat, diffc.to(dev), S)
-                mel = df.sample(sched, x, noise)
-                torch.cuda.synchronize()
-                if r:
-                    times.append((time.perf_counter() - t0) / args.iterations)
-            print("ab %-10s diff S=%d it=%d: %.4f ms/iteration (min %.4f)  total %.1f ms  mel %s" %
-                  (args.tag, S, args.iterations, 1e3 * sum(times) / len(times), 1e3 * min(times), 1e3 * args.iterations * sum(times) / len(times), digest(mel)), flush=True)
-            df.close()
+            fvs = [int(v) for v in args.flash_variants.split(";") if v.strip()] or [None]
+            for fv in fvs:
+                tag = args.tag
+                if fv is not None:
+                    E.load_library().tt_flash_variant(fv)
+                    tag = "flash32=%d" % fv
+                df = stages.DiffusionStage(sd, cfg, dtype=E.dtype_code(args.dtype), max_seq=max(S, 128), max_codes=max(M, 64), max_steps=args.iterations)
+                times = []
+                mel = None
+                for r in range(args.reps + 1):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    df.condition(lat, diffc.to(dev), S)
+                    mel = df.sample(sched, x, noise)
+                    torch.cuda.synchronize()
+                    if r:
+                        times.append((time.perf_counter() - t0) / args.iterations)
+                print("ab %-10s diff S=%d it=%d: %.4f ms/iteration (min %.4f)  total %.1f ms  mel %s" %
+                      (tag, S, args.iterations, 1e3 * sum(times) / len(times), 1e3 * min(times), 1e3 * args.iterations * sum(times) / len(times), digest(mel)), flush=True)
+                df.close()
+            if fvs != [None]:
+                E.load_library().tt_flash_variant(1)
 
 
 if __name__ == "__main__":

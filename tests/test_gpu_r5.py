@@ -104,6 +104,8 @@ def test_five_launch_decode_step_is_deterministic_and_batch_independent(eos_boos
     cond, text = G.ar_inputs(cfg)
     B, steps = 64, 40
     st = _stage(cfg, sd, B)
+    assert st.stat(3) == 0 and st.stat(2) == 7 * cfg.layers + 4, "the seven-launch form is the measured default"
+    st.set_option(E.TT_AR_OPT_FUSED_STEP, 1)
     assert st.stat(3) == 1 and st.stat(2) == 5 * cfg.layers + 5, f"decode step: {st.stat(2)} launches, five-launch form {st.stat(3)}"
     st.prefill(cond, text)
     base, n0 = st.generate(B, steps, seed=11)

@@ -531,6 +531,255 @@ __global__ __launch_bounds__(256 * KS, 2) void flash_lds_kernel(FlashArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- 32-query waves (round 5)
+// The same algorithm on v_mfma_f32_32x32x16: a wave owns 32 queries, a workgroup 128 (4 query groups x KS key halves), K / V^T tiles
+// of 64 keys staged once per workgroup through the same 3-stage LDS-DMA ring.  Why: flash_lds_kernel issues 15.7 VALU instructions per
+// 16x16x32 MFMA (profiles/r03_pmc_flash_kbench.txt) - per 16 queries x 32 keys a lane holds 8 scores, and everything that is per ROW
+// (cross-lane maximum, running-state update, the relative-position window test, the LDS fragment addresses) is paid per 8 scores.  Here
+// a lane holds ONE query (l & 31) and 16 scores of it per 32-key block; its row maximum is 15 in-lane v_max + one permlane32 swap, the
+// fragment reads serve twice the flops (a K fragment feeds a 32 x 32 x 16 product), and the P^T operand of the second product is again
+// the score registers in the order the first product left them: lane half h = l >> 5 holds keys 4 h + 8 i + j of the block (reg 4 i + j),
+// so k-slot e of PV step kk is score register 8 kk + e, and V^T is read with that permutation (two 8-byte reads per fragment).
+template <typename T, int KS>
+__global__ __launch_bounds__(256 * KS, 2 * KS) void flash32_kernel(FlashArgs a) {
+  typedef typename Vec<T>::x8 x8;
+  typedef typename Vec<T>::x4 x4;
+  constexpr int ST = 3, KT = 64;
+  constexpr int STAGE = 2 * KT * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* ring = (T*)smem_raw;
+  float* rp = (float*)(ring + ST * STAGE);
+  int bx = blockIdx.x, bh = blockIdx.y;
+  {
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    const int lin = bh * gx + bx, xcd = lin & 7, slot = lin >> 3;
+    const int per = total >> 3, rem = total & 7;
+    const int lin2 = xcd * per + min(xcd, rem) + slot;
+    bh = lin2 / gx;
+    bx = lin2 - bh * gx;
+  }
+  const int h = bh % a.heads, b = bh / a.heads;
+  const int lane = threadIdx.x & 63, wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = wave_id & 3, kp_own = wave_id >> 2;
+  const int ql = lane & 31, hh = lane >> 5;
+  const int ns = a.n;
+  const int n = a.nv_period > 0 ? a.nv[b % a.nv_period] : a.n;
+  const int qblock = bx * 128;
+  if (qblock >= n) return;
+  if (a.relpos) {
+    if (threadIdx.x < 129) rp[threadIdx.x] = a.relpos[h * 129 + threadIdx.x];
+    __syncthreads();
+  }
+  const int qbase = qblock + wave * 32;
+  const T* Q = (const T*)a.q + (size_t)bh * ns * 64;
+  const T* K = (const T*)a.k + (size_t)bh * ns * 64;
+  const T* VT = (const T*)a.vt + (size_t)bh * 64 * a.n_pad;
+
+  x8 qf[4];
+  {
+    const int qr = min(qbase + ql, n - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const x8*)(Q + (size_t)qr * 64 + ks * 16 + hh * 8);
+  }
+  float m_run = -1e30f, l_run = 0.f;
+  f32x16 acc[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[db][v] = 0.f;
+  const int q_last_blk = min(qblock + 128, n) - 1;
+  const int q_last = min(qbase + 32, n) - 1;
+  const int kend_blk = a.causal ? q_last_blk + 1 : n;
+  const int kend = qbase >= n ? 0 : (a.causal ? q_last + 1 : n);
+  const int ntile = (kend_blk + KT - 1) / KT;
+
+  const int lr = lane >> 3, lc = lane & 7;
+  auto issue = [&](int t, int stage) {
+    const int key0 = t * KT;
+    T* base = ring + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4 / KS; ++i) {
+      const int piece = wave_id + 4 * KS * i;
+      const int row = (piece & 7) * 8 + lr;
+      const int chunk = lc ^ ((row >> 1) & 7);
+      const T* src;
+      if (piece < 8) src = K + (size_t)min(key0 + row, n - 1) * 64 + chunk * 8;
+      else src = VT + (size_t)row * a.n_pad + min(key0 + chunk * 8, a.n_pad - 8);
+      __builtin_amdgcn_global_load_lds((gbl_void_a*)src, (lds_void_a*)(base + piece * 512), 16, 0, 0);
+    }
+  };
+
+  constexpr float LOG2E = 1.4426950408889634f;
+  const int qi = qbase + ql;
+  // one 32-key block (kp = 0 / 1 of the staged tile; key0 = its first key) against this wave's 32 queries
+  auto process = [&](const T* kt, const T* vt, int kp, int key0) {
+    x8 kf[4], vf[2][2];
+    {
+      const int r = kp * 32 + ql;
+      const int sw = (r >> 1) & 7;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const x8*)(kt + r * 64 + (((ks * 2 + hh) ^ sw) * 8));
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int d = db * 32 + ql;
+      const int sw = (d >> 1) & 7;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int c = kp * 4 + 2 * kk;  // 8-key chunk of keys 16 kk .. +7 of the block; this lane half takes keys 4 hh .. +3 of it and of the next
+        const x4 lo = *(const x4*)(vt + d * 64 + ((c ^ sw) * 8) + hh * 4);
+        const x4 hi = *(const x4*)(vt + d * 64 + (((c + 1) ^ sw) * 8) + hh * 4);
+        x8 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        vf[db][kk] = v;
+      }
+    }
+    f32x16 st;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) st[v] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[ks], st);
+    float sv[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) sv[v] = st[v];
+    // score register v <-> key key0 + 8 (v >> 2) + 4 hh + (v & 3)
+    float cbias = 0.f;
+    if (a.relpos) {
+      if (key0 - (qbase + 31) >= 64) {
+        cbias = rp[128];
+      } else if (qbase - (key0 + 31) >= 64) {
+        cbias = rp[0];
+      } else {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          int d = key0 + 8 * (v >> 2) + 4 * hh + (v & 3) - qi;
+          d = d < -64 ? -64 : (d > 64 ? 64 : d);
+          sv[v] += rp[d + 64];
+        }
+      }
+    }
+    if (key0 + 32 > n || (a.causal && key0 + 31 > qbase)) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int key = key0 + 8 * (v >> 2) + 4 * hh + (v & 3);
+        if (key >= n || (a.causal && key > qi)) sv[v] = -INFINITY;
+      }
+    }
+    float mx = vmax3(sv[0], sv[1], sv[2]);
+    mx = vmax3(mx, sv[3], sv[4]);
+    mx = vmax3(mx, sv[5], sv[6]);
+    mx = vmax3(mx, sv[7], sv[8]);
+    mx = vmax3(mx, sv[9], sv[10]);
+    mx = vmax3(mx, sv[11], sv[12]);
+    mx = vmax3(mx, sv[13], sv[14]);
+    mx = vmax(mx, sv[15]);
+    {
+      float x0, x1;
+      pair_xor32(mx, x0, x1);
+      mx = vmax(x0, x1) + cbias;
+    }
+    const float m_new = vmax(m_run, mx);
+    if (__any(m_new > m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[db][v] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = (m_new - cbias) * LOG2E;
+    float pv[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) pv[v] = __builtin_amdgcn_exp2f(fmaf(sv[v], LOG2E, -mc));
+    x8 pf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[kk][e] = (T)pv[kk * 8 + e];
+    l_run += (((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]))) +
+             (((pv[8] + pv[9]) + (pv[10] + pv[11])) + ((pv[12] + pv[13]) + (pv[14] + pv[15])));
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) acc[db] = mfma32(vf[db][kk], pf[kk], acc[db]);
+  };
+
+  constexpr int G = 4 / KS;
+  const int last = ntile - 1;
+#pragma unroll
+  for (int s_ = 0; s_ < ST - 1; ++s_) issue(min(s_, last), s_);
+  int slot = 0;
+  for (int t = 0; t < ntile; ++t) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * G) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int nslot = slot + ST - 1;
+    if (nslot >= ST) nslot -= ST;
+    issue(min(t + ST - 1, last), nslot);
+    const int key0 = t * KT;
+    const T* kt = ring + slot * STAGE;
+    const T* vt = kt + KT * 64;
+    if constexpr (KS == 1) {
+      if (key0 < kend) process(kt, vt, 0, key0);
+      if (key0 + 32 < kend) process(kt, vt, 1, key0 + 32);
+    } else {
+      if (key0 + kp_own * 32 < kend) process(kt, vt, kp_own, key0 + kp_own * 32);
+    }
+    slot = slot + 1 == ST ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (KS == 2) {
+    float* mg = (float*)ring;  // [4 query groups][34][64 lanes]
+    __syncthreads();
+    if (kp_own == 1) {
+      float* d = mg + (size_t)wave * 34 * 64 + lane;
+      d[0] = m_run;
+      d[64] = l_run;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) d[(2 + db * 16 + v) * 64] = acc[db][v];
+    }
+    __syncthreads();
+    if (kp_own == 1) return;
+    const float* d = mg + (size_t)wave * 34 * 64 + lane;
+    const float m1 = d[0], l1 = d[64];
+    const float mm = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f((m_run - mm) * LOG2E), a1 = __builtin_amdgcn_exp2f((m1 - mm) * LOG2E);
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[db][v] = acc[db][v] * a0 + d[(2 + db * 16 + v) * 64] * a1;
+  }
+  l_run = add_xor32(l_run);
+  if (qi < n) {
+    const float inv = 1.0f / l_run;
+    T* o = (T*)a.out + ((size_t)b * ns + qi) * a.ldo + h * 64 + hh * 4;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *(x4*)(o + db * 32 + i * 8) = pack4<T>(acc[db][4 * i] * inv, acc[db][4 * i + 1] * inv, acc[db][4 * i + 2] * inv, acc[db][4 * i + 3] * inv);
+  }
+}
+
+template <typename T, int KS>
+static int launch_flash32(const ProfScope& ps, const FlashArgs& a, hipStream_t stream) {
+  constexpr int smem = 3 * 2 * 64 * 64 * 2 + 132 * 4;
+  static_assert(KS == 1 || 4 * 34 * 64 * 4 <= 3 * 2 * 64 * 64 * 2, "the merge scratch must fit the ring");
+  static bool attr_set = false;
+  if (!attr_set) {
+    TT_CHECK_HIP(hipFuncSetAttribute((const void*)flash32_kernel<T, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.n, 128), a.BH);
+  launch_timed(ps, flash32_kernel<T, KS>, grid, dim3(256 * KS), smem, stream, a);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename T, int NQ, int KS>
 static int launch_flash_lds(const ProfScope& ps, const FlashArgs& a, hipStream_t stream) {
   constexpr int smem = 3 * 2 * 64 * 64 * 2 + 132 * 4;
@@ -546,6 +795,8 @@ static int launch_flash_lds(const ProfScope& ps, const FlashArgs& a, hipStream_t
   return 0;
 }
 
+bool g_flash32 = true;  // tt_flash_variant: 0 = the 16-query-wave kernels everywhere (A/B runs)
+
 int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
   if (dtype == DT_F32) return flash_f32_launch(a, stream);  // verification mode (attention_f32.hip)
   TT_REQUIRE(a.BH > 0 && a.n > 0 && a.heads > 0 && a.BH % a.heads == 0, "flash: bad shape BH=%d n=%d heads=%d", a.BH, a.n, a.heads);
@@ -554,6 +805,13 @@ int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
   // 32 queries per wave once there is enough work to fill the chip; 16 otherwise.
   // QK^T + PV: 4 * n * n * 64 flops per (batch, head) (halved when causal); Q, K, V read + O written once
   ProfScope ps(PROF_FLASH, stream, 4.0 * a.BH * (double)a.n * a.n * 64 * (a.causal ? 0.5 : 1.0), 4.0 * a.BH * (double)a.n * 64 * 2.0, true);
+  if (a.n > 128 && !a.causal && a.variant != 2 && g_flash32) {
+    // 32-query waves on v_mfma_f32_32x32x16 (flash32_kernel), 128 queries per workgroup; launches of fewer than ~2 workgroups per CU
+    // split every key tile over two wave groups (the denoiser: 7 x 32 workgroups)
+    const long blocks128 = (long)cdiv(a.n, 128) * a.BH;
+    if (blocks128 < 512 && a.variant != 1) return dtype == DT_BF16 ? launch_flash32<bf16, 2>(ps, a, stream) : launch_flash32<f16, 2>(ps, a, stream);
+    return dtype == DT_BF16 ? launch_flash32<bf16, 1>(ps, a, stream) : launch_flash32<f16, 1>(ps, a, stream);
+  }
   if (a.n > 128) {
     // LDS-staged kernel: 64 queries per block while that keeps >= 2 blocks per CU busy, 128 otherwise (half the K / V traffic per
     // flop; measured on the kbench shapes: 32 queries per wave only pays from ~2048 blocks of 64 queries on)

@@ -42,6 +42,16 @@ __device__ __forceinline__ f32x4 mfma16(Vec<f16>::x8 a, Vec<f16>::x8 b, f32x4 c)
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// D(32x32 f32) += A(32x16) * B(16x32).  Lane l holds A[row = l&31][k = (l>>5)*8 .. +7], B[k = (l>>5)*8 .. +7][col = l&31];
+// D lane l reg r = D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__device__ __forceinline__ f32x16 mfma32(Vec<bf16>::x8 a, Vec<bf16>::x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(Vec<f16>::x8 a, Vec<f16>::x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 

@@ -87,7 +87,12 @@ struct tt_ar {
   int lookahead = 6;
   // five-launch decode step (see the header comment): needs the folded weights of every layer (tt_gpt_layer *_ln), D % 64 == 0, D <= 1024
   bool can_fuse = false;
-  int fused = 1;               // tt_ar_set_option(TT_AR_OPT_FUSED_STEP): 0 keeps the seven-launch form (A/B runs, bisecting)
+  // tt_ar_set_option(TT_AR_OPT_FUSED_STEP).  Default 0: measured in situ (profiles/r05_ab_ar_five_launch_step.txt, one handle, 256 candidates x
+  // 200 tokens) the five-launch step takes 2.020 ms against 1.888 ms for seven launches - the last arriver's ticket + slab re-read tail
+  // (EPI_RESID 10.7 us against 6.7 + 4.2 us for slab GEMM + row norm) and the statistics epilogue of the folded GEMMs (+1 us each) cost more
+  // than the two kernel boundaries they remove.  Kept as an option: it is the measured answer to "fold the row norms away", and its tests
+  // guard the EPI_RESID / folded-LayerNorm kernels.
+  int fused = 0;
   float* lnstats = nullptr;    // [max_batch][D / 32][2] row statistics left by the projections
   unsigned* tickets = nullptr; // arrival counters of the projections' output tiles (zero between launches)
   int captures = 0;   // decode-step captures so far (tt_ar_stat: tests assert the kept graph is reused)
@@ -766,7 +771,7 @@ int tt_ar_stat(tt_ar* e, int which) {
 }
 
 // Engine options of a handle (defaults in brackets):
-//   TT_AR_OPT_FUSED_STEP  [1]  five-launch decode step (LayerNorm folded into the QKV / c_fc GEMMs, in-launch split-K fold); 0: seven launches
+//   TT_AR_OPT_FUSED_STEP  [0]  1: five-launch decode step (LayerNorm folded into the QKV / c_fc GEMMs, in-launch split-K fold); 0: seven launches
 //   TT_AR_OPT_LOOKAHEAD   [6]  decode steps the host may run ahead of the device (>= 1)
 int tt_ar_set_option(tt_ar* e, int option, int value) {
   TT_REQUIRE(e != nullptr, "tt_ar_set_option: null handle");

@@ -85,7 +85,7 @@ struct FlashArgs {
   // the row stride of the operands.  nv_period == 0: all n rows are valid.
   int nv_period;
   int nv[32];
-  int variant;  // 0: chosen from the shape; 1: never the key-split form (microbenchmarks / A-B runs)
+  int variant;  // 0: chosen from the shape; 1: never the key-split form; 2: never the 32-query-wave kernel (microbenchmarks / A-B runs)
 };
 int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream);
 int flash_f32_launch(const FlashArgs& a, hipStream_t stream);  // fp32 verification mode (attention_f32.hip)
