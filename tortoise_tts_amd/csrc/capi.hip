@@ -3,6 +3,7 @@
 #include "../../include/tortoise_mi355x.h"
 
 using namespace tt;
+namespace tt { extern bool g_flash32; }  // attention.hip
 
 extern "C" {
 
@@ -120,7 +121,6 @@ int tt_op_resid_ln(int dtype, const void* A, int K, const void* W, const float* 
 // Process-wide A/B switch of the attention kernels (like tt_graph_replay): 1 (default) = 32-query waves on v_mfma_f32_32x32x16 for
 // non-causal sequences of more than 128 rows, 0 = the 16-query-wave kernels everywhere.  Returns the previous value.  Set it before an
 // engine captures its graphs (a kept graph replays the kernels it was captured with).
-namespace tt { extern bool g_flash32; }
 int tt_flash_variant(int v) {
   const int prev = tt::g_flash32 ? 1 : 0;
   tt::g_flash32 = v != 0;
