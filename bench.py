@@ -74,6 +74,7 @@ def cpu_baseline(sds, text, latents, preset_kw, M, cores):
     tt = F.pad(text.int()[None], (0, 1))
     N, iters = preset_kw["num_autoregressive_samples"], preset_kw["diffusion_iterations"]
     Bc = 16  # reference default AR batch on a >=14 GB device (api.py:156-157)
+    AR_STEPS, CLVP_C, PAIRS = 10, 4, 3  # bounded sample: cached AR steps, CLVP candidates, conditioned / conditioning-free denoiser pairs
     with torch.no_grad():
         sd = sds["autoregressive"]
         torch.set_num_threads(min(cores, 16))
@@ -96,16 +97,24 @@ def cpu_baseline(sds, text, latents, preset_kw, M, cores):
                 O.warp_logits(lg, torch.zeros(Bc, 60, dtype=torch.long))
             sweep[th] = (time.perf_counter() - t0) / 3
         best = min(sweep, key=sweep.get)
-        t_step = sweep[best]
         torch.set_num_threads(best)
+        # the sample proper: AR_STEPS cached steps on the best thread count (the sweep above only picks it)
+        lg, kv = O.ar_step(sd, ar_cfg, tok, ctx_extra + 1, kv0)
+        t0 = time.perf_counter()
+        for s_ in range(AR_STEPS):
+            lg, kv = O.ar_step(sd, ar_cfg, tok, ctx_extra + s_ + 2, kv)
+            O.warp_logits(lg, torch.zeros(Bc, 60, dtype=torch.long))
+        sweep[best] = (time.perf_counter() - t0) / AR_STEPS
+        t_step = sweep[best]
         t0 = time.perf_counter()
         O.ar_prefill(sd, ar_cfg, prefix, Bc)
         t_pf = time.perf_counter() - t0
         ar_total = (N / Bc) * (t_pf + (M - 1) * t_step)
         codes = torch.randint(0, 8192, (1, M))
+        ccodes = torch.randint(0, 8192, (CLVP_C, M))
         t0 = time.perf_counter()
-        O.clvp_score(sds["clvp"], clvp_cfg, tt.long(), codes)
-        clvp_total = (time.perf_counter() - t0) * N
+        O.clvp_score(sds["clvp"], clvp_cfg, tt.long(), ccodes)
+        clvp_total = (time.perf_counter() - t0) / CLVP_C * N
         t0 = time.perf_counter()
         lat = O.ar_latents(sd, ar_cfg, auto, tt, codes)
         lat_total = time.perf_counter() - t0
@@ -115,27 +124,42 @@ def cpu_baseline(sds, text, latents, preset_kw, M, cores):
         emb = O.diffusion_timestep_independent(dsd, d_cfg, lat, diffc, S)
         t_ti = time.perf_counter() - t0
         x = torch.randn(1, 100, S)
-        ts = torch.tensor([2000])
         t0 = time.perf_counter()
-        O.diffusion_forward(dsd, d_cfg, x, ts, emb, False)
-        O.diffusion_forward(dsd, d_cfg, x, ts, emb, True)
-        t_pair = time.perf_counter() - t0
+        for tv in (3900, 2000, 100)[:PAIRS]:
+            ts = torch.tensor([tv])
+            O.diffusion_forward(dsd, d_cfg, x, ts, emb, False)
+            O.diffusion_forward(dsd, d_cfg, x, ts, emb, True)
+        t_pair = (time.perf_counter() - t0) / PAIRS
         diff_total = t_ti + iters * (t_pair if preset_kw.get("cond_free", True) else t_pair / 2)
         t0 = time.perf_counter()
         O.univnet_inference(sds["vocoder"], v_cfg, torch.randn(1, 100, S), torch.randn(1, 64, S + 10))
         voc_total = time.perf_counter() - t0
     total = ar_total + clvp_total + lat_total + diff_total + voc_total
     audio_s = S * 256 / 24000.0
-    return {"value": audio_s / total, "unit": "audio-s/wall-s", "cores": best, "host_cores": cores, "kind": "port",
+    stages_s = {"ar": ar_total, "clvp": clvp_total, "latents": lat_total, "diffusion": diff_total, "vocoder": voc_total}
+    # calibration of this port against the reference's OWN classes (oracle/calibrate_cpu_baseline.py, run where /root/reference exists: same
+    # bounded sample, same threads): per-stage t_reference / t_oracle; the utterance factor below weights them with THIS run's stage times
+    ref_ratio = None
+    try:
+        import json as _json
+        cal = _json.load(open(os.path.join(ROOT, "profiles", "r05_cpu_reference_vs_oracle.json")))
+        rr = cal["ratio_reference_over_oracle"]
+        ref_total = sum(stages_s[k] * rr[k] for k in stages_s)
+        ref_ratio = {"per_stage": {k: round(rr[k], 4) for k in stages_s}, "utterance": round(ref_total / total, 4),
+                     "value_reference_equivalent": audio_s / ref_total,
+                     "source": "profiles/r05_cpu_reference_vs_oracle.json (reference nn.Modules vs this oracle, %d threads, build container)" % cal["threads"]}
+    except Exception as ex:  # the calibration file travels with the repository; without it the line says so
+        ref_ratio = {"error": "calibration file unreadable: %s" % ex}
+    return {"value": audio_s / total, "unit": "audio-s/wall-s", "cores": best, "host_cores": cores, "kind": "port", "reference_ratio": ref_ratio,
             "what": "the CPU ORACLE (oracle/tortoise_oracle.py: fp32 restatement of the reference algorithm, pinned against the reference's modules), "
                     "not the reference's own classes - /root/reference does not exist on the GPU box; bounded sample, extrapolated",
             "context": "AR step timed at the MEAN decode context (prefix + M / 2 cached tokens); lines of rounds <= 2 timed it right after the prefill",
             "latency_s_extrapolated": total,
             "ar_step_s_by_threads": {str(k): round(v, 4) for k, v in sweep.items()},
-            "sample": (f"oracle fp32 on {best} threads (best of {sorted(sweep)} on the AR step): AR prefill + 3 cached steps at the mean decode context (prefix + {ctx_extra + 1} tokens) at B={Bc} "
-                       f"({t_pf:.2f}s + {t_step:.3f}s/step), CLVP 1 of {N} candidates, 1 latent pass, timestep_independent + 1 cond/uncond "
-                       f"denoiser pair of {iters} ({t_pair:.2f}s), full UnivNet ({voc_total:.2f}s); stages extrapolated linearly to the full utterance"),
-            "stages_s": {"ar": ar_total, "clvp": clvp_total, "latents": lat_total, "diffusion": diff_total, "vocoder": voc_total}}
+            "sample": (f"oracle fp32 on {best} threads (best of {sorted(sweep)} on the AR step): AR prefill + {AR_STEPS} cached steps at the mean decode context (prefix + {ctx_extra + 1} tokens) at B={Bc} "
+                       f"({t_pf:.2f}s + {t_step:.3f}s/step), CLVP {CLVP_C} of {N} candidates, 1 latent pass, timestep_independent + {PAIRS} cond/uncond "
+                       f"denoiser pairs of {iters} ({t_pair:.2f}s each), full UnivNet ({voc_total:.2f}s); stages extrapolated linearly to the full utterance"),
+            "stages_s": stages_s}
 
 
 def dtype_label(per_stage):

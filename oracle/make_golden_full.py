@@ -30,6 +30,7 @@ AR_B, AR_STEPS, AR_TOK_SEED = 16, 3, 21
 LAT_N, LAT_SEED = 200, 22
 CLVP_B, CLVP_N, CLVP_SEED = 4, 200, 23
 DIFF_M, DIFF_SEED, DIFF_TS, DIFF_LOOP_STEPS = 200, 24, 2000, 8
+CLVP64_B, CLVP64_SEED = 64, 27             # round 5: ranking of many candidates (Spearman / top-k agreement of the 16-bit engines)
 VOC_S, VOC_SEED = 870, 25
 DRIFT_STEPS, DRIFT_SEED = 200, 26       # 'standard' schedule length on the reduced-width denoiser (G.DIFF_CFG)
 CODE_EMB_STRIDE = 8                     # code_emb is stored at every 8th position (3.5 MB otherwise)
@@ -54,6 +55,11 @@ def latent_codes():
 def clvp_codes():
     g = torch.Generator().manual_seed(CLVP_SEED)
     return torch.randint(0, 8192, (CLVP_B, CLVP_N), generator=g)
+
+
+def clvp64_codes():
+    g = torch.Generator().manual_seed(CLVP64_SEED)
+    return torch.randint(0, 8192, (CLVP64_B, CLVP_N), generator=g)
 
 
 def diff_inputs(cfg, M=DIFF_M, seed=DIFF_SEED, steps=DIFF_LOOP_STEPS):
@@ -144,6 +150,21 @@ def full_clvp(ref, sds):
 
 
 @torch.no_grad()
+def full_clvp64(ref, sds):
+    """64 candidates for ONE text (api.py:460-477 ranks num_autoregressive_samples of them): the reference module's scores, against which
+    the 16-bit engines' RANKING is held (tests/test_gpu_r5.py)."""
+    cfg = CLVPConfig()
+    m = ref.CLVP(dim_text=cfg.dim, dim_speech=cfg.dim, dim_latent=cfg.dim_latent, num_text_tokens=256,
+                 text_enc_depth=cfg.depth, text_seq_len=350, text_heads=cfg.heads, num_speech_tokens=8192,
+                 speech_enc_depth=cfg.depth, speech_heads=cfg.heads, speech_seq_len=430, use_xformers=True).eval()
+    m.load_state_dict(sds["clvp"], strict=True)
+    text, _, _ = prompt()
+    codes = clvp64_codes()
+    scores = m(text.long().repeat(CLVP64_B, 1), codes, return_loss=False)
+    np.savez_compressed(os.path.join(OUT, "full_clvp64.npz"), scores=scores.numpy())
+
+
+@torch.no_grad()
 def full_diffusion(ref, sds):
     cfg = DiffusionConfig()
     m = build_ref_diffusion(ref, cfg, sds["diffusion"])
@@ -187,7 +208,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_shims.import_reference()
     sds = bench.synthetic_weights()
+    if "--clvp64" in sys.argv:  # (round 5 addition: generate this file alone)
+        full_clvp64(ref, sds)
+        print("full_clvp64.npz", os.path.getsize(os.path.join(OUT, "full_clvp64.npz")))
+        return
     full_ar(ref, sds)
+    full_clvp64(ref, sds)
     full_clvp(ref, sds)
     full_diffusion(ref, sds)
     full_vocoder(ref, sds)

@@ -95,7 +95,12 @@ def main():
                         us = bw_probe(mode, waves, nb, fp, per)
                         print(f"bw_probe {tag:24s} {mtag:44s} {waves} waves x {nb} blocks: {us:8.2f} us  {nb * per / us / 1e6:7.2f} TB/s  {per * (nb / 256) / us / 1e3:6.1f} GB/s per CU", flush=True)
     if "flash" in which:
-        for (B, H, n, causal, rel) in ((2, 16, 870, 0, 1), (2, 16, 2176, 0, 1), (32, 16, 870, 0, 1), (256, 12, 200, 0, 0), (1, 16, 260, 1, 0)):
+        if os.environ.get("TT_FLASH_VARIANT"):  # 1 = 32-query waves (flash32_kernel), 0 = 16-query waves
+            lib.tt_flash_variant(int(os.environ["TT_FLASH_VARIANT"]))
+        shapes = ((2, 16, 870, 0, 1), (2, 16, 2176, 0, 1), (32, 16, 870, 0, 1), (256, 12, 200, 0, 0), (1, 16, 260, 1, 0))
+        if os.environ.get("KB_FLASH_SHAPES") == "denoiser":
+            shapes = shapes[:1]
+        for (B, H, n, causal, rel) in shapes:
             us = D(0)
             chk(lib.tt_kb_flash(B, H, n, causal, rel, 16, 10, C.byref(us)))
             fl = 4.0 * B * H * n * n * 64 * (0.5 if causal else 1.0)

@@ -29,12 +29,21 @@ class FakeArStage:
     def __init__(self, sd, cfg, device="cpu", dtype=0, max_batch=256, max_text=402, max_new_tokens=500, max_latent_candidates=4,
                  share_weights_with=None, kv_cache=True, max_groups=1):
         self.sd = sd if sd is not None else share_weights_with.sd
+        self.dtype = dtype
         self.cfg, self.kv_cache, self.max_batch, self.max_groups = cfg, kv_cache, max_batch, max_groups
         self.groups = None
 
     def prefill(self, cond_latent, text_tokens):
         self.cond, self.text = cond_latent[:1].float().cpu(), text_tokens[:1].cpu()
         self.groups = None
+
+    def guard(self, reset=True):
+        """Operand-overflow guard of the engine stage: with fp16 operands the stand-in reports `FakeArStage.trip` overflows after a
+        generation and hands out stop-filled ("cut short") codes, like a decode whose logits went non-finite."""
+        return getattr(FakeArStage, "trip", 0) if getattr(self, "dtype", 0) == 1 and getattr(self, "generated", False) else 0
+
+    def close(self):
+        self.closed = True
 
     def prefill_group(self, group, n_groups, cond_latent, text_tokens):
         assert n_groups <= self.max_groups and 0 <= group < n_groups
@@ -48,6 +57,9 @@ class FakeArStage:
     def generate(self, B, max_new, temperature=0.8, top_p=0.8, repetition_penalty=2.0, top_k=50, seed=0, row_offset=0, exp_noise=None,
                  group_seeds=None):
         assert B <= self.max_batch
+        self.generated = True
+        if self.dtype == 1 and getattr(FakeArStage, "trip", 0):  # an overflowed fp16 decode: rows cut short with the stop token
+            return torch.full((B, max_new), self.cfg.stop_mel_token, dtype=torch.long), max_new
         if self.groups is not None and len(self.groups) > 1:
             # the engine decodes the groups in one batch with per-group prefixes and Philox keys; its contract is "every group's codes
             # equal decoding it alone" (tests/test_gpu_stages.py), which is how the stand-in produces them

@@ -88,3 +88,31 @@ def test_collective_init_failure_leaves_rank0_serving_under_torch_distributed_ru
     assert r.returncode == 0, r.stderr[-2000:]
     assert (tmp_path / "rank0_served").exists(), r.stderr[-2000:]
     assert r.stderr.count("falling back to single-GPU operation") == 3
+
+
+@torch.no_grad()
+def test_tts_many_decodes_again_when_the_fp16_autoregressive_stage_overflowed(monkeypatch):
+    """Round-4 advisor finding: with utterance_batch == 1 tts_many decodes every utterance's candidates up front and hands them to tts()
+    as '_ar_samples'; an overflowed fp16 decode (rows cut short with the stop token) was then rendered, and re-rendered after the
+    demotion, from the SAME stale codes.  The guard is read right behind the decode now: the stage is rebuilt with bf16 operands and
+    the texts are decoded again - same audio as an engine that ran bf16 from the start."""
+    fake_stages.install(monkeypatch)
+    from tests.test_api_flow_cpu import small_setup, voice_latents
+    from tortoise_tts_amd.api import TextToSpeech
+    sds, cfgs = small_setup()
+    lat = voice_latents(cfgs)
+    texts = [list(range(30, 40)), list(range(41, 49))]
+    kw = dict(conditioning_latents=lat, num_autoregressive_samples=4, diffusion_iterations=2, max_mel_tokens=10, use_deterministic_seed=4, verbose=False)
+    ref = TextToSpeech(state_dicts=sds, configs=cfgs, max_candidates=8, max_mel_tokens=16, kv_cache=True).tts_many(texts, **kw)
+    tts = TextToSpeech(state_dicts=sds, configs=cfgs, max_candidates=8, max_mel_tokens=16, kv_cache=True, dtype={"ar": "fp16"})
+    assert tts.dtype_names()["ar"] == "fp16"
+    first = tts.ar
+    fake_stages.FakeArStage.trip = 2
+    try:
+        with pytest.warns(UserWarning, match="ar stage overflowed fp16"):
+            out = tts.tts_many(texts, **kw)
+    finally:
+        fake_stages.FakeArStage.trip = 0
+    assert tts.demotions == ["ar"] and tts.dtype_names()["ar"] == "bf16"
+    assert tts.ar is not first and getattr(first, "closed", False)
+    assert len(out) == len(ref) and all(torch.equal(a, b) for a, b in zip(out, ref)), "rendered from the overflowed stage's codes"

@@ -462,6 +462,9 @@ class TextToSpeech:
         tripped = self._tripped_stages(wav_ok)
         if tripped:
             self._demote(tripped)
+            if "ar" in tripped and noise.get("_ar_samples") is not None:
+                # candidates decoded ahead of this call (tts_many) came from the stage that just overflowed: decode them again
+                noise = {k_: v_ for k_, v_ in noise.items() if k_ != "_ar_samples"}
             return self.tts(text, voice_samples=voice_samples, conditioning_latents=conditioning_latents, k=k, verbose=verbose,
                             use_deterministic_seed=seed, return_deterministic_state=return_deterministic_state,
                             num_autoregressive_samples=num_autoregressive_samples, temperature=temperature, length_penalty=length_penalty,
@@ -545,6 +548,13 @@ class TextToSpeech:
             ev = _StageTimer(2)
             ev.mark(0)
             samples = [smp for idx in waves for smp in ar_wave(idx)]
+            # The candidates of every utterance are decoded up front; an overflowed fp16 autoregressive stage must be caught HERE - the
+            # per-utterance tts() calls below would otherwise render (and, after their own demotion, re-render) from codes the overflowed
+            # stage produced.  (ar.generate() synchronises, so the guard counter is current.)
+            ar_guard = getattr(self.ar, "guard", None)
+            if ar_guard is not None and ar_guard():
+                self._demote(["ar"])
+                return self.tts_many(texts, conditioning_latents=conditioning_latents, use_deterministic_seed=seed, verbose=verbose, **kwargs)
             ev.mark(1)
             for j, (t, smp) in enumerate(zip(toks, samples)):
                 out[j] = self.tts(t[0, :-1], conditioning_latents=conditioning_latents, k=1, verbose=verbose, use_deterministic_seed=seed,

@@ -566,8 +566,10 @@ __global__ __launch_bounds__(256 * KS, 2 * KS) void flash32_kernel(FlashArgs a) 
   const int n = a.nv_period > 0 ? a.nv[b % a.nv_period] : a.n;
   const int qblock = bx * 128;
   if (qblock >= n) return;
+  // relative-position table with the saturated buckets extended by 64 entries on both sides: rp[i] = bias(clamp(i - 128, -64, 64)), so a
+  // tile that straddles the +-64 window reads rp[key - query + 128] without clamping (|key - query| <= 125 there)
   if (a.relpos) {
-    if (threadIdx.x < 129) rp[threadIdx.x] = a.relpos[h * 129 + threadIdx.x];
+    for (int i = threadIdx.x; i < 257; i += 256 * KS) rp[i] = a.relpos[h * 129 + min(max(i - 64, 0), 128)];
     __syncthreads();
   }
   const int qbase = qblock + wave * 32;
@@ -647,16 +649,13 @@ __global__ __launch_bounds__(256 * KS, 2 * KS) void flash32_kernel(FlashArgs a) 
     float cbias = 0.f;
     if (a.relpos) {
       if (key0 - (qbase + 31) >= 64) {
-        cbias = rp[128];
+        cbias = rp[256];
       } else if (qbase - (key0 + 31) >= 64) {
         cbias = rp[0];
       } else {
+        const float* rb = rp + (key0 - qi + 4 * hh + 128);  // one address per lane, 16 reads at constant offsets
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          int d = key0 + 8 * (v >> 2) + 4 * hh + (v & 3) - qi;
-          d = d < -64 ? -64 : (d > 64 ? 64 : d);
-          sv[v] += rp[d + 64];
-        }
+        for (int v = 0; v < 16; ++v) sv[v] += rb[8 * (v >> 2) + (v & 3)];
       }
     }
     if (key0 + 32 > n || (a.causal && key0 + 31 > qbase)) {
@@ -767,7 +766,7 @@ __global__ __launch_bounds__(256 * KS, 2 * KS) void flash32_kernel(FlashArgs a) 
 
 template <typename T, int KS>
 static int launch_flash32(const ProfScope& ps, const FlashArgs& a, hipStream_t stream) {
-  constexpr int smem = 3 * 2 * 64 * 64 * 2 + 132 * 4;
+  constexpr int smem = 3 * 2 * 64 * 64 * 2 + 260 * 4;
   static_assert(KS == 1 || 4 * 34 * 64 * 4 <= 3 * 2 * 64 * 64 * 2, "the merge scratch must fit the ring");
   static bool attr_set = false;
   if (!attr_set) {
