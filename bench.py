@@ -364,7 +364,7 @@ def main():
     if args.workload == "stream":
         return stream_bench(args)
     from tortoise_tts_amd import dist as tdist
-    rank, world, local = tdist.init_from_env()
+    rank, world, local = tdist.init_from_env_or_exit()
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     # (a launch whose collectives could not initialise continues on rank 0 alone: the line then reports n_gpus = 1 and says so)
     fell_back = tdist.FALLBACK_SINGLE and world == 1

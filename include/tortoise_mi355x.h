@@ -312,7 +312,7 @@ int tt_diff_split_end(tt_diff* h);
 /* Operand-overflow guard of this stage (see tt_ar_guard): GroupNorm statistics / sampler inputs that came out non-finite, as of the
  * last finished sampling run (after the caller synchronised its stream).  The reference runs this stage in fp32 (api.py:540-560). */
 int tt_diff_guard(tt_diff* h, int reset);
-int tt_diff_stat(tt_diff* h, int which);
+int tt_diff_stat(tt_diff* h, int which);  /* which = 0: sampler-step graph captures so far (the step graph stays on the handle) */
 /* TT_DIFF_OPT_OVERLAP_PREPASS [1]: the conditioning_timestep_integrator of every step (diffusion_decoder.py:292-293; it depends on the
  * timestep and the conditioning, not on x_t) is evaluated in chunks of the schedule on a second stream WHILE the sampler loop walks
  * the steps whose chunks are complete; 0 = whole pre-pass first (one stream).  Same results either way. */
@@ -320,7 +320,7 @@ int tt_diff_stat(tt_diff* h, int which);
 /* TT_DIFF_OPT_FUSED_GN: ResBlock in_layers (diffusion_decoder.py:60-80: GroupNorm32 -> SiLU -> 1x1 conv) as ONE launch - the conv's
  * GEMM normalises, activates and casts its own f32 A rows (csrc/gemm_gna.h); 0 = stand-alone apply launch + 16-bit tensor. */
 #define TT_DIFF_OPT_FUSED_GN 2
-int tt_diff_set_option(tt_diff* h, int option, int value);  /* which = 0: sampler-step graph captures so far (the step graph stays on the handle) */
+int tt_diff_set_option(tt_diff* h, int option, int value);  /* option = TT_DIFF_OPT_*; switching TT_DIFF_OPT_FUSED_GN drops the kept step graph */
 
 /* ============================================================================================
  * Stage 3 — UnivNetGenerator.inference   (reference: tortoise/models/vocoder.py:300-312, api.py:559)
@@ -346,6 +346,9 @@ void tt_voc_destroy(tt_voc* h);
 /* mel f32 [mel_channels][S] (channels-first, as the diffusion stage emits it); z f32 [64][S+10];
  * audio f32 [S*256].  Pads 10 frames of -11.5129 and drops the matching tail (vocoder.py:303-311). */
 int tt_voc_run(tt_voc* h, const float* mel, int S, const float* z, float* audio, void* stream);
+/* operand-overflow guard of this stage (see tt_ar_guard): workgroups of the location-variable convolutions that met a non-finite predicted
+ * kernel value, as of the end of the last tt_voc_run once the caller has synchronised its stream; reset != 0 clears it */
+int tt_voc_guard(tt_voc* h, int reset);
 
 /* ============================================================================================
  * Diagnostics (bench.py's roofline leg, the graph-vs-eager tests, counter passes).  Never used on the product path.
@@ -450,6 +453,9 @@ int tt_op_resid_ln(int dtype, const void* A, int K, const void* W, const float* 
 /* process-wide A/B switch of the attention kernels (diagnostics, like tt_graph_replay): 1 (default) = 32-query waves on
  * v_mfma_f32_32x32x16 for non-causal sequences of more than 128 rows, 0 = the 16-query-wave kernels everywhere; returns the previous value */
 int tt_flash_variant(int v);
+/* the same for UnivNet's audio-rate kernels (vocoder.py:134-146, 182-216): 1 (default) = dilated 32 -> 32 convolutions and location-variable
+ * convolutions (hop 64 / 256) on v_mfma_f32_32x32x2_f32 (exact f32 products), 0 = the thread-per-sample VALU kernels */
+int tt_voc_variant(int v);
 int tt_op_flash_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int heads, int n, int n_pad,
                           int causal, const float* relpos, void* stream);
 int tt_op_sample(const float* logits, int ldl, int B, int V, unsigned* seen, const tt_sampling* s, int step, int* unfinished,

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--flash-variants", default="",
                     help="';'-separated tt_flash_variant settings (1 = 32-query-wave attention kernel, 0 = 16-query waves) to time the diffusion "
                          "stage with, one fresh stage object each, e.g. '1;0;1;0'")
+    ap.add_argument("--voc-variants", default="", help="';'-separated tt_voc_variant settings (1 = f32-MFMA audio-rate kernels, 0 = VALU) for the 'voc' stage")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     args = ap.parse_args()
     from bench import bench_prompt
@@ -106,6 +107,27 @@ def main():
                 df.close()
             if fvs != [None]:
                 E.load_library().tt_flash_variant(1)
+        if "voc" in args.stages:
+            from tortoise_tts_amd import engine as E
+            from tortoise_tts_amd.config import VocoderConfig
+            vcfg = VocoderConfig()
+            vsd = W.fold_weight_norm(W.synthetic_state_dict(W.vocoder_manifest(vcfg), 1234 + 3))
+            S = args.mel_tokens * 4 * 24000 // 22050
+            g = torch.Generator().manual_seed(6)
+            mel = (torch.randn(1, 100, S, generator=g) * 2 - 5).to(dev)
+            z = torch.randn(1, vcfg.noise_dim, S + 10, generator=g).to(dev)
+            vs = stages.VocoderStage(vsd, vcfg, dtype=E.dtype_code(args.dtype), max_frames=S + 8)
+            for vv in [int(v) for v in args.voc_variants.split(";") if v.strip()] or [1]:
+                E.load_library().tt_voc_variant(vv)
+                wav = vs.inference(mel, z)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    wav = vs.inference(mel, z)
+                torch.cuda.synchronize()
+                print("ab voc_mfma=%d voc  S=%d: %.3f ms per utterance  wav %s  guard %d" % (vv, S, 1e3 * (time.perf_counter() - t0) / 20, digest(wav), vs.guard()), flush=True)
+            E.load_library().tt_voc_variant(1)
+            vs.close()
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@ def main():
         return
     from bench import synthetic_weights, synthetic_prompt
     from tortoise_tts_amd import dist as tdist
-    rank, world, _ = tdist.init_from_env()
+    rank, world, _ = tdist.init_from_env_or_exit()
     from tortoise_tts_amd.api import TextToSpeech
     text, latents = synthetic_prompt()
     tts = TextToSpeech(state_dicts=synthetic_weights(), max_candidates=args.candidates // world, max_mel_tokens=max(args.mel_tokens, 32))

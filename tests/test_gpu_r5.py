@@ -240,3 +240,32 @@ def test_full_width_clvp_ranking_of_64_candidates(sds, name, dt, tdt, tol):
     # the engine's winner is, in the REFERENCE's scoring, within the score error of the reference's winner (a flip can only happen inside it)
     assert float(want.max() - want[got.argmax()]) <= 2 * err + 1e-6
     assert rho > (0.9 if tdt == torch.bfloat16 else 0.98), f"Spearman {rho:.4f}"
+
+
+@torch.no_grad()
+def test_vocoder_overflow_guard_sees_what_the_waveform_hides():
+    """Round-4 advisor finding: the vocoder's only overflow check was isfinite() on the waveform, but a saturated fp16 KernelPredictor
+    operand turns into inf / NaN predicted kernels whose effect the sigmoid * tanh gate and the final tanh map back to finite samples.
+    The location-variable convolutions count non-finite predicted kernels themselves (tt_voc_guard)."""
+    from tortoise_tts_amd.config import VocoderConfig
+    cfg = VocoderConfig()
+    sd = W.fold_weight_norm(W.synthetic_state_dict(W.vocoder_manifest(cfg), seed=G.VOC_SEED))
+    g = torch.Generator().manual_seed(3)
+    S = 40
+    mel = torch.randn(1, 100, S, generator=g) * 2 - 5
+    z = torch.randn(1, cfg.noise_dim, S + 10, generator=g)
+    st = stages.VocoderStage(sd, cfg, dtype=E.TT_F16, max_frames=64)
+    wav = st.inference(mel, z)
+    torch.cuda.synchronize()
+    assert st.guard() == 0 and bool(torch.isfinite(wav).all())
+    st.close()
+    # the KernelPredictor's hidden state (an fp16 GEMM operand of kernel_conv) beyond 65504: the bias of its input convolution
+    hot = {k: (v + 1e6 if "kernel_predictor.input_conv.0.bias" in k else v) for k, v in sd.items()}
+    assert any("kernel_predictor.input_conv.0.bias" in k for k in sd), "the KernelPredictor's input convolution was not found: the test lost its point"
+    st = stages.VocoderStage(hot, cfg, dtype=E.TT_F16, max_frames=64)
+    wav = st.inference(mel, z)
+    torch.cuda.synchronize()
+    n = st.guard()
+    print(f"[guard] vocoder with out-of-range predicted kernels: {n} workgroup(s) counted, waveform finite: {bool(torch.isfinite(wav).all())}")
+    assert n > 0
+    st.close()

@@ -77,7 +77,13 @@ def test_collective_init_failure_leaves_rank0_serving_under_torch_distributed_ru
             raise RuntimeError("simulated RCCL initialisation failure")
         dist.init_process_group = boom
         from tortoise_tts_amd import dist as tdist
-        rank, world, local = tdist.init_from_env()   # ranks != 0 leave here (SystemExit 0)
+        try:
+            tdist.init_from_env()
+            caught = False
+        except Exception as ex:   # the library raises an ordinary exception (round 5): an embedding host can catch it ...
+            caught = isinstance(ex, tdist.CollectiveInitFailed) and isinstance(ex, RuntimeError)
+        assert caught == (int(os.environ["RANK"]) != 0)
+        rank, world, local = tdist.init_from_env_or_exit()   # ... and the entry-point form makes ranks != 0 leave here with status 0
         assert (rank, world) == (0, 1) and tdist.FALLBACK_SINGLE
         assert tdist.any_over_ranks([True, False]) == [True, False] and tdist.max_over_ranks(2.5) == 2.5
         open(os.path.join({str(tmp_path)!r}, "rank0_served"), "w").write("ok")

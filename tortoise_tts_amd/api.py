@@ -250,7 +250,8 @@ class TextToSpeech:
         for name in ("ar", "clvp", "diffusion"):
             g = getattr(getattr(self, name), "guard", None)
             flags.append(bool(g()) if g is not None else False)
-        flags.append(not wav_ok)
+        vg = getattr(self.vocoder, "guard", None)  # non-finite predicted LVC kernels: the gate and the final tanh would hide them from wav_ok
+        flags.append((not wav_ok) or (bool(vg()) if vg is not None else False))
         if self.world > 1:
             flags = tdist.any_over_ranks(flags)
         # only the FIRST tripped stage in pipeline order is at fault for certain: the later ones may merely have been fed its

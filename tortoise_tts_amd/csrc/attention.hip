@@ -637,27 +637,30 @@ __global__ __launch_bounds__(256 * KS, 2 * KS) void flash32_kernel(FlashArgs a) 
         vf[db][kk] = v;
       }
     }
+    // score register v <-> key key0 + 8 (v >> 2) + 4 hh + (v & 3).  Relative-position bias: a block entirely >= 64 positions after (or
+    // before) every query of the group gets ONE saturated bucket value for all its scores - folded into the row maximum and the exponent
+    // below; a block that straddles the window takes its 16 bias values as the ACCUMULATOR INPUT of the first product (S^T = K Q^T + C), so
+    // no score register is touched after the MFMA chain on either path (a post-MFMA add made hipcc copy all 16 registers out and back on
+    // the common, saturated path).
+    float cbias = 0.f;
     f32x16 st;
+    const bool window = a.relpos != nullptr && key0 - (qbase + 31) < 64 && qbase - (key0 + 31) < 64;  // wave-uniform
+    if (window) {
+      const float* rb = rp + (key0 - qi + 4 * hh + 128);  // one address per lane, 16 reads at constant offsets
 #pragma unroll
-    for (int v = 0; v < 16; ++v) st[v] = 0.f;
+      for (int v = 0; v < 16; ++v) st[v] = rb[8 * (v >> 2) + (v & 3)];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[ks], st);
+      for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[ks], st);
+    } else {
+      if (a.relpos) cbias = key0 - (qbase + 31) >= 64 ? rp[256] : rp[0];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) st[v] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) st = mfma32(kf[ks], qf[ks], st);
+    }
     float sv[16];
 #pragma unroll
     for (int v = 0; v < 16; ++v) sv[v] = st[v];
-    // score register v <-> key key0 + 8 (v >> 2) + 4 hh + (v & 3)
-    float cbias = 0.f;
-    if (a.relpos) {
-      if (key0 - (qbase + 31) >= 64) {
-        cbias = rp[256];
-      } else if (qbase - (key0 + 31) >= 64) {
-        cbias = rp[0];
-      } else {
-        const float* rb = rp + (key0 - qi + 4 * hh + 128);  // one address per lane, 16 reads at constant offsets
-#pragma unroll
-        for (int v = 0; v < 16; ++v) sv[v] += rb[8 * (v >> 2) + (v & 3)];
-      }
-    }
     if (key0 + 32 > n || (a.causal && key0 + 31 > qbase)) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) {

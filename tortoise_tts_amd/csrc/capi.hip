@@ -3,7 +3,7 @@
 #include "../../include/tortoise_mi355x.h"
 
 using namespace tt;
-namespace tt { extern bool g_flash32; }  // attention.hip
+namespace tt { extern bool g_flash32; extern bool g_voc_mfma; }  // attention.hip, univnet.hip
 
 extern "C" {
 
@@ -124,6 +124,14 @@ int tt_op_resid_ln(int dtype, const void* A, int K, const void* W, const float* 
 int tt_flash_variant(int v) {
   const int prev = tt::g_flash32 ? 1 : 0;
   tt::g_flash32 = v != 0;
+  return prev;
+}
+
+// The same switch for UnivNet's audio-rate kernels: 1 (default) = the 32 -> 32 dilated convolutions and the location-variable convolutions of
+// hop 64 / 256 on v_mfma_f32_32x32x2_f32 (exact f32), 0 = the thread-per-sample VALU kernels.  Returns the previous value.
+int tt_voc_variant(int v) {
+  const int prev = tt::g_voc_mfma ? 1 : 0;
+  tt::g_voc_mfma = v != 0;
   return prev;
 }
 

@@ -190,7 +190,7 @@ static int run_res_block(tt_diff* e, DiffWork& w_, const tt_res_block& w, const 
     gf.gn_part = part; gf.gn_seq = S;
     if (gemm_gna_supported(dt, EPI_STD, gf, n)) {
       TT_TRY(gemm_gna_launch(dt, EPI_STD, gf, n, s));
-      w_.stats_ptr = gf.out_f32; w_.stats_part = part; w_.stats_rows = 32; w_.stats_seq = S;
+      w_.stats_ptr = gf.out_f32; w_.stats_part = part; w_.stats_rows = gemm_gna_stat_rows(); w_.stats_seq = S;
       fused_gn = true;
     }
   }

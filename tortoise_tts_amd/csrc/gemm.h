@@ -108,6 +108,7 @@ struct GemmGnArgs {
 // true when gemm_gna_launch has a kernel for this problem (else: groupnorm_launch + gemm_launch)
 bool gemm_gna_supported(int dtype, int epi, const GemmArgs& a, const GemmGnArgs& n);
 int gemm_gna_launch(int dtype, int epi, const GemmArgs& a, const GemmGnArgs& n, hipStream_t stream);
+int gemm_gna_stat_rows();  // rows per statistics tile its epilogue emits (the kernel's tile height: a build knob, TT_GNA_BM)
 
 // dtype: DT_BF16 / DT_F16 (DT_F32: the slow fp32-operand verification kernel, gemm_f32.hip).  Returns 0 or a negative error (message via tt::last_error()).
 int gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t stream);

@@ -216,6 +216,8 @@ int gemm_gna_launch(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs& n,
   return gemm_gna_launch_typed<f16>(a, plan, d, stream);
 }
 
+int gemm_gna_stat_rows() { return kGnaBM; }
+
 int gemm_init() {
   TT_TRY(gemm_init_typed<bf16>());
   TT_TRY(gemm_init_typed<f16>());

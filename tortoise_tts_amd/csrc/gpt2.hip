@@ -12,6 +12,7 @@
 //   * latents:   teacher-forced full pass for the CLVP winners (autoregressive.py:454-506).
 #include "runtime.h"
 #include <unistd.h>
+#include <chrono>
 #include "../../include/tortoise_mi355x.h"
 
 using namespace tt;
@@ -629,11 +630,18 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
   bool stop_seen = false;
   for (int step = first_step; step < target; ++step) {
     // stay at most `lookahead` steps ahead of the device; the words are written by the last kernel of every step
-    int spins = 0;
+    const auto wait0 = std::chrono::steady_clock::now();
     while (step - prog[0] >= e->lookahead && prog[1] < 0) {
-      if (++spins > 4000) {  // >= 200 ms without the expected progress: fall back to a queue drain (always correct, only slower)
+      // 200 ms of wall time without the expected progress (not a spin count: a slow first replay - code-object load, a profiler - must
+      // not look like lost progress words): fall back to a queue drain, always correct, only slower - and take the progress from the
+      // DEVICE state the words mirror, so a host that cannot see the mapped words still paces and ends the loop correctly
+      if (std::chrono::steady_clock::now() - wait0 > std::chrono::milliseconds(200)) {
+        int st3[3] = {0, 0, -1};
         hipError_t ce = hipStreamSynchronize(s);
-        if (ce != hipSuccess) { set_error("tt_ar_generate: %s", hipGetErrorString(ce)); rc = -2; }
+        if (ce == hipSuccess) ce = hipMemcpy(st3, e->state, sizeof(st3), hipMemcpyDeviceToHost);
+        if (ce != hipSuccess) { set_error("tt_ar_generate: %s", hipGetErrorString(ce)); rc = -2; break; }
+        prog[0] = st3[0];
+        if (st3[2] >= 0) prog[1] = st3[2];
         e->drains += 1;
         break;
       }

@@ -237,6 +237,7 @@ struct LvcArgs {
   float* x;             // [32][T] residual stream: x += sigmoid(o[:32]) * tanh(o[32:])
   int L, hop;
   float in_slope;
+  int* guard;           // optional device counter: += 1 per workgroup that staged a non-finite predicted kernel value (operand-overflow guard)
 };
 int lvc_launch(const LvcArgs& a, hipStream_t stream);
 

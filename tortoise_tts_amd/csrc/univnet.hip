@@ -48,8 +48,69 @@ __global__ __launch_bounds__(256) void conv1d_direct_kernel(Conv1dArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- 32 -> 32 channel k3 dilated conv1d on the f32 matrix cores (round 5)
+// y[co][t] = act(b[co] + sum_{ci,tap} w[co][ci][tap] * lrelu(x[ci][t + (tap - 1) dil])) is the GEMM  W[32][96] . X_unf[96][T]  with
+// kidx = 3 ci + tap - exactly the weight's own [Cout][Cin][k] row.  v_mfma_f32_32x32x2_f32 multiplies f32 operands exactly (the f32
+// vector rate, 64 FLOP / clk / SIMD) but takes both operands from REGISTERS, one LDS read each per 4096 flops: the thread-per-sample
+// kernel above issues one broadcast LDS weight read per FMA and ran at ~10 % of the vector rate (45 us per launch at T = 225 280).
+// One workgroup = 128 samples: the input window (128 + 2 dil columns, LeakyReLU applied, zeros outside [0, T)) and the transposed
+// weights sit in LDS; wave w owns samples 32 w .. 32 w + 31, 48 MFMA steps of two k each.
+constexpr int CVM_TS = 128, CVM_MAXD = 27, CVM_ROW = CVM_TS + 2 * CVM_MAXD + 2;
+__global__ __launch_bounds__(256) void conv1d_mfma_kernel(Conv1dArgs a) {
+  __shared__ float xs[32][CVM_ROW];
+  __shared__ float wl[96][33];  // [kidx][co] (+1: the transposing fill is conflict-free)
+  const int t0 = blockIdx.x * CVM_TS, d = a.dilation, width = CVM_TS + 2 * d;
+  for (int i = threadIdx.x; i < 32 * 96; i += 256) {
+    const int co = i / 96, kidx = i - co * 96;
+    wl[kidx][co] = a.w[i];
+  }
+  for (int ci = threadIdx.x >> 6; ci < 32; ci += 4) {  // a wave per input row: coalesced
+    for (int i = threadIdx.x & 63; i < width; i += 64) {
+      const int t = t0 - d + i;
+      float v = (t >= 0 && t < a.T) ? a.x[(size_t)ci * a.T + t] : 0.f;
+      if (a.in_slope >= 0.f) v = v > 0.f ? v : v * a.in_slope;
+      xs[ci][i] = v;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  int ci = 0, tap = h;  // kidx = 2 p + h = 3 ci + tap
+  const float* xb = &xs[0][wave * 32 + j];
+#pragma unroll 8
+  for (int p = 0; p < 48; ++p) {
+    const float av = wl[2 * p + h][j];
+    const float bv = xb[ci * CVM_ROW + tap * d];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    tap += 2;
+    if (tap >= 3) { tap -= 3; ++ci; }
+  }
+  const int t = t0 + wave * 32 + j;
+  if (t < a.T) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+      float v = acc[r] + (a.bias ? a.bias[co] : 0.f);
+      if (a.out_act == ACT_LRELU) v = v > 0.f ? v : v * a.out_slope;
+      else if (a.out_act == 5) v = tanhf(v);
+      a.y[(size_t)co * a.T + t] = v;
+    }
+  }
+}
+
+bool g_voc_mfma = true;  // tt_voc_variant: 0 = the thread-per-sample VALU kernels (A/B runs)
+
 int conv1d_direct_launch(const Conv1dArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.Cout == 32 || a.Cout == 1, "conv1d_direct: Cout=%d unsupported (32 or 1)", a.Cout);
+  if (g_voc_mfma && a.Cin == 32 && a.Cout == 32 && a.k == 3 && !a.reflect && a.dilation >= 1 && a.dilation <= CVM_MAXD) {
+    ProfScope ps(PROF_CONV1D, stream, 2.0 * a.Cin * a.Cout * a.k * (double)a.T, 4.0 * (a.Cin + a.Cout) * (double)a.T);
+    conv1d_mfma_kernel<<<cdiv(a.T, CVM_TS), 256, 0, stream>>>(a);
+    TT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   const size_t smem = (size_t)a.Cin * a.k * a.Cout * sizeof(float);
   TT_REQUIRE(smem <= 60 * 1024, "conv1d_direct: weights do not fit LDS");
   const int blocks = cdiv(a.T, 256);
@@ -113,7 +174,14 @@ __global__ __launch_bounds__(256) void lvc_kernel(LvcArgs a) {
   const int l = blockIdx.x;
   const int T = a.L * HOP;
   const float* kg = a.kernels + (size_t)l * a.ldk + a.koff;
-  for (int i = threadIdx.x * 4; i < 32 * 64 * 3; i += 1024) *(float4*)(wk + i) = *(const float4*)(kg + i);
+  bool bad = false;
+  for (int i = threadIdx.x * 4; i < 32 * 64 * 3; i += 1024) {
+    const float4 kv = *(const float4*)(kg + i);
+    bad = bad || !(fabsf(kv.x) < INFINITY) || !(fabsf(kv.y) < INFINITY) || !(fabsf(kv.z) < INFINITY) || !(fabsf(kv.w) < INFINITY);
+    *(float4*)(wk + i) = kv;
+  }
+  // an overflowed fp16 KernelPredictor operand shows up HERE as inf / NaN taps; behind the sigmoid * tanh gate it would be a finite sample
+  if (a.guard && __any(bad) && (threadIdx.x & 63) == 0) atomicAdd(a.guard, 1);
   for (int i = threadIdx.x; i < 32 * (HOP + 2); i += 256) {
     const int ci = i / (HOP + 2), off = i % (HOP + 2);
     const int t = l * HOP + off - 1;
@@ -149,7 +217,79 @@ __global__ __launch_bounds__(256) void lvc_kernel(LvcArgs a) {
     a.x[(size_t)o * T + t] += g * tanhf(acc[HALF + u]);
   }
 }
+// The same on the f32 matrix cores (round 5; hops of 64 and 256 samples): per frame, out[64][HOP] = K_l[64][96] . X_unf[96][HOP] with
+// kidx = 3 ci + tap; K_l is the frame's predicted kernel as the KernelPredictor GEMM left it ([ci][co][tap]: co is the MFMA row, read at a
+// stride of 3 floats - conflict-free).  A wave owns sample blocks of 32 and BOTH output halves of them (sigmoid half rows 0 .. 31, tanh
+// half rows 32 .. 63 land in the same lane / register of two accumulators), so the gate needs no exchange.
+template <int HOP>
+__global__ __launch_bounds__(256) void lvc_mfma_kernel(LvcArgs a) {
+  constexpr int NSB = HOP / 32;                    // sample blocks per frame
+  constexpr int SBW = NSB >= 4 ? NSB / 4 : 1;      // sample blocks per wave (waves beyond NSB idle after the staging)
+  __shared__ __attribute__((aligned(16))) float wk[32 * 64 * 3];
+  __shared__ float xs[32][HOP + 2];
+  const int l = blockIdx.x;
+  const int T = a.L * HOP;
+  const float* kg = a.kernels + (size_t)l * a.ldk + a.koff;
+  bool bad = false;
+  for (int i = threadIdx.x * 4; i < 32 * 64 * 3; i += 1024) {
+    const float4 kv = *(const float4*)(kg + i);
+    bad = bad || !(fabsf(kv.x) < INFINITY) || !(fabsf(kv.y) < INFINITY) || !(fabsf(kv.z) < INFINITY) || !(fabsf(kv.w) < INFINITY);
+    *(float4*)(wk + i) = kv;
+  }
+  // an overflowed fp16 KernelPredictor operand shows up HERE as inf / NaN taps; behind the sigmoid * tanh gate it would be a finite sample
+  if (a.guard && __any(bad) && (threadIdx.x & 63) == 0) atomicAdd(a.guard, 1);
+  for (int i = threadIdx.x; i < 32 * (HOP + 2); i += 256) {
+    const int ci = i / (HOP + 2), off = i % (HOP + 2);
+    const int t = l * HOP + off - 1;
+    float v = (t >= 0 && t < T) ? a.x_in[(size_t)ci * T + t] : 0.f;
+    if (a.in_slope >= 0.f) v = v > 0.f ? v : v * a.in_slope;
+    xs[ci][off] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave * SBW >= NSB) return;
+  const int j = lane & 31, h = lane >> 5;
+  f32x16 acc[SBW][2];
+#pragma unroll
+  for (int u = 0; u < SBW; ++u)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][c][r] = 0.f;
+  int ci = 0, tap = h;
+#pragma unroll 4
+  for (int p = 0; p < 48; ++p) {
+    const float a0 = wk[ci * 192 + j * 3 + tap], a1 = wk[ci * 192 + (32 + j) * 3 + tap];
+#pragma unroll
+    for (int u = 0; u < SBW; ++u) {
+      const float bv = xs[ci][(wave * SBW + u) * 32 + j + tap];
+      acc[u][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[u][0], 0, 0, 0);
+      acc[u][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[u][1], 0, 0, 0);
+    }
+    tap += 2;
+    if (tap >= 3) { tap -= 3; ++ci; }
+  }
+  const float* bl = a.bias + (size_t)l * a.ldb + a.boff;
+#pragma unroll
+  for (int u = 0; u < SBW; ++u) {
+    const int t = l * HOP + (wave * SBW + u) * 32 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float g = 1.f / (1.f + expf(-(acc[u][0][r] + bl[o])));
+      a.x[(size_t)o * T + t] += g * tanhf(acc[u][1][r] + bl[32 + o]);
+    }
+  }
+}
+
 int lvc_launch(const LvcArgs& a, hipStream_t stream) {
+  if (g_voc_mfma && a.in_slope < 0.f && (a.hop == 64 || a.hop == 256) && a.ldk % 4 == 0 && a.koff % 4 == 0) {
+    ProfScope ps(PROF_LVC, stream, 2.0 * 96 * 64 * (double)a.L * a.hop, 4.0 * (6144.0 + 64) * a.L + 4.0 * 96 * (double)a.L * a.hop);
+    if (a.hop == 64) lvc_mfma_kernel<64><<<a.L, 256, 0, stream>>>(a);
+    else lvc_mfma_kernel<256><<<a.L, 256, 0, stream>>>(a);
+    TT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   TT_REQUIRE(a.ldk % 4 == 0 && a.koff % 4 == 0, "lvc: kernel rows must be 16-byte aligned");
   // algorithmic bytes: the predicted kernels (L x 6144 f32) are read once, x_in read + x updated
   ProfScope ps(PROF_LVC, stream, 2.0 * 96 * 64 * (double)a.L * a.hop, 4.0 * (6144.0 + 64) * a.L + 4.0 * 96 * (double)a.L * a.hop);

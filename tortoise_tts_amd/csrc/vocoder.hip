@@ -24,6 +24,8 @@ struct tt_voc {
   float* xa = nullptr;       // [32][T] ping
   float* xb = nullptr;       // [32][T] pong
   float* o = nullptr;        // [32][T] conv output
+  int* guard = nullptr;      // [4] device counter: workgroups of the location-variable convolutions that met a non-finite predicted kernel value
+  int* guard_host = nullptr; // pinned copy, refreshed at the end of every tt_voc_run
 };
 
 __global__ void voc_pad_mel_kernel(const float* mel, float* c, int S, int L, int C) {
@@ -61,6 +63,9 @@ int tt_voc_create(const tt_voc_config* cfg, const tt_voc_weights* w, tt_voc** ou
   if (!rc) rc = e->arena.alloc_t(&e->xa, 32 * T);
   if (!rc) rc = e->arena.alloc_t(&e->xb, 32 * T);
   if (!rc) rc = e->arena.alloc_t(&e->o, 32 * T);
+  if (!rc) rc = e->arena.alloc_t(&e->guard, 4);
+  if (!rc && hipHostMalloc((void**)&e->guard_host, 4 * sizeof(int)) != hipSuccess) { set_error("tt_voc_create: hipHostMalloc failed"); rc = -2; }
+  if (!rc) e->guard_host[0] = 0;
   if (rc) {
     tt_voc_destroy(e);
     return rc;
@@ -72,9 +77,24 @@ int tt_voc_create(const tt_voc_config* cfg, const tt_voc_weights* w, tt_voc** ou
 void tt_voc_destroy(tt_voc* e) {
   if (!e) return;
   (void)hipDeviceSynchronize();
+  if (e->guard_host) (void)hipHostFree(e->guard_host);
   e->arena.release();
   e->sb.destroy();
   delete e;
+}
+
+// Operand-overflow guard of this stage (see tt_ar_guard): workgroups that met non-finite predicted kernels (an fp16 KernelPredictor operand
+// beyond 65504 upstream - behind the sigmoid * tanh gate and the final tanh the waveform itself would come out finite), as of the end of the
+// last tt_voc_run after the caller synchronised its stream.  reset != 0 clears it.
+int tt_voc_guard(tt_voc* e, int reset) {
+  if (!e) { set_error("tt_voc_guard: null handle"); return -1; }
+  const int n = e->guard_host[0];
+  if (n > 0) set_error("vocoder stage: %d workgroup(s) met non-finite predicted kernels (operand overflow in %s)", n, e->cfg.dtype == DT_F16 ? "fp16: re-run this stage with bf16 operands" : "bf16");
+  if (reset && n > 0) {
+    if (hipMemsetAsync(e->guard, 0, 4 * sizeof(int), e->sb.own) != hipSuccess || hipStreamSynchronize(e->sb.own) != hipSuccess) { set_error("tt_voc_guard: reset failed"); return -2; }
+    e->guard_host[0] = 0;
+  }
+  return n;
 }
 
 int tt_voc_run(tt_voc* e, const float* mel, int S, const float* z, float* audio, void* stream) {
@@ -137,7 +157,7 @@ int tt_voc_run(tt_voc* e, const float* mel, int S, const float* z, float* audio,
       LvcArgs la;
       memset(&la, 0, sizeof(la));
       la.x_in = e->o; la.kernels = e->kernels; la.ldk = 24576; la.koff = j * 6144; la.bias = e->kbias; la.ldb = 256; la.boff = j * 64;
-      la.x = x; la.L = L; la.hop = hop; la.in_slope = -1.f;
+      la.x = x; la.L = L; la.hop = hop; la.in_slope = -1.f; la.guard = e->guard;
       TT_TRY(lvc_launch(la, s));
     }
   }
@@ -147,6 +167,7 @@ int tt_voc_run(tt_voc* e, const float* mel, int S, const float* z, float* audio,
   ca.reflect = 1; ca.in_slope = 0.2f; ca.out_act = 5;
   TT_TRY(conv1d_direct_launch(ca, s));
   TT_CHECK_HIP(hipMemcpyAsync(audio, e->o, (size_t)S * hop * sizeof(float), hipMemcpyDeviceToDevice, s));
+  TT_CHECK_HIP(hipMemcpyAsync(e->guard_host, e->guard, sizeof(int), hipMemcpyDeviceToHost, s));
   return e->sb.leave(us);
 }
 

@@ -17,6 +17,7 @@ import torch.distributed as dist
 def init_from_env(device_index=None):
     """Initialise torch.distributed from torchrun's environment (no-op for a single process).
     Backend: nccl (== RCCL on ROCm) when a GPU is present, gloo otherwise (CPU tests)."""
+    global FALLBACK_SINGLE
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -28,6 +29,10 @@ def init_from_env(device_index=None):
         if device_index is None:
             device_index = local % torch.cuda.device_count() if share else local
         torch.cuda.set_device(device_index)
+    if world > 1 and FALLBACK_SINGLE:  # an earlier call already fell back: same answer, no second attempt
+        if rank != 0:
+            raise CollectiveInitFailed(rank, "collective")
+        return 0, 1, local
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -42,27 +47,28 @@ def init_from_env(device_index=None):
                   f"falling back to single-GPU operation on rank 0", file=sys.stderr)
             if dist.is_initialized():
                 dist.destroy_process_group()
-            global FALLBACK_SINGLE
             FALLBACK_SINGLE = True
             # Only rank 0 keeps serving (as an ordinary single-GPU engine); every other rank must stop, or each of them would
             # render the whole utterance again as an independent "rank 0".  This covers the failure that hits every rank
             # (driver / IPC / topology).  A PARTIAL failure - some ranks inside the forced all_reduce, some out - is not
             # recoverable here: the survivors block in the collective until the launcher's timeout tears the job down.
-            # The other ranks leave with exit status 0 (CollectiveInitFailed is a SystemExit): under torch.distributed.run a worker
-            # that FAILS makes the elastic agent terminate the whole group, rank 0 included - an idle rank that exits cleanly does not.
+            # The other ranks raise CollectiveInitFailed; entry points turn that into exit status 0 (init_from_env_or_exit): under
+            # torch.distributed.run a worker that FAILS makes the elastic agent terminate the whole group, rank 0 included.
             if rank != 0:
                 raise CollectiveInitFailed(rank, backend)
             return 0, 1, local
     return rank, world, local
 
 
-class CollectiveInitFailed(SystemExit):
+class CollectiveInitFailed(RuntimeError):
     """Raised on ranks != 0 when the multi-rank launch could not initialise its collectives (rank 0 falls back to one GPU).
-    A SystemExit with status 0: uncaught, the idle rank ends cleanly and the launcher keeps rank 0 alive; callers that want to keep
-    the process (tests, a server that parks the worker) can catch it."""
+    A RuntimeError (round 5; it was a SystemExit(0) in round 4, which `except Exception` handlers cannot catch and which made an
+    embedding server's idle ranks vanish with status 0): a library must not end its host process.  The ENTRY POINTS decide - bench.py and
+    scripts/dist_check.py catch it and leave with exit status 0 (`exit_idle_rank`), because under torch.distributed.run a worker that
+    FAILS makes the elastic agent terminate the whole group, rank 0 included, while an idle rank that exits cleanly does not."""
 
     def __init__(self, rank, backend):
-        super().__init__(0)
+        super().__init__(rank, backend)
         self.rank, self.backend = rank, backend
 
     def __str__(self):
@@ -216,3 +222,14 @@ def max_over_ranks(value):
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def init_from_env_or_exit():
+    """init_from_env for PROCESS ENTRY POINTS (bench.py, scripts): an idle rank of a launch whose collectives could not initialise
+    leaves with exit status 0, so that the launcher keeps rank 0 - which carries on as a one-GPU engine - alive."""
+    import sys
+    try:
+        return init_from_env()
+    except CollectiveInitFailed as ex:
+        print(f"[dist] {ex}", file=sys.stderr, flush=True)
+        sys.exit(0)

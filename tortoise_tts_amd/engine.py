@@ -191,6 +191,7 @@ _PROTOS = {
     "tt_voc_create": (_i, [C.POINTER(VocConfig), C.POINTER(VocWeights), C.POINTER(vp)]),
     "tt_voc_destroy": (None, [vp]),
     "tt_voc_run": (_i, [vp, vp, _i, vp, vp, vp]),
+    "tt_voc_guard": (_i, [vp, _i]),
     "tt_prof_enable": (_i, [_i]),
     "tt_graph_replay": (_i, [_i]),
     "tt_prof_classes": (_i, []),
@@ -204,6 +205,7 @@ _PROTOS = {
     "tt_op_gn_gemm_workspace": (_sz, [_i, _i]),
     "tt_op_resid_ln": (_i, [_i, vp, _i, vp, vp, vp, _i, _i, _i, vp, vp, vp, _i, vp, vp, vp, vp]),
     "tt_flash_variant": (_i, [_i]),
+    "tt_voc_variant": (_i, [_i]),
     "tt_op_flash_attention": (_i, [_i, vp, vp, vp, vp, _i, _i, _i, _i, _i, vp, vp]),
     "tt_op_sample": (_i, [vp, _i, _i, _i, vp, C.POINTER(Sampling), _i, vp, _i, vp, _i, vp]),
     "tt_op_conv1d": (_i, [vp, vp, vp, vp, _i, _i, _i, _i, _i, _i, _f, _i, _f, vp]),

@@ -615,6 +615,10 @@ class VocoderStage:
         except Exception:
             pass
 
+    def guard(self, reset=True):
+        """Workgroups that met non-finite predicted LVC kernels since the last reset (operand-overflow guard; read after a synchronisation)."""
+        return E.guard_count(self.lib.tt_voc_guard(self.h, int(reset)))
+
     def inference(self, mel, z):
         """mel f32 [1, 100, S]; z f32 [1, 64, S+10] -> audio [1, 1, S*256]."""
         m = mel[0].to(self.device).float().contiguous()
