@@ -7,6 +7,10 @@ def klass(k):
     """rocprofv3 kernel name -> the engine profiler's class name (tortoise_tts_amd/csrc/common.hip g_prof_names)."""
     if "gemm_gna_kernel" in k:
         return "gemm_gna<32,256,EpiStd,stats>"
+    if "gemm_glds_kernel" in k and "EpiResid" in k:      # round 5: the optional five-launch decode step (tile-agnostic classes)
+        return "gemm_glds<EpiResid>"
+    if "gemm_glds_kernel" in k and "EpiLn" in k:
+        return "gemm_glds<EpiLn<EpiQkvDecode>>" if "EpiQkvDecode" in k else "gemm_glds<EpiLn<EpiStd,gelu>>"
     m = re.search(r"gemm_glds_kernelI\w+?Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ENS_\d+(EpiStd|EpiQkvHeads|EpiQkvDecode|EpiGeglu)(\w*?)EELb([01])ELb[01]E", k)
     if m:
         bm, bn, epi, targs, conv = m.groups()
@@ -25,7 +29,7 @@ def klass(k):
             bm, bn, epi, conv = m.groups()
             return "gemm_glds<%s,%s,%s%s>" % (bm, bn, epi, (",conv" if conv == "true" else ",1x1") if epi == "EpiStd" else "")
         return "gemm_glds<?>"
-    for pat, name in (("flash_lds_kernel", "flash_kernel"), ("flash_kernel", "flash_kernel"), ("decode_attn_lds_kernel", "decode_attn_kernel"), ("decode_attn_kernel", "decode_attn_kernel"),
+    for pat, name in (("flash32_kernel", "flash_kernel"), ("conv1d_mfma", "conv1d_direct_kernel"), ("lvc_mfma", "lvc_kernel"), ("flash_lds_kernel", "flash_kernel"), ("flash_kernel", "flash_kernel"), ("decode_attn_lds_kernel", "decode_attn_kernel"), ("decode_attn_kernel", "decode_attn_kernel"),
                       ("gn_apply", "gn_apply_kernel(+gn_stats)"), ("gn_stats", "gn_apply_kernel(+gn_stats)"), ("rownorm", "rownorm_kernel"),
                       ("sample_kernel", "sample_kernel"), ("lvc_kernel", "lvc_kernel"), ("conv1d_direct", "conv1d_direct_kernel"), ("convt1d", "convt1d_kernel")):
         if pat in k:

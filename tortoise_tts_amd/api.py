@@ -251,7 +251,8 @@ class TextToSpeech:
             g = getattr(getattr(self, name), "guard", None)
             flags.append(bool(g()) if g is not None else False)
         vg = getattr(self.vocoder, "guard", None)  # non-finite predicted LVC kernels: the gate and the final tanh would hide them from wav_ok
-        flags.append((not wav_ok) or (bool(vg()) if vg is not None else False))
+        voc_tripped = bool(vg()) if vg is not None else False  # (always read: reading resets the counter)
+        flags.append((not wav_ok) or voc_tripped)
         if self.world > 1:
             flags = tdist.any_over_ranks(flags)
         # only the FIRST tripped stage in pipeline order is at fault for certain: the later ones may merely have been fed its
