@@ -214,7 +214,13 @@ struct EpiStd {
     if (has_f32(e)) {
       float* o = e.out_f32 + (size_t)m * e.ldo32 + n;
       if (AL || (nvalid == 4 && (e.ldo32 & 3) == 0)) {
+#if defined(TT_WT_F32)
+        // A/B knob (build.py --variant wt -DTT_WT_F32; profiles/r05_ab_writethrough_f32.txt): the f32 result written THROUGH (sc1), so that
+        // the kernel boundary finds no dirty lines to flush; every wave drains its stores at the end of run_epilogue
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(v) : "memory");
+#else
         *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+#endif
       } else {
         for (int i = 0; i < nvalid; ++i) o[i] = v[i];
       }
@@ -637,6 +643,9 @@ __device__ __forceinline__ void run_epilogue(const GemmCore& c, const typename E
       }
     }
   }
+#if defined(TT_WT_F32)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
