@@ -263,7 +263,7 @@ def stage_rooflines(stages_s, N, M, iters, cond_free, text_tokens):
     return out
 
 
-PMC_SUMMARY = os.path.join("profiles", "r04_pmc_bench.json")
+PMC_SUMMARY = os.path.join("profiles", "r05_pmc_bench.json")
 
 
 def pmc_traffic(kernel_class):
