@@ -541,11 +541,13 @@ __global__ __launch_bounds__(256 * KS, 2) void flash_lds_kernel(FlashArgs a) {
 // the score registers in the order the first product left them: lane half h = l >> 5 holds keys 4 h + 8 i + j of the block (reg 4 i + j),
 // so k-slot e of PV step kk is score register 8 kk + e, and V^T is read with that permutation (two 8-byte reads per fragment).
 template <typename T, int KS>
-__global__ __launch_bounds__(256 * KS, 2 * KS) void flash32_kernel(FlashArgs a) {
+__global__ __launch_bounds__(256 * KS, KS == 4 ? 4 : 2 * KS) void flash32_kernel(FlashArgs a) {
   typedef typename Vec<T>::x8 x8;
   typedef typename Vec<T>::x4 x4;
-  constexpr int ST = 3, KT = 64;
+  // KS = 4 (fewer than one workgroup per CU: the denoiser alone): 16 waves, tiles of 128 keys, every wave one 32-key block of each
+  constexpr int ST = 3, KT = KS == 4 ? 128 : 64;
   constexpr int STAGE = 2 * KT * 64;
+  constexpr int CPR = KT / 8, RPP = 64 / CPR;   // V^T tile: 16-byte chunks per row (64 d-rows of KT keys), d-rows per 1-KiB piece
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* ring = (T*)smem_raw;
   float* rp = (float*)(ring + ST * STAGE);
@@ -596,17 +598,22 @@ __global__ __launch_bounds__(256 * KS, 2 * KS) void flash32_kernel(FlashArgs a) 
   const int ntile = (kend_blk + KT - 1) / KT;
 
   const int lr = lane >> 3, lc = lane & 7;
+  constexpr int G = (KT / 4) / (4 * KS);  // LDS-DMA pieces per wave per tile: KT / 8 pieces of K + KT / 8 of V^T over 4 KS waves
   auto issue = [&](int t, int stage) {
     const int key0 = t * KT;
     T* base = ring + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < 4 / KS; ++i) {
+    for (int i = 0; i < G; ++i) {
       const int piece = wave_id + 4 * KS * i;
-      const int row = (piece & 7) * 8 + lr;
-      const int chunk = lc ^ ((row >> 1) & 7);
       const T* src;
-      if (piece < 8) src = K + (size_t)min(key0 + row, n - 1) * 64 + chunk * 8;
-      else src = VT + (size_t)row * a.n_pad + min(key0 + chunk * 8, a.n_pad - 8);
+      if (piece < KT / 8) {                      // K rows: 8 rows x 8 chunks per piece
+        const int row = piece * 8 + lr;
+        src = K + (size_t)min(key0 + row, n - 1) * 64 + (lc ^ ((row >> 1) & 7)) * 8;
+      } else {                                   // V^T rows: RPP rows x CPR chunks per piece, the low 3 chunk bits swizzled
+        const int row = (piece - KT / 8) * RPP + lane / CPR, pc = lane % CPR;
+        const int chunk = (pc & ~7) | ((pc & 7) ^ ((row >> 1) & 7));
+        src = VT + (size_t)row * a.n_pad + min(key0 + chunk * 8, a.n_pad - 8);
+      }
       __builtin_amdgcn_global_load_lds((gbl_void_a*)src, (lds_void_a*)(base + piece * 512), 16, 0, 0);
     }
   };
@@ -629,8 +636,8 @@ __global__ __launch_bounds__(256 * KS, 2 * KS) void flash32_kernel(FlashArgs a) 
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int c = kp * 4 + 2 * kk;  // 8-key chunk of keys 16 kk .. +7 of the block; this lane half takes keys 4 hh .. +3 of it and of the next
-        const x4 lo = *(const x4*)(vt + d * 64 + ((c ^ sw) * 8) + hh * 4);
-        const x4 hi = *(const x4*)(vt + d * 64 + (((c + 1) ^ sw) * 8) + hh * 4);
+        const x4 lo = *(const x4*)(vt + d * KT + (((c & ~7) | ((c & 7) ^ sw)) * 8) + hh * 4);
+        const x4 hi = *(const x4*)(vt + d * KT + ((((c + 1) & ~7) | (((c + 1) & 7) ^ sw)) * 8) + hh * 4);
         x8 v;
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
         v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
@@ -708,7 +715,6 @@ __global__ __launch_bounds__(256 * KS, 2 * KS) void flash32_kernel(FlashArgs a) 
       for (int db = 0; db < 2; ++db) acc[db] = mfma32(vf[db][kk], pf[kk], acc[db]);
   };
 
-  constexpr int G = 4 / KS;
   const int last = ntile - 1;
 #pragma unroll
   for (int s_ = 0; s_ < ST - 1; ++s_) issue(min(s_, last), s_);
@@ -731,29 +737,37 @@ __global__ __launch_bounds__(256 * KS, 2 * KS) void flash32_kernel(FlashArgs a) 
     slot = slot + 1 == ST ? 0 : slot + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (KS == 2) {
-    float* mg = (float*)ring;  // [4 query groups][34][64 lanes]
-    __syncthreads();
-    if (kp_own == 1) {
-      float* d = mg + (size_t)wave * 34 * 64 + lane;
-      d[0] = m_run;
-      d[64] = l_run;
+  if constexpr (KS >= 2) {
+    // merge the key splits' (m, l, acc) per query row through the ring (free now): the upper half of the splits parks, the lower half combines;
+    // KS = 4 does that twice (splits 2, 3 into 0, 1, then 1 into 0)
+    float* mg = (float*)ring;  // [KS / 2][4 query groups][34][64 lanes]
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+    for (int half = KS / 2; half >= 1; half >>= 1) {
+      __syncthreads();  // every wave is done with the ring / with the previous round's scratch
+      if (kp_own >= half && kp_own < 2 * half) {
+        float* d = mg + ((size_t)((kp_own - half) * 4 + wave) * 34) * 64 + lane;
+        d[0] = m_run;
+        d[64] = l_run;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) d[(2 + db * 16 + v) * 64] = acc[db][v];
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) d[(2 + db * 16 + v) * 64] = acc[db][v];
+      }
+      __syncthreads();
+      if (kp_own < half) {
+        const float* d = mg + ((size_t)(kp_own * 4 + wave) * 34) * 64 + lane;
+        const float m1 = d[0], l1 = d[64];
+        const float mm = fmaxf(m_run, m1);
+        const float a0 = __builtin_amdgcn_exp2f((m_run - mm) * LOG2E), a1 = __builtin_amdgcn_exp2f((m1 - mm) * LOG2E);
+        l_run = l_run * a0 + l1 * a1;
+        m_run = mm;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[db][v] = acc[db][v] * a0 + d[(2 + db * 16 + v) * 64] * a1;
+      }
     }
-    __syncthreads();
-    if (kp_own == 1) return;
-    const float* d = mg + (size_t)wave * 34 * 64 + lane;
-    const float m1 = d[0], l1 = d[64];
-    const float mm = fmaxf(m_run, m1);
-    const float a0 = __builtin_amdgcn_exp2f((m_run - mm) * LOG2E), a1 = __builtin_amdgcn_exp2f((m1 - mm) * LOG2E);
-    l_run = l_run * a0 + l1 * a1;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[db][v] = acc[db][v] * a0 + d[(2 + db * 16 + v) * 64] * a1;
+    if (kp_own != 0) return;
   }
   l_run = add_xor32(l_run);
   if (qi < n) {
@@ -769,8 +783,9 @@ __global__ __launch_bounds__(256 * KS, 2 * KS) void flash32_kernel(FlashArgs a) 
 
 template <typename T, int KS>
 static int launch_flash32(const ProfScope& ps, const FlashArgs& a, hipStream_t stream) {
-  constexpr int smem = 3 * 2 * 64 * 64 * 2 + 260 * 4;
-  static_assert(KS == 1 || 4 * 34 * 64 * 4 <= 3 * 2 * 64 * 64 * 2, "the merge scratch must fit the ring");
+  constexpr int KT = KS == 4 ? 128 : 64;
+  constexpr int smem = 3 * 2 * KT * 64 * 2 + 260 * 4;
+  static_assert(KS == 1 || (KS / 2) * 4 * 34 * 64 * 4 <= 3 * 2 * KT * 64 * 2, "the merge scratch must fit the ring");
   static bool attr_set = false;
   if (!attr_set) {
     TT_CHECK_HIP(hipFuncSetAttribute((const void*)flash32_kernel<T, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -797,7 +812,8 @@ static int launch_flash_lds(const ProfScope& ps, const FlashArgs& a, hipStream_t
   return 0;
 }
 
-bool g_flash32 = true;  // tt_flash_variant: 0 = the 16-query-wave kernels everywhere (A/B runs)
+bool g_flash32 = true;      // tt_flash_variant: 0 = the 16-query-wave kernels everywhere (A/B runs)
+bool g_flash32_ks4 = true;  // tt_flash_variant: 2 = flash32 without the 16-wave / 4-way key split for launches of <= one workgroup per CU
 
 int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
   if (dtype == DT_F32) return flash_f32_launch(a, stream);  // verification mode (attention_f32.hip)
@@ -811,6 +827,7 @@ int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
     // 32-query waves on v_mfma_f32_32x32x16 (flash32_kernel), 128 queries per workgroup; launches of fewer than ~2 workgroups per CU
     // split every key tile over two wave groups (the denoiser: 7 x 32 workgroups)
     const long blocks128 = (long)cdiv(a.n, 128) * a.BH;
+    if (blocks128 <= 256 && a.variant != 1 && g_flash32_ks4) return dtype == DT_BF16 ? launch_flash32<bf16, 4>(ps, a, stream) : launch_flash32<f16, 4>(ps, a, stream);
     if (blocks128 < 512 && a.variant != 1) return dtype == DT_BF16 ? launch_flash32<bf16, 2>(ps, a, stream) : launch_flash32<f16, 2>(ps, a, stream);
     return dtype == DT_BF16 ? launch_flash32<bf16, 1>(ps, a, stream) : launch_flash32<f16, 1>(ps, a, stream);
   }

@@ -561,18 +561,45 @@ __device__ __forceinline__ void run_epilogue(const GemmCore& c, const typename E
   }
   // phase 2: arithmetic and GroupNorm partial statistics, registers only
   float s0[FN], q0[FN], s1[FN], q1[FN];
+  // big wave tiles read the skip here, strip by strip - ONE STRIP AHEAD (round 5): with the strip's own four quads as the only loads in flight
+  // the 256 x 256 tile's epilogue was a chain of four dependent HBM round trips per wave (40 us per tile at the pre-pass shapes, as long as
+  // its 16-k-tile main loop); the next strip's quads are requested before this strip is worked on, in the registers its predecessor's
+  // accumulators have just left
+#if defined(TT_EPI_NO_PREFETCH)   // A/B knob (build.py --variant nopf -DTT_EPI_NO_PREFETCH): the round-4 form, each strip's quads requested when it is worked on
+  constexpr bool AHEAD = false;
+#else
+  constexpr bool AHEAD = true;
+#endif
+  constexpr bool LATE = Epi::kId == 0 && FM * FN > 8;
+  float4 rq_cur[LATE ? FM : 1], rq_nxt[LATE ? FM : 1];
+  auto fetch_skip = [&](float4 (&dst)[LATE ? FM : 1], int i) {
+    if constexpr (LATE) {
+      const int n = n0w + i * 16 + fg * 4;
+      const int nvalid = c.N - n >= 4 ? 4 : c.N - n;
+#pragma unroll
+      for (int j = 0; j < FM; ++j) dst[j] = Epi::has_res(e) ? Epi::template load_res<AL>(c, e, m0w + j * 16 + fr, n, nvalid) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch_skip(rq_cur, 0);
 #pragma unroll
   for (int i = 0; i < FN; ++i) {
     const int n = n0w + i * 16 + fg * 4;
     const int nvalid = c.N - n >= 4 ? 4 : c.N - n;
     s0[i] = q0[i] = s1[i] = q1[i] = 0.f;
+    if constexpr (LATE) {
+      if constexpr (AHEAD) {
+        if (i + 1 < FN) fetch_skip(rq_nxt, i + 1);
+      } else if (i > 0) {
+        fetch_skip(rq_cur, i);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
       const int m = m0w + j * 16 + fr;
       if constexpr (Epi::kId == 0) {
         float4 rq = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (Epi::template late_res<FM, FN>()) {
-          if (Epi::has_res(e)) rq = Epi::template load_res<AL>(c, e, m, n, nvalid);
+          rq = rq_cur[j];
         } else {
           rq = o.rv[i][j];
         }
@@ -605,6 +632,10 @@ __device__ __forceinline__ void run_epilogue(const GemmCore& c, const typename E
         if (m < c.M && n < c.N) Epi::template store<AL>(c, e, step_t, m, n, acc[i][j], nvalid, z);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LATE && AHEAD) {
+#pragma unroll
+        for (int j = 0; j < FM; ++j) rq_cur[j] = rq_nxt[j];
+      }
     }
   }
   // phase 3: stores, back to back
