@@ -159,8 +159,8 @@ def _attn_ref(q, k, v, causal, relpos):
 @pytest.mark.parametrize("n,B", [(70, 2), (300, 40), (870, 2), (200, 96), (129, 3), (300, 60)])
 def test_flash_attention(lib, name, dt, tdt, tol, mode, n, B):
     """n <= 128 and every causal case: the 16-query-wave kernels (register-prefetch / LDS-staged).  Non-causal n > 128 (round 5):
-    flash32_kernel, 32-query waves on v_mfma_f32_32x32x16 - 16 waves with a 4-way key split for launches of <= 256 workgroups (n = 870 x 4
-    pairs: the denoiser's form; ragged tails 129 / 300), 8 waves / 2-way for 256 .. 512 (300 x 120 pairs), 4 waves for more (200 x 1152 pairs)."""
+    flash32_kernel, 32-query waves on v_mfma_f32_32x32x16 - 8 waves with a 2-way key split for launches of < 512 workgroups (n = 870 x 4
+    pairs: the denoiser's form; ragged tails 129 / 300; 300 x 120 pairs), 4 waves for more (200 x 1152 pairs)."""
     g = torch.Generator().manual_seed(n)
     H = 2 if n != 200 else 12
     n_pad = (n + 31) // 32 * 32

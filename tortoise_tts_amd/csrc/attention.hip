@@ -544,7 +544,8 @@ template <typename T, int KS>
 __global__ __launch_bounds__(256 * KS, KS == 4 ? 4 : 2 * KS) void flash32_kernel(FlashArgs a) {
   typedef typename Vec<T>::x8 x8;
   typedef typename Vec<T>::x4 x4;
-  // KS = 4 (fewer than one workgroup per CU: the denoiser alone): 16 waves, tiles of 128 keys, every wave one 32-key block of each
+  // (KS = 4: 16 waves, tiles of 128 keys, every wave one 32-key block of each - built and measured equal to KS = 2 at the denoiser's shape,
+  //  profiles/r05_ab_flash_ks4_and_epilogue_prefetch.txt; not instantiated)
   constexpr int ST = 3, KT = KS == 4 ? 128 : 64;
   constexpr int STAGE = 2 * KT * 64;
   constexpr int CPR = KT / 8, RPP = 64 / CPR;   // V^T tile: 16-byte chunks per row (64 d-rows of KT keys), d-rows per 1-KiB piece
@@ -812,8 +813,7 @@ static int launch_flash_lds(const ProfScope& ps, const FlashArgs& a, hipStream_t
   return 0;
 }
 
-bool g_flash32 = true;      // tt_flash_variant: 0 = the 16-query-wave kernels everywhere (A/B runs)
-bool g_flash32_ks4 = true;  // tt_flash_variant: 2 = flash32 without the 16-wave / 4-way key split for launches of <= one workgroup per CU
+bool g_flash32 = true;  // tt_flash_variant: 0 = the 16-query-wave kernels everywhere (A/B runs)
 
 int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
   if (dtype == DT_F32) return flash_f32_launch(a, stream);  // verification mode (attention_f32.hip)
@@ -827,7 +827,6 @@ int flash_attention_launch(int dtype, const FlashArgs& a, hipStream_t stream) {
     // 32-query waves on v_mfma_f32_32x32x16 (flash32_kernel), 128 queries per workgroup; launches of fewer than ~2 workgroups per CU
     // split every key tile over two wave groups (the denoiser: 7 x 32 workgroups)
     const long blocks128 = (long)cdiv(a.n, 128) * a.BH;
-    if (blocks128 <= 256 && a.variant != 1 && g_flash32_ks4) return dtype == DT_BF16 ? launch_flash32<bf16, 4>(ps, a, stream) : launch_flash32<f16, 4>(ps, a, stream);
     if (blocks128 < 512 && a.variant != 1) return dtype == DT_BF16 ? launch_flash32<bf16, 2>(ps, a, stream) : launch_flash32<f16, 2>(ps, a, stream);
     return dtype == DT_BF16 ? launch_flash32<bf16, 1>(ps, a, stream) : launch_flash32<f16, 1>(ps, a, stream);
   }

@@ -3,7 +3,7 @@
 #include "../../include/tortoise_mi355x.h"
 
 using namespace tt;
-namespace tt { extern bool g_flash32; extern bool g_flash32_ks4; extern bool g_voc_mfma; }  // attention.hip, univnet.hip
+namespace tt { extern bool g_flash32; extern bool g_voc_mfma; }  // attention.hip, univnet.hip
 
 extern "C" {
 
@@ -122,9 +122,8 @@ int tt_op_resid_ln(int dtype, const void* A, int K, const void* W, const float* 
 // non-causal sequences of more than 128 rows, 0 = the 16-query-wave kernels everywhere.  Returns the previous value.  Set it before an
 // engine captures its graphs (a kept graph replays the kernels it was captured with).
 int tt_flash_variant(int v) {
-  const int prev = !tt::g_flash32 ? 0 : tt::g_flash32_ks4 ? 1 : 2;
+  const int prev = tt::g_flash32 ? 1 : 0;
   tt::g_flash32 = v != 0;
-  tt::g_flash32_ks4 = v != 2;  // 2: flash32 without the 4-way key split (A/B of that form alone)
   return prev;
 }
 

@@ -561,14 +561,15 @@ __device__ __forceinline__ void run_epilogue(const GemmCore& c, const typename E
   }
   // phase 2: arithmetic and GroupNorm partial statistics, registers only
   float s0[FN], q0[FN], s1[FN], q1[FN];
-  // big wave tiles read the skip here, strip by strip - ONE STRIP AHEAD (round 5): with the strip's own four quads as the only loads in flight
-  // the 256 x 256 tile's epilogue was a chain of four dependent HBM round trips per wave (40 us per tile at the pre-pass shapes, as long as
-  // its 16-k-tile main loop); the next strip's quads are requested before this strip is worked on, in the registers its predecessor's
-  // accumulators have just left
-#if defined(TT_EPI_NO_PREFETCH)   // A/B knob (build.py --variant nopf -DTT_EPI_NO_PREFETCH): the round-4 form, each strip's quads requested when it is worked on
-  constexpr bool AHEAD = false;
-#else
+  // big wave tiles read the skip here, strip by strip.  With the strip's own four quads as the only loads in flight the 256 x 256 tile's
+  // epilogue is a chain of four dependent HBM round trips per wave (~40 us per tile at the pre-pass shapes, as long as its 16-k-tile main
+  // loop).  Requesting the NEXT strip's quads before this strip is worked on (AHEAD, round 5) needs 16 more live registers in a 128-VGPR
+  // wave: hipcc spills 40 bytes per lane and the long-form reading workload ran 2.3 % slower (profiles/r05_ab_flash_ks4_and_epilogue_prefetch.txt)
+  // - the knob stays off.
+#if defined(TT_EPI_PREFETCH)   // A/B knob (build.py --variant pf -DTT_EPI_PREFETCH), default OFF: measured slower, see below
   constexpr bool AHEAD = true;
+#else
+  constexpr bool AHEAD = false;
 #endif
   constexpr bool LATE = Epi::kId == 0 && FM * FN > 8;
   float4 rq_cur[LATE ? FM : 1], rq_nxt[LATE ? FM : 1];
