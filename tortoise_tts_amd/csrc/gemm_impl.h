@@ -264,49 +264,6 @@ struct EpiQkvHeads {
   static __device__ __forceinline__ void apply(const Args&, f32x4& v, const float4& bv, const float4&) {
     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
   }
-  // V^T stores (round 5).  In the swapped MFMA form a lane holds four consecutive COLUMNS of one row, so the transposed copy of V went out as
-  // four 2-byte stores per fragment at a stride of seq_pad (32 store instructions per lane for a V wave tile against 8 for a Q / K one, and
-  // the launch lasts as long as its slowest tiles).  A wave whose columns are V columns - wave-uniform, and only when nothing but V^T is
-  // written - therefore issues its MFMAs UNSWAPPED (activation fragment as the A operand: D[row = m][col = n], a lane holds four consecutive
-  // ROWS m .. m + 3 = positions s .. s + 3 of one column), and writes them as ONE 8-byte store into V^T[d][s .. s + 3].
-#if defined(TT_NO_VT_ROWS4)  // A/B knob (build.py --variant novt -DTT_NO_VT_ROWS4): the round-4 form, V^T as 2-byte stores from the swapped layout
-  static __device__ __forceinline__ bool v_transposed(const Args&, int) { return false; }
-#else
-  static __device__ __forceinline__ bool v_transposed(const Args& e, int n0w) { return e.vt != nullptr && e.v == nullptr && (unsigned)n0w >= 2u * e.dmodel.d; }
-#endif
-  template <int FM, int FN>
-  static __device__ __forceinline__ void store_vt(const GemmCore& c, const Args& e, const f32x4 (&acc)[FN][FM], int m0w, int n0w, int lane) {
-    typedef typename Vec<T>::x4 __attribute__((aligned(4))) x4u;  // (rows of V^T start at multiples of 32 elements; s is even whenever seq_len is)
-    const int col = lane & 15, rq = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < FN; ++i) {
-      const int n = n0w + i * 16 + col;
-      if (n >= c.N) continue;
-      const int cc = n - 2 * (int)e.dmodel.d;
-      const int h = cc >> 6, d = cc & 63;
-      const float bias = e.bias ? e.bias[n] : 0.f;
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        const int m = m0w + j * 16 + rq * 4;
-        if (m >= c.M) continue;
-        unsigned s;
-        const unsigned b = fdiv((unsigned)m, c.seq, s);
-        T* o = (T*)e.vt + (((size_t)b * e.heads + h) * 64 + d) * e.seq_pad + s;
-        if ((int)s + 3 < c.seq_len && m + 3 < c.M && (s & 1u) == 0u) {
-          *(x4u*)o = pack4<T>(acc[i][j][0] + bias, acc[i][j][1] + bias, acc[i][j][2] + bias, acc[i][j][3] + bias);
-        } else {  // the quad straddles a sequence boundary / the end of the rows, or sits at an odd position: element stores
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (m + r < c.M) {
-              unsigned s2;
-              const unsigned b2 = fdiv((unsigned)(m + r), c.seq, s2);
-              ((T*)e.vt)[(((size_t)b2 * e.heads + h) * 64 + d) * e.seq_pad + s2] = (T)(acc[i][j][r] + bias);
-            }
-          }
-        }
-      }
-    }
-  }
   template <bool AL>
   static __device__ __forceinline__ void store(const GemmCore& c, const Args& e, int, int m, int n, const f32x4& v, int, int) {
     unsigned cc, s;
@@ -889,8 +846,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
   };
 
   const int fr = lane & 15, fg = lane >> 4;
-  bool vswap = false;  // EpiQkvHeads: this wave's columns are V columns whose only output is V^T: unswapped MFMAs (see EpiQkvHeads::store_vt)
-  if constexpr (Epi::kId == 1) vswap = Epi::v_transposed(g.e, n0 + wn * TN);
   auto compute = [&](int buf) {
     const T* as = As + buf * BM * BK;
     const T* ws = Ws + buf * BN * BK;
@@ -907,17 +862,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
         const int r = wn * TN + i * 16 + fr;
         fw[i] = *(const x8*)(ws + r * BK + (((ks * 4 + fg) ^ ((r >> 1) & 7)) * 8));
       }
-      if (Epi::kId == 1 && vswap) {
 #pragma unroll
-        for (int i = 0; i < FN; ++i)
+      for (int i = 0; i < FN; ++i)
 #pragma unroll
-          for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(fa[j], fw[i], acc[i][j]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < FN; ++i)
-#pragma unroll
-          for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
-      }
+        for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
     }
   };
 
@@ -1038,12 +986,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
     }
     run_epilogue<EOut, FM, FN, TM, TN, AL>(c, g.e, tser, none, 0, m0 + wm * TM, n0 + wn * TN, lane, z);
   } else {
-    if constexpr (Epi::kId == 1) {
-      if (vswap) {
-        Epi::template store_vt<FM, FN>(c, g.e, acc, m0 + wm * TM, n0 + wn * TN, lane);
-        return;
-      }
-    }
     run_epilogue<Epi, FM, FN, TM, TN, AL>(c, g.e, acc, eo, eo.step(), m0 + wm * TM, n0 + wn * TN, lane, z);
   }
 }
