@@ -38,5 +38,13 @@ echo "after workloads: $(( $(date +%s) - $(cat $OUT/final_t0) )) s"
 timeout 600 python -m pytest tests -q -m gpu -s -p no:cacheprovider > $OUT/pytest_gpu_final.log 2>&1; echo "pytest-gpu rc=$?"; tail -2 $OUT/pytest_gpu_final.log
 grep "\[parity\]\|\[guard\]" $OUT/pytest_gpu_final.log | sed "s/^\.*//" > $OUT/parity_final.txt; wc -l $OUT/parity_final.txt
 timeout 120 python __graft_entry__.py smoke > $OUT/smoke_final.log 2>&1; tail -2 $OUT/smoke_final.log
+# the complete multi-rank flows with the ranks sharing the box's one GPU over gloo (control flow only; the numbers mean nothing)
+for n in 2 8; do
+  TT_DIST_SHARE_DEVICE=1 OMP_NUM_THREADS=8 timeout 420 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2962$n bench.py --gpus $n --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_${n}rank_shared.log 2> $OUT/bench_${n}rank_shared.err
+  echo "bench --gpus $n (shared device) rc=$?"
+  tail -1 $OUT/bench_${n}rank_shared.log | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','n_gpus','ms_per_step','dtype')}, d['config']['parallelism'][:100])" || tail -5 $OUT/bench_${n}rank_shared.err
+done
 echo "total: $(( $(date +%s) - $(cat $OUT/final_t0) )) s"
 exit 0
