@@ -317,8 +317,10 @@ int tt_diff_stat(tt_diff* h, int which);  /* which = 0: sampler-step graph captu
  * timestep and the conditioning, not on x_t) is evaluated in chunks of the schedule on a second stream WHILE the sampler loop walks
  * the steps whose chunks are complete; 0 = whole pre-pass first (one stream).  Same results either way. */
 #define TT_DIFF_OPT_OVERLAP_PREPASS 1
-/* TT_DIFF_OPT_FUSED_GN: ResBlock in_layers (diffusion_decoder.py:60-80: GroupNorm32 -> SiLU -> 1x1 conv) as ONE launch - the conv's
- * GEMM normalises, activates and casts its own f32 A rows (csrc/gemm_gna.h); 0 = stand-alone apply launch + 16-bit tensor. */
+/* TT_DIFF_OPT_FUSED_GN [1]: ResBlock in_layers (diffusion_decoder.py:60-80: GroupNorm32 -> SiLU -> 1x1 conv) as ONE launch - the conv's
+ * GEMM normalises, activates and casts its own f32 A rows (csrc/gemm_gna.h); 0 = stand-alone apply launch + 16-bit tensor;
+ * 2 = additionally the AttentionBlock norm (arch_util.py:104-123) on the QKV GEMM's A path (measured, not the default:
+ * profiles/r05_ab_gna_qkv.txt). */
 #define TT_DIFF_OPT_FUSED_GN 2
 int tt_diff_set_option(tt_diff* h, int option, int value);  /* option = TT_DIFF_OPT_*; switching TT_DIFF_OPT_FUSED_GN drops the kept step graph */
 

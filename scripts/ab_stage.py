@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--flash-variants", default="",
                     help="';'-separated tt_flash_variant settings (1 = 32-query-wave attention kernel, 0 = 16-query waves) to time the diffusion "
                          "stage with, one fresh stage object each, e.g. '1;0;1;0'")
+    ap.add_argument("--gn-variants", default="",
+                    help="';'-separated TT_DIFF_OPT_FUSED_GN values (0 = stand-alone applies, 1 = ResBlock in_layers fused, 2 = + the attention norm on "
+                         "the QKV GEMM's A path) timed one after the other on ONE diffusion stage object, e.g. '1;2;1;2'")
     ap.add_argument("--voc-variants", default="", help="';'-separated tt_voc_variant settings (1 = f32-MFMA audio-rate kernels, 0 = VALU) for the 'voc' stage")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     args = ap.parse_args()
@@ -92,18 +95,23 @@ def main():
                     E.load_library().tt_flash_variant(fv)
                     tag = "flash32=%d" % fv
                 df = stages.DiffusionStage(sd, cfg, dtype=E.dtype_code(args.dtype), max_seq=max(S, 128), max_codes=max(M, 64), max_steps=args.iterations)
-                times = []
-                mel = None
-                for r in range(args.reps + 1):
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    df.condition(lat, diffc.to(dev), S)
-                    mel = df.sample(sched, x, noise)
-                    torch.cuda.synchronize()
-                    if r:
-                        times.append((time.perf_counter() - t0) / args.iterations)
-                print("ab %-10s diff S=%d it=%d: %.4f ms/iteration (min %.4f)  total %.1f ms  mel %s" %
-                      (tag, S, args.iterations, 1e3 * sum(times) / len(times), 1e3 * min(times), 1e3 * args.iterations * sum(times) / len(times), digest(mel)), flush=True)
+                for gv in [int(v) for v in args.gn_variants.split(";") if v.strip()] or [None]:
+                    gtag = tag
+                    if gv is not None:
+                        df.set_option(E.TT_DIFF_OPT_FUSED_GN, gv)
+                        gtag = "fused_gn=%d" % gv
+                    times = []
+                    mel = None
+                    for r in range(args.reps + 1):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        df.condition(lat, diffc.to(dev), S)
+                        mel = df.sample(sched, x, noise)
+                        torch.cuda.synchronize()
+                        if r:
+                            times.append((time.perf_counter() - t0) / args.iterations)
+                    print("ab %-10s diff S=%d it=%d: %.4f ms/iteration (min %.4f)  total %.1f ms  mel %s" %
+                          (gtag, S, args.iterations, 1e3 * sum(times) / len(times), 1e3 * min(times), 1e3 * args.iterations * sum(times) / len(times), digest(mel)), flush=True)
                 df.close()
             if fvs != [None]:
                 E.load_library().tt_flash_variant(1)

@@ -1,25 +1,17 @@
 #!/bin/bash
-# round 5, call H: V^T written as 8-byte row quads from unswapped MFMAs (QKV GEMM epilogue) against the 2-byte-store form: parity (diffusion / CLVP /
-# AR prefill at full width), per-class kernel time of the two builds (bench roofline leg), stage A/B, CLVP stage time
+# round 5, call H: the AttentionBlock norm on the QKV GEMM's A path (TT_DIFF_OPT_FUSED_GN = 2) - parity test, in-situ A/B on one diffusion stage
+# object (values alternating), and a kernel trace of the fused form for the per-launch durations
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=gpurun_out
 mkdir -p $OUT
-NOVT=$PWD/tortoise_tts_amd/lib/libtortoise_mi355x_novt.so
-timeout 400 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_stages.py tests/test_gpu_parity_r3.py tests/test_gpu_f32.py -q -m gpu -p no:cacheprovider -x > $OUT/r5h_parity.log 2>&1; echo "parity rc=$?"; tail -3 $OUT/r5h_parity.log
-for lib in "" "$NOVT"; do
-  tag=$([ -z "$lib" ] && echo quads || echo bytes)
-  TORTOISE_MI355X_LIB=$lib timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('$tag', {k:round(v,4) for k,v in d['stages_s_per_step'].items()})
-for k in d['kernel_breakdown_ms']:
-    if 'QkvHeads' in k['kernel'] or 'flash' in k['kernel']: print('$tag', k)"
-done
-: > $OUT/ab_r5h.txt
-for rep in 1 2; do
-  timeout 200 python scripts/ab_stage.py diff --dtype fp16 --reps 2 --tag quads >> $OUT/ab_r5h.txt 2>&1
-  TORTOISE_MI355X_LIB=$NOVT timeout 200 python scripts/ab_stage.py diff --dtype fp16 --reps 2 --tag bytes >> $OUT/ab_r5h.txt 2>&1
-done
-grep "^ab " $OUT/ab_r5h.txt
+timeout 400 python -m pytest tests/test_gpu_r5.py tests/test_gpu_r4.py -q -m gpu -s -p no:cacheprovider -k "attention_norm_on_the_qkv or fused_groupnorm" > $OUT/r5h_tests.log 2>&1; echo "tests rc=$?"; grep -E "passed|failed|Error|assert|\[parity\]" $OUT/r5h_tests.log | tail -8
+timeout 400 python scripts/ab_stage.py diff --dtype fp16 --reps 2 --gn-variants "1;2;1;2;1;2;0" > $OUT/ab_r5h_gn.txt 2>&1; echo "ab gn rc=$?"; grep "^ab " $OUT/ab_r5h_gn.txt
+TT_DIFF_OVERLAP_PREPASS=0 timeout 300 python scripts/ab_stage.py diff --dtype fp16 --reps 2 --gn-variants "1;2;1;2" > $OUT/ab_r5h_gn_serial.txt 2>&1; echo "ab gn (pre-pass first) rc=$?"; grep "^ab " $OUT/ab_r5h_gn_serial.txt
+rm -rf $OUT/prof_r5h
+TT_DIFF_FUSED_GN=2 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_r5h -o gn2 --output-format csv -- python scripts/ab_stage.py diff --dtype fp16 --reps 1 --iterations 100 > $OUT/prof_r5h.log 2>&1; echo "trace rc=$?"
+f=$(find $OUT/prof_r5h -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && { cp "$f" $OUT/r5h_kernel_stats_gn2.csv; head -12 "$f" | cut -c1-200; }
+find $OUT/prof_r5h -name "*kernel_trace.csv" -delete
 exit 0

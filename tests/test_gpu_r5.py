@@ -269,3 +269,42 @@ def test_vocoder_overflow_guard_sees_what_the_waveform_hides():
     print(f"[guard] vocoder with out-of-range predicted kernels: {n} workgroup(s) counted, waveform finite: {bool(torch.isfinite(wav).all())}")
     assert n > 0
     st.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [E.TT_F16, E.TT_BF16])
+@torch.no_grad()
+def test_attention_norm_on_the_qkv_a_path_matches_the_standalone_apply(dtype):
+    """TT_DIFF_OPT_FUSED_GN = 2: the AttentionBlock's GroupNorm32 (arch_util.py:104-123, no activation) applied on the QKV GEMM's A
+    path (csrc/gemm_gna.h with the head-layout epilogue) against value 1 (stand-alone apply + the 128 x 128 DMA GEMM), full-width
+    denoiser at S = 870, 30 iterations; and fewer launches per sampler step.  Same rounding argument as the ResBlock form."""
+    from tortoise_tts_amd.config import DiffusionConfig
+    from tortoise_tts_amd.schedule import Schedule
+    cfg = DiffusionConfig()
+    sd = W.synthetic_state_dict(W.diffusion_manifest(cfg), 1237)
+    M, iters = 200, 30
+    S = M * 4 * 24000 // 22050
+    st = stages.DiffusionStage(sd, cfg, dtype=dtype, max_seq=S + 8, max_codes=M + 8, max_steps=64)
+    g = torch.Generator().manual_seed(6)
+    lat = torch.randn(1, M, 1024, generator=g)
+    dcond = torch.randn(1, 2048, generator=g) * 0.5
+    sched = Schedule(iters, cfg.trained_steps, True, 2)
+    x = torch.randn(1, 100, S, generator=g)
+    noise = torch.randn(iters, 1, 100, S, generator=g)
+    st.set_option(E.TT_DIFF_OPT_FUSED_GN, 1)
+    st.condition(lat, dcond, S)
+    want = st.sample(sched, x, noise).clone()
+    assert torch.isfinite(want).all() and st.guard() == 0
+    st.set_option(E.TT_DIFF_OPT_FUSED_GN, 2)
+    got = []
+    for rep in range(2):
+        st.condition(lat, dcond, S)
+        got.append(st.sample(sched, x, noise).clone())
+        assert torch.isfinite(got[-1]).all() and st.guard() == 0
+    assert torch.equal(got[0], got[1]), "the fused path is not deterministic"
+    rel = float((got[0] - want).norm() / want.norm())
+    mx = float((got[0] - want).abs().max())
+    print(f"[parity] attention norm on the QKV A path vs stand-alone apply ({E.DTYPE_NAMES[dtype]}, S={S}, {iters} iterations): rel-L2 {rel:.3e} max-abs {mx:.3e}")
+    assert rel < (4e-3 if dtype == E.TT_F16 else 3e-2), rel
+    st.set_option(E.TT_DIFF_OPT_FUSED_GN, 1)
+    st.close()

@@ -152,11 +152,27 @@ static int gemm_with_stats(tt_diff* e, DiffWork& w_, GemmArgs& g, int S, hipStre
 static int run_attn_block(tt_diff* e, DiffWork& w_, const tt_attn_block& w, const float* in, int B, int S, float* out_f32, void* out_t, int ldot,
                           hipStream_t s) {
   const int C = e->C, H = e->H, dt = e->cfg.dtype, M = B * S, n_pad = round_up(S, 32);
-  TT_TRY(run_gn(e, w_, in, B, S, w.norm_g, w.norm_b, nullptr, 0, 1, ACT_NONE, w_.act, C, nullptr, s));
   GemmArgs g = gemm_args(w_.act, C, w.w_qkv, C, M, 3 * C, C);
   g.bias = w.b_qkv; g.seq_len = S; g.dmodel = C; g.heads = H; g.q = w_.q; g.k = w_.k; g.vt = w_.vt; g.seq_pad = n_pad;
   g.q_scale = 0.125f;  // (q * 64^-1/4) . (k * 64^-1/4)  ==  (q/8) . k   (arch_util.py:64-67)
-  TT_TRY(gemm_launch(dt, EPI_QKV_HEADS, g, s));
+  bool fused_gn = false;
+  if (e->fuse_gn >= 2 && !e->masked && in == w_.stats_ptr && w_.stats_seq == S && S >= w_.stats_rows) {
+    // TT_DIFF_OPT_FUSED_GN = 2 (measured, not the default: profiles/r05_ab_gna_qkv.txt): the attention norm on the QKV GEMM's A path as well
+    GemmGnArgs n;
+    memset(&n, 0, sizeof(n));
+    n.gamma = w.norm_g; n.beta = w.norm_b; n.gemm_part = w_.stats_part; n.part_rows = w_.stats_rows; n.S = S; n.eps = 1e-5f; n.act = ACT_NONE;
+    n.guard = e->guard;
+    GemmArgs gf = g;
+    gf.A = in; gf.lda = C;
+    if (gemm_gna_supported(dt, EPI_QKV_HEADS, gf, n)) {
+      TT_TRY(gemm_gna_launch(dt, EPI_QKV_HEADS, gf, n, s));
+      fused_gn = true;
+    }
+  }
+  if (!fused_gn) {
+    TT_TRY(run_gn(e, w_, in, B, S, w.norm_g, w.norm_b, nullptr, 0, 1, ACT_NONE, w_.act, C, nullptr, s));
+    TT_TRY(gemm_launch(dt, EPI_QKV_HEADS, g, s));
+  }
   FlashArgs f;
   memset(&f, 0, sizeof(f));
   f.q = w_.q; f.k = w_.k; f.vt = w_.vt; f.out = w_.att; f.ldo = C; f.BH = B * H; f.heads = H; f.n = S; f.n_pad = n_pad;
@@ -756,8 +772,8 @@ int tt_diff_set_option(tt_diff* e, int option, int value) {
   TT_REQUIRE(e != nullptr, "tt_diff_set_option: null handle");
   TT_REQUIRE(option == TT_DIFF_OPT_OVERLAP_PREPASS || option == TT_DIFF_OPT_FUSED_GN, "tt_diff_set_option: unknown option %d", option);
   if (option == TT_DIFF_OPT_FUSED_GN) {
-    if ((value != 0) != (e->fuse_gn != 0)) diff_drop_step_graph(e);  // the kept sampler step was captured with the other launch sequence
-    e->fuse_gn = value != 0;
+    if (value != e->fuse_gn) diff_drop_step_graph(e);  // the kept sampler step was captured with the other launch sequence
+    e->fuse_gn = value < 0 ? 0 : value > 2 ? 2 : value;  // 0: stand-alone applies; 1 (default): ResBlock in_layers fused; 2: + the attention norm -> qkv
     return 0;
   }
   e->overlap_prepass = value < 0 ? 0 : value > 2 ? 2 : value;

@@ -186,13 +186,13 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
 bool gemm_gna_supported(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs& n) {
   GemmArgs a = a0;
   normalise(a);
-  const bool al16 = ((size_t)a.A & 15) == 0 && (a.lda & 3) == 0 && ((size_t)n.gamma & 15) == 0 && ((size_t)n.beta & 15) == 0 &&
-                    (!n.ss || (((size_t)n.ss & 15) == 0 && (n.ss_stride & 3) == 0)) && a.bias && ((size_t)a.bias & 15) == 0 && a.out_f32 &&
-                    ((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0 && (a.ldw & 7) == 0;
-  return (dtype == DT_BF16 || dtype == DT_F16) && epi == EPI_STD && al16 && a.taps == 1 && a.splitk == 1 && a.serial_k <= 1 && a.K == kGnaC && !a.A2 &&
-         a.N % kGnaBN == 0 && a.M > 256 && a.M <= 4096 && n.S >= kGnaBM && a.M % n.S == 0 && n.gemm_part && n.part_rows > 0 &&
-         (n.part_rows & (n.part_rows - 1)) == 0 && n.S >= n.part_rows && a.gn_part != nullptr && !a.res && !a.out_t && a.act == ACT_NONE && a.gn_vperiod == 0 &&
-         n.act == ACT_SILU && !n.ss;
+  const bool common = (dtype == DT_BF16 || dtype == DT_F16) && ((size_t)a.A & 15) == 0 && (a.lda & 3) == 0 && ((size_t)n.gamma & 15) == 0 && ((size_t)n.beta & 15) == 0 &&
+                      (a.ldw & 7) == 0 && a.taps == 1 && a.splitk == 1 && a.serial_k <= 1 && a.K == kGnaC && !a.A2 && a.N % kGnaBN == 0 && a.M > 256 && a.M <= 4096 &&
+                      n.S >= kGnaBM && a.M % n.S == 0 && n.gemm_part && n.part_rows > 0 && (n.part_rows & (n.part_rows - 1)) == 0 && n.S >= n.part_rows && a.gn_vperiod == 0 && !n.ss;
+  if (epi == EPI_QKV_HEADS)  // AttentionBlock norm -> qkv: no activation, head-layout epilogue
+    return common && n.act == ACT_NONE && a.q && a.k && a.vt && a.dmodel % 64 == 0 && a.N == 3 * a.dmodel && a.heads * 64 == a.dmodel && (!a.bias || ((size_t)a.bias & 15) == 0);
+  const bool al16 = a.bias && ((size_t)a.bias & 15) == 0 && a.out_f32 && ((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0;
+  return common && epi == EPI_STD && al16 && a.gn_part != nullptr && !a.res && !a.out_t && a.act == ACT_NONE && n.act == ACT_SILU;
 }
 
 int gemm_gna_launch(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs& n, hipStream_t stream) {
@@ -201,6 +201,7 @@ int gemm_gna_launch(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs& n,
   TT_REQUIRE(gemm_gna_supported(dtype, epi, a0, n), "gemm_gna: unsupported problem (M=%d N=%d K=%d S=%d)", a.M, a.N, a.K, n.S);
   a.gn_ncol16 = a.N / 16;
   a.seq_len = n.S;
+  if (epi != EPI_QKV_HEADS) a.q = nullptr;  // (gemm_gna_launch_typed tells the two forms apart by the q pointer)
   GemmPlan plan;
   plan_core(a, epi, plan, TILE_64x64, kGnaBM, kGnaBN);
   plan.conv3s = false;

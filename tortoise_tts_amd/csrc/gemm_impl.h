@@ -1441,6 +1441,19 @@ template <typename T>
 int gemm_gna_launch_typed(const GemmArgs& a, const GemmPlan& plan, const GnaArgs& n, hipStream_t stream) {
   const dim3 grid(plan.core.gx * plan.core.gy, 1, 1);
   ProfScope ps(plan.prof_id, stream, plan.flops, plan.bytes, true);
+  if (a.q != nullptr) {
+    // AttentionBlock norm -> qkv (arch_util.py:104-123; round 5, measured against gn_apply + the 128 x 128 DMA GEMM: profiles/r05_ab_gna_qkv.txt):
+    // GroupNorm32 without activation on the A path, head-layout epilogue (32-column wave tiles never straddle a head)
+    GemmGnaDev<EpiQkvHeadsArgs> d;
+    d.c = plan.core;
+    memset(&d.e, 0, sizeof(d.e));
+    d.e.bias = a.bias; d.e.q = a.q; d.e.k = a.k; d.e.v = a.v; d.e.vt = a.vt; d.e.heads = a.heads; d.e.seq_pad = a.seq_pad; d.e.q_scale = a.q_scale;
+    d.e.dmodel = make_fastdiv(a.dmodel);
+    d.n = n;
+    launch_timed(ps, gemm_gna_kernel<T, kGnaBM, kGnaBN, kGnaNW, kGnaWM, kGnaST, EpiQkvHeads<T>, false, false>, grid, dim3(kGnaNW * 64), kGnaSmem, stream, d);
+    TT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   typedef EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_F32> EStF32;
   GemmGnaDev<EpiStdArgs> d;
   d.c = plan.core;
