@@ -272,12 +272,15 @@ def test_vocoder_overflow_guard_sees_what_the_waveform_hides():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("value", [2, 3, 4])
 @pytest.mark.parametrize("dtype", [E.TT_F16, E.TT_BF16])
 @torch.no_grad()
-def test_attention_norm_on_the_qkv_a_path_matches_the_standalone_apply(dtype):
+def test_more_groupnorm_fusions_match_the_standalone_apply(dtype, value):
     """TT_DIFF_OPT_FUSED_GN = 2: the AttentionBlock's GroupNorm32 (arch_util.py:104-123, no activation) applied on the QKV GEMM's A
-    path (csrc/gemm_gna.h with the head-layout epilogue) against value 1 (stand-alone apply + the 128 x 128 DMA GEMM), full-width
-    denoiser at S = 870, 30 iterations; and fewer launches per sampler step.  Same rounding argument as the ResBlock form."""
+    path (csrc/gemm_gna.h with the head-layout epilogue); = 3: ResBlock out_layers' norm + scale-shift + SiLU
+    (diffusion_decoder.py:104-120) applied to the in_layers GEMM's accumulators behind a device-wide barrier, the f32 tensor never
+    written; = 4: both.  Against value 1 (stand-alone applies), full-width denoiser at S = 870 (the row tile at 864 .. 895 straddles
+    the two samples), 30 iterations, run twice.  Same rounding argument as the ResBlock in_layers form."""
     from tortoise_tts_amd.config import DiffusionConfig
     from tortoise_tts_amd.schedule import Schedule
     cfg = DiffusionConfig()
@@ -295,7 +298,7 @@ def test_attention_norm_on_the_qkv_a_path_matches_the_standalone_apply(dtype):
     st.condition(lat, dcond, S)
     want = st.sample(sched, x, noise).clone()
     assert torch.isfinite(want).all() and st.guard() == 0
-    st.set_option(E.TT_DIFF_OPT_FUSED_GN, 2)
+    st.set_option(E.TT_DIFF_OPT_FUSED_GN, value)
     got = []
     for rep in range(2):
         st.condition(lat, dcond, S)
@@ -304,7 +307,8 @@ def test_attention_norm_on_the_qkv_a_path_matches_the_standalone_apply(dtype):
     assert torch.equal(got[0], got[1]), "the fused path is not deterministic"
     rel = float((got[0] - want).norm() / want.norm())
     mx = float((got[0] - want).abs().max())
-    print(f"[parity] attention norm on the QKV A path vs stand-alone apply ({E.DTYPE_NAMES[dtype]}, S={S}, {iters} iterations): rel-L2 {rel:.3e} max-abs {mx:.3e}")
+    what = {2: "attention norm on the QKV A path", 3: "out_layers norm in the in_layers launch (device-wide barrier)", 4: "both GroupNorm fusions"}[value]
+    print(f"[parity] {what} vs stand-alone apply ({E.DTYPE_NAMES[dtype]}, S={S}, {iters} iterations): rel-L2 {rel:.3e} max-abs {mx:.3e}")
     assert rel < (4e-3 if dtype == E.TT_F16 else 3e-2), rel
     st.set_option(E.TT_DIFF_OPT_FUSED_GN, 1)
     st.close()

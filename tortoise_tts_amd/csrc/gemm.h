@@ -104,7 +104,20 @@ struct GemmGnArgs {
   float eps;
   int act;                // ACT_NONE / ACT_SILU
   int* guard;             // optional operand-overflow counter (non-finite statistics)
+  // optional (EPI_STD form only): the OUTPUT group-normalised in the same launch behind a device-wide barrier (gemm_gna.h, NOUT) -
+  // y = SiLU(GroupNorm32(W . act(GN(x)) + bias) * (1 + scale) + shift) written to o_out in the operand type, out_f32 NOT written.
+  // The grid must fit the device's CUs (gemm_gna_supported checks); the caller zeroes *o_count once per pass and numbers the launches.
+  const float* o_gamma;
+  const float* o_beta;
+  const float* o_ss;
+  size_t o_ss_stride;
+  int o_ss_div;
+  void* o_out;
+  int o_ldo;
+  unsigned* o_count;
+  int o_seq;              // launches of this form since *o_count was zeroed
 };
+int gemm_gna_grid(const GemmArgs& a);  // workgroups a gemm_gna launch of this problem takes
 // true when gemm_gna_launch has a kernel for this problem (else: groupnorm_launch + gemm_launch)
 bool gemm_gna_supported(int dtype, int epi, const GemmArgs& a, const GemmGnArgs& n);
 int gemm_gna_launch(int dtype, int epi, const GemmArgs& a, const GemmGnArgs& n, hipStream_t stream);

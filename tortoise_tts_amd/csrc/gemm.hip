@@ -192,8 +192,22 @@ bool gemm_gna_supported(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs
   if (epi == EPI_QKV_HEADS)  // AttentionBlock norm -> qkv: no activation, head-layout epilogue
     return common && n.act == ACT_NONE && a.q && a.k && a.vt && a.dmodel % 64 == 0 && a.N == 3 * a.dmodel && a.heads * 64 == a.dmodel && (!a.bias || ((size_t)a.bias & 15) == 0);
   const bool al16 = a.bias && ((size_t)a.bias & 15) == 0 && a.out_f32 && ((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0;
+  if (n.o_out) {  // output norm behind a device-wide barrier: every workgroup must be resident at once (one per CU)
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      hipDeviceProp_t pr;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return false;
+      cus = pr.multiProcessorCount;
+    }
+    if (gemm_gna_grid(a) > cus || a.N != kGnaC || !n.o_gamma || !n.o_beta || !n.o_count || ((size_t)n.o_gamma & 15) || ((size_t)n.o_beta & 15) ||
+        ((size_t)n.o_ss & 15) || (n.o_ss_stride & 3) || ((size_t)n.o_out & 7) || (n.o_ldo & 3))
+      return false;
+  }
   return common && epi == EPI_STD && al16 && a.gn_part != nullptr && !a.res && !a.out_t && a.act == ACT_NONE && n.act == ACT_SILU;
 }
+
+int gemm_gna_grid(const GemmArgs& a) { return cdiv(a.M, kGnaBM) * cdiv(a.N, kGnaBN); }
 
 int gemm_gna_launch(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs& n, hipStream_t stream) {
   GemmArgs a = a0;
@@ -213,6 +227,13 @@ int gemm_gna_launch(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs& n,
   d.part_shift = 31 - __builtin_clz((unsigned)n.part_rows);
   d.S = n.S; d.eps = n.eps; d.act = n.act; d.guard = n.guard;
   d.inv_count = 1.0 / ((double)n.S * (double)(kGnaC / 32));
+  if (n.o_out) {
+    d.o_gamma = n.o_gamma; d.o_beta = n.o_beta; d.o_ss = n.o_ss; d.o_ss_stride = n.o_ss_stride; d.o_ss_div = n.o_ss_div; d.o_out = n.o_out; d.o_ldo = n.o_ldo;
+    d.o_part = a.gn_part;
+    d.o_part_bytes = cdiv(a.M, kGnaBM) * 2 * (kGnaC / 16) * 2 * (int)sizeof(float);
+    d.o_count = n.o_count;
+    d.o_target = (unsigned)(n.o_seq + 1) * (unsigned)gemm_gna_grid(a);
+  }
   if (dtype == DT_BF16) return gemm_gna_launch_typed<bf16>(a, plan, d, stream);
   return gemm_gna_launch_typed<f16>(a, plan, d, stream);
 }

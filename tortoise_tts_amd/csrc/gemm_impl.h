@@ -1459,7 +1459,8 @@ int gemm_gna_launch_typed(const GemmArgs& a, const GemmPlan& plan, const GnaArgs
   d.c = plan.core;
   d.e = make_epi_std(a);
   d.n = n;
-  if (n.act == ACT_SILU && !n.ss) launch_timed(ps, gemm_gna_kernel<T, kGnaBM, kGnaBN, kGnaNW, kGnaWM, kGnaST, EStF32, false, true>, grid, dim3(kGnaNW * 64), kGnaSmem, stream, d);
+  if (n.act == ACT_SILU && !n.ss && n.o_out) launch_timed(ps, gemm_gna_kernel<T, kGnaBM, kGnaBN, kGnaNW, kGnaWM, kGnaST, EStF32, false, true, true>, grid, dim3(kGnaNW * 64), kGnaSmem, stream, d);
+  else if (n.act == ACT_SILU && !n.ss) launch_timed(ps, gemm_gna_kernel<T, kGnaBM, kGnaBN, kGnaNW, kGnaWM, kGnaST, EStF32, false, true>, grid, dim3(kGnaNW * 64), kGnaSmem, stream, d);
   else {
     set_error("gemm_gna: no kernel for act %d scale_shift %d", n.act, n.ss != nullptr);
     return -1;
