@@ -319,8 +319,10 @@ int tt_diff_stat(tt_diff* h, int which);  /* which = 0: sampler-step graph captu
 #define TT_DIFF_OPT_OVERLAP_PREPASS 1
 /* TT_DIFF_OPT_FUSED_GN [1]: ResBlock in_layers (diffusion_decoder.py:60-80: GroupNorm32 -> SiLU -> 1x1 conv) as ONE launch - the conv's
  * GEMM normalises, activates and casts its own f32 A rows (csrc/gemm_gna.h); 0 = stand-alone apply launch + 16-bit tensor;
- * 2 = additionally the AttentionBlock norm (arch_util.py:104-123) on the QKV GEMM's A path (measured, not the default:
- * profiles/r05_ab_gna_qkv.txt). */
+ * 2 = additionally the AttentionBlock norm (arch_util.py:104-123) on the QKV GEMM's A path; 3 = 1 + ResBlock out_layers' norm
+ * (diffusion_decoder.py:104-120) applied to the in_layers GEMM's accumulators behind a device-wide barrier (sampler step only, the
+ * grid must fit the CUs); 4 = 2 + 3.  Values 2 - 4 are measured experiments, slower than 1 in the default configuration
+ * (profiles/r05_ab_fused_groupnorm.txt): they stay reachable for the A/B and their parity tests, nothing selects them. */
 #define TT_DIFF_OPT_FUSED_GN 2
 int tt_diff_set_option(tt_diff* h, int option, int value);  /* option = TT_DIFF_OPT_*; switching TT_DIFF_OPT_FUSED_GN drops the kept step graph */
 

@@ -160,7 +160,7 @@ static int run_attn_block(tt_diff* e, DiffWork& w_, const tt_attn_block& w, cons
   g.q_scale = 0.125f;  // (q * 64^-1/4) . (k * 64^-1/4)  ==  (q/8) . k   (arch_util.py:64-67)
   bool fused_gn = false;
   if ((e->fuse_gn == 2 || e->fuse_gn == 4) && !e->masked && in == w_.stats_ptr && w_.stats_seq == S && S >= w_.stats_rows) {
-    // TT_DIFF_OPT_FUSED_GN = 2 (measured, not the default: profiles/r05_ab_gna_qkv.txt): the attention norm on the QKV GEMM's A path as well
+    // TT_DIFF_OPT_FUSED_GN = 2 (measured, not the default: profiles/r05_ab_fused_groupnorm.txt): the attention norm on the QKV GEMM's A path as well
     GemmGnArgs n;
     memset(&n, 0, sizeof(n));
     n.gamma = w.norm_g; n.beta = w.norm_b; n.gemm_part = w_.stats_part; n.part_rows = w_.stats_rows; n.S = S; n.eps = 1e-5f; n.act = ACT_NONE;

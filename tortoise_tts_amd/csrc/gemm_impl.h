@@ -1442,7 +1442,7 @@ int gemm_gna_launch_typed(const GemmArgs& a, const GemmPlan& plan, const GnaArgs
   const dim3 grid(plan.core.gx * plan.core.gy, 1, 1);
   ProfScope ps(plan.prof_id, stream, plan.flops, plan.bytes, true);
   if (a.q != nullptr) {
-    // AttentionBlock norm -> qkv (arch_util.py:104-123; round 5, measured against gn_apply + the 128 x 128 DMA GEMM: profiles/r05_ab_gna_qkv.txt):
+    // AttentionBlock norm -> qkv (arch_util.py:104-123; round 5, measured against gn_apply + the 128 x 128 DMA GEMM: profiles/r05_ab_fused_groupnorm.txt):
     // GroupNorm32 without activation on the A path, head-layout epilogue (32-column wave tiles never straddle a head)
     GemmGnaDev<EpiQkvHeadsArgs> d;
     d.c = plan.core;
