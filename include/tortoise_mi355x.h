@@ -457,6 +457,9 @@ int tt_op_resid_ln(int dtype, const void* A, int K, const void* W, const float* 
 /* process-wide A/B switch of the attention kernels (diagnostics, like tt_graph_replay): 1 (default) = 32-query waves on
  * v_mfma_f32_32x32x16 for non-causal sequences of more than 128 rows, 0 = the 16-query-wave kernels everywhere; returns the previous value */
 int tt_flash_variant(int v);
+/* the same for the 256 x 256 GEMM tile: 1 (default) = the 8-wave eight-phase kernel (csrc/gemm_p8.h) where it applies, 0 = the 16-wave
+ * two-stage kernel everywhere; the two produce identical bits */
+int tt_gemm_variant(int v);
 /* the same for UnivNet's audio-rate kernels (vocoder.py:134-146, 182-216): 1 (default) = dilated 32 -> 32 convolutions and location-variable
  * convolutions (hop 64 / 256) on v_mfma_f32_32x32x2_f32 (exact f32 products), 0 = the thread-per-sample VALU kernels */
 int tt_voc_variant(int v);

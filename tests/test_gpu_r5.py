@@ -312,3 +312,41 @@ def test_more_groupnorm_fusions_match_the_standalone_apply(dtype, value):
     assert rel < (4e-3 if dtype == E.TT_F16 else 3e-2), rel
     st.set_option(E.TT_DIFF_OPT_FUSED_GN, 1)
     st.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES[:2])
+def test_eight_phase_256_tile_is_bit_identical_to_the_16_wave_tile(name, dt, tdt, tol):
+    """csrc/gemm_p8.h (8 waves, eight-phase schedule, counted LDS-DMA waits) against gemm_glds_kernel<256, 256, 16 waves> on the same
+    launches (tt_gemm_variant): the accumulation order per output element is the same, so every output form must agree bit for bit -
+    ragged M, N not a multiple of the tile, 4 and 16 k-tiles; run several times (a misplaced wait shows as rare wrong tiles)."""
+    lib = E.init()
+    g = torch.Generator().manual_seed(23)
+    for (M, N, K) in ((22003, 768, 256), (17001, 1000, 1024)):
+        A = torch.randn(M, K, generator=g).to(tdt).cuda()
+        Wt = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        res = torch.randn(M, N, generator=g).cuda()
+
+        def run(variant):
+            prev = lib.tt_gemm_variant(variant)
+            try:
+                o1 = res.clone()
+                E.check(lib.tt_op_gemm(dt, E.ptr(A), K, E.ptr(Wt), K, M, N, K, 1, 0, 1, E.ptr(bias), E.ACT_NONE, E.ptr(o1), E.ptr(o1), None, None))
+                o2 = torch.zeros(M, N, device="cuda", dtype=tdt)
+                E.check(lib.tt_op_gemm(dt, E.ptr(A), K, E.ptr(Wt), K, M, N, K, 1, 0, 1, E.ptr(bias), E.ACT_NONE, None, None, E.ptr(o2), None))
+                o3 = torch.zeros(M, N, device="cuda", dtype=tdt)
+                E.check(lib.tt_op_gemm(dt, E.ptr(A), K, E.ptr(Wt), K, M, N, K, 1, 0, 1, E.ptr(bias), E.ACT_GELU_TANH, None, None, E.ptr(o3), None))
+                torch.cuda.synchronize()
+            finally:
+                lib.tt_gemm_variant(prev)
+            return o1, o2, o3
+
+        want = run(0)
+        ref = A.float() @ Wt.float().t() + bias + res
+        report(f"gemm 256-tile (16 waves) {name} bias + skip {M}x{N}x{K}", want[0], ref, 2e-5)
+        for rep in range(6):
+            got = run(1)
+            for a, b, what in zip(got, want, ("bias + skip -> f32", "bias -> T", "gelu -> T")):
+                assert torch.equal(a, b), f"eight-phase tile differs from the 16-wave tile: {what}, {M}x{N}x{K}, repetition {rep}: {(a.float() - b.float()).abs().max().item()}"
+    print(f"[parity] gemm eight-phase 256 x 256 tile vs 16-wave tile ({name}): bit-identical, 3 output forms x 2 shapes x 6 repetitions")

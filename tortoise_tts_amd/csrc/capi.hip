@@ -3,7 +3,7 @@
 #include "../../include/tortoise_mi355x.h"
 
 using namespace tt;
-namespace tt { extern bool g_flash32; extern bool g_voc_mfma; }  // attention.hip, univnet.hip
+namespace tt { extern bool g_flash32; extern bool g_voc_mfma; extern bool g_gemm_p8; }  // attention.hip, univnet.hip, gemm.hip
 
 extern "C" {
 
@@ -121,6 +121,12 @@ int tt_op_resid_ln(int dtype, const void* A, int K, const void* W, const float* 
 // Process-wide A/B switch of the attention kernels (like tt_graph_replay): 1 (default) = 32-query waves on v_mfma_f32_32x32x16 for
 // non-causal sequences of more than 128 rows, 0 = the 16-query-wave kernels everywhere.  Returns the previous value.  Set it before an
 // engine captures its graphs (a kept graph replays the kernels it was captured with).
+int tt_gemm_variant(int v) {
+  const int prev = tt::g_gemm_p8 ? 1 : 0;
+  tt::g_gemm_p8 = v != 0;
+  return prev;
+}
+
 int tt_flash_variant(int v) {
   const int prev = tt::g_flash32 ? 1 : 0;
   tt::g_flash32 = v != 0;

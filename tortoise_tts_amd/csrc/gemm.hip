@@ -207,6 +207,8 @@ bool gemm_gna_supported(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs
   return common && epi == EPI_STD && al16 && a.gn_part != nullptr && !a.res && !a.out_t && a.act == ACT_NONE && n.act == ACT_SILU;
 }
 
+bool g_gemm_p8 = true;  // tt_gemm_variant
+
 int gemm_gna_grid(const GemmArgs& a) { return cdiv(a.M, kGnaBM) * cdiv(a.N, kGnaBN); }
 
 int gemm_gna_launch(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs& n, hipStream_t stream) {

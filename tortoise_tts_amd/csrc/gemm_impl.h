@@ -1158,7 +1158,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv3s_kernel(const GemmDev<type
 // ---------------------------------------------------------------------------------------------- host side (per operand type)
 }  // namespace tt
 #include "gemm_gna.h"
+#include "gemm_p8.h"
 namespace tt {
+
+extern bool g_gemm_p8;  // gemm.hip; tt_gemm_variant: 0 = the 16-wave 256 x 256 tile everywhere (A/B runs)
+constexpr int kP8Smem = 2 * 4 * 128 * 64 * 2;
+// the 8-wave eight-phase 256 x 256 kernel takes this launch (gemm_p8.h: plain 1 x 1, one K source, no split-K, even k-tile count, 31-bit byte offsets)
+static inline bool p8_ok(const GemmCore& c, const dim3& grid) {
+  return grid.z == 1 && c.sk_rem == 0 && c.sk_quot >= 2 && (c.sk_quot & 1) == 0 && c.cin_tiles == c.sk_quot && c.A2 == nullptr &&
+         ((size_t)c.M * c.lda + (size_t)c.sk_quot * 64) * 2 < 0x7fffffffull && ((size_t)c.N * c.ldw + (size_t)c.sk_quot * 64) * 2 < 0x7fffffffull;
+}
 
 enum Tile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x256 = 3, TILE_COUNT = 4 };
 // EPI_STD kernel variants: the generic one tests everything at run time, the others compile the unused features out
@@ -1184,8 +1193,19 @@ struct KernelRef {
   typedef typename Epi::Args EA;
   static constexpr int smem = smem_bytes_glds<BM, BN, ST>();
   static constexpr int threads = NW * 64;
+  static constexpr bool kP8 = BM == 256 && BN == 256 && !CONV && AL && HA2 == 0 && !Epi::kSerial && !Epi::kLn && !Epi::kResid && Epi::kId != 2;
   static const void* fn() { return (const void*)gemm_glds_kernel<T, BM, BN, NW, WM, ST, Epi, CONV, AL, HA2>; }
+  static const void* fn_p8() {
+    if constexpr (kP8) return (const void*)gemm_p8_kernel<T, Epi>;
+    else return nullptr;
+  }
   static void launch(const ProfScope& ps, dim3 grid, hipStream_t s, const GemmDev<EA>& d) {
+    if constexpr (kP8) {
+      if (g_gemm_p8 && p8_ok(d.c, grid)) {
+        launch_timed(ps, gemm_p8_kernel<T, Epi>, grid, dim3(512), kP8Smem, s, d);
+        return;
+      }
+    }
     launch_timed(ps, gemm_glds_kernel<T, BM, BN, NW, WM, ST, Epi, CONV, AL, HA2>, grid, dim3(NW * 64), smem, s, d);
   }
 };
@@ -1475,6 +1495,7 @@ int gemm_init_typed() {
   int bad = 0;
   auto setattr = [&](auto kr) -> int {
     if (hipFuncSetAttribute(decltype(kr)::fn(), hipFuncAttributeMaxDynamicSharedMemorySize, decltype(kr)::smem) != hipSuccess) ++bad;
+    if (decltype(kr)::fn_p8() && hipFuncSetAttribute(decltype(kr)::fn_p8(), hipFuncAttributeMaxDynamicSharedMemorySize, kP8Smem) != hipSuccess) ++bad;
     return 0;
   };
   for (int tile = 0; tile < TILE_COUNT; ++tile) {

@@ -205,6 +205,7 @@ _PROTOS = {
     "tt_op_gn_gemm_workspace": (_sz, [_i, _i]),
     "tt_op_resid_ln": (_i, [_i, vp, _i, vp, vp, vp, _i, _i, _i, vp, vp, vp, _i, vp, vp, vp, vp]),
     "tt_flash_variant": (_i, [_i]),
+    "tt_gemm_variant": (_i, [_i]),
     "tt_voc_variant": (_i, [_i]),
     "tt_op_flash_attention": (_i, [_i, vp, vp, vp, vp, _i, _i, _i, _i, _i, vp, vp]),
     "tt_op_sample": (_i, [vp, _i, _i, _i, vp, C.POINTER(Sampling), _i, vp, _i, vp, _i, vp]),
