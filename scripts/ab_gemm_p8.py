@@ -14,7 +14,8 @@ def main():
     shapes = [("batched denoiser 1x1 -> f32 + skip", 26100, 1024, 1024, "res"), ("batched denoiser qkv-like -> T", 26100, 3072, 1024, "t"),
               ("pre-pass chunk 1x1 -> f32 + skip", 27840, 1024, 1024, "res"), ("clvp ff1-like gelu -> T", 51200, 3072, 768, "gelu"),
               ("square 8192 -> T", 8192, 8192, 8192, "t")]
-    for dt, tdt, name in ((E.TT_F16, torch.float16, "fp16"), (E.TT_BF16, torch.bfloat16, "bf16")):
+    quick = "--quick" in sys.argv
+    for dt, tdt, name in ((E.TT_F16, torch.float16, "fp16"),) if quick else ((E.TT_F16, torch.float16, "fp16"), (E.TT_BF16, torch.bfloat16, "bf16")):
         for label, M, N, K, form in shapes:
             A = torch.randn(M, K, generator=g).to(tdt).cuda()
             Wt = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt).cuda()

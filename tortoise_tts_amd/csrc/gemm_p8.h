@@ -124,10 +124,15 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmDev<typename Epi
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[q][i][j] = mfma16(fw[wh][i][ks], fa[j][ks], acc[q][i][j]);
   };
+#if defined(TT_P8_NO_LGKM0)   // A/B knob: leave the fragment-read waits to the compiler's counted lgkmcnt in front of each MFMA
+#define TT_P8_LGKM0
+#else
+#define TT_P8_LGKM0 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #define TT_P8_SYNC_MFMA(q, wh)                          \
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      \
   __builtin_amdgcn_s_barrier();                         \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+  TT_P8_LGKM0                                           \
   __builtin_amdgcn_sched_barrier(0);                    \
   __builtin_amdgcn_s_setprio(1);                        \
   quadrant(q, wh);                                      \
@@ -171,16 +176,23 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmDev<typename Epi
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the surplus re-fills of the tail)
 #undef TT_P8_KTILE
 #undef TT_P8_SYNC_MFMA
+#undef TT_P8_LGKM0
 
-  // epilogue, quadrant by quadrant; the operands of quadrant q + 1 are requested before quadrant q is worked on
-  typename Epi::template Ops<4, 2> eo[2];
+  // epilogue, quadrant by quadrant.  The fragment registers are dead: the operands (bias, skip quads) of TT_P8_EPI_DEPTH quadrants are requested
+  // before the first one is worked on and each finished quadrant's slot is re-used for the quadrant DEPTH ahead.
+#ifndef TT_P8_EPI_DEPTH
+#define TT_P8_EPI_DEPTH 2
+#endif
+  constexpr int ED = TT_P8_EPI_DEPTH;
+  typename Epi::template Ops<4, 2> eo[ED];
   auto qm = [&](int q) { return m0 + (q >> 1) * 128 + wr * 64; };
   auto qn = [&](int q) { return n0 + (q & 1) * 128 + wc * 32; };
-  Epi::template fetch<4, 2, true>(c, g.e, eo[0], qm(0), qn(0), lane);
+#pragma unroll
+  for (int q = 0; q < ED && q < 4; ++q) Epi::template fetch<4, 2, true>(c, g.e, eo[q], qm(q), qn(q), lane);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    if (q < 3) Epi::template fetch<4, 2, true>(c, g.e, eo[(q + 1) & 1], qm(q + 1), qn(q + 1), lane);
-    run_epilogue<Epi, 4, 2, 64, 32, true>(c, g.e, acc[q], eo[q & 1], eo[q & 1].step(), qm(q), qn(q), lane, 0);
+    run_epilogue<Epi, 4, 2, 64, 32, true>(c, g.e, acc[q], eo[q % ED], eo[q % ED].step(), qm(q), qn(q), lane, 0);
+    if (q + ED < 4) Epi::template fetch<4, 2, true>(c, g.e, eo[q % ED], qm(q + ED), qn(q + ED), lane);
   }
 }
 

@@ -248,6 +248,10 @@ def init():
     lib = load_library()
     if not _initialised:
         check(lib.tt_init())
+        # process-wide kernel A/B switches (diagnostics; the defaults are the measured winners)
+        for env, fn in (("TT_GEMM_VARIANT", "tt_gemm_variant"), ("TT_FLASH_VARIANT", "tt_flash_variant"), ("TT_VOC_VARIANT", "tt_voc_variant")):
+            if os.environ.get(env, "") != "":
+                getattr(lib, fn)(int(os.environ[env]))
         _initialised = True
     return lib
 
