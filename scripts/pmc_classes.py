@@ -7,6 +7,8 @@ def klass(k):
     """rocprofv3 kernel name -> the engine profiler's class name (tortoise_tts_amd/csrc/common.hip g_prof_names)."""
     if "gemm_gna_kernel" in k:
         return "gemm_gna<32,256,EpiStd,stats>"
+    if "gemm_p8_kernel" in k:                              # round 5: the eight-phase 256 x 256 tile reports under the classes of the 16-wave tile it replaces
+        return "gemm_glds<256,256,EpiQkvHeads>" if "EpiQkvHeads" in k else "gemm_glds<256,256,EpiStd,1x1>"
     if "gemm_glds_kernel" in k and "EpiResid" in k:      # round 5: the optional five-launch decode step (tile-agnostic classes)
         return "gemm_glds<EpiResid>"
     if "gemm_glds_kernel" in k and "EpiLn" in k:

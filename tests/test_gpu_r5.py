@@ -350,3 +350,43 @@ def test_eight_phase_256_tile_is_bit_identical_to_the_16_wave_tile(name, dt, tdt
             for a, b, what in zip(got, want, ("bias + skip -> f32", "bias -> T", "gelu -> T")):
                 assert torch.equal(a, b), f"eight-phase tile differs from the 16-wave tile: {what}, {M}x{N}x{K}, repetition {rep}: {(a.float() - b.float()).abs().max().item()}"
     print(f"[parity] gemm eight-phase 256 x 256 tile vs 16-wave tile ({name}): bit-identical, 3 output forms x 2 shapes x 6 repetitions")
+
+
+@pytest.mark.gpu
+@torch.no_grad()
+def test_engines_agree_bit_for_bit_with_either_256_tile(sds):
+    """The two 256 x 256 GEMM kernels behind their users: CLVP scores of 64 candidates (QKV-heads, GEGLU and bias -> T epilogues at
+    12 800 rows) and a full-width denoiser sample of 12 iterations whose conditioning-integrator pre-pass runs its 1 x 1 GEMMs and
+    QKV projections on that tile (statistics, skip and head-layout epilogues) - identical bits with tt_gemm_variant 0 and 1."""
+    from tortoise_tts_amd.config import DiffusionConfig
+    from tortoise_tts_amd.schedule import Schedule
+    lib = E.init()
+    text, _, _ = GF.prompt()
+    codes = GF.clvp64_codes()
+    dcfg = DiffusionConfig()
+    M, iters = 200, 12   # 12 x 2 x 870 rows in the pre-pass: >= 256 tiles of 256 x 256 for N = 1024 too
+    S = M * 4 * 24000 // 22050
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(1, M, 1024, generator=g)
+    dcond = torch.randn(1, 2048, generator=g) * 0.5
+    x = torch.randn(1, 100, S, generator=g)
+    noise = torch.randn(iters, 1, 100, S, generator=g)
+    sched = Schedule(iters, dcfg.trained_steps, True, 2)
+    out = {}
+    for v in (0, 1):
+        prev = lib.tt_gemm_variant(v)
+        try:
+            cs = stages.ClvpStage(sds["clvp"], CLVPConfig(), dtype=E.TT_BF16, max_rows=256 * GF.CLVP_N)
+            scores = cs.score(text, codes).cpu().clone()
+            cs.close()
+            ds = stages.DiffusionStage(sds["diffusion"], dcfg, dtype=E.TT_F16, max_seq=S + 8, max_codes=M + 8, max_steps=64)
+            ds.condition(lat, dcond, S)
+            mel = ds.sample(sched, x, noise).cpu().clone()
+            assert ds.guard() == 0
+            ds.close()
+        finally:
+            lib.tt_gemm_variant(prev)
+        out[v] = (scores, mel)
+    assert torch.equal(out[0][0], out[1][0]), "CLVP scores differ between the 256 x 256 tile kernels"
+    assert torch.equal(out[0][1], out[1][1]), "denoiser output differs between the 256 x 256 tile kernels"
+    print("[parity] engines with the eight-phase vs the 16-wave 256 x 256 tile: CLVP scores (64 candidates) and a 12-iteration mel bit-identical")
