@@ -355,8 +355,8 @@ def test_eight_phase_256_tile_is_bit_identical_to_the_16_wave_tile(name, dt, tdt
 @pytest.mark.gpu
 @torch.no_grad()
 def test_engines_agree_bit_for_bit_with_either_256_tile(sds):
-    """The two 256 x 256 GEMM kernels behind their users: CLVP scores of 64 candidates (QKV-heads, GEGLU and bias -> T epilogues at
-    12 800 rows) and a full-width denoiser sample of 12 iterations whose conditioning-integrator pre-pass runs its 1 x 1 GEMMs and
+    """The two 256 x 256 GEMM kernels behind their users: CLVP scores of 64 candidates (QKV-heads and bias -> T epilogues at
+    12 800 rows; the GEGLU feed-forward stays on the 16-wave tile) and a full-width denoiser sample of 12 iterations whose conditioning-integrator pre-pass runs its 1 x 1 GEMMs and
     QKV projections on that tile (statistics, skip and head-layout epilogues) - identical bits with tt_gemm_variant 0 and 1."""
     from tortoise_tts_amd.config import DiffusionConfig
     from tortoise_tts_amd.schedule import Schedule

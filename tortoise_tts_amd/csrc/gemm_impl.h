@@ -1193,7 +1193,9 @@ struct KernelRef {
   typedef typename Epi::Args EA;
   static constexpr int smem = smem_bytes_glds<BM, BN, ST>();
   static constexpr int threads = NW * 64;
-  static constexpr bool kP8 = BM == 256 && BN == 256 && !CONV && AL && HA2 == 0 && !Epi::kSerial && !Epi::kLn && !Epi::kResid && Epi::kId != 2;
+  // (kId 2: the decode-step QKV scatter never runs on this tile; kId 3: the GEGLU epilogue's 16 output columns per quadrant make 32-byte row
+  //  segments - measured 9 % slower than the 16-wave tile's 64-byte ones on one box, profiles/r05_ab_gemm_eight_phase.txt - so it stays there)
+  static constexpr bool kP8 = BM == 256 && BN == 256 && !CONV && AL && HA2 == 0 && !Epi::kSerial && !Epi::kLn && !Epi::kResid && Epi::kId != 2 && Epi::kId != 3;
   static const void* fn() { return (const void*)gemm_glds_kernel<T, BM, BN, NW, WM, ST, Epi, CONV, AL, HA2>; }
   static const void* fn_p8() {
     if constexpr (kP8) return (const void*)gemm_p8_kernel<T, Epi>;
