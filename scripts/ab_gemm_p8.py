@@ -15,6 +15,10 @@ def main():
               ("pre-pass chunk 1x1 -> f32 + skip", 27840, 1024, 1024, "res"), ("clvp ff1-like gelu -> T", 51200, 3072, 768, "gelu"),
               ("square 8192 -> T", 8192, 8192, 8192, "t")]
     quick = "--quick" in sys.argv
+    if "--prepass" in sys.argv:  # the conditioning-integrator pre-pass chunks: 18 (benchmark) and 24 (the PMC pass) timesteps x 2 rows x 870 positions
+        shapes = [("pre-pass 18 steps qkv-like -> T", 31320, 3072, 1024, "t"), ("pre-pass 24 steps qkv-like -> T", 41760, 3072, 1024, "t"),
+                  ("pre-pass 18 steps 1x1 -> f32 + skip", 31320, 1024, 1024, "res"), ("pre-pass 24 steps 1x1 -> f32 + skip", 41760, 1024, 1024, "res"),
+                  ("clvp 256 x 200 linear -> T", 51200, 768, 768, "t"), ("clvp qkv-like -> T", 51200, 2304, 768, "t")]
     for dt, tdt, name in ((E.TT_F16, torch.float16, "fp16"),) if quick else ((E.TT_F16, torch.float16, "fp16"), (E.TT_BF16, torch.bfloat16, "bf16")):
         for label, M, N, K, form in shapes:
             A = torch.randn(M, K, generator=g).to(tdt).cuda()
