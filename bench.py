@@ -9,6 +9,12 @@ hyper-parameters (tortoise/api.py:217-236) with seeded synthetic weights; the st
 suppressed and the decode length fixed at M (default 200 -> 9.28 s of 24 kHz audio) exactly as
 SURVEY.md §8(d) prescribes, because random weights never emit a meaningful end-of-speech.
 
+Launching: `python bench.py --gpus N` is enough - with no WORLD_SIZE in the environment the script starts its N ranks itself
+(torch.distributed.run, rendezvous on 127.0.0.1, a free port) and rank 0 prints the line; under an external
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it uses the ranks it was given.  For N > 1 the line also
+carries `replica_rtf` (N utterances, one per GPU, no data-path collective: where N GPUs pay for this pipeline) next to the
+sharded-latency `value`, and `rccl_ranks_seen` (ranks that answered an all_gather over the active backend).
+
 One JSON line on rank 0.  Extra legs inside the same command (rank 0, N == 1):
   roofline      one additional un-captured step with every kernel launch bracketed by HIP events on its
                 launch stream; reports the dominant kernel class against the gfx950 roofline
@@ -337,6 +343,53 @@ def stream_bench(args):
         "engine_build_s": t_build}))
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch_command(argv, gpus, port):
+    """The command `python bench.py --gpus N` re-executes itself with when nobody launched its ranks (the driver's own form for N > 1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv, gpus):
+    """Start the N ranks and relay rank 0's line (the ranks inherit stdout / stderr); returns the launcher's exit status."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // gpus)))
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if 0 < have < gpus and env.get("TT_DIST_SHARE_DEVICE") != "1":
+        print(f"bench.py: --gpus {gpus} but {have} GPU(s) are visible (TT_DIST_SHARE_DEVICE=1 runs the ranks on shared devices over gloo: "
+              f"a control-flow test mode whose number means nothing)", file=sys.stderr)
+        return 2
+    return subprocess.call(self_launch_command(argv, gpus, free_port()), env=env)
+
+
+def rank_check():
+    """`--rank-check`: rendezvous + THE collective of the path on stand-in data, no engines: every rank contributes 2 scores and 2 x 8 codes
+    through dist.gather_candidates, rank 0 prints what it saw.  Runs on CPU ranks (gloo) as well: the launcher test of tests/."""
+    from tortoise_tts_amd import dist as tdist
+    rank, world, local = tdist.init_from_env_or_exit()
+    n_loc, M = 2, 8
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    scores = torch.arange(n_loc, dtype=torch.float32, device=dev) + 10.0 * rank
+    codes = (torch.arange(n_loc * M, dtype=torch.int32, device=dev).reshape(n_loc, M) + 100 * rank)
+    s_all, c_all = tdist.gather_candidates(scores, codes)
+    seen, backend = tdist.ranks_seen()
+    ok = bool(s_all.numel() == world * n_loc and all(float(s_all[r * n_loc]) == 10.0 * r and int(c_all[r * n_loc, 0]) == 100 * r for r in range(world)))
+    tdist.barrier()
+    if rank == 0:
+        print(json.dumps({"rank_check": ok, "n_gpus": world, "rccl_ranks_seen": seen, "backend": backend,
+                          "all_gather_calls": tdist.COLLECTIVE_CALLS.get("all_gather", 0), "device": dev}))
+    tdist.barrier()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -359,7 +412,17 @@ def main():
                     "(counter passes only: rocprofv3 --pmc crashes under graph replay); same kernels, same order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--candidates-per-rank", type=int, default=None,
+                    help="one-GPU PREDICTION of the sharded job's per-rank critical path: decode and rank only this many candidates (32 = the "
+                         "8-GPU share of 'standard'), then the full tail; the line is labelled as such (metric suffix, config.projection)")
+    ap.add_argument("--no-replica", action="store_true", help="N > 1: skip the replica-throughput leg (replica_rtf)")
+    ap.add_argument("--rank-check", action="store_true", help="rendezvous + the path's one all_gather on stand-in data, no engines (launcher test)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # nobody launched the ranks: do it here
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+    if args.rank_check:
+        sys.exit(rank_check())
 
     if args.workload == "stream":
         return stream_bench(args)
@@ -382,6 +445,13 @@ def main():
         preset_kw["diffusion_iterations"] = args.diffusion_iterations
         extra_kw["diffusion_iterations"] = args.diffusion_iterations
     N = preset_kw["num_autoregressive_samples"]
+    if args.candidates_per_rank is not None:
+        assert world == 1, "--candidates-per-rank is the ONE-GPU prediction of a sharded job's per-rank work"
+        assert N % args.candidates_per_rank == 0, f"{args.candidates_per_rank} candidates per rank do not divide the preset's {N}"
+        projected_gpus = N // args.candidates_per_rank
+        N = args.candidates_per_rank
+        preset_kw["num_autoregressive_samples"] = N
+        extra_kw["num_autoregressive_samples"] = N
     M = args.mel_tokens
     t_build = time.perf_counter()
     sds = synthetic_weights()
@@ -389,7 +459,8 @@ def main():
     read_mode = args.workload == "read"
     # read: every rank holds a complete engine with the full candidate batch and renders whole chunks (no candidate sharding)
     ubatch = (args.utterance_batch or 16) if read_mode else 1
-    tts = TextToSpeech(state_dicts=sds, dtype=args.dtype, max_candidates=N if read_mode else N // world, max_mel_tokens=max(M, 32),
+    replica_leg = world > 1 and not read_mode and not args.no_replica
+    tts = TextToSpeech(state_dicts=sds, dtype=args.dtype, max_candidates=N if (read_mode or replica_leg) else N // world, max_mel_tokens=max(M, 32),
                        candidate_sharding=not read_mode, utterance_batch=ubatch)
     t_build = time.perf_counter() - t_build
     S_audio = M * 4 * 24000 // 22050 * 256 / 24000.0  # seconds of audio per fixed-length utterance (api.py:122, hop 256 @ 24 kHz)
@@ -430,6 +501,30 @@ def main():
         assert abs(float(wav.shape[-1]) / 24000.0 - audio_s) < 1e-6, (wav.shape, audio_s)
         assert torch.isfinite(wav).all() and wav.abs().max() <= 1.0
 
+    # N > 1: the same engines as REPLICAS - every rank renders its own complete utterance (all N candidates on its GPU, its own seed), no
+    # data-path collective; N utterances per step.  This is where N GPUs pay for this pipeline (one utterance does not hold N GPUs' worth
+    # of parallel work after the candidates are sharded: the winner's tail is serial).
+    replica = None
+    ranks_seen, backend = tdist.ranks_seen() if world > 1 else (1, None)
+    if replica_leg:
+        tts.set_candidate_sharding(False)
+        for i in range(args.warmup):
+            tts.tts_with_preset(text, preset=args.preset, conditioning_latents=latents, max_mel_tokens=M, use_deterministic_seed=5000 + 97 * rank + i,
+                                k=1, verbose=False, **extra_kw)
+        tdist.barrier()
+        torch.cuda.synchronize()
+        t0r = time.perf_counter()
+        for i in range(args.steps):
+            rw = tts.tts_with_preset(text, preset=args.preset, conditioning_latents=latents, max_mel_tokens=M,
+                                     use_deterministic_seed=6000 + 97 * rank + i, k=1, verbose=False, **extra_kw)
+        tdist.barrier()
+        torch.cuda.synchronize()
+        dtr = tdist.max_over_ranks(time.perf_counter() - t0r)
+        assert rw is not None and torch.isfinite(rw).all()
+        replica = {"value": world * S_audio * args.steps / dtr, "unit": "audio-s/wall-s", "utterances_per_step": world, "ms_per_step": 1e3 * dtr / args.steps,
+                   "what": f"{world} independent utterances per step, one per GPU ({N} candidates each on that GPU), no data-path collective"}
+        tts.set_candidate_sharding(True)
+
     roof, breakdown, cpu = None, [], None
     if not args.no_roofline and not read_mode:
         roof, breakdown = roofline_leg(tts, lambda: run_step(999))  # every rank runs it (the step contains a collective)
@@ -443,7 +538,8 @@ def main():
                                          int(text.numel()))
     if rank == 0:
         out = {
-            "metric": "rtf_standard_preset" if not read_mode else "rtf_longform_read", "value": audio_s * args.steps / dt, "unit": "audio-s/wall-s",
+            "metric": ("rtf_standard_preset" if not read_mode else "rtf_longform_read") + ("_per_rank_projection" if args.candidates_per_rank else ""),
+            "value": audio_s * args.steps / dt, "unit": "audio-s/wall-s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "latency_s": dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": dtype_label(tts.dtype_names()), "dtype_per_stage": tts.dtype_names(), "overflow_demotions": list(tts.demotions),
@@ -454,12 +550,18 @@ def main():
                                    f"UnivNet; prompt = do_tts.py default sentence (54 BPE ids + pad = 55 text tokens) with the reference's pat.pth "
                                    f"voice latents (tests/golden/bench_prompt.npz); {audio_s:.2f} s of 24 kHz audio per step",
                        "weights": "seeded synthetic at the reference hyper-parameters (no checkpoints offline)",
+                       **({"projection": f"ONE GPU doing the per-rank work of a {projected_gpus}-GPU candidate-sharded job: {N} of the preset's "
+                                          f"{N * projected_gpus} candidates decoded + ranked, then the winner's full tail (no all_gather, tail not split)"}
+                          if args.candidates_per_rank else {}),
                        "parallelism": (f"chunk j on rank j % {world} (replicas, complete pipeline per rank), clips sent to rank 0" if read_mode else
                                        f"candidates sharded {N // world}/GPU, 1 all_gather of scores+codes, "
                                        + ("winner's diffusion tail split over ranks 0/1 (one denoiser row each, 1 exchange per step), vocoder on rank 0"
                                           if tts.split_diffusion else "winner rendered on rank 0"))},
             "stages_s_per_step": stages_mean,
             "collective_fallback": bool(fell_back),
+            "rccl_ranks_seen": ranks_seen, "collective_backend": backend,
+            "all_gather_calls_per_utterance": (tdist.COLLECTIVE_CALLS.get("all_gather", 0) / max(1, args.steps + args.warmup + (0 if args.no_roofline or read_mode else 1))) if world > 1 else 0,
+            "replica_rtf": replica["value"] if replica else None, "replica": replica,
             "audio_seconds_per_step": audio_s, "engine_build_s": t_build,
             "roofline": roof, "cpu_baseline": cpu,
             "kernel_breakdown_ms": [{"kernel": r["kernel"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),

@@ -51,16 +51,6 @@ typedef struct tt_gpt_layer {
   const float* ln2_g; const float* ln2_b;
   const void* w_fc;   const float* b_fc;      /* T [4D][D] */
   const void* w_proj2; const float* b_proj2;  /* T [D][4D] */
-  /* Optional (all six or none; needs 16-bit operands, D % 64 == 0, D <= 1024): the weights of the five-launch decode step, in which
-   * LayerNorm is folded into the QKV / c_fc GEMMs - LN(x) W^T + b = rstd (x Wg^T - mean colsum) + b' (transformers GPT2Block.forward:
-   * ln_1 -> attn.c_attn, ln_2 -> mlp.c_fc; tortoise/models/autoregressive.py:150-163 runs it per token).  Without them the decode
-   * step keeps a LayerNorm kernel in front of each of the two GEMMs. */
-  const void* w_qkv_ln;       /* T [3D][D]  w_qkv[n][k] * ln1_g[k], rounded to T once */
-  const float* c_qkv_ln;      /* f32 [3D]   sum_k of the ROUNDED w_qkv_ln[n][k] */
-  const float* b_qkv_ln;      /* f32 [3D]   b_qkv[n] + sum_k w_qkv[n][k] * ln1_b[k] */
-  const void* w_fc_ln;        /* T [4D][D]  w_fc * ln2_g */
-  const float* c_fc_ln;       /* f32 [4D] */
-  const float* b_fc_ln;       /* f32 [4D] */
 } tt_gpt_layer;
 
 typedef struct tt_ar_config {
@@ -142,14 +132,8 @@ int tt_ar_generate_chunk(tt_ar* h, int B, int first, int n_more, int ldcodes, co
 int tt_ar_stream_latents(tt_ar* h, int B, int n, float* out, void* stream);
 
 /* Engine options of a handle (not part of the reference's surface; defaults in brackets):
- *   TT_AR_OPT_FUSED_STEP [0]  1 = five kernel launches per layer of the decode step (LayerNorm folded into the QKV / c_fc GEMMs, split-K
- *                             partial sums folded inside the projection launches by the last-arriving workgroup); 0 = seven launches
- *                             (split-K slabs folded by a LayerNorm kernel).  Both forms are deterministic and independent of the batch
- *                             size; they are two roundings of the same network.  Measured on MI355X the five-launch form is 7 % SLOWER
- *                             (DESIGN.md 5.7), hence the default; it needs tt_gpt_layer's *_ln weights and 16-bit operands
  *   TT_AR_OPT_LOOKAHEAD  [6]  decode steps the host may launch ahead of the device (the loop is paced by progress words the
  *                             last kernel of a step publishes to pinned memory; no queue drain inside the loop) */
-#define TT_AR_OPT_FUSED_STEP 2
 #define TT_AR_OPT_LOOKAHEAD 4
 int tt_ar_set_option(tt_ar* h, int option, int value);
 /* Operand-overflow guard: the row norms and the sampler count launches that met a non-finite value (an fp16 operand beyond 65504
@@ -158,7 +142,7 @@ int tt_ar_set_option(tt_ar* h, int option, int value);
  * (api.py:413-414); the host side re-runs a tripped stage with bf16 operands. */
 int tt_ar_guard(tt_ar* h, int reset);
 /* Counters for tests: which = 0 decode-step graph captures so far, 1 queue drains the launch loop fell back to (expected 0),
- * 2 kernel launches of one decode step in its current form, 3 = 1 when the five-launch form is in use. */
+ * 2 kernel launches of one decode step. */
 int tt_ar_stat(tt_ar* h, int which);
 
 /* Teacher-forced single steps for parity tests: tt_ar_begin resets per-sequence state for B rows
@@ -318,11 +302,8 @@ int tt_diff_stat(tt_diff* h, int which);  /* which = 0: sampler-step graph captu
  * the steps whose chunks are complete; 0 = whole pre-pass first (one stream).  Same results either way. */
 #define TT_DIFF_OPT_OVERLAP_PREPASS 1
 /* TT_DIFF_OPT_FUSED_GN [1]: ResBlock in_layers (diffusion_decoder.py:60-80: GroupNorm32 -> SiLU -> 1x1 conv) as ONE launch - the conv's
- * GEMM normalises, activates and casts its own f32 A rows (csrc/gemm_gna.h); 0 = stand-alone apply launch + 16-bit tensor;
- * 2 = additionally the AttentionBlock norm (arch_util.py:104-123) on the QKV GEMM's A path; 3 = 1 + ResBlock out_layers' norm
- * (diffusion_decoder.py:104-120) applied to the in_layers GEMM's accumulators behind a device-wide barrier (sampler step only, the
- * grid must fit the CUs); 4 = 2 + 3.  Values 2 - 4 are measured experiments, slower than 1 in the default configuration
- * (profiles/r05_ab_fused_groupnorm.txt): they stay reachable for the A/B and their parity tests, nothing selects them. */
+ * GEMM normalises, activates and casts its own f32 A rows (csrc/gemm_gna.h); 0 = stand-alone apply launch + 16-bit tensor.  (The other
+ * two GroupNorm sites were built fused as well and measured slower - profiles/r05_ab_fused_groupnorm.txt - and are not in the library.) */
 #define TT_DIFF_OPT_FUSED_GN 2
 int tt_diff_set_option(tt_diff* h, int option, int value);  /* option = TT_DIFF_OPT_*; switching TT_DIFF_OPT_FUSED_GN drops the kept step graph */
 
@@ -432,46 +413,6 @@ int tt_hifi_output_frames(int n_latents);
 /* latents f32 [T][in_channels] (GPT latents of ONE sequence), g f32 [cond_channels] (AR conditioning latent)
  * -> wav f32 [*n_samples] in [-1, 1] (tanh), *n_samples = tt_hifi_output_frames(T) * prod(up_factor) */
 int tt_hifi_run(tt_hifi* h, const float* latents, int T, const float* g, float* wav, int* n_samples, void* stream);
-
-/* ============================================================================================
- * Operator-level entry points (used by tests/ to check single kernels against torch references)
- * ============================================================================================ */
-int tt_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int taps, int seq_len,
-               int splitk, const float* bias, int act, const float* res, float* out_f32, void* out_t, void* stream);
-int tt_op_layernorm(int dtype, const float* x, int M, int D, const float* g, const float* b, float eps, int rms,
-                    void* out_t, float* out_f32, void* stream);
-int tt_op_groupnorm(int dtype, const float* x, int B, int S, int C, const float* g, const float* b, const float* scale_shift,
-                    int act, void* out_t, float* out_f32, float* workspace, void* stream);
-size_t tt_op_groupnorm_workspace(int B, int S);
-/* the fused ResBlock in_layers launch (TT_DIFF_OPT_FUSED_GN; diffusion_decoder.py:60-80): out_f32[B*S][N] = W . act(GroupNorm32(x)) + bias,
- * x f32 [B][S][1024] token-major, act = 3 (SiLU); 256 < B*S <= 4096, S >= 32, N % 256 == 0, 16-bit operand types */
-int tt_op_gn_gemm(int dtype, const float* x, int B, int S, const float* gamma, const float* beta, int act, const void* W,
-                  const float* bias, int N, float* out_f32, float* workspace, void* stream);
-size_t tt_op_gn_gemm_workspace(int B, int S);
-/* the decode step's fused pair (GPT2Block: attn.c_proj / mlp.c_proj + residual, then ln -> c_fc + gelu_new): x [M][D] += A [M][K] W[D][K]^T + bias
- * with the split-K fold inside the launch (splitk > 1: arrival tickets; <= 1: -splitk K ranges folded by one workgroup), leaving xt (T copy of x)
- * and stats f32 [M][D / 32][2] = per-32-column (sum, sum of squares); then, unless Wg is null, out_t [M][N2] = gelu_tanh(LN(x) W2^T + b2) from
- * the folded operands Wg = W2 * gamma (T), colsum [N2], bias2 = b2 + W2 beta.  16-bit operand types, D % 64 == 0, D <= 1024. */
-int tt_op_resid_ln(int dtype, const void* A, int K, const void* W, const float* bias, float* x, int M, int D, int splitk, const void* Wg,
-                   const float* colsum, const float* bias2, int N2, void* out_t, void* xt, float* stats, void* stream);
-/* process-wide A/B switch of the attention kernels (diagnostics, like tt_graph_replay): 1 (default) = 32-query waves on
- * v_mfma_f32_32x32x16 for non-causal sequences of more than 128 rows, 0 = the 16-query-wave kernels everywhere; returns the previous value */
-int tt_flash_variant(int v);
-/* the same for the 256 x 256 GEMM tile: 1 (default) = the 8-wave eight-phase kernel (csrc/gemm_p8.h) where it applies, 0 = the 16-wave
- * two-stage kernel everywhere; the two produce identical bits */
-int tt_gemm_variant(int v);
-/* the same for UnivNet's audio-rate kernels (vocoder.py:134-146, 182-216): 1 (default) = dilated 32 -> 32 convolutions and location-variable
- * convolutions (hop 64 / 256) on v_mfma_f32_32x32x2_f32 (exact f32 products), 0 = the thread-per-sample VALU kernels */
-int tt_voc_variant(int v);
-int tt_op_flash_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int heads, int n, int n_pad,
-                          int causal, const float* relpos, void* stream);
-int tt_op_sample(const float* logits, int ldl, int B, int V, unsigned* seen, const tt_sampling* s, int step, int* unfinished,
-                 int stop_token, int* codes, int ldcodes, void* stream);
-int tt_op_conv1d(const float* x, const float* w, const float* bias, float* y, int Cin, int Cout, int T, int k, int dilation,
-                 int reflect, float in_slope, int out_act, float out_slope, void* stream);
-int tt_op_convt1d(const float* x, const float* w, const float* bias, float* y, int C, int Tin, int stride, float in_slope, void* stream);
-int tt_op_lvc(const float* x_in, const float* kernels, int ldk, int koff, const float* bias, int ldb, int boff, float* x, int L,
-              int hop, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,8 @@ weights and prompt) over
   * the 'standard' schedule          — 200 iterations, conditioning-free guidance on (api.py:327),
   * the 'high_quality' schedule      — 400 iterations, conditioning-free guidance on (api.py:328),
   * the 'ultra_fast' schedule        — 30 iterations, cond_free=False (api.py:325; diffusion.py:341-384 takes the plain branch),
+  * the 'fast' schedule (round 6)    — 80 iterations, conditioning-free guidance on (api.py:326: BASELINE config #2's own spaced schedule,
+                                       `space_timesteps(4000, [80])`, diffusion.py:1152-1205),
 with injected noise that the GPU tests rebuild from the seeds below (only the 348 KB outputs are stored).
 """
 import os
@@ -27,7 +29,7 @@ from tortoise_tts_amd.config import DiffusionConfig  # noqa: E402
 
 OUT = G.OUT
 # (name, iterations, cond_free, seed) — the GPU tests rebuild (latents, x_T, per-step noise) with GF.diff_inputs(cfg, 200, seed, N)
-CASES = (("std200", 200, True, 41), ("hq400", 400, True, 42), ("uf30", 30, False, 43))
+CASES = (("std200", 200, True, 41), ("hq400", 400, True, 42), ("uf30", 30, False, 43), ("fast80", 80, True, 44))
 
 
 def ref_loop(ref, m, N, S, x, code_emb, step_noise, cond_free):

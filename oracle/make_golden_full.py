@@ -34,6 +34,12 @@ CLVP64_B, CLVP64_SEED = 64, 27             # round 5: ranking of many candidates
 VOC_S, VOC_SEED = 870, 25
 DRIFT_STEPS, DRIFT_SEED = 200, 26       # 'standard' schedule length on the reduced-width denoiser (G.DIFF_CFG)
 CODE_EMB_STRIDE = 8                     # code_emb is stored at every 8th position (3.5 MB otherwise)
+# round 6: the decode step at the CONTEXTS the benchmark runs (1 .. 200 own keys; 500 = the maximum decode length): 8 distinct rows
+# teacher-forced for 500 steps through the reference's GPT2InferenceModel; logits kept after feeding ARL_CHECK[i] tokens (= that many own
+# keys in the cache: 63 / 64 / 65 and 127 / 128 straddle the 64-key blocks of the decode attention kernels), rows 0..3 only beyond 200
+ARL_B, ARL_STEPS, ARL_TOK_SEED = 8, 500, 31
+ARL_CHECK = (1, 63, 64, 65, 127, 128, 199, 200, 320, 499, 500)
+ARL_ROWS_LONG = 4
 
 
 def prompt():
@@ -45,6 +51,11 @@ def prompt():
 def ar_tokens():
     g = torch.Generator().manual_seed(AR_TOK_SEED)
     return torch.randint(0, 8192, (AR_STEPS, AR_B), generator=g)
+
+
+def arl_tokens():
+    g = torch.Generator().manual_seed(ARL_TOK_SEED)
+    return torch.randint(0, 8192, (ARL_STEPS, ARL_B), generator=g)
 
 
 def latent_codes():
@@ -137,6 +148,34 @@ def full_ar(ref, sds):
 
 
 @torch.no_grad()
+def full_ar_long(ref, sds):
+    """GPT2InferenceModel.forward (autoregressive.py:108-186) KV-cached for 500 teacher-forced steps: what the decode step computes at the
+    contexts `bench.py` runs it at (own keys 1 .. 200) and at the maximum decode length (500, api.py:338 max_mel_tokens)."""
+    cfg = ARConfig()
+    m = G.build_ref_ar(ref, cfg, sds["autoregressive"])
+    text, auto, _ = prompt()
+    t = F.pad(text, (0, 1), value=m.stop_text_token)
+    t, _ = m.build_aligned_inputs_and_targets(t, m.start_text_token, m.stop_text_token)
+    emb = torch.cat([auto.unsqueeze(1), m.text_embedding(t) + m.text_pos_embedding(t)], dim=1)
+    m.inference_model.store_mel_emb(emb)
+    P = emb.shape[1]
+    ids = torch.full((ARL_B, P + 1), 1, dtype=torch.long)
+    ids[:, -1] = m.start_mel_token
+    out = m.inference_model(input_ids=ids, attention_mask=torch.ones_like(ids), use_cache=True, return_dict=True)
+    past = out.past_key_values
+    keep = {}
+    for s, tk in enumerate(arl_tokens()):
+        ids = torch.cat([ids, tk[:, None]], dim=1)
+        out = m.inference_model(input_ids=tk[:, None], past_key_values=past, attention_mask=torch.ones_like(ids),
+                                use_cache=True, return_dict=True)
+        past = out.past_key_values
+        if s + 1 in ARL_CHECK:
+            rows = ARL_B if s + 1 <= 200 else ARL_ROWS_LONG
+            keep["logits_%d" % (s + 1)] = out.logits[:rows, -1].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "full_ar_long.npz"), **keep)
+
+
+@torch.no_grad()
 def full_clvp(ref, sds):
     cfg = CLVPConfig()
     m = ref.CLVP(dim_text=cfg.dim, dim_speech=cfg.dim, dim_latent=cfg.dim_latent, num_text_tokens=256,
@@ -208,11 +247,16 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_shims.import_reference()
     sds = bench.synthetic_weights()
+    if "--ar-long" in sys.argv:  # (round 6 addition: generate this file alone, ~2 minutes)
+        full_ar_long(ref, sds)
+        print("full_ar_long.npz", os.path.getsize(os.path.join(OUT, "full_ar_long.npz")))
+        return
     if "--clvp64" in sys.argv:  # (round 5 addition: generate this file alone)
         full_clvp64(ref, sds)
         print("full_clvp64.npz", os.path.getsize(os.path.join(OUT, "full_clvp64.npz")))
         return
     full_ar(ref, sds)
+    full_ar_long(ref, sds)
     full_clvp64(ref, sds)
     full_clvp(ref, sds)
     full_diffusion(ref, sds)

@@ -36,7 +36,7 @@ def main():
             res = {}
             for rnd in range(3):
                 for v in (1, 0):
-                    lib.tt_gemm_variant(v)
+                    lib.ttx_kernel_variant(E.TTX_GEMM_P8, v)
                     once()
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -47,7 +47,7 @@ def main():
                     e1.record()
                     torch.cuda.synchronize()
                     res.setdefault(v, []).append(e0.elapsed_time(e1) * 1e3 / n)
-            lib.tt_gemm_variant(1)
+            lib.ttx_kernel_variant(E.TTX_GEMM_P8, 1)
             us1, us0 = min(res[1]), min(res[0])
             tf = lambda us: 2.0 * M * N * K / us / 1e6
             print("ab gemm %-4s %-36s M=%6d N=%5d K=%5d: eight-phase %8.1f us %7.1f TFLOP/s | 16-wave %8.1f us %7.1f TFLOP/s | x%.3f" %

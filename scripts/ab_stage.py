@@ -29,8 +29,7 @@ def main():
     ap.add_argument("--mel-tokens", type=int, default=200)
     ap.add_argument("--iterations", type=int, default=200)
     ap.add_argument("--ar-variants", default="",
-                    help="';'-separated 'fused[,lookahead]' settings of tt_ar_set_option to time one after the other on ONE "
-                         "handle (same weights, same box, same process), e.g. '1;0;1;0' = five- / seven-launch decode step alternating")
+                    help="';'-separated host-lookahead settings of tt_ar_set_option to time one after the other on ONE handle")
     ap.add_argument("--flash-variants", default="",
                     help="';'-separated tt_flash_variant settings (1 = 32-query-wave attention kernel, 0 = 16-query waves) to time the diffusion "
                          "stage with, one fresh stage object each, e.g. '1;0;1;0'")
@@ -59,9 +58,8 @@ def main():
             for var in variants:
                 tag = args.tag
                 if var is not None:
-                    ar.set_option(E.TT_AR_OPT_FUSED_STEP, var[0])
-                    ar.set_option(E.TT_AR_OPT_LOOKAHEAD, var[1] if len(var) > 1 else 6)
-                    tag = "fused=%d%s" % (var[0], " look=%d" % var[1] if len(var) > 1 else "")
+                    ar.set_option(E.TT_AR_OPT_LOOKAHEAD, var[0])
+                    tag = "look=%d" % var[0]
                 times = []
                 codes = None
                 for r in range(args.reps + 1):
@@ -92,7 +90,7 @@ def main():
             for fv in fvs:
                 tag = args.tag
                 if fv is not None:
-                    E.load_library().tt_flash_variant(fv)
+                    E.load_library().ttx_kernel_variant(E.TTX_FLASH32, fv)
                     tag = "flash32=%d" % fv
                 df = stages.DiffusionStage(sd, cfg, dtype=E.dtype_code(args.dtype), max_seq=max(S, 128), max_codes=max(M, 64), max_steps=args.iterations)
                 for gv in [int(v) for v in args.gn_variants.split(";") if v.strip()] or [None]:
@@ -114,7 +112,7 @@ def main():
                           (gtag, S, args.iterations, 1e3 * sum(times) / len(times), 1e3 * min(times), 1e3 * args.iterations * sum(times) / len(times), digest(mel)), flush=True)
                 df.close()
             if fvs != [None]:
-                E.load_library().tt_flash_variant(1)
+                E.load_library().ttx_kernel_variant(E.TTX_FLASH32, 1)
         if "voc" in args.stages:
             from tortoise_tts_amd import engine as E
             from tortoise_tts_amd.config import VocoderConfig
@@ -126,7 +124,7 @@ def main():
             z = torch.randn(1, vcfg.noise_dim, S + 10, generator=g).to(dev)
             vs = stages.VocoderStage(vsd, vcfg, dtype=E.dtype_code(args.dtype), max_frames=S + 8)
             for vv in [int(v) for v in args.voc_variants.split(";") if v.strip()] or [1]:
-                E.load_library().tt_voc_variant(vv)
+                E.load_library().ttx_kernel_variant(E.TTX_VOC_MFMA, vv)
                 wav = vs.inference(mel, z)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -134,7 +132,7 @@ def main():
                     wav = vs.inference(mel, z)
                 torch.cuda.synchronize()
                 print("ab voc_mfma=%d voc  S=%d: %.3f ms per utterance  wav %s  guard %d" % (vv, S, 1e3 * (time.perf_counter() - t0) / 20, digest(wav), vs.guard()), flush=True)
-            E.load_library().tt_voc_variant(1)
+            E.load_library().ttx_kernel_variant(E.TTX_VOC_MFMA, 1)
             vs.close()
 
 

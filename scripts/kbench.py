@@ -96,7 +96,7 @@ def main():
                         print(f"bw_probe {tag:24s} {mtag:44s} {waves} waves x {nb} blocks: {us:8.2f} us  {nb * per / us / 1e6:7.2f} TB/s  {per * (nb / 256) / us / 1e3:6.1f} GB/s per CU", flush=True)
     if "flash" in which:
         if os.environ.get("TT_FLASH_VARIANT"):  # 1 = 32-query waves (flash32_kernel), 0 = 16-query waves
-            lib.tt_flash_variant(int(os.environ["TT_FLASH_VARIANT"]))
+            lib.ttx_kernel_variant(0, int(os.environ["TT_FLASH_VARIANT"]))  # TTX_FLASH32
         shapes = ((2, 16, 870, 0, 1), (2, 16, 2176, 0, 1), (32, 16, 870, 0, 1), (256, 12, 200, 0, 0), (1, 16, 260, 1, 0))
         if os.environ.get("KB_FLASH_SHAPES") == "denoiser":
             shapes = shapes[:1]

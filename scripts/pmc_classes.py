@@ -9,10 +9,6 @@ def klass(k):
         return "gemm_gna<32,256,EpiStd,stats>"
     if "gemm_p8_kernel" in k:                              # round 5: the eight-phase 256 x 256 tile reports under the classes of the 16-wave tile it replaces
         return "gemm_glds<256,256,EpiQkvHeads>" if "EpiQkvHeads" in k else "gemm_glds<256,256,EpiStd,1x1>"
-    if "gemm_glds_kernel" in k and "EpiResid" in k:      # round 5: the optional five-launch decode step (tile-agnostic classes)
-        return "gemm_glds<EpiResid>"
-    if "gemm_glds_kernel" in k and "EpiLn" in k:
-        return "gemm_glds<EpiLn<EpiQkvDecode>>" if "EpiQkvDecode" in k else "gemm_glds<EpiLn<EpiStd,gelu>>"
     m = re.search(r"gemm_glds_kernelI\w+?Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ENS_\d+(EpiStd|EpiQkvHeads|EpiQkvDecode|EpiGeglu)(\w*?)EELb([01])ELb[01]E", k)
     if m:
         bm, bn, epi, targs, conv = m.groups()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """Per-kernel-class dispatch timings of a short generation at the benchmark shape (eager launches, tt_prof_*)."""
+import argparse
 import ctypes as C
 import os
 import sys
@@ -12,22 +13,29 @@ from bench import bench_prompt  # noqa: E402
 from tortoise_tts_amd import engine as E, stages, weights as W  # noqa: E402
 from tortoise_tts_amd.config import ARConfig  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--candidates", type=int, default=256)
+ap.add_argument("--tokens", type=int, default=40)
+ap.add_argument("--fused", type=int, default=0)
+args = ap.parse_args()
+B, NT = args.candidates, args.tokens
 lib = E.init()
 cfg = ARConfig()
 sd = W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(cfg), 1234), cfg)
-ar = stages.ArStage(sd, cfg, max_batch=256, max_new_tokens=64, max_latent_candidates=1)
+ar = stages.ArStage(sd, cfg, max_batch=B, max_new_tokens=max(64, NT + 8), max_latent_candidates=1)
 text, (auto, _) = bench_prompt()
 tt = F.pad(text.int()[None], (0, 1)).cuda()
 ar.prefill(auto.cuda(), tt)
-codes = ar.generate(256, 40, seed=1)[0]
+codes = ar.generate(B, NT, seed=1)[0]
 lib.tt_graph_replay(0)
 lib.tt_prof_enable(1)
 ar.prefill(auto.cuda(), tt)
-codes2 = ar.generate(256, 40, seed=1)[0]
+codes2 = ar.generate(B, NT, seed=1)[0]
 torch.cuda.synchronize()
 lib.tt_prof_enable(0)
 lib.tt_graph_replay(1)
 assert torch.equal(codes, codes2)
+print("prof AR decode, %d candidates x %d tokens (eager launches, dispatch timestamps):" % (B, NT))
 buf = (C.c_double * 4)()
 for i in range(lib.tt_prof_classes()):
     lib.tt_prof_read(i, buf)

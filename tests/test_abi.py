@@ -20,24 +20,30 @@ def lib():
     return E.load_library()
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "tortoise_mi355x.h")).read()
+def declared_symbols(header="tortoise_mi355x.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(tt_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(ttx?_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_every_declared_symbol_is_exported(lib):
+    """Both headers under include/: the drop-in boundary and the operator-level test entries."""
     names = declared_symbols()
-    assert len(names) >= 30
+    assert 30 <= len(names) <= 60, len(names)  # the boundary a maintainer binds stays small: experiments and test hooks live elsewhere
+    assert not [n for n in names if n.startswith(("tt_op_", "ttx_"))], "test / experiment entries belong in tortoise_mi355x_test.h"
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert set(names) == set(E._PROTOS), set(names) ^ set(E._PROTOS)
+    tnames = declared_symbols("tortoise_mi355x_test.h")
+    missing = [n for n in tnames if not hasattr(lib, n)]
+    assert not missing, f"declared in the test header but not exported: {missing}"
+    assert set(tnames) == set(E._TEST_PROTOS), set(tnames) ^ set(E._TEST_PROTOS)
 
 
 def test_struct_mirrors_match(lib):
     for i, st in enumerate(E.BOUNDARY_STRUCTS):
         assert C.sizeof(st) == lib.tt_struct_size(i), st.__name__
-    assert lib.tt_abi_version() == 4
+    assert lib.tt_abi_version() == 5
 
 
 def test_fails_loudly_without_gpu(lib):
@@ -55,8 +61,8 @@ def test_header_constants_match_the_host_mirror():
     """Every integer `#define TT_*` of the header that the ctypes host names too has the header's value (dtype codes, option ids)."""
     src = open(os.path.join(ROOT, "include", "tortoise_mi355x.h")).read()
     defines = {k: int(v) for k, v in re.findall(r"^#define\s+(TT_[A-Z0-9_]+)\s+(-?\d+)\s*$", src, flags=re.M)}
-    assert {"TT_BF16", "TT_F16", "TT_F32", "TT_AR_OPT_FUSED_STEP", "TT_AR_OPT_LOOKAHEAD", "TT_DIFF_OPT_OVERLAP_PREPASS", "TT_DIFF_OPT_FUSED_GN"} <= set(defines)
+    assert {"TT_BF16", "TT_F16", "TT_F32", "TT_AR_OPT_LOOKAHEAD", "TT_DIFF_OPT_OVERLAP_PREPASS", "TT_DIFF_OPT_FUSED_GN"} <= set(defines)
     mirrored = [k for k in defines if hasattr(E, k)]
-    assert len(mirrored) >= 7
+    assert len(mirrored) >= 6
     for k in mirrored:
         assert getattr(E, k) == defines[k], k

@@ -153,7 +153,8 @@ def test_constructor_flags(monkeypatch):
     sds, cfgs = small_setup()
     kw = dict(state_dicts=sds, configs=cfgs, max_candidates=8, max_mel_tokens=16)
     t = TextToSpeech(**kw)  # reference defaults: kv_cache=False, half=False
-    assert t.kv_cache is False and t.ar.kv_cache is False and t.dtype == E.TT_BF16
+    assert t.kv_cache is False and t.ar.kv_cache is False and t.dtype == E.TT_F16  # round 6: fp16 + overflow guard is the default operand type
+    assert TextToSpeech(dtype="bf16", **kw).dtype == E.TT_BF16
     assert TextToSpeech(half=True, **kw).dtype == E.TT_F16
     assert TextToSpeech(dtype="fp16", **kw).dtype == E.TT_F16
     with pytest.raises(ValueError):

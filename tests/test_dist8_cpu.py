@@ -48,6 +48,8 @@ def _worker(rank, world, port, out_dir):
         best1 = tts.last_best_codes.clone()
         three = tts.tts(TEXT, conditioning_latents=lat, k=3, **KW)
         best3 = tts.last_best_codes.clone()
+        if world > 1:  # ONE data-path all_gather per utterance (scores + codes in one packed buffer), two utterances so far
+            assert tdist.COLLECTIVE_CALLS.get("all_gather", 0) == 2, tdist.COLLECTIVE_CALLS
         flags = tdist.any_over_ranks([rank == 5, False]) if world > 1 else [True, False]
         assert flags == [True, False]
         if rank == 0:

@@ -50,6 +50,8 @@ DRIFT_BOUNDS = {  # measured (profiles/r03_parity_gpu.txt): std200 bf16 8.6e-3 /
     ("std200", "bf16"): (1.8e-2, 2.3), ("std200", "f16"): (2.3e-3, 0.23),
     ("hq400", "f16"): (2.3e-3, 0.21), ("hq400", "bf16"): (1.8e-2, 1.9),
     ("uf30", "bf16"): (1.0e-2, 1.4), ("uf30", "f16"): (1.2e-3, 0.16),
+    # round 6: BASELINE config #2's own schedule ('fast': 80 iterations, api.py:326); bounds = the 200-iteration ones until measured
+    ("fast80", "bf16"): (1.8e-2, 2.3), ("fast80", "f16"): (2.3e-3, 0.23),
 }
 
 

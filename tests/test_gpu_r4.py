@@ -133,7 +133,7 @@ def test_tts_demotes_an_overflowing_fp16_stage_to_bf16():
     """TextToSpeech with per-stage operand types: the diffusion stage (fp16 by default) is given weights whose x-path overflows fp16;
     the guard trips, the stage is rebuilt with bf16 operands and the utterance rendered again - finite audio, one demotion on record."""
     from tortoise_tts_amd.api import TextToSpeech, resolve_stage_dtypes
-    assert resolve_stage_dtypes(None, False) == {"ar": E.TT_BF16, "clvp": E.TT_BF16, "diffusion": E.TT_F16, "vocoder": E.TT_F16}
+    assert resolve_stage_dtypes(None, False) == {"ar": E.TT_F16, "clvp": E.TT_F16, "diffusion": E.TT_F16, "vocoder": E.TT_F16}
     ar, clvp, diff = ARConfig(**G.AR_CFG), CLVPConfig(**G.CLVP_CFG), DiffusionConfig(**G.DIFF_CFG)
     dsd = dict(W.synthetic_state_dict(W.diffusion_manifest(diff), seed=G.DIFF_SEED))
     # inp_block scaled so that the integrating conv's operand inp_block(x) ~ 1e6 overflows fp16 while bf16 holds it
@@ -144,7 +144,7 @@ def test_tts_demotes_an_overflowing_fp16_stage_to_bf16():
            "diffusion": dsd,
            "vocoder": W.fold_weight_norm(W.synthetic_state_dict(W.vocoder_manifest(VocoderConfig()), seed=G.VOC_SEED))}
     tts = TextToSpeech(state_dicts=sds, configs={"ar": ar, "clvp": clvp, "diffusion": diff}, max_candidates=8, max_mel_tokens=32)
-    assert tts.dtype_names() == {"ar": "bf16", "clvp": "bf16", "diffusion": "fp16", "vocoder": "fp16"}
+    assert tts.dtype_names() == {"ar": "fp16", "clvp": "fp16", "diffusion": "fp16", "vocoder": "fp16"}
     g = torch.Generator().manual_seed(2)
     lat = (torch.randn(1, ar.model_dim, generator=g) * 0.5, torch.randn(1, 2 * diff.model_channels, generator=g) * 0.5)
     with pytest.warns(UserWarning, match="diffusion stage overflowed fp16"):

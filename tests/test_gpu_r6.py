@@ -1,0 +1,169 @@
+"""-m gpu, round 6: the decode step pinned at the CONTEXTS the benchmark runs it at, and BASELINE config #2 at its own shapes.
+
+  * `tt_op_decode_attention` (the dominant kernel of the headline, csrc/attention.hip decode_attn_lds_kernel / decode_attn_kernel) at 16 heads x
+    256 sequences, 59 shared-prefix keys, 1 .. 500 own keys against torch fp32 from the same rounded operands - every other attention form
+    already had such a test (tests/test_gpu_ops.py::test_flash_attention).
+  * the autoregressive engine teacher-forced for 500 steps at B = 96 ('fast' preset, ragged on the 64-row decode tiles) and B = 256 against
+    the reference's own GPT2InferenceModel (tests/golden/full_ar_long.npz from oracle/make_golden_full.py::full_ar_long;
+    tortoise/models/autoregressive.py:108-186): logits after 1, 63, 64, 65, 127, 128, 199, 200, 320, 499, 500 fed tokens, and the warped
+    sampling distribution (HF processors, stream_generator.py:916-1000) there: total variation, nucleus-set agreement, top-1.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import make_golden_full as GF
+from oracle import tortoise_oracle as O
+from tortoise_tts_amd import engine as E
+from tortoise_tts_amd import stages
+from tortoise_tts_amd.config import ARConfig
+from tests.gpu_util import DTYPES, report
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+F32 = ("f32", E.TT_F32, torch.float32, 2e-5)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return E.init()
+
+
+@pytest.fixture(scope="module")
+def sds():
+    import bench
+    return bench.synthetic_weights()
+
+
+def _decode_attention_reference(q, kp, vp, k_own, v_own):
+    """q [B,H,64] (pre-scaled), kp / vp [H,P1,64], k_own / v_own [B,H,t,64], fp32: softmax over [prefix | own keys] (GPT2Attention._attn)."""
+    B = q.shape[0]
+    k = torch.cat([kp[None].expand(B, -1, -1, -1), k_own], dim=2)
+    v = torch.cat([vp[None].expand(B, -1, -1, -1), v_own], dim=2)
+    w = torch.einsum("bhd,bhkd->bhk", q, k)
+    return torch.einsum("bhk,bhkd->bhd", torch.softmax(w, dim=-1), v)
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES + [F32])
+@pytest.mark.parametrize("B,P1,tgen,tmax", [(256, 59, 1, 208), (256, 59, 64, 208), (256, 59, 65, 208), (256, 59, 200, 208), (256, 59, 500, 508),
+                                            (96, 59, 127, 208), (32, 59, 128, 208), (7, 33, 3, 16)])
+def test_decode_attention_operator(lib, name, dt, tdt, tol, B, P1, tgen, tmax):
+    """Own keys 1 / 64 / 65 / 127 / 128 straddle the 64-key slots of the score loop and the two-slot prefetch; 200 = the benchmark's last
+    step, 500 = the maximum decode length; B = 96 / 32 / 7: ragged and small batches (surplus waves of the last workgroup).  Variants:
+    the shape's default (LDS-staged shared prefix, 4 sequences per workgroup), 16 per workgroup, and the per-wave prefix kernel."""
+    H = 16
+    g = torch.Generator().manual_seed(B * 1000 + tgen)
+    q = (torch.randn(B, H, 64, generator=g) * 0.125 * 2).to(tdt)
+    kp = (torch.randn(H, P1, 64, generator=g) * 2).to(tdt)
+    vp = torch.randn(H, P1, 64, generator=g).to(tdt)
+    k_own = (torch.randn(B, H, tgen, 64, generator=g) * 2).to(tdt)
+    v_own = torch.randn(B, H, tgen, 64, generator=g).to(tdt)
+    # cache layouts (include/tortoise_mi355x.h): keys [B][H][8 chunks][tmax][8], values [B][H][tmax][64]; slots >= tgen hold garbage on purpose
+    kc = torch.full((B, H, 8, tmax, 8), 1e4).to(tdt)
+    kc[:, :, :, :tgen] = k_own.reshape(B, H, tgen, 8, 8).permute(0, 1, 3, 2, 4)
+    vc = torch.full((B, H, tmax, 64), -1e4).to(tdt)
+    vc[:, :, :tgen] = v_own
+    want = _decode_attention_reference(q.float(), kp.float(), vp.float(), k_own.float(), v_own.float()).reshape(B, H * 64)
+    dq, dkp, dvp, dkc, dvc = (t.cuda().contiguous() for t in (q.reshape(B, H * 64), kp, vp, kc, vc))
+    for variant in ((0, 2, 1) if dt != E.TT_F32 else (0,)):
+        out = torch.zeros(B, H * 64, device="cuda", dtype=tdt)
+        E.check(lib.tt_op_decode_attention(dt, E.ptr(dq), E.ptr(dkp), E.ptr(dvp), P1, E.ptr(dkc), E.ptr(dvc), tmax, tgen, E.ptr(out), B, H, variant, None))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        # the output is rounded to T once (f32 accumulation): 2^-9 (bf16) / 2^-12 (fp16) relative per element
+        report(f"decode attention {name} B={B} P1={P1} own keys={tgen} variant={variant}", out.float(), want,
+               {"bf16": 4e-3, "f16": 6e-4, "f32": 2e-6}[name])
+
+
+def _warped(logits, ids):
+    return torch.softmax(O.warp_logits(logits.float(), ids, 2.0, 0.8, 50, 0.8), dim=-1)
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES + [F32])
+@torch.no_grad()
+def test_full_width_decode_at_the_benchmarked_contexts(sds, name, dt, tdt, tol):
+    """8 distinct rows, teacher-forced for 500 steps, placed cyclically into B = 96 and B = 256 (fp32 verification mode: B = 96, 200 steps)."""
+    g = np.load(os.path.join(GOLD, "full_ar_long.npz"))
+    cfg = ARConfig()
+    text, auto, _ = GF.prompt()
+    toks = GF.arl_tokens()
+    keep = torch.ones(cfg.number_mel_codes, dtype=torch.bool)
+    keep[cfg.stop_mel_token] = False  # suppressed (-1e9) in the benchmark weights
+    f32 = dt == E.TT_F32
+    steps = 200 if f32 else GF.ARL_STEPS
+    st = stages.ArStage(sds["autoregressive"], cfg, dtype=dt, max_batch=96 if f32 else 256, max_text=80, max_new_tokens=steps + 8, max_latent_candidates=1)
+    for B in ((96,) if f32 else (96, 256)):
+        rep = B // GF.ARL_B
+        st.prefill(auto, text)
+        st.begin(B)
+        tv_all, jac_all, top1_all, worst_rel = [], [], [], 0.0
+        for s in range(steps):
+            st.decode_step(toks[s].repeat(rep))
+            n = s + 1
+            if n not in GF.ARL_CHECK:
+                continue
+            want8 = torch.from_numpy(g["logits_%d" % n])
+            rows = want8.shape[0]
+            got = st.logits(B).cpu()
+            # every copy of a row computes the same bits, wherever it sits in the batch (row tiles, split-K and attention workgroups differ)
+            assert torch.equal(got[:GF.ARL_B], got[B - GF.ARL_B:]), f"a row's logits depend on its position in the decode batch (B={B}, step {n})"
+            got8 = got[:rows]
+            worst_rel = max(worst_rel, report(f"FULL AR logits after {n} fed tokens {name} B={B} vs reference golden", got8[:, keep], want8[:, keep],
+                                              2e-5 if f32 else tol * 1.6))
+            ids = torch.cat([torch.full((rows, 1), 1, dtype=torch.long), torch.full((rows, 1), cfg.start_mel_token, dtype=torch.long), toks[:n, :rows].t()], dim=1)
+            p, q = _warped(got8, ids), _warped(want8, ids)
+            tv_all.append(0.5 * (p - q).abs().sum(-1))
+            sp, sq = p > 0, q > 0
+            jac_all.append((sp & sq).sum(-1).float() / (sp | sq).sum(-1).float())
+            top1_all.append((p.argmax(-1) == q.argmax(-1)).float())
+        tv, jac, top1 = torch.cat(tv_all), torch.cat(jac_all), torch.cat(top1_all)
+        print(f"[parity] FULL AR warped distribution at contexts {[c for c in GF.ARL_CHECK if c <= steps]} {name} B={B}: total variation mean {float(tv.mean()):.4f} "
+              f"max {float(tv.max()):.4f} | nucleus-set Jaccard mean {float(jac.mean()):.4f} min {float(jac.min()):.4f} | top-1 agreement {float(top1.mean()):.4f} "
+              f"| worst logits rel-L2 {worst_rel:.3e} ({len(tv)} (row, step) samples)")
+        tv_mean_bound, tv_max_bound, jac_bound = {"bf16": (0.05, 0.35, 0.85), "f16": (0.01, 0.10, 0.95), "f32": (1e-4, 1e-3, 0.999)}[name]
+        assert float(tv.mean()) < tv_mean_bound and float(tv.max()) < tv_max_bound and float(jac.mean()) > jac_bound
+    st.close()
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("M", [1, 7, 16, 32, 33, 64])
+def test_skinny_decode_tiles_are_bit_identical_to_the_64x64_tile(lib, name, dt, tdt, tol, M):
+    """Round 6: weight-streaming GEMMs of a small decode batch (M <= 64 rows, N >= 1024) run on 32 x 16 / 64 x 16 tiles - 192 .. 513 workgroups
+    instead of 48 .. 64 (csrc/gemm_impl.h Tile).  Same MFMA, same k order per output element, same split-K ranges: every output form the decode
+    step uses (f32 + bias: lm_head at the padded vocabulary 8196; split-K slabs: the projections; bias + tanh-GELU + T: c_fc; bias + residual)
+    must agree BIT FOR BIT with the 64 x 64 tile (ttx_kernel_variant(TTX_GEMM_SKINNY, 0)) - which is what keeps a candidate's sampled codes
+    independent of the per-rank batch it is decoded in - and both must agree with torch."""
+    g = torch.Generator().manual_seed(M)
+    cases = [(8196, 1024, 1, E.ACT_NONE, "f32"), (1024, 4096, 4, E.ACT_NONE, "slab"), (1024, 1024, 4, E.ACT_NONE, "slab"), (4096, 1024, 1, E.ACT_GELU_TANH, "t"),
+             (1024, 1024, 1, E.ACT_NONE, "res")]
+    for (N, K, sk, act, form) in cases:
+        A = (torch.randn(M, K, generator=g)).to(tdt).cuda()
+        Wt = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        res = torch.randn(M, N, generator=g).cuda()
+        outs = []
+        for skinny in (1, 0):
+            prev = lib.ttx_kernel_variant(E.TTX_GEMM_SKINNY, skinny)
+            try:
+                o32 = torch.zeros(max(sk, 1), M, N, device="cuda") if form != "t" else None
+                ot = torch.zeros(M, N, device="cuda", dtype=tdt) if form == "t" else None
+                E.check(lib.tt_op_gemm(dt, E.ptr(A), K, E.ptr(Wt), K, M, N, K, 1, 0, sk, E.ptr(bias) if form != "slab" else None, act,
+                                       E.ptr(res) if form == "res" else None, E.ptr(o32), E.ptr(ot), None))
+                torch.cuda.synchronize()
+            finally:
+                lib.ttx_kernel_variant(E.TTX_GEMM_SKINNY, prev)
+            outs.append(o32 if o32 is not None else ot)
+        assert torch.equal(outs[0], outs[1]), f"skinny tile differs from the 64 x 64 tile: M={M} N={N} K={K} splitk={sk} {form}"
+        ref = A.float() @ Wt.float().t()
+        if form == "slab":
+            got = outs[0].sum(0)
+        elif form == "t":
+            got, ref = outs[0].float(), torch.nn.functional.gelu(ref + bias, approximate="tanh")
+        elif form == "res":
+            got, ref = outs[0][0], ref + bias + res
+        else:
+            got, ref = outs[0][0], ref + bias
+        report(f"skinny GEMM {name} M={M} N={N} K={K} splitk={sk} {form}", got, ref, 2e-5 if form != "t" else {"bf16": 4e-3, "f16": 6e-4}[name])

@@ -18,10 +18,10 @@ def test_stage_dtype_resolution():
     from tortoise_tts_amd.api import resolve_stage_dtypes
     bf, fp = E.TT_BF16, E.TT_F16
     # the reference: AR + CLVP under fp16 autocast only with half=True (api.py:413-414); diffusion + vocoder in fp32 always (api.py:225, 540-560)
-    assert resolve_stage_dtypes(None, False) == {"ar": bf, "clvp": bf, "diffusion": fp, "vocoder": fp}
+    assert resolve_stage_dtypes(None, False) == {"ar": fp, "clvp": fp, "diffusion": fp, "vocoder": fp}  # round 6: fp16 + overflow guard everywhere
     assert resolve_stage_dtypes(None, True) == {"ar": fp, "clvp": fp, "diffusion": fp, "vocoder": fp}
     assert resolve_stage_dtypes("bf16", False) == {k: bf for k in ("ar", "clvp", "diffusion", "vocoder")}
-    assert resolve_stage_dtypes({"diffusion": "bf16"}, False) == {"ar": bf, "clvp": bf, "diffusion": bf, "vocoder": fp}
+    assert resolve_stage_dtypes({"diffusion": "bf16"}, False) == {"ar": fp, "clvp": fp, "diffusion": bf, "vocoder": fp}
     assert resolve_stage_dtypes({"ar": "fp16", "clvp": "f16"}, True)["ar"] == fp
     with pytest.raises(ValueError, match="half=True"):
         resolve_stage_dtypes("bf16", True)
@@ -44,7 +44,7 @@ def test_overflowing_fp16_stage_is_rebuilt_with_bf16_and_the_utterance_rendered_
     from tortoise_tts_amd.api import TextToSpeech
     sds, cfgs = small_setup()
     tts = TextToSpeech(state_dicts=sds, configs=cfgs, max_candidates=8, max_mel_tokens=16, kv_cache=True)
-    assert tts.dtype_names() == {"ar": "bf16", "clvp": "bf16", "diffusion": "fp16", "vocoder": "fp16"}
+    assert tts.dtype_names() == {"ar": "fp16", "clvp": "fp16", "diffusion": "fp16", "vocoder": "fp16"}
     lat = voice_latents(cfgs)
     kw = dict(conditioning_latents=lat, num_autoregressive_samples=4, diffusion_iterations=2, max_mel_tokens=10, use_deterministic_seed=4, verbose=False)
     clean = tts.tts(list(range(30, 40)), **kw)

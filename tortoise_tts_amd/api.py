@@ -119,16 +119,16 @@ def resolve_stage_dtypes(dtype, half):
     """MFMA operand type per stage -> {'ar' | 'clvp' | 'diffusion' | 'vocoder': engine dtype code}.
 
     The reference autocasts ONLY the autoregressive + CLVP stages to fp16, and only under half=True (api.py:413-414, 460-463); its
-    diffusion decoder and vocoder always run in fp32 (api.py:225 use_fp16=False, 540-560 no autocast).  Defaults here:
-      ar, clvp           bf16 (half=True: fp16, the reference's autocast type) - the residual stream of a GPT-2 trunk is where outlier
-                         channels live, and bf16 keeps the fp32 exponent range at no cost in speed;
-      diffusion, vocoder fp16 - the closest MFMA operand type to the reference's fp32 (3 more mantissa bits than bf16: 8-10x tighter
-                         against the reference's own p_sample_loop at the same speed); GroupNorm and the x0 clamp
-                         bound the activations, and an overflow guard (tt_diff_guard) watches for the case they do not: a tripped
-                         stage is rebuilt with bf16 operands and the utterance re-rendered (TextToSpeech._demote).
+    diffusion decoder and vocoder always run in fp32 (api.py:225 use_fp16=False, 540-560 no autocast).  Default here (round 6): **fp16 for
+    every stage** - the MFMA operand type closest to the reference's fp32 (3 more mantissa bits than bf16) at the same speed.  Measured
+    against the reference's own fp32 modules at the benchmarked width (profiles/r06_parity_gpu.txt): decode logits over
+    500 teacher-forced steps rel-L2 8e-4 (bf16 6.5e-3), total variation of the sampler's warped distribution mean 0.002 / max 0.020
+    (bf16 0.009 / 0.038), CLVP Spearman 0.9999 (0.9993), 200-iteration mel 1.1e-3 (8.6e-3).  fp16 saturates at 65504, so every stage
+    counts non-finite values behind its operand casts (tt_*_guard): a tripped stage is rebuilt with bf16 operands - the fp32 exponent
+    range - and the utterance re-rendered with the same seed (TextToSpeech._demote).  half=True (the reference's fp16 autocast flag) is
+    therefore the default behaviour already; dtype='bf16' (or a dict per stage) selects bf16 operands up front.
     `dtype` may be None (defaults), one name for every stage, or a dict overriding some stages."""
-    base = "fp16" if half else "bf16"
-    out = {"ar": base, "clvp": base, "diffusion": "fp16", "vocoder": "fp16"}
+    out = {"ar": "fp16", "clvp": "fp16", "diffusion": "fp16", "vocoder": "fp16"}
     if isinstance(dtype, dict):
         unknown = set(dtype) - set(STAGE_NAMES)
         if unknown:
@@ -219,6 +219,15 @@ class TextToSpeech:
         self.stop_mel_token = self.ar_cfg.stop_mel_token
         self.mel_length_compression = self.ar_cfg.mel_length_compression
         self.timings = {}
+
+    def set_candidate_sharding(self, on):
+        """Switch an instance inside a multi-rank job between sharding the candidates of ONE utterance over the ranks (on: one
+        all_gather per utterance, the winner rendered by ranks 0 / 1) and rendering whole utterances on its own GPU (off: replicas, no
+        data-path collective).  The engines need max_candidates >= the candidates a call decodes on this rank in either mode."""
+        self.rank, self.world = tdist.world() if on else (0, 1)
+        self.split_diffusion = self.world >= 2 and os.environ.get("TT_SPLIT_DIFFUSION", "1") != "0"
+        if self.split_diffusion:
+            tdist.pair_group()
 
     def _build_stage(self, name):
         """(Re)build one stage engine with self.dtypes[name] operands."""

@@ -1,14 +1,15 @@
 // Process-level and operator-level C-ABI entry points (include/tortoise_mi355x.h).
 #include "runtime.h"
 #include "../../include/tortoise_mi355x.h"
+#include "../../include/tortoise_mi355x_test.h"
 
 using namespace tt;
-namespace tt { extern bool g_flash32; extern bool g_voc_mfma; extern bool g_gemm_p8; }  // attention.hip, univnet.hip, gemm.hip
+namespace tt { extern bool g_flash32; extern bool g_voc_mfma; extern bool g_gemm_p8; extern bool g_gemm_skinny; }  // attention.hip, univnet.hip, gemm.hip
 
 extern "C" {
 
 const char* tt_last_error(void) { return tt::last_error(); }
-int tt_abi_version(void) { return 4; }  // ABI changes
+int tt_abi_version(void) { return 5; }  // ABI changes
 
 int tt_init(void) {
   int dev = 0;
@@ -85,59 +86,13 @@ int tt_op_gn_gemm(int dtype, const float* x, int B, int S, const float* gamma, c
   return gemm_gna_launch(dtype, EPI_STD, g, n, s);
 }
 
-// Test entry of the decode step's fused pair (gemm.h EPI_RESID + a folded LayerNorm): the projection x += A W^T + bias with the split-K fold
-// inside the launch (splitk > 1: arrival tickets; splitk <= 1: -splitk K ranges folded by one workgroup, 0 / -1 = one range), which leaves x
-// (f32, in place), xt (T copy) and stats ([M][D / 32][2]); then out_t[M][N2] = gelu_tanh(LN(x) W2^T + b2) from the folded operands
-// (Wg = W2 * gamma, colsum, bias2 = b2 + W2 beta).  Wg == nullptr skips the second launch.  Scratch (slabs, counters) is allocated here.
-int tt_op_resid_ln(int dtype, const void* A, int K, const void* W, const float* bias, float* x, int M, int D, int splitk, const void* Wg,
-                   const float* colsum, const float* bias2, int N2, void* out_t, void* xt, float* stats, void* stream) {
-  TT_REQUIRE(A && W && bias && x && xt && stats && M >= 1, "tt_op_resid_ln: null argument");
-  hipStream_t s = (hipStream_t)stream;
-  float* slabs = nullptr;
-  unsigned* count = nullptr;
-  const int sk = splitk > 1 ? splitk : 1;
-  TT_CHECK_HIP(hipMalloc((void**)&slabs, (size_t)sk * M * D * sizeof(float) + 256));
-  TT_CHECK_HIP(hipMalloc((void**)&count, ((size_t)cdiv(M, 64) * (D / 64) + 64) * sizeof(unsigned)));
-  TT_CHECK_HIP(hipMemsetAsync(count, 0, ((size_t)cdiv(M, 64) * (D / 64) + 64) * sizeof(unsigned), s));
-  GemmArgs g = gemm_args(A, K, W, K, M, D, K);
-  g.bias = bias; g.res = x; g.ldres = D; g.out_f32 = x; g.ldo32 = D; g.out_t = xt; g.ldot = D; g.rs_stats = stats;
-  if (splitk > 1) { g.splitk = splitk; g.rs_slabs = slabs; g.rs_count = count; }
-  else g.serial_k = splitk < -1 ? -splitk : 1;
-  int rc = gemm_launch(dtype, EPI_RESID, g, s);
-  if (!rc && Wg) {
-    g = gemm_args(xt, D, Wg, D, M, N2, D);
-    g.bias = bias2; g.act = ACT_GELU_TANH; g.out_t = out_t; g.ldot = N2;
-    g.ln_stats = stats; g.ln_colsum = colsum; g.ln_bands = D / 32; g.ln_eps = 1e-5f;
-    rc = gemm_launch(dtype, EPI_STD, g, s);
-  }
-  hipError_t e = hipStreamSynchronize(s);
-  (void)hipFree(slabs);
-  (void)hipFree(count);
-  TT_TRY(rc);
-  TT_CHECK_HIP(e);
-  return 0;
-}
-
-// Process-wide A/B switch of the attention kernels (like tt_graph_replay): 1 (default) = 32-query waves on v_mfma_f32_32x32x16 for
-// non-causal sequences of more than 128 rows, 0 = the 16-query-wave kernels everywhere.  Returns the previous value.  Set it before an
-// engine captures its graphs (a kept graph replays the kernels it was captured with).
-int tt_gemm_variant(int v) {
-  const int prev = tt::g_gemm_p8 ? 1 : 0;
-  tt::g_gemm_p8 = v != 0;
-  return prev;
-}
-
-int tt_flash_variant(int v) {
-  const int prev = tt::g_flash32 ? 1 : 0;
-  tt::g_flash32 = v != 0;
-  return prev;
-}
-
-// The same switch for UnivNet's audio-rate kernels: 1 (default) = the 32 -> 32 dilated convolutions and the location-variable convolutions of
-// hop 64 / 256 on v_mfma_f32_32x32x2_f32 (exact f32), 0 = the thread-per-sample VALU kernels.  Returns the previous value.
-int tt_voc_variant(int v) {
-  const int prev = tt::g_voc_mfma ? 1 : 0;
-  tt::g_voc_mfma = v != 0;
+// Process-wide A/B switches of kernel families (include/tortoise_mi355x_test.h; like tt_graph_replay: set them before an engine captures
+// its graphs - a kept graph replays the kernels it was captured with).  Returns the previous value.
+int ttx_kernel_variant(int which, int v) {
+  bool* sw = which == TTX_FLASH32 ? &tt::g_flash32 : which == TTX_GEMM_P8 ? &tt::g_gemm_p8 : which == TTX_VOC_MFMA ? &tt::g_voc_mfma : which == TTX_GEMM_SKINNY ? &tt::g_gemm_skinny : nullptr;
+  TT_REQUIRE(sw != nullptr, "ttx_kernel_variant: unknown kernel family %d", which);
+  const int prev = *sw ? 1 : 0;
+  *sw = v != 0;
   return prev;
 }
 
@@ -148,6 +103,29 @@ int tt_op_flash_attention(int dtype, const void* q, const void* k, const void* v
   f.q = q; f.k = k; f.vt = vt; f.out = out; f.ldo = heads * 64; f.BH = B * heads; f.heads = heads; f.n = n; f.n_pad = n_pad;
   f.causal = causal; f.relpos = relpos;
   return flash_attention_launch(dtype, f, (hipStream_t)stream);
+}
+
+// The decode step's attention (HF GPT2Attention with a KV cache: one query per (sequence, head) over [shared prefix | own keys]) on
+// caller-provided caches.  tgen own keys (slots 0 .. tgen - 1) are valid; the device-side step word the kernels read is made here.
+int tt_op_decode_attention(int dtype, const void* q, const void* kp, const void* vp, int P1, const void* kc, const void* vc, int tmax, int tgen,
+                           void* out, int B, int heads, int variant, void* stream) {
+  TT_REQUIRE(q && kp && vp && kc && vc && out && tgen >= 1 && tgen <= tmax, "tt_op_decode_attention: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int* step = nullptr;
+  TT_CHECK_HIP(hipMalloc((void**)&step, sizeof(int)));
+  const int newest = tgen - 1;
+  TT_CHECK_HIP(hipMemcpyAsync(step, &newest, sizeof(int), hipMemcpyHostToDevice, s));
+  TT_CHECK_HIP(hipStreamSynchronize(s));
+  DecodeAttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = q; a.kp = kp; a.vp = vp; a.P1 = P1; a.kc = kc; a.vc = vc; a.tmax = tmax; a.step = step; a.host_tgen = tgen;
+  a.out = out; a.B = B; a.heads = heads; a.variant = variant;
+  int rc = decode_attention_launch(dtype, a, s);
+  hipError_t e = hipStreamSynchronize(s);
+  (void)hipFree(step);
+  TT_TRY(rc);
+  TT_CHECK_HIP(e);
+  return 0;
 }
 
 // One sampling step on caller-provided state (seen bitmask, unfinished flags); `step` indexes codes / exp_noise.

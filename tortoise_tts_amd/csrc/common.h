@@ -205,9 +205,7 @@ enum ProfId {  // one class per kernel instantiation that actually runs (names: 
   PROF_FLASH, PROF_DECODE_ATTN, PROF_ROWNORM, PROF_GROUPNORM, PROF_SAMPLE, PROF_GLUE, PROF_CONV1D, PROF_CONVT, PROF_LVC,
   PROF_GEMM_64x64_STATS,  // the denoiser's 1x1 GEMMs with the GroupNorm-statistics epilogue (M = 1740): kept apart from the decode GEMMs of the same tile
   PROF_GEMM_GNA,          // GEMM with the GroupNorm apply on its A path (gemm_gna.h)
-  PROF_GEMM_RESID,        // decode projection with the in-launch split-K fold + residual update + LayerNorm statistics (EPI_RESID)
-  PROF_GEMM_LN_QKVDEC,    // decode QKV GEMM with LayerNorm folded in
-  PROF_GEMM_LN_FC,        // decode c_fc GEMM with LayerNorm folded in
+  PROF_GEMM_32x16_STD, PROF_GEMM_32x16_QKVDEC, PROF_GEMM_64x16_STD, PROF_GEMM_64x16_QKVDEC,  // skinny decode tiles (small batches)
   PROF_COUNT
 };
 extern bool g_prof_on;

@@ -87,9 +87,6 @@ struct tt_diff {
   // sampling run ends with a copy into the pinned word tt_diff_guard reads
   int* guard = nullptr;
   int* guard_host = nullptr;
-  unsigned* bar_count = nullptr;  // TT_DIFF_OPT_FUSED_GN = 3: arrival counter of the in-launch output norm (gemm_gna.h NOUT), zeroed at the start of a pass
-  int bar_seq = 0;                //   launches of that form in the pass being enqueued
-  bool bar_armed = false;         //   true while diff_forward enqueues a sampler pass (the counter has been zeroed on its stream)
   // The captured sampler step stays on the handle between calls: the caller's noise / output pointers reach the sampler kernel
   // through a device-side table (io_dev, refreshed per call), so the key is the geometry alone (utterances, lengths, guidance rows,
   // steps).  Replaces the per-call capture + instantiate of round 3 (and the destroy-right-after-the-last-launch that went with it).
@@ -158,24 +155,8 @@ static int run_attn_block(tt_diff* e, DiffWork& w_, const tt_attn_block& w, cons
   GemmArgs g = gemm_args(w_.act, C, w.w_qkv, C, M, 3 * C, C);
   g.bias = w.b_qkv; g.seq_len = S; g.dmodel = C; g.heads = H; g.q = w_.q; g.k = w_.k; g.vt = w_.vt; g.seq_pad = n_pad;
   g.q_scale = 0.125f;  // (q * 64^-1/4) . (k * 64^-1/4)  ==  (q/8) . k   (arch_util.py:64-67)
-  bool fused_gn = false;
-  if ((e->fuse_gn == 2 || e->fuse_gn == 4) && !e->masked && in == w_.stats_ptr && w_.stats_seq == S && S >= w_.stats_rows) {
-    // TT_DIFF_OPT_FUSED_GN = 2 (measured, not the default: profiles/r05_ab_fused_groupnorm.txt): the attention norm on the QKV GEMM's A path as well
-    GemmGnArgs n;
-    memset(&n, 0, sizeof(n));
-    n.gamma = w.norm_g; n.beta = w.norm_b; n.gemm_part = w_.stats_part; n.part_rows = w_.stats_rows; n.S = S; n.eps = 1e-5f; n.act = ACT_NONE;
-    n.guard = e->guard;
-    GemmArgs gf = g;
-    gf.A = in; gf.lda = C;
-    if (gemm_gna_supported(dt, EPI_QKV_HEADS, gf, n)) {
-      TT_TRY(gemm_gna_launch(dt, EPI_QKV_HEADS, gf, n, s));
-      fused_gn = true;
-    }
-  }
-  if (!fused_gn) {
-    TT_TRY(run_gn(e, w_, in, B, S, w.norm_g, w.norm_b, nullptr, 0, 1, ACT_NONE, w_.act, C, nullptr, s));
-    TT_TRY(gemm_launch(dt, EPI_QKV_HEADS, g, s));
-  }
+  TT_TRY(run_gn(e, w_, in, B, S, w.norm_g, w.norm_b, nullptr, 0, 1, ACT_NONE, w_.act, C, nullptr, s));
+  TT_TRY(gemm_launch(dt, EPI_QKV_HEADS, g, s));
   FlashArgs f;
   memset(&f, 0, sizeof(f));
   f.q = w_.q; f.k = w_.k; f.vt = w_.vt; f.out = w_.att; f.ldo = C; f.BH = B * H; f.heads = H; f.n = S; f.n_pad = n_pad;
@@ -196,7 +177,7 @@ static int run_res_block(tt_diff* e, DiffWork& w_, const tt_res_block& w, const 
   const int C = e->C, dt = e->cfg.dtype, M = B * S;
   GemmArgs g = gemm_args(w_.act, C, w.w_in, C, M, C, C);
   g.bias = w.b_in; g.out_f32 = w_.tmp_c; g.ldo32 = C;
-  bool fused_gn = false, fused_out = false;
+  bool fused_gn = false;
   if (e->fuse_gn && !e->masked && in == w_.stats_ptr && w_.stats_seq == S && S >= w_.stats_rows) {
     // in_layers as ONE launch: GroupNorm32 + SiLU applied on the 1x1 conv's A path (gemm_gna.h), statistics for out_layers' norm in its epilogue
     GemmGnArgs n;
@@ -207,20 +188,7 @@ static int run_res_block(tt_diff* e, DiffWork& w_, const tt_res_block& w, const 
     gf.A = in; gf.lda = C;
     float* part = w_.stats_part == w_.gn_gemm_part ? w_.gn_gemm_part2 : w_.gn_gemm_part;
     gf.gn_part = part; gf.gn_seq = S;
-    if (e->fuse_gn >= 3 && e->bar_armed) {
-      // TT_DIFF_OPT_FUSED_GN = 3 (measured: profiles/r05_ab_fused_groupnorm.txt): out_layers' norm + scale-shift + SiLU in the same launch,
-      // behind a device-wide barrier (sampler step only: the grid must fit the CUs); the f32 tensor tmp_c is never written
-      GemmGnArgs no = n;
-      no.o_gamma = w.gn2_g; no.o_beta = w.gn2_b; no.o_ss = ss; no.o_ss_stride = ss_stride; no.o_ss_div = ss_div; no.o_out = w_.act; no.o_ldo = C;
-      no.o_count = e->bar_count; no.o_seq = e->bar_seq;
-      if (gemm_gna_supported(dt, EPI_STD, gf, no)) {
-        TT_TRY(gemm_gna_launch(dt, EPI_STD, gf, no, s));
-        ++e->bar_seq;
-        w_.stats_ptr = nullptr;
-        fused_gn = fused_out = true;
-      }
-    }
-    if (!fused_gn && gemm_gna_supported(dt, EPI_STD, gf, n)) {
+    if (gemm_gna_supported(dt, EPI_STD, gf, n)) {
       TT_TRY(gemm_gna_launch(dt, EPI_STD, gf, n, s));
       w_.stats_ptr = gf.out_f32; w_.stats_part = part; w_.stats_rows = gemm_gna_stat_rows(); w_.stats_seq = S;
       fused_gn = true;
@@ -230,7 +198,7 @@ static int run_res_block(tt_diff* e, DiffWork& w_, const tt_res_block& w, const 
     TT_TRY(run_gn(e, w_, in, B, S, w.gn1_g, w.gn1_b, nullptr, 0, 1, ACT_SILU, w_.act, C, nullptr, s));
     TT_TRY(gemm_with_stats(e, w_, g, S, s));
   }
-  if (!fused_out) TT_TRY(run_gn(e, w_, w_.tmp_c, B, S, w.gn2_g, w.gn2_b, ss, ss_stride, ss_div, ACT_SILU, w_.act, C, nullptr, s));
+  TT_TRY(run_gn(e, w_, w_.tmp_c, B, S, w.gn2_g, w.gn2_b, ss, ss_stride, ss_div, ACT_SILU, w_.act, C, nullptr, s));
   g = gemm_args(w_.act, C, w.w_out, 3 * C, M, C, 3 * C);
   g.taps = 3; g.seq_len = S; g.bias = w.b_out; g.res = in; g.ldres = C; g.out_f32 = out_f32; g.ldo32 = C;
   return gemm_with_stats(e, w_, g, S, s);
@@ -279,10 +247,6 @@ static int diff_forward(tt_diff* e, int B, hipStream_t s) {
   const float* ss = e->ss_cur;  // the current step's [NR][2C] rows (staged by slot_advance_launch / diff_prepare_timesteps)
   DiffWork& w_ = e->wk[0];
   w_.stats_ptr = nullptr;       // no epilogue statistics are valid at the start of a pass
-  e->bar_armed = e->fuse_gn >= 3 && !e->masked;
-  e->bar_seq = 0;
-  if (e->bar_armed) TT_CHECK_HIP(hipMemsetAsync(e->bar_count, 0, sizeof(unsigned), s));  // (a memset node when the step is being captured)
-  struct Disarm { tt_diff* e; ~Disarm() { e->bar_armed = false; } } disarm{e};  // the pre-pass and every other caller of run_res_block: never
   // inp_block (k3, in_pad -> C): left half of the integrating conv's K
   GemmArgs g = gemm_args(e->x_t, e->cfg.in_pad, e->w.w_inp, 3 * e->cfg.in_pad, M, C, 3 * e->cfg.in_pad);
   g.taps = 3; g.seq_len = S; g.bias = e->w.b_inp; g.out_t = e->cat; g.ldot = C;
@@ -422,7 +386,6 @@ int tt_diff_create(const tt_diff_config* cfg, const tt_diff_weights* w, tt_diff*
   if (!rc) rc = e->arena.alloc(&e->x_t, (B2 * cfg->max_seq + 8) * cfg->in_pad * es);
   if (!rc) rc = e->arena.alloc_t(&e->out, B2 * cfg->max_seq * cfg->out_channels);
   if (!rc) rc = e->arena.alloc_t(&e->guard, 4);
-  if (!rc) rc = e->arena.alloc_t(&e->bar_count, 4);
   if (!rc) rc = e->arena.alloc_t(&e->io_dev, 32);
   if (!rc && (hipHostMalloc((void**)&e->guard_host, 4 * sizeof(int)) != hipSuccess || hipHostMalloc((void**)&e->io_host, 32 * sizeof(void*)) != hipSuccess)) {
     set_error("tt_diff_create: hipHostMalloc failed");
@@ -794,8 +757,8 @@ int tt_diff_set_option(tt_diff* e, int option, int value) {
   TT_REQUIRE(option == TT_DIFF_OPT_OVERLAP_PREPASS || option == TT_DIFF_OPT_FUSED_GN, "tt_diff_set_option: unknown option %d", option);
   if (option == TT_DIFF_OPT_FUSED_GN) {
     if (value != e->fuse_gn) diff_drop_step_graph(e);  // the kept sampler step was captured with the other launch sequence
-    e->fuse_gn = value < 0 ? 0 : value > 4 ? 4 : value;  // 0: stand-alone applies; 1 (default): ResBlock in_layers fused; 2: + the attention norm -> qkv;
-                                                          // 3: 1 + out_layers' norm in the in_layers launch (device-wide barrier); 4: 2 + 3
+    TT_REQUIRE(value == 0 || value == 1, "tt_diff_set_option: TT_DIFF_OPT_FUSED_GN takes 0 (stand-alone applies) or 1 (default: ResBlock in_layers fused), got %d", value);
+    e->fuse_gn = value;
     return 0;
   }
   e->overlap_prepass = value < 0 ? 0 : value > 2 ? 2 : value;

@@ -10,7 +10,7 @@
 
 namespace tt {
 
-enum EpiKind { EPI_STD = 0, EPI_QKV_HEADS = 1, EPI_QKV_DECODE = 2, EPI_GEGLU = 3, EPI_RESID = 4 };
+enum EpiKind { EPI_STD = 0, EPI_QKV_HEADS = 1, EPI_QKV_DECODE = 2, EPI_GEGLU = 3 };
 
 struct GemmArgs {
   // operands
@@ -70,23 +70,6 @@ struct GemmArgs {
   void* kc;         // [b][h][8][tmax][8]  (16-byte dim chunks are key-major: coalesced lane-per-key reads)
   void* vc;         // [b][h][tmax][64]
   int tmax;
-  // LayerNorm folded into this GEMM (decode step; EPI_QKV_DECODE, or EPI_STD with bias + activation + T output): A holds the T copy of the RAW
-  // residual rows x, W the weight with the norm's gain folded in (W[n][k] * gamma[k], rounded once), and the epilogue forms
-  //   LN(x) W^T + b = rstd_m * (sum_k x[m][k] Wg[n][k] - mean_m * colsum[n]) + bias'[n],   bias' = b + W beta
-  // from the per-row statistics the producer of x left (EPI_RESID): ln_stats[m][ln_bands][2] = (sum, sum of squares) per 32-column band.
-  const float* ln_stats;
-  const float* ln_colsum;  // [N]  sum_k Wg[n][k] of the ROUNDED folded weight
-  int ln_bands;            // D / 32
-  float ln_eps;
-  int* ln_guard;           // optional operand-overflow counter (a row with non-finite statistics)
-  // EPI_RESID (decode projections): x[m][n] = (((x[m][n] + bias[n]) + P0) + P1) + ... in ONE launch, P_z = partial product over the z-th of
-  // `splitk` K ranges.  splitk > 1: every K-range workgroup writes its partial tile through to memory, takes a ticket on the tile's
-  // counter, and the LAST arriver folds the slabs in slab order (the bits of slabs + row-norm kernel); serial_k > 1: one workgroup per
-  // tile folds its own K ranges (same bits).  The folding workgroup writes x (f32, in place: res == out_f32), its T copy (the next GEMM's
-  // A operand) and the row statistics ln_stats of the rows it completes.
-  float* rs_slabs;         // [splitk][M][N] f32 scratch
-  unsigned* rs_count;      // [row tiles * column tiles] arrival counters, zero before the launch (the last arriver re-zeroes its own)
-  float* rs_stats;         // [M][N / 32][2]
 };
 
 // GroupNorm-apply on the A path (gemm_gna.h): `a.A` is the F32 tensor the GroupNorm reads ([M][1024], lda in floats), normalised with the
@@ -104,20 +87,7 @@ struct GemmGnArgs {
   float eps;
   int act;                // ACT_NONE / ACT_SILU
   int* guard;             // optional operand-overflow counter (non-finite statistics)
-  // optional (EPI_STD form only): the OUTPUT group-normalised in the same launch behind a device-wide barrier (gemm_gna.h, NOUT) -
-  // y = SiLU(GroupNorm32(W . act(GN(x)) + bias) * (1 + scale) + shift) written to o_out in the operand type, out_f32 NOT written.
-  // The grid must fit the device's CUs (gemm_gna_supported checks); the caller zeroes *o_count once per pass and numbers the launches.
-  const float* o_gamma;
-  const float* o_beta;
-  const float* o_ss;
-  size_t o_ss_stride;
-  int o_ss_div;
-  void* o_out;
-  int o_ldo;
-  unsigned* o_count;
-  int o_seq;              // launches of this form since *o_count was zeroed
 };
-int gemm_gna_grid(const GemmArgs& a);  // workgroups a gemm_gna launch of this problem takes
 // true when gemm_gna_launch has a kernel for this problem (else: groupnorm_launch + gemm_launch)
 bool gemm_gna_supported(int dtype, int epi, const GemmArgs& a, const GemmGnArgs& n);
 int gemm_gna_launch(int dtype, int epi, const GemmArgs& a, const GemmGnArgs& n, hipStream_t stream);

@@ -25,7 +25,19 @@ template <> int gemm_init_typed<float>();
 // A GEMM that emits GroupNorm statistics keeps the 128x64 tile for every M > 256: the statistics are grouped per wave tile,
 // so the same tile at one and at two batch rows keeps the denoiser's conditioned row bit-identical whether it is evaluated
 // alone (split tail) or batched with the conditioning-free row.
-static int pick_tile(const GemmArgs& a) {
+//   weight-streaming 1 x 1 GEMMs of a small decode batch (M <= 64, N >= 1024, aligned, no statistics / second source / serial fold):
+//                             32x16 (M <= 32) / 64x16, 2 waves, 8-stage ring - 192 - 512 workgroups instead of 48 - 64 (gemm_impl.h Tile)
+static bool skinny_ok(const GemmArgs& a, int epi) {
+  if (a.M > 64 || a.N < 1024 || a.taps != 1 || a.A2 || a.gn_part || a.serial_k > 1 || a.act_t != ACT_NONE) return false;
+  if (epi == EPI_QKV_DECODE) return true;
+  if (epi != EPI_STD) return false;
+  return (a.N & 3) == 0 && (!a.bias || ((size_t)a.bias & 15) == 0) && (!a.res || (((size_t)a.res & 15) == 0 && (a.ldres & 3) == 0)) &&
+         (!a.out_f32 || (((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0)) && (!a.out_t || (((size_t)a.out_t & 7) == 0 && (a.ldot & 3) == 0));
+}
+bool g_gemm_skinny = true;  // ttx_kernel_variant(TTX_GEMM_SKINNY): 0 = the 64 x 64 tile for small decode batches as well (A/B runs)
+
+static int pick_tile(const GemmArgs& a, int epi = EPI_STD) {
+  if (g_gemm_skinny && skinny_ok(a, epi)) return a.M <= 32 ? TILE_32x16 : TILE_64x16;
   const long b256 = (long)cdiv(a.M, 256) * cdiv(a.N, 256) * a.splitk;
   if (b256 >= 256 && a.N >= 256 && a.M >= 2048 && a.serial_k <= 1) return TILE_256x256;  // (the pre-pass, CLVP's speech tower, a batched denoiser)
   const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk;
@@ -43,6 +55,8 @@ static int tile_stat_rows(int tile) { return (tile == TILE_128x128 || tile == TI
 
 // ProfScope classes: (tile, epilogue, conv?) -> one class per kernel that actually runs
 static int prof_class(int tile, int epi, bool conv, bool stats = false) {
+  if (tile == TILE_32x16) return epi == EPI_QKV_DECODE ? PROF_GEMM_32x16_QKVDEC : PROF_GEMM_32x16_STD;
+  if (tile == TILE_64x16) return epi == EPI_QKV_DECODE ? PROF_GEMM_64x16_QKVDEC : PROF_GEMM_64x16_STD;
   if (tile == TILE_64x64 && epi == EPI_STD && !conv && stats) return PROF_GEMM_64x64_STATS;
   const int base = tile == TILE_64x64 ? PROF_GEMM_64x64_STD : tile == TILE_128x64 ? PROF_GEMM_128x64_STD : tile == TILE_128x128 ? PROF_GEMM_128x128_STD : PROF_GEMM_256x256_STD;
   if (epi == EPI_STD) return base + (conv ? 1 : 0);
@@ -53,12 +67,9 @@ static int prof_class(int tile, int epi, bool conv, bool stats = false) {
 // Device argument core: tile grid, XCD row bands (minimise the bytes one XCD pulls over the fabric, A / bands + W * bands / 8),
 // split-K ranges and the reciprocals the kernel divides by.
 static void plan_core(const GemmArgs& a, int epi, GemmPlan& p, int force_tile = -1, int force_bm = 0, int force_bn = 0) {
-  // EPI_RESID: the two tiles with 32-column wave tiles (one LayerNorm-statistics band per wave); both give a row the same bits
-  if (epi == EPI_RESID && force_tile < 0) force_tile = a.M > 1024 ? TILE_128x64 : TILE_64x64;
-  int tile = force_tile >= 0 ? force_tile : pick_tile(a);
-  if (a.ln_stats && tile == TILE_256x256) tile = TILE_128x128;  // (no folded-LayerNorm kernel on the 256 x 256 tile)
-  const int bm = force_bm ? force_bm : tile == TILE_64x64 ? 64 : tile == TILE_256x256 ? 256 : 128;
-  const int bn = force_bn ? force_bn : tile == TILE_256x256 ? 256 : tile == TILE_128x128 ? 128 : 64;
+  int tile = force_tile >= 0 ? force_tile : pick_tile(a, epi);
+  const int bm = force_bm ? force_bm : tile == TILE_32x16 ? 32 : (tile == TILE_64x64 || tile == TILE_64x16) ? 64 : tile == TILE_256x256 ? 256 : 128;
+  const int bn = force_bn ? force_bn : (tile == TILE_32x16 || tile == TILE_64x16) ? 16 : tile == TILE_256x256 ? 256 : tile == TILE_128x128 ? 128 : 64;
   GemmCore& c = p.core;
   memset(&c, 0, sizeof(c));
   c.A = a.A; c.W = a.W; c.lda = a.lda; c.ldw = a.ldw; c.M = a.M; c.N = a.N;
@@ -100,11 +111,10 @@ static void plan_core(const GemmArgs& a, int epi, GemmPlan& p, int force_tile = 
                     a.out_f32 && ((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0;
   p.conv3s = epi == EPI_STD && tile == TILE_128x64 && a.taps == 3 && a.dilation <= 1 && a.splitk == 1 && a.gn_part != nullptr && a.bias != nullptr &&
              a.out_t == nullptr && a.act == ACT_NONE && a.A2 == nullptr && al16 && a.cin >= 256;
-  p.prof_id = epi == EPI_RESID ? PROF_GEMM_RESID : (a.ln_stats && epi == EPI_QKV_DECODE) ? PROF_GEMM_LN_QKVDEC : (a.ln_stats && epi == EPI_STD) ? PROF_GEMM_LN_FC
-              : prof_class(tile, epi, a.taps > 1, a.gn_part != nullptr);
+  p.prof_id = prof_class(tile, epi, a.taps > 1, a.gn_part != nullptr);
   // algorithmic work of this launch: 2*M*N*K flops; operands read once + ONE result written once (the extra split-K slabs
   // a launch writes are an implementation cost: they show up in the PMC traffic, not here)
-  const bool std_epi = epi == EPI_STD || epi == EPI_RESID;
+  const bool std_epi = epi == EPI_STD;
   const double out_bytes = (double)a.M * (epi == EPI_GEGLU ? a.N / 2 : a.N) * ((std_epi && a.out_f32 ? 4.0 : 0.0) + (a.out_t || !std_epi ? 2.0 : 0.0));
   p.flops = 2.0 * a.M * a.N * a.K;
   p.bytes = ((double)a.N * a.K + (double)a.M * a.cin) * 2.0 + out_bytes + (a.res ? 4.0 * a.M * a.N : 0.0);
@@ -128,27 +138,9 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
   TT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   TT_REQUIRE(a.K % 64 == 0 && a.cin % 64 == 0, "gemm: K=%d (taps=%d) must be a multiple of 64 per tap", a.K, a.taps);
   TT_REQUIRE((a.lda % 8 == 0 && a.ldw % 8 == 0) || (dtype == DT_F32 && a.lda % 4 == 0 && a.ldw % 4 == 0), "gemm: lda=%d / ldw=%d must be multiples of 8 elements", a.lda, a.ldw);
-  TT_REQUIRE(a.splitk == 1 || ((epi == EPI_STD || epi == EPI_RESID) && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
-  if (epi == EPI_RESID) {
-    TT_REQUIRE(dtype != DT_F32, "gemm: EPI_RESID has no fp32 verification kernel (the decode step keeps the row-norm form there)");
-    TT_REQUIRE(a.taps == 1 && !a.A2 && !a.gn_part && a.act == ACT_NONE && a.bias && a.res && a.out_f32 && a.res == a.out_f32 && a.ldres == a.ldo32 && a.out_t && a.rs_stats &&
-                   a.N % 64 == 0 && ((size_t)a.bias & 15) == 0 && ((size_t)a.res & 15) == 0 && (a.ldres & 3) == 0 && ((size_t)a.out_t & 7) == 0 && (a.ldot & 3) == 0 &&
-                   ((size_t)a.rs_stats & 7) == 0,
-               "gemm: EPI_RESID needs bias, an in-place f32 residual (res == out_f32), a T copy, a statistics buffer, N %% 64 == 0 and aligned operands");
-    TT_REQUIRE(a.splitk == 1 || (a.serial_k <= 1 && a.rs_slabs && a.rs_count && ((size_t)a.rs_slabs & 15) == 0 && (size_t)a.splitk * a.M * a.N * sizeof(float) < (1ull << 31)),
-               "gemm: EPI_RESID with split-K needs a slab buffer (< 2 GiB) and arrival counters, and excludes serial_k");
-    TT_REQUIRE(a.serial_k <= 1 || (a.K / 64) % a.serial_k == 0, "gemm: K / 64 = %d is not divisible by serial_k = %d", a.K / 64, a.serial_k);
-  }
-  if (a.ln_stats) {
-    TT_REQUIRE(dtype != DT_F32 && a.taps == 1 && !a.A2 && a.splitk == 1 && a.serial_k <= 1 && a.ln_colsum && a.ln_bands * 32 == a.K && a.K <= 32 * 8 * 4 && (a.ln_bands & 1) == 0 &&
-                   ((size_t)a.ln_stats & 15) == 0 && ((size_t)a.ln_colsum & 15) == 0 && (a.N & 3) == 0,
-               "gemm: a folded LayerNorm needs K = 32 * ln_bands <= 1024 columns (an even band count), a column-sum vector and aligned statistics");
-    TT_REQUIRE(epi == EPI_QKV_DECODE || (epi == EPI_STD && a.act == ACT_GELU_TANH && a.bias && a.out_t && !a.out_f32 && !a.res && !a.gn_part && !a.act_t &&
-                                         ((size_t)a.bias & 15) == 0 && ((size_t)a.out_t & 7) == 0 && (a.ldot & 3) == 0),
-               "gemm: a folded LayerNorm is built for the decode QKV epilogue and for bias + tanh-GELU + T output (c_fc)");
-  }
+  TT_REQUIRE(a.splitk == 1 || (epi == EPI_STD && a.out_f32 != nullptr), "gemm: split-K needs EPI_STD with an f32 slab output");
   TT_REQUIRE(a.splitk <= a.K / 64, "gemm: splitk=%d exceeds the %d k-tiles", a.splitk, a.K / 64);
-  if (a.serial_k > 1 && epi != EPI_RESID)
+  if (a.serial_k > 1)
     TT_REQUIRE(epi == EPI_STD && a.splitk == 1 && a.bias && a.res && a.out_f32 && !a.out_t && !a.gn_part && a.taps == 1 && !a.A2 && a.act == ACT_NONE &&
                    (a.K / 64) % a.serial_k == 0 && (a.N & 3) == 0 && ((size_t)a.bias & 15) == 0 && ((size_t)a.res & 15) == 0 && (a.ldres & 3) == 0 &&
                    ((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0,
@@ -163,7 +155,7 @@ int gemm_launch(int dtype, int epi, const GemmArgs& a0, hipStream_t stream) {
     TT_REQUIRE(a.taps == 1 && a.splitk == 1 && a.out_t && a.N % 32 == 0 && a.ldot >= a.N / 2 && (a.ldot & 3) == 0 && ((size_t)a.out_t & 15) == 0 &&
                    (a.bias == nullptr || ((size_t)a.bias & 15) == 0) && !a.A2 && !a.gn_part && !a.res && !a.out_f32,
                "gemm: the GEGLU epilogue takes a plain GEMM with N %% 32 == 0 (value / gate strips interleaved), an aligned T output of N / 2 columns and nothing else");
-  } else if (epi != EPI_STD && epi != EPI_RESID) {
+  } else if (epi != EPI_STD) {
     TT_REQUIRE(epi == EPI_QKV_HEADS || epi == EPI_QKV_DECODE, "gemm: unknown epilogue %d", epi);
     TT_REQUIRE(a.taps == 1, "gemm: conv taps are only supported with the standard epilogue");
     TT_REQUIRE(a.dmodel % 64 == 0 && a.N == 3 * a.dmodel && a.heads * 64 == a.dmodel, "gemm: qkv epilogue needs N == 3*dmodel, head_dim 64");
@@ -189,27 +181,11 @@ bool gemm_gna_supported(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs
   const bool common = (dtype == DT_BF16 || dtype == DT_F16) && ((size_t)a.A & 15) == 0 && (a.lda & 3) == 0 && ((size_t)n.gamma & 15) == 0 && ((size_t)n.beta & 15) == 0 &&
                       (a.ldw & 7) == 0 && a.taps == 1 && a.splitk == 1 && a.serial_k <= 1 && a.K == kGnaC && !a.A2 && a.N % kGnaBN == 0 && a.M > 256 && a.M <= 4096 &&
                       n.S >= kGnaBM && a.M % n.S == 0 && n.gemm_part && n.part_rows > 0 && (n.part_rows & (n.part_rows - 1)) == 0 && n.S >= n.part_rows && a.gn_vperiod == 0 && !n.ss;
-  if (epi == EPI_QKV_HEADS)  // AttentionBlock norm -> qkv: no activation, head-layout epilogue
-    return common && n.act == ACT_NONE && a.q && a.k && a.vt && a.dmodel % 64 == 0 && a.N == 3 * a.dmodel && a.heads * 64 == a.dmodel && (!a.bias || ((size_t)a.bias & 15) == 0);
   const bool al16 = a.bias && ((size_t)a.bias & 15) == 0 && a.out_f32 && ((size_t)a.out_f32 & 15) == 0 && (a.ldo32 & 3) == 0;
-  if (n.o_out) {  // output norm behind a device-wide barrier: every workgroup must be resident at once (one per CU)
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t pr;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return false;
-      cus = pr.multiProcessorCount;
-    }
-    if (gemm_gna_grid(a) > cus || a.N != kGnaC || !n.o_gamma || !n.o_beta || !n.o_count || ((size_t)n.o_gamma & 15) || ((size_t)n.o_beta & 15) ||
-        ((size_t)n.o_ss & 15) || (n.o_ss_stride & 3) || ((size_t)n.o_out & 7) || (n.o_ldo & 3))
-      return false;
-  }
   return common && epi == EPI_STD && al16 && a.gn_part != nullptr && !a.res && !a.out_t && a.act == ACT_NONE && n.act == ACT_SILU;
 }
 
 bool g_gemm_p8 = true;  // tt_gemm_variant
-
-int gemm_gna_grid(const GemmArgs& a) { return cdiv(a.M, kGnaBM) * cdiv(a.N, kGnaBN); }
 
 int gemm_gna_launch(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs& n, hipStream_t stream) {
   GemmArgs a = a0;
@@ -217,7 +193,6 @@ int gemm_gna_launch(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs& n,
   TT_REQUIRE(gemm_gna_supported(dtype, epi, a0, n), "gemm_gna: unsupported problem (M=%d N=%d K=%d S=%d)", a.M, a.N, a.K, n.S);
   a.gn_ncol16 = a.N / 16;
   a.seq_len = n.S;
-  if (epi != EPI_QKV_HEADS) a.q = nullptr;  // (gemm_gna_launch_typed tells the two forms apart by the q pointer)
   GemmPlan plan;
   plan_core(a, epi, plan, TILE_64x64, kGnaBM, kGnaBN);
   plan.conv3s = false;
@@ -229,13 +204,6 @@ int gemm_gna_launch(int dtype, int epi, const GemmArgs& a0, const GemmGnArgs& n,
   d.part_shift = 31 - __builtin_clz((unsigned)n.part_rows);
   d.S = n.S; d.eps = n.eps; d.act = n.act; d.guard = n.guard;
   d.inv_count = 1.0 / ((double)n.S * (double)(kGnaC / 32));
-  if (n.o_out) {
-    d.o_gamma = n.o_gamma; d.o_beta = n.o_beta; d.o_ss = n.o_ss; d.o_ss_stride = n.o_ss_stride; d.o_ss_div = n.o_ss_div; d.o_out = n.o_out; d.o_ldo = n.o_ldo;
-    d.o_part = a.gn_part;
-    d.o_part_bytes = cdiv(a.M, kGnaBM) * 2 * (kGnaC / 16) * 2 * (int)sizeof(float);
-    d.o_count = n.o_count;
-    d.o_target = (unsigned)(n.o_seq + 1) * (unsigned)gemm_gna_grid(a);
-  }
   if (dtype == DT_BF16) return gemm_gna_launch_typed<bf16>(a, plan, d, stream);
   return gemm_gna_launch_typed<f16>(a, plan, d, stream);
 }

@@ -28,20 +28,6 @@ struct GnaArgs {
   int act;                  // ACT_NONE / ACT_SILU
   double inv_count;         // 1 / (S * C / 32)
   int* guard;
-  // NOUT (round 5, measured: profiles/r05_ab_fused_groupnorm.txt): the OUTPUT is group-normalised in this launch as well - ResBlock
-  // out_layers' norm (diffusion_decoder.py:104-120: GroupNorm32 -> * (1 + scale) + shift -> SiLU) applied to the accumulators after a
-  // device-wide barrier, the f32 tensor never written (its only reader was the stand-alone apply)
-  const float* o_gamma;
-  const float* o_beta;
-  const float* o_ss;        // scale / shift rows of the output norm (same addressing as ss)
-  size_t o_ss_stride;
-  int o_ss_div;
-  void* o_out;              // [M][o_ldo] operand type
-  int o_ldo;
-  float* o_part;            // exchange buffer [row_tile][2][C / 16][2] (the layout of gemm_part, row tiles of BM rows)
-  int o_part_bytes;
-  unsigned* o_count;        // arrival counter, zeroed by the host side once per pass
-  unsigned o_target;        // arrivals that complete this launch's barrier: (launches of the pass so far + 1) * workgroups
 };
 template <typename EA>
 struct GemmGnaDev {
@@ -53,7 +39,7 @@ struct GemmGnaDev {
 constexpr int kGnaC = 1024;  // channels (= K): 32 groups of 32 channels = 2 statistics strips of 16 per group
 
 
-template <typename T, int BM, int BN, int NW, int WM, int PF, typename Epi, bool SS, bool SILU, bool NOUT = false>
+template <typename T, int BM, int BN, int NW, int WM, int PF, typename Epi, bool SS, bool SILU>
 __global__ __launch_bounds__(NW * 64) void gemm_gna_kernel(const GemmGnaDev<typename Epi::Args> g) {
   typedef typename Vec<T>::x8 x8;
   constexpr int BK = 64;
@@ -308,126 +294,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_gna_kernel(const GemmGnaDev<type
       compute(kt);
     }
   }
-  if constexpr (!NOUT) {
-    run_epilogue<Epi, FM, FN, TM, TN, true>(c, g.e, acc, eo, eo.step(), m0 + wm * TM, n0 + wn * TN, lane, 0);
-  } else {
-    // ---- output norm in the same launch.  A wave's 32 columns are exactly one group of the output norm; the (sample, group) statistics
-    // need every row tile's partial sums, so the workgroups (all co-resident: the host side launches this form only with a grid that
-    // fits the CUs) exchange them through o_part behind a device-wide barrier built like the split-K ticket (gemm_impl.h): sc1 stores,
-    // every wave drains, one lane arrives with a relaxed agent-scope add and polls the counter, sc1 loads after it.
-    static_assert(WM == 1 && TN == 32 && FM == 2 && FN == 2 && Epi::kId == 0, "gemm_gna NOUT: 32 x 32 wave tiles of an EpiStd GEMM");
-    const int n0w = n0 + wn * TN;
-    // operands of the apply, requested before the barrier
-    float4 ogm[FN], obt[FN], osc[2][FN], osh[2][FN];
-#pragma unroll
-    for (int i = 0; i < FN; ++i) {
-      const int nc = n0w + i * 16 + fg * 4;
-      ogm[i] = *(const float4*)(n.o_gamma + nc);
-      obt[i] = *(const float4*)(n.o_beta + nc);
-      const int div = n.o_ss_div > 0 ? n.o_ss_div : 1;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        osc[s][i] = osh[s][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n.o_ss) {
-          const float* row = n.o_ss + (size_t)((b0 + (straddle ? s : 0)) / div) * n.o_ss_stride;
-          osc[s][i] = *(const float4*)(row + nc);
-          osh[s][i] = *(const float4*)(row + kGnaC + nc);
-        }
-      }
-    }
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)n.o_part, 0, n.o_part_bytes, 0x00020000);
-    constexpr int nc16 = kGnaC >> 4;
-#pragma unroll
-    for (int i = 0; i < FN; ++i) {
-      float sv[2] = {0.f, 0.f}, qv[2] = {0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        Epi::apply(g.e, acc[i][j], eo.bv[i], make_float4(0.f, 0.f, 0.f, 0.f));  // + bias
-        const int m = m0 + j * 16 + fr;
-        const int sl = m >= next_start ? 1 : 0;
-        const bool ok = m < c.M;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float ev = ok ? acc[i][j][r] : 0.f;
-          sv[sl] += ev;
-          qv[sl] += ev * ev;
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const float a = wave_sum(sv[s]), b = wave_sum(qv[s]);
-        if (lane == 0) {
-          typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
-          const float2 v = make_float2(a, b);
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, v), prs, (int)(((((unsigned)bx * 2 + s) * nc16) + ((n0w >> 4) + i)) * 8u), 0, 16 /* sc1 */);
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_fetch_add(n.o_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned polls = 0;
-      while (__hip_atomic_fetch_add(n.o_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n.o_target) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++polls > (1u << 21)) __builtin_trap();  // not every workgroup became resident: fail loudly instead of hanging the queue
-      }
-    }
-    __syncthreads();
-    // this wave's group, samples b0 (and b0 + 1): the items in tile order, summed in fp64 (lane-strided, then a fixed butterfly)
-    const int grp = n0w >> 5;
-    float mu_[2] = {0.f, 0.f}, rs_[2] = {0.f, 0.f};
-    const int nsamp = straddle ? 2 : 1;
-    constexpr int bshift = BM == 32 ? 5 : BM == 64 ? 6 : 7;
-    static_assert((1 << bshift) == BM, "gemm_gna NOUT: row tiles of 32 / 64 / 128 rows");
-    for (int s = 0; s < nsamp; ++s) {
-      const int b = b0 + s;
-      const int t0 = (b * S) >> bshift, t1 = ((b + 1) * S - 1) >> bshift;
-      const int nitems = (t1 - t0 + 1) << 1;
-      double su = 0.0, qu = 0.0;
-      for (int it = lane; it < nitems; it += 64) {
-        typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
-        const int t = t0 + (it >> 1), strip = (grp << 1) + (it & 1);
-        const int slot = ((t << bshift) < b * S) ? 1 : 0;
-        const float2 v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(prs, (int)(((((unsigned)t * 2 + slot) * nc16) + strip) * 8u), 0, 16 /* sc1 */));
-        su += (double)v.x;
-        qu += (double)v.y;
-      }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        su += __shfl_xor(su, o);
-        qu += __shfl_xor(qu, o);
-      }
-      const double mu = su * n.inv_count;
-      double var = qu * n.inv_count - mu * mu;
-      if (n.guard && lane == 0 && !(var < 1.0e300)) atomicAdd(n.guard, 1);
-      if (var < 0.0) var = 0.0;
-      mu_[s] = (float)mu;
-      rs_[s] = rsqrtf((float)var + n.eps);
-    }
-    T* out = (T*)n.o_out;
-#pragma unroll
-    for (int i = 0; i < FN; ++i) {
-      const int nc = n0w + i * 16 + fg * 4;
-      const float gmv[4] = {ogm[i].x, ogm[i].y, ogm[i].z, ogm[i].w}, btv[4] = {obt[i].x, obt[i].y, obt[i].z, obt[i].w};
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        const int m = m0 + j * 16 + fr;
-        const int sl = m >= next_start ? 1 : 0;
-        const float mu = sl ? mu_[1] : mu_[0], rs = sl ? rs_[1] : rs_[0];
-        const float4 sc4 = sl ? osc[1][i] : osc[0][i], sh4 = sl ? osh[1][i] : osh[0][i];
-        const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
-        float y[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          y[r] = (acc[i][j][r] - mu) * rs * gmv[r] + btv[r];
-          y[r] = y[r] * (1.f + scv[r]) + shv[r];
-          y[r] = silu(y[r]);
-        }
-        if (m < c.M) *(typename Vec<T>::x4*)(out + (size_t)m * n.o_ldo + nc) = pack4<T>(y[0], y[1], y[2], y[3]);
-      }
-    }
-  }
+  run_epilogue<Epi, FM, FN, TM, TN, true>(c, g.e, acc, eo, eo.step(), m0 + wm * TM, n0 + wn * TN, lane, 0);
 }
 
 }  // namespace tt

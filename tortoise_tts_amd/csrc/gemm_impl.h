@@ -126,8 +126,6 @@ struct EpiStd {
   static constexpr int kId = 0;
   static constexpr int kStats = STATS;
   static constexpr bool kSerial = false;
-  static constexpr bool kLn = false;
-  static constexpr bool kResid = false;
   template <int FM, int FN> struct Ops { float4 bv[FN], rv[FN][FM]; __device__ __forceinline__ int step() const { return 0; } };
   static __device__ __forceinline__ bool slab(const Args& e) { return MODE < 0 ? e.splitk > 1 : (MODE & EB_SLAB) != 0; }
   static __device__ __forceinline__ bool has_bias(const Args& e) { return MODE < 0 ? (e.bias != nullptr && e.splitk <= 1) : (MODE & EB_BIAS) != 0; }
@@ -249,8 +247,6 @@ struct EpiQkvHeads {
   static constexpr int kId = 1;
   static constexpr int kStats = 0;
   static constexpr bool kSerial = false;
-  static constexpr bool kLn = false;
-  static constexpr bool kResid = false;
   template <int FM, int FN> struct Ops { float4 bv[FN]; __device__ __forceinline__ int step() const { return 0; } };
   template <int FM, int FN, bool AL>
   static __device__ __forceinline__ void fetch(const GemmCore& c, const Args& e, Ops<FM, FN>& o, int, int n0w, int lane) {
@@ -297,8 +293,6 @@ struct EpiQkvDecode {
   static constexpr int kId = 2;
   static constexpr int kStats = 0;
   static constexpr bool kSerial = false;
-  static constexpr bool kLn = false;
-  static constexpr bool kResid = false;
   template <int FM, int FN> struct Ops { float4 bv[FN]; int t; __device__ __forceinline__ int step() const { return t; } };
   template <int FM, int FN, bool AL>
   static __device__ __forceinline__ void fetch(const GemmCore& c, const Args& e, Ops<FM, FN>& o, int, int n0w, int lane) {
@@ -344,8 +338,6 @@ struct EpiGeglu {
   static constexpr int kId = 3;
   static constexpr int kStats = 0;
   static constexpr bool kSerial = false;
-  static constexpr bool kLn = false;
-  static constexpr bool kResid = false;
   template <int FM, int FN> struct Ops { float4 bv[FN]; __device__ __forceinline__ int step() const { return 0; } };
   template <int FM, int FN, bool AL>
   static __device__ __forceinline__ void fetch(const GemmCore& c, const Args& e, Ops<FM, FN>& o, int, int n0w, int lane) {
@@ -379,128 +371,6 @@ struct EpiSerial : EpiStd<T, ACT_NONE, 0, EB_BIAS | EB_RES | EB_F32> {
   static constexpr bool kSerial = true;
 };
 
-// ---------------------------------------------------------------------------------------------- decode-step fusions
-// (a) LayerNorm folded into the consuming GEMM.  With Wg[n][k] = W[n][k] * gamma[k] (rounded to T once, at pack time),
-//     colsum[n] = sum_k Wg[n][k] and bias'[n] = b[n] + sum_k W[n][k] * beta[k]:
-//         LN(x) W^T + b  =  rstd_m * (sum_k x[m][k] Wg[n][k]  -  mean_m * colsum[n])  +  bias'[n]
-//     so the GEMM streams the T copy of the RAW residual rows (all-DMA k-loop, unchanged) and the norm is two FMAs per output in
-//     the epilogue; (mean, rstd) of a row come from the per-band (sum, sum of squares) the producer of x left next to it
-//     (EpiResid below): stats[m][bands][2], one band = 32 columns.  A lane sums the band pairs fg, fg + 4, ... of its rows and the four
-//     lane groups exchange through permlane swaps: a fixed order, independent of the batch size.
-struct LnFields {
-  const float* stats;
-  const float* colsum;
-  int* guard;
-  int bands;
-  float eps, inv_dim;
-};
-template <typename BA>
-struct LnArgs : BA {
-  LnFields ln;
-};
-constexpr int kLnPairLoads = 4;  // band pairs per lane: 4 lane groups x 4 loads x 2 bands x 32 columns = 1024 columns at most
-template <typename Base>
-struct EpiLn : Base {
-  typedef LnArgs<typename Base::Args> Args;
-  static constexpr bool kLn = true;
-  template <int FM, int FN>
-  struct Ops : Base::template Ops<FM, FN> {
-    float4 cg[FN];
-    float4 st[FM][kLnPairLoads];
-  };
-  template <int FM, int FN, bool AL>
-  static __device__ __forceinline__ void fetch(const GemmCore& c, const Args& e, Ops<FM, FN>& o, int m0w, int n0w, int lane) {
-    Base::template fetch<FM, FN, AL>(c, e, o, m0w, n0w, lane);
-    const int fr = lane & 15, fg = lane >> 4;
-    const int npairs = e.ln.bands >> 1;
-#pragma unroll
-    for (int i = 0; i < FN; ++i) o.cg[i] = *(const float4*)(e.ln.colsum + max(min(n0w + i * 16 + fg * 4, c.N - 4), 0));
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const float* p = e.ln.stats + (size_t)min(m0w + j * 16 + fr, c.M - 1) * e.ln.bands * 2;
-#pragma unroll
-      for (int t = 0; t < kLnPairLoads; ++t) o.st[j][t] = *(const float4*)(p + min(fg + 4 * t, npairs - 1) * 4);  // (clamped: unconditional loads)
-    }
-  }
-  // (mean, rstd) of this lane's FM rows
-  template <int FM, int FN>
-  static __device__ __forceinline__ void row_stats(const Args& e, const Ops<FM, FN>& o, int lane, float (&mu)[FM], float (&rs)[FM]) {
-    const int fg = lane >> 4;
-    const int npairs = e.ln.bands >> 1;
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int t = 0; t < kLnPairLoads; ++t) {
-        const bool live = fg + 4 * t < npairs;
-        s += live ? o.st[j][t].x + o.st[j][t].z : 0.f;
-        q += live ? o.st[j][t].y + o.st[j][t].w : 0.f;
-      }
-      s = add_xor16(s); s = add_xor32(s);
-      q = add_xor16(q); q = add_xor32(q);
-      const float mean = s * e.ln.inv_dim;
-      const float var = (float)((double)q * (double)e.ln.inv_dim - (double)mean * (double)mean);
-      bad = bad || !(var < INFINITY);
-      mu[j] = mean;
-      rs[j] = rsqrtf(fmaxf(var, 0.f) + e.ln.eps);
-    }
-    if (e.ln.guard && bad && fg == 0) atomicAdd(e.ln.guard, 1);  // NaN / inf in a row: an operand overflowed upstream (rare)
-  }
-};
-
-// (b) Decode projection with the residual update and the split-K fold INSIDE the launch (gemm.h EPI_RESID):
-//         x[m][n] = (((x[m][n] + bias[n]) + P0) + P1) + ...        (the bits of: split-K slabs + the row-norm kernel's fold)
-//     SERIAL: one workgroup per tile walks the K ranges itself (batches of >= 1024 rows, or one range).  Otherwise the K ranges are
-//     grid.z workgroups: each writes its partial tile THROUGH to memory (16-byte sc1 stores), every wave drains its stores, one lane takes
-//     a ticket on the tile's counter; the workgroup that draws splitk - 1 is last, reads all slabs back with sc1 loads (they bypass this
-//     CU's L1; the producers stored sc1, so no release / acquire fence is needed - the microarchitecture guide's R1 hand-off) and folds
-//     them in slab order, so the result does not depend on which range arrived last.  The folding workgroup writes x (f32, in place),
-//     its T copy (A operand of the next GEMM) and the rows' LayerNorm statistics per 32-column band (one wave tile = one band).
-struct EpiResidArgs : EpiStdArgs {
-  float* slabs;
-  unsigned* count;
-  void* xt;
-  float* stats;
-  int ldxt, bands;
-  unsigned slab_bytes;
-};
-template <typename T, bool SERIAL>
-struct EpiResid : EpiStd<T, ACT_NONE, 0, EB_BIAS | EB_RES | EB_F32> {
-  typedef EpiResidArgs Args;
-  static constexpr int kId = 4;
-  static constexpr bool kSerial = SERIAL;
-  static constexpr bool kResid = true;
-};
-template <typename T, int FM, int FN, int TN>
-__device__ __forceinline__ void resid_output(const GemmCore& c, const EpiResidArgs& e, const f32x4 (&t)[FN][FM], int m0w, int n0w, int lane) {
-  static_assert(TN == 32, "one wave tile = one 32-column statistics band");
-  const int fr = lane & 15, fg = lane >> 4;
-#pragma unroll
-  for (int j = 0; j < FM; ++j) {
-    const int m = m0w + j * 16 + fr;
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s += t[i][j][r];
-        q += t[i][j][r] * t[i][j][r];
-      }
-    s = add_xor16(s); s = add_xor32(s);
-    q = add_xor16(q); q = add_xor32(q);
-    if (m < c.M) {
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int n = n0w + i * 16 + fg * 4;
-        *(float4*)(e.out_f32 + (size_t)m * e.ldo32 + n) = make_float4(t[i][j][0], t[i][j][1], t[i][j][2], t[i][j][3]);
-        *(typename Vec<T>::x4*)((T*)e.xt + (size_t)m * e.ldxt + n) = pack4<T>(t[i][j][0], t[i][j][1], t[i][j][2], t[i][j][3]);
-      }
-      if (fg == 0) *(float2*)(e.stats + ((size_t)m * e.bands + (n0w >> 5)) * 2) = make_float2(s, q);
-    }
-  }
-}
-
 // Epilogue.  With GroupNorm statistics on (EPI_STD, f32 output feeding a GroupNorm32) every wave also emits (sum, sum of
 // squares) of the values it just produced, per 16-column strip of its TM-row tile:
 // gn_part[row_tile][slot][n / 16][2], slot 1 = rows that belong to the NEXT sequence when the row tile straddles a
@@ -525,19 +395,6 @@ __device__ __forceinline__ void run_epilogue(const GemmCore& c, const typename E
     }
     (void)step_t; (void)z;
     return;
-  }
-  if constexpr (Epi::kLn) {  // folded LayerNorm: acc = rstd_m * (acc - mean_m * colsum_n); bias' / activation / stores follow as usual
-    float mu[FM], rs[FM];
-    Epi::template row_stats<FM, FN>(e, o, lane, mu, rs);
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        acc[i][j][0] = rs[j] * (acc[i][j][0] - mu[j] * o.cg[i].x);
-        acc[i][j][1] = rs[j] * (acc[i][j][1] - mu[j] * o.cg[i].y);
-        acc[i][j][2] = rs[j] * (acc[i][j][2] - mu[j] * o.cg[i].z);
-        acc[i][j][3] = rs[j] * (acc[i][j][3] - mu[j] * o.cg[i].w);
-      }
   }
   constexpr bool BIG = FM * FN > 8;
   bool stats = false;
@@ -918,64 +775,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const GemmDev<typena
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 
-  if constexpr (Epi::kResid) {
-    const int m0w = m0 + wm * TM, n0w = n0 + wn * TN;
-    if constexpr (Epi::kSerial) {
-      resid_output<T, FM, FN, TN>(c, g.e, tser, m0w, n0w, lane);
-    } else {
-      // publish this K range's partial tile write-through, drain, take a ticket
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.e.slabs, 0, (int)g.e.slab_bytes, 0x00020000);
-      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-          const int m = m0w + j * 16 + fr, n = n0w + i * 16 + fg * 4;
-          if (m < c.M) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsrc, (int)((((unsigned)z * c.M + m) * c.N + n) * 4u), 0, 16 /* sc1 */);
-        }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave: its write-through stores have left before the ticket is taken
-      __syncthreads();
-      unsigned* flag = (unsigned*)smem_raw;  // (the ring is dead; no second __shared__ object: it would make hipcc drain the LDS-DMA queue in the k-loop)
-      const unsigned tile = bx * c.gy + by;
-      if (tid == 0) flag[0] = __hip_atomic_fetch_add(g.e.count + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      const int nsl = g.e.splitk;
-      if (flag[0] != (unsigned)(nsl - 1)) return;
-      if (tid == 0) __hip_atomic_store(g.e.count + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-      // last arriver: x + bias, then the slabs in slab order (all loads of up to 4 slabs in flight at once)
-      f32x4 tt_[FN][FM];
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j)
-          tt_[i][j] = f32x4{eo.rv[i][j].x + eo.bv[i].x, eo.rv[i][j].y + eo.bv[i].y, eo.rv[i][j].z + eo.bv[i].z, eo.rv[i][j].w + eo.bv[i].w};
-      for (int s0 = 0; s0 < nsl; s0 += 4) {
-        f32x4 P[4][FN][FM];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const unsigned zs = (unsigned)min(s0 + s, nsl - 1);  // (clamped: unconditional loads; the surplus ones are not summed)
-#pragma unroll
-          for (int i = 0; i < FN; ++i)
-#pragma unroll
-            for (int j = 0; j < FM; ++j) {
-              const int m = min(m0w + j * 16 + fr, c.M - 1), n = n0w + i * 16 + fg * 4;
-              P[s][i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((zs * c.M + m) * c.N + n) * 4u), 0, 16 /* sc1 */));
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const bool live = s0 + s < nsl;
-#pragma unroll
-          for (int i = 0; i < FN; ++i)
-#pragma unroll
-            for (int j = 0; j < FM; ++j)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) tt_[i][j][r] = live ? tt_[i][j][r] + P[s][i][j][r] : tt_[i][j][r];
-        }
-      }
-      resid_output<T, FM, FN, TN>(c, g.e, tt_, m0w, n0w, lane);
-    }
-  } else if constexpr (Epi::kSerial) {
+  if constexpr (Epi::kSerial) {
     typedef EpiStd<T, ACT_NONE, 0, EB_F32> EOut;  // the running value already holds skip + bias: store it, nothing else
     typename EOut::template Ops<FM, FN> none;
 #pragma unroll
@@ -1169,7 +969,12 @@ static inline bool p8_ok(const GemmCore& c, const dim3& grid) {
          ((size_t)c.M * c.lda + (size_t)c.sk_quot * 64) * 2 < 0x7fffffffull && ((size_t)c.N * c.ldw + (size_t)c.sk_quot * 64) * 2 < 0x7fffffffull;
 }
 
-enum Tile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x256 = 3, TILE_COUNT = 4 };
+// TILE_32x16 / TILE_64x16 (round 6): "skinny" tiles for the weight-streaming GEMMs of a SMALL decode batch (M <= 64 rows, N >= 1024).  With
+// 64 x 64 tiles a 32-row decode GEMM occupies 48 - 64 of the 256 CUs and every one of them pulls 192 - 256 KB through its ~50 GB/s
+// L2 -> LDS path; 16-column tiles spread the same weight stream over 192 - 256 CUs at 96 KB each.  Same MFMA, same k order per output
+// element, same split-K ranges: a row's bits do not depend on which tile computed it (asserted by the batch-independence tests).
+enum Tile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x256 = 3, TILE_32x16 = 4, TILE_64x16 = 5, TILE_COUNT = 6 };
+constexpr int kSkinnyStages = 8;
 // EPI_STD kernel variants: the generic one tests everything at run time, the others compile the unused features out
 enum StdVariant { V_GEN = 0, V_NONE = 1, V_SLAB = 2, V_GELU_T = 3, V_ST_F32 = 4, V_ST_RES = 5, V_ST_A2 = 6, V_BIAS_T = 7, V_SERIAL = 8, V_COUNT = 9 };
 constexpr int kNoKernel = -100;  // visit_*: this combination is not instantiated
@@ -1195,7 +1000,7 @@ struct KernelRef {
   static constexpr int threads = NW * 64;
   // (kId 2: the decode-step QKV scatter never runs on this tile; kId 3: the GEGLU epilogue's 16 output columns per quadrant make 32-byte row
   //  segments - measured 9 % slower than the 16-wave tile's 64-byte ones on one box, profiles/r05_ab_gemm_eight_phase.txt - so it stays there)
-  static constexpr bool kP8 = BM == 256 && BN == 256 && !CONV && AL && HA2 == 0 && !Epi::kSerial && !Epi::kLn && !Epi::kResid && Epi::kId != 2 && Epi::kId != 3;
+  static constexpr bool kP8 = BM == 256 && BN == 256 && !CONV && AL && HA2 == 0 && !Epi::kSerial && Epi::kId != 2 && Epi::kId != 3;
   static const void* fn() { return (const void*)gemm_glds_kernel<T, BM, BN, NW, WM, ST, Epi, CONV, AL, HA2>; }
   static const void* fn_p8() {
     if constexpr (kP8) return (const void*)gemm_p8_kernel<T, Epi>;
@@ -1256,9 +1061,25 @@ static int visit_std_tile(int variant, bool conv, bool al, V&& v) {
   }
   return kNoKernel;
 }
+// the skinny tiles exist for the aligned 1 x 1 forms of a decode step only (slabs, bias + gelu + T, bias + T, run-time outputs, generic)
+template <typename T, int BM, int BN, typename V>
+static int visit_skinny(int variant, bool conv, bool al, V&& v) {
+  if (conv || !al) return kNoKernel;
+  constexpr int NW = 2, WM = 2, ST = kSkinnyStages;
+  switch (variant) {
+    case V_GEN: return v(KernelRef<T, BM, BN, NW, WM, ST, EpiStd<T, -1, 0, -1>, false, true, 0>{});
+    case V_NONE: return v(KernelRef<T, BM, BN, NW, WM, ST, EpiStd<T, ACT_NONE, 0, -1>, false, true, 0>{});
+    case V_SLAB: return v(KernelRef<T, BM, BN, NW, WM, ST, EpiStd<T, ACT_NONE, 0, EB_SLAB>, false, true, 0>{});
+    case V_GELU_T: return v(KernelRef<T, BM, BN, NW, WM, ST, EpiStd<T, ACT_GELU_TANH, 0, EB_BIAS | EB_T>, false, true, 0>{});
+    case V_BIAS_T: return v(KernelRef<T, BM, BN, NW, WM, ST, EpiStd<T, ACT_NONE, 0, EB_BIAS | EB_T>, false, true, 0>{});
+  }
+  return kNoKernel;
+}
 template <typename T, typename V>
 static int visit_std(int tile, int variant, bool conv, bool al, V&& v) {
   switch (tile) {
+    case TILE_32x16: return visit_skinny<T, 32, 16>(variant, conv, al, v);
+    case TILE_64x16: return visit_skinny<T, 64, 16>(variant, conv, al, v);
     case TILE_256x256: return visit_std_tile<T, 256, 256, 16, 4, 2>(variant, conv, al, v);   // 4 x 4 waves of 64 x 64, two 64 KB stages
     case TILE_128x128: return visit_std_tile<T, 128, 128, 8, 2, 2>(variant, conv, al, v);
     case TILE_128x64: return visit_std_tile<T, 128, 64, 8, 4, 4>(variant, conv, al, v);   // 4 x 2 waves of 32 x 32: 1 LDS fragment read per MFMA (2 x 4 of 64 x 16: 1.25)
@@ -1267,6 +1088,14 @@ static int visit_std(int tile, int variant, bool conv, bool al, V&& v) {
 }
 template <typename T, typename Epi, typename V>
 static int visit_qkv(int tile, V&& v) {
+  if (tile == TILE_32x16 || tile == TILE_64x16) {  // decode-step QKV scatter only
+    if constexpr (Epi::kId == 2) {
+      if (tile == TILE_32x16) return v(KernelRef<T, 32, 16, 2, 2, kSkinnyStages, Epi, false, true, 0>{});
+      return v(KernelRef<T, 64, 16, 2, 2, kSkinnyStages, Epi, false, true, 0>{});
+    } else {
+      return kNoKernel;
+    }
+  }
   switch (tile) {
     case TILE_256x256: return v(KernelRef<T, 256, 256, 16, 4, 2, Epi, false, true, 0>{});
     case TILE_128x128: return v(KernelRef<T, 128, 128, 8, 2, 2, Epi, false, true, 0>{});
@@ -1275,28 +1104,6 @@ static int visit_qkv(int tile, V&& v) {
     case TILE_128x64: return v(KernelRef<T, 128, 64, 8, 4, 4, Epi, false, true, 0>{});
     default: return v(KernelRef<T, 64, 64, 4, 2, 4, Epi, false, true, 0>{});
   }
-}
-
-// decode-step fusions: EpiResid exists for the two tiles whose wave tile is 32 columns wide (one statistics band per wave)
-template <typename T, bool SERIAL, typename V>
-static int visit_resid(int tile, V&& v) {
-  switch (tile) {
-    case TILE_128x64: return v(KernelRef<T, 128, 64, 8, 4, 4, EpiResid<T, SERIAL>, false, true, 0>{});
-    case TILE_64x64: return v(KernelRef<T, 64, 64, 4, 2, 4, EpiResid<T, SERIAL>, false, true, 0>{});
-    default: return kNoKernel;
-  }
-}
-// folded-LayerNorm epilogues: every tile but 256 x 256 (its 128-VGPR waves cannot hold the statistics quads next to 64 accumulators)
-template <typename T, typename Epi, typename V>
-static int visit_ln(int tile, V&& v) {
-  return tile == TILE_256x256 ? kNoKernel : visit_qkv<T, Epi>(tile, v);
-}
-template <typename T> using EpiLnQkvDecode = EpiLn<EpiQkvDecode<T>>;
-template <typename T> using EpiLnGeluT = EpiLn<EpiStd<T, ACT_GELU_TANH, 0, EB_BIAS | EB_T>>;
-template <typename A>
-static inline void fill_ln(LnArgs<A>& d, const GemmArgs& a) {
-  d.ln.stats = a.ln_stats; d.ln.colsum = a.ln_colsum; d.ln.guard = a.ln_guard; d.ln.bands = a.ln_bands; d.ln.eps = a.ln_eps;
-  d.ln.inv_dim = 1.0f / (float)a.K;
 }
 
 static inline EpiStdArgs make_epi_std(const GemmArgs& a) {
@@ -1332,42 +1139,7 @@ int gemm_launch_typed(int epi, const GemmArgs& a, const GemmPlan& plan, hipStrea
     TT_CHECK_HIP(hipGetLastError());
     return 0;
   }
-  if (epi == EPI_RESID) {
-    GemmDev<EpiResidArgs> d;
-    d.c = plan.core;
-    (EpiStdArgs&)d.e = make_epi_std(a);
-    d.e.slabs = a.rs_slabs; d.e.count = a.rs_count; d.e.xt = a.out_t; d.e.stats = a.rs_stats; d.e.ldxt = a.ldot; d.e.bands = a.N / 32;
-    d.e.slab_bytes = (unsigned)((size_t)a.splitk * a.M * a.N * sizeof(float));
-    d.e.out_t = nullptr;
-    const bool serial = a.splitk == 1;
-    d.e.splitk = serial ? (a.serial_k > 1 ? a.serial_k : 1) : a.splitk;
-    auto go = [&](auto kr) -> int {
-      decltype(kr)::launch(ps, grid, stream, d);
-      return 0;
-    };
-    rc = serial ? visit_resid<T, true>(plan.tile, go) : visit_resid<T, false>(plan.tile, go);
-  } else if (epi == EPI_STD && a.ln_stats) {  // c_fc with LayerNorm folded in (gemm_launch validated the form)
-    GemmDev<LnArgs<EpiStdArgs>> d;
-    d.c = plan.core;
-    (EpiStdArgs&)d.e = make_epi_std(a);
-    fill_ln(d.e, a);
-    rc = visit_ln<T, EpiLnGeluT<T>>(plan.tile, [&](auto kr) -> int {
-      decltype(kr)::launch(ps, grid, stream, d);
-      return 0;
-    });
-  } else if (epi == EPI_QKV_DECODE && a.ln_stats) {
-    GemmDev<LnArgs<EpiQkvDecodeArgs>> d;
-    d.c = plan.core;
-    memset(&d.e, 0, sizeof(d.e));
-    d.e.bias = a.bias; d.e.step = a.step; d.e.qbuf = a.qbuf; d.e.kc = a.kc; d.e.vc = a.vc; d.e.heads = a.heads; d.e.tmax = a.tmax; d.e.dmodel_i = a.dmodel;
-    d.e.q_scale = a.q_scale;
-    d.e.dmodel = make_fastdiv(a.dmodel);
-    fill_ln(d.e, a);
-    rc = visit_ln<T, EpiLnQkvDecode<T>>(plan.tile, [&](auto kr) -> int {
-      decltype(kr)::launch(ps, grid, stream, d);
-      return 0;
-    });
-  } else if (epi == EPI_STD) {
+  if (epi == EPI_STD) {
     GemmDev<EpiStdArgs> d;
     d.c = plan.core;
     d.e = make_epi_std(a);
@@ -1463,26 +1235,12 @@ template <typename T>
 int gemm_gna_launch_typed(const GemmArgs& a, const GemmPlan& plan, const GnaArgs& n, hipStream_t stream) {
   const dim3 grid(plan.core.gx * plan.core.gy, 1, 1);
   ProfScope ps(plan.prof_id, stream, plan.flops, plan.bytes, true);
-  if (a.q != nullptr) {
-    // AttentionBlock norm -> qkv (arch_util.py:104-123; round 5, measured against gn_apply + the 128 x 128 DMA GEMM: profiles/r05_ab_fused_groupnorm.txt):
-    // GroupNorm32 without activation on the A path, head-layout epilogue (32-column wave tiles never straddle a head)
-    GemmGnaDev<EpiQkvHeadsArgs> d;
-    d.c = plan.core;
-    memset(&d.e, 0, sizeof(d.e));
-    d.e.bias = a.bias; d.e.q = a.q; d.e.k = a.k; d.e.v = a.v; d.e.vt = a.vt; d.e.heads = a.heads; d.e.seq_pad = a.seq_pad; d.e.q_scale = a.q_scale;
-    d.e.dmodel = make_fastdiv(a.dmodel);
-    d.n = n;
-    launch_timed(ps, gemm_gna_kernel<T, kGnaBM, kGnaBN, kGnaNW, kGnaWM, kGnaST, EpiQkvHeads<T>, false, false>, grid, dim3(kGnaNW * 64), kGnaSmem, stream, d);
-    TT_CHECK_HIP(hipGetLastError());
-    return 0;
-  }
   typedef EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_F32> EStF32;
   GemmGnaDev<EpiStdArgs> d;
   d.c = plan.core;
   d.e = make_epi_std(a);
   d.n = n;
-  if (n.act == ACT_SILU && !n.ss && n.o_out) launch_timed(ps, gemm_gna_kernel<T, kGnaBM, kGnaBN, kGnaNW, kGnaWM, kGnaST, EStF32, false, true, true>, grid, dim3(kGnaNW * 64), kGnaSmem, stream, d);
-  else if (n.act == ACT_SILU && !n.ss) launch_timed(ps, gemm_gna_kernel<T, kGnaBM, kGnaBN, kGnaNW, kGnaWM, kGnaST, EStF32, false, true>, grid, dim3(kGnaNW * 64), kGnaSmem, stream, d);
+  if (n.act == ACT_SILU && !n.ss) launch_timed(ps, gemm_gna_kernel<T, kGnaBM, kGnaBN, kGnaNW, kGnaWM, kGnaST, EStF32, false, true>, grid, dim3(kGnaNW * 64), kGnaSmem, stream, d);
   else {
     set_error("gemm_gna: no kernel for act %d scale_shift %d", n.act, n.ss != nullptr);
     return -1;
@@ -1507,10 +1265,6 @@ int gemm_init_typed() {
     (void)visit_qkv<T, EpiQkvHeads<T>>(tile, setattr);
     (void)visit_qkv<T, EpiQkvDecode<T>>(tile, setattr);
     (void)visit_qkv<T, EpiGeglu<T>>(tile, setattr);
-    (void)visit_ln<T, EpiLnQkvDecode<T>>(tile, setattr);
-    (void)visit_ln<T, EpiLnGeluT<T>>(tile, setattr);
-    (void)visit_resid<T, true>(tile, setattr);
-    (void)visit_resid<T, false>(tile, setattr);
   }
   if (hipFuncSetAttribute(conv3s_fn<T, EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_RES | EB_F32>>(), hipFuncAttributeMaxDynamicSharedMemorySize, kConv3sSmem) != hipSuccess) ++bad;
   if (hipFuncSetAttribute(conv3s_fn<T, EpiStd<T, ACT_NONE, 1, EB_BIAS | EB_F32>>(), hipFuncAttributeMaxDynamicSharedMemorySize, kConv3sSmem) != hipSuccess) ++bad;

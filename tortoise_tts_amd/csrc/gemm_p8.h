@@ -34,7 +34,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmDev<typename Epi
   typedef typename Vec<T>::x8 x8;
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int HT = 128 * BK;  // elements of a half-tile
-  static_assert(!Epi::kSerial && !Epi::kLn && !Epi::kResid, "gemm_p8: plain epilogues only");
+  static_assert(!Epi::kSerial, "gemm_p8: plain epilogues only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* L = (T*)smem_raw;  // [2][4][128][64]
   const GemmCore& c = g.c;

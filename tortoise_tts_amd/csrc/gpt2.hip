@@ -2,13 +2,14 @@
 //   * prefill:   every candidate of an utterance shares the same [cond | text | start] prefix, so it is
 //                evaluated once (M = P+1 rows) and its K/V are shared by all sequences
 //                (the reference recomputes it B times: autoregressive.py:134-144 + repeat_interleave).
-//   * decode:    KV-cached step for B sequences, FIVE launches per layer: QKV GEMM with LayerNorm folded in (K / V appended by
-//                its epilogue), decode attention, attention projection, c_fc GEMM with LayerNorm folded in, MLP projection.
-//                The two projections fold their split-K partial sums INSIDE the launch (arrival ticket per tile, last arriver sums the
-//                slabs in slab order: deterministic, no float atomics), update the residual stream and leave the rows' LayerNorm
-//                statistics + a T copy of the raw rows for the next GEMM (gemm.h EPI_RESID / ln_stats).  Sampling on device; the
-//                whole step is replayed from one hipGraph.  (fp32 verification mode and handles without the folded weights: the
-//                seven-launch form - split-K slabs folded by a LayerNorm kernel in front of the QKV / c_fc GEMMs.)
+//   * decode:    KV-cached step for B sequences, seven launches per layer: LayerNorm (folds the split-K slabs + bias of the MLP projection
+//                before it into the residual stream), QKV GEMM (K / V appended by its epilogue), decode attention, attention projection
+//                (split-K slabs), LayerNorm (folds them), c_fc GEMM + gelu, MLP projection (slabs).  Sampling on device; the whole step
+//                is replayed from one hipGraph.  Batches of <= 64 sequences (the per-rank share of a candidate-sharded job) run their
+//                GEMMs on 16-column tiles so that the weight stream is spread over 192 - 512 workgroups (gemm_impl.h Tile).
+//                (A five-launch form - LayerNorm folded into the GEMMs algebraically, split-K folded in-launch behind arrival tickets -
+//                was built and measured 0.7 - 10 % slower at every batch size from 16 to 256: profiles/r05_ab_ar_five_launch_step.txt,
+//                profiles/r06_ab_small_batch_decode.txt; it is not in the library.)
 //   * latents:   teacher-forced full pass for the CLVP winners (autoregressive.py:454-506).
 #include "runtime.h"
 #include <unistd.h>
@@ -86,16 +87,6 @@ struct tt_ar {
   int* progress_host = nullptr;
   int* progress_dev = nullptr;
   int lookahead = 6;
-  // five-launch decode step (see the header comment): needs the folded weights of every layer (tt_gpt_layer *_ln), D % 64 == 0, D <= 1024
-  bool can_fuse = false;
-  // tt_ar_set_option(TT_AR_OPT_FUSED_STEP).  Default 0: measured in situ (profiles/r05_ab_ar_five_launch_step.txt, one handle, 256 candidates x
-  // 200 tokens) the five-launch step takes 2.020 ms against 1.888 ms for seven launches - the last arriver's ticket + slab re-read tail
-  // (EPI_RESID 10.7 us against 6.7 + 4.2 us for slab GEMM + row norm) and the statistics epilogue of the folded GEMMs (+1 us each) cost more
-  // than the two kernel boundaries they remove.  Kept as an option: it is the measured answer to "fold the row norms away", and its tests
-  // guard the EPI_RESID / folded-LayerNorm kernels.
-  int fused = 0;
-  float* lnstats = nullptr;    // [max_batch][D / 32][2] row statistics left by the projections
-  unsigned* tickets = nullptr; // arrival counters of the projections' output tiles (zero between launches)
   int captures = 0;   // decode-step captures so far (tt_ar_stat: tests assert the kept graph is reused)
   int drains = 0;     // host-side queue drains the launch loop fell back to (0 when the progress words arrive)
 };
@@ -225,47 +216,18 @@ static int ar_head(tt_ar* e, float* x, int M, const float* add_bias, int nslab, 
   return ar_head_gemm(e, M, s, logits_row0);
 }
 
-static inline bool ar_fused(const tt_ar* e) { return e->can_fuse && e->fused != 0; }
-
-// Attention / MLP projection of the five-launch decode step: x += A W^T + b with the split-K fold inside the launch; leaves the T copy
-// of the updated rows in e->h and their LayerNorm statistics in e->lnstats (gemm.h EPI_RESID).
-static int ar_proj_resid(tt_ar* e, const void* A, int K, const void* W, const float* bias, int nb, hipStream_t s) {
-  const int D = e->D;
-  GemmArgs g = ar_gemm(e, A, K, W, K, nb, D, K);
-  g.bias = bias; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
-  g.out_t = e->h; g.ldot = D; g.rs_stats = e->lnstats;
-  const int sk = pick_split(nb, D, K);
-  if (nb >= 1024 || sk == 1) {  // one workgroup per tile fills the chip (or there is one K range): the ranges are folded by that workgroup
-    g.serial_k = sk;
-  } else {
-    g.splitk = sk; g.rs_slabs = e->slabs; g.rs_count = e->tickets;
-  }
-  return gemm_launch(e->cfg.dtype, EPI_RESID, g, s);
-}
-static inline void ar_ln_fold(tt_ar* e, GemmArgs& g, const float* colsum) {
-  g.ln_stats = e->lnstats; g.ln_colsum = colsum; g.ln_bands = e->D / 32; g.ln_eps = 1e-5f; g.ln_guard = e->guard;
-}
-
 // The 30 layers of one KV-cached decode step for the e->B sequences + the input norm of lm_head, all on stream s.
 static int decode_layers_enqueue(tt_ar* e, hipStream_t s) {
   const int D = e->D, H = e->H, dt = e->cfg.dtype, nb = e->B;
   float* x = e->x;
   float* slabs = e->slabs;
-  const bool fused = ar_fused(e);
   const float* pend_bias = nullptr;
   int pend_slabs = 0;
   for (int l = 0; l < e->cfg.layers; ++l) {
     const tt_gpt_layer& w = e->L[l];
-    GemmArgs g;
-    if (fused && l > 0) {  // LayerNorm folded into the GEMM: A = T copy of the raw rows (left by the previous layer's MLP projection)
-      g = ar_gemm(e, e->h, D, w.w_qkv_ln, D, nb, 3 * D, D);
-      g.bias = w.b_qkv_ln;
-      ar_ln_fold(e, g, w.c_qkv_ln);
-    } else {               // (layer 0 of the five-launch form: the rows come from the embedding, nothing has left statistics yet)
-      TT_TRY(ar_rownorm_rows(e, x, e->h, nb, w.ln1_g, w.ln1_b, pend_bias, slabs, pend_slabs, nb, s));
-      g = ar_gemm(e, e->h, D, w.w_qkv, D, nb, 3 * D, D);
-      g.bias = w.b_qkv;
-    }
+    TT_TRY(ar_rownorm_rows(e, x, e->h, nb, w.ln1_g, w.ln1_b, pend_bias, slabs, pend_slabs, nb, s));
+    GemmArgs g = ar_gemm(e, e->h, D, w.w_qkv, D, nb, 3 * D, D);
+    g.bias = w.b_qkv;
     g.dmodel = D; g.heads = H; g.q_scale = 0.125f;
     g.step = e->state + 1; g.qbuf = e->q;
     g.kc = offset_t(e->kc, (size_t)l * e->gen_layer_elems, e->es);
@@ -285,16 +247,7 @@ static int decode_layers_enqueue(tt_ar* e, hipStream_t s) {
     a.P1 = e->P1; a.kc = g.kc; a.vc = g.vc; a.tmax = e->tmax; a.step = e->state + 1;
     a.out = e->attn; a.B = nb; a.heads = H; a.host_tgen = e->host_slot + 1;
     TT_TRY(decode_attention_launch(dt, a, s));
-    if (fused) {
-      TT_TRY(ar_proj_resid(e, e->attn, D, w.w_proj, w.b_proj, nb, s));
-      g = ar_gemm(e, e->h, D, w.w_fc_ln, D, nb, 4 * D, D);
-      g.bias = w.b_fc_ln; g.act = ACT_GELU_TANH; g.out_t = e->ff; g.ldot = 4 * D;
-      ar_ln_fold(e, g, w.c_fc_ln);
-      TT_TRY(gemm_launch(dt, EPI_STD, g, s));
-      TT_TRY(ar_proj_resid(e, e->ff, 4 * D, w.w_proj2, w.b_proj2, nb, s));
-      continue;
-    }
-    // seven-launch form.  >= 1024 sequences (several utterances per batch): one block per output tile fills the chip, so the split-K partial
+    // >= 1024 sequences (several utterances per batch): one block per output tile fills the chip, so the split-K partial
     // sums are folded inside the launch in slab order (gemm.h serial_k: the same bits as slabs + row norm, without the slab traffic)
     const bool serial = nb >= 1024;
     int sk = pick_split(nb, D, D);
@@ -430,14 +383,6 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
   if (!rc) {
     e->guard_host[0] = 0;
     e->progress_host[0] = 0; e->progress_host[1] = -1; e->progress_host[2] = e->progress_host[3] = 0;
-  }
-  // five-launch decode step: the folded weights of every layer, 16-bit operands, D a multiple of 64 and <= 1024 (4 x 4 band pairs per lane)
-  e->can_fuse = cfg->dtype != DT_F32 && D % 64 == 0 && D <= 1024;
-  for (const tt_gpt_layer& l : e->L)
-    if (!l.w_qkv_ln || !l.c_qkv_ln || !l.b_qkv_ln || !l.w_fc_ln || !l.c_fc_ln || !l.b_fc_ln) e->can_fuse = false;
-  if (!rc && e->can_fuse) {
-    rc = e->arena.alloc_t(&e->lnstats, (size_t)(cfg->max_batch + 64) * (D / 32) * 2);
-    if (!rc) rc = e->arena.alloc_t(&e->tickets, (size_t)cdiv(cfg->max_batch, 64) * (D / 64) + 64);
   }
   if (rc) {
     tt_ar_destroy(e);
@@ -595,9 +540,6 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
 
   const bool use_graph = graphs_enabled() && target - e->gen_done > 1;
   int rc = 0;
-  // (the projections' arrival counters are zero between launches - the last arriver of a tile re-zeroes it; a generation starts from
-  //  a known state whatever an aborted launch may have left)
-  if (e->tickets) TT_CHECK_HIP(hipMemsetAsync(e->tickets, 0, ((size_t)cdiv(e->cfg.max_batch, 64) * (e->D / 64) + 64) * sizeof(unsigned), s));
   auto tail_enqueue = [&](hipStream_t st) -> int {
     TT_TRY(sample_launch(sa, st));
     return ar_state_advance_launch(e->state, e->unfinished_count, e->progress_dev, st);
@@ -609,7 +551,6 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
     memcpy(key.data(), &sa, sizeof(sa));
     int geo[24] = {B, e->G, e->P1, g_prof_on ? 1 : 0};
     for (int gi = 0; gi < 16; ++gi) geo[4 + gi] = gi < e->G ? e->P1g[gi] : 0;
-    geo[20] = ar_fused(e) ? 1 : 0;
     memcpy(key.data() + sizeof(sa), geo, sizeof(geo));
     if (e->step_exec == nullptr || key != e->step_key) {
       ar_drop_step_graph(e);
@@ -771,23 +712,18 @@ int tt_ar_guard(tt_ar* e, int reset) {
 }
 
 // Counters for tests / diagnostics: 0 = decode-step graph captures so far, 1 = queue drains of the launch loop (expected 0),
-// 2 = kernel launches of one decode step in its current form (layers + head + sampler + step counter), 3 = 1 when the five-launch form runs.
+// 2 = kernel launches of one decode step (layers + head + sampler + step counter).
 int tt_ar_stat(tt_ar* e, int which) {
   if (!e) { set_error("tt_ar_stat: null handle"); return -1; }
-  const int per_step = ar_fused(e) ? 5 * e->cfg.layers + 1 + 4 : 7 * e->cfg.layers + 4;
-  return which == 0 ? e->captures : which == 1 ? e->drains : which == 2 ? per_step : which == 3 ? (ar_fused(e) ? 1 : 0) : -1;
+  const int per_step = 7 * e->cfg.layers + 4;
+  return which == 0 ? e->captures : which == 1 ? e->drains : which == 2 ? per_step : -1;
 }
 
 // Engine options of a handle (defaults in brackets):
-//   TT_AR_OPT_FUSED_STEP  [0]  1: five-launch decode step (LayerNorm folded into the QKV / c_fc GEMMs, in-launch split-K fold); 0: seven launches
 //   TT_AR_OPT_LOOKAHEAD   [6]  decode steps the host may run ahead of the device (>= 1)
 int tt_ar_set_option(tt_ar* e, int option, int value) {
   TT_REQUIRE(e != nullptr, "tt_ar_set_option: null handle");
   switch (option) {
-    case TT_AR_OPT_FUSED_STEP:
-      TT_REQUIRE(value == 0 || value == 1, "tt_ar_set_option: TT_AR_OPT_FUSED_STEP takes 0 or 1, got %d", value);
-      e->fused = value;
-      break;
     case TT_AR_OPT_LOOKAHEAD:
       TT_REQUIRE(value >= 1 && value <= 64, "tt_ar_set_option: lookahead %d outside 1 .. 64", value);
       e->lookahead = value;

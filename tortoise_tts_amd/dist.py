@@ -64,7 +64,7 @@ class CollectiveInitFailed(RuntimeError):
     """Raised on ranks != 0 when the multi-rank launch could not initialise its collectives (rank 0 falls back to one GPU).
     A RuntimeError (round 5; it was a SystemExit(0) in round 4, which `except Exception` handlers cannot catch and which made an
     embedding server's idle ranks vanish with status 0): a library must not end its host process.  The ENTRY POINTS decide - bench.py and
-    scripts/dist_check.py catch it and leave with exit status 0 (`exit_idle_rank`), because under torch.distributed.run a worker that
+    scripts/dist_check.py call `init_from_env_or_exit`, which catches it and leaves with exit status 0, because under torch.distributed.run a worker that
     FAILS makes the elastic agent terminate the whole group, rank 0 included, while an idle rank that exits cleanly does not."""
 
     def __init__(self, rank, backend):
@@ -103,30 +103,57 @@ def shard_range(n, rank, world_size):
     return rank * per, (rank + 1) * per
 
 
-def gather_candidates(scores_local, codes_local):
-    """all_gather of CLVP scores f32 [n] and codes [n, M] (sent as int16: mel codes are < 8194) -> global
-    ([N] f32, [N, M] int32) on every rank, ordered by global candidate index."""
-    if _single():
-        return scores_local, codes_local
-    ws = dist.get_world_size()
-    scores_local = scores_local.contiguous()
+def pack_candidates(scores_local, codes_local):
+    """One rank's gather payload as int32 words: [n f32 scores, bit-cast | n x M int16 codes, two per word, zero-padded to a whole word]."""
     if codes_local.numel() and (int(codes_local.max()) > 32767 or int(codes_local.min()) < 0):
         raise ValueError("gather_candidates: codes do not fit int16")
-    n_loc, M = codes_local.shape
-    # int16 payload moved as int32 words (two codes per word; gloo has no int16 all_gather): pad each rank's block to even length
     flat = codes_local.to(torch.int16).reshape(-1)
     if flat.numel() % 2:
         flat = torch.cat([flat, flat.new_zeros(1)])
-    words_local = flat.contiguous().view(torch.int32)
+    return torch.cat([scores_local.contiguous().float().view(torch.int32).reshape(-1), flat.contiguous().view(torch.int32)])
+
+
+def unpack_candidates(words_all, ws, n_loc, M):
+    """Inverse of pack_candidates over the concatenated payloads of `ws` ranks -> ([ws * n_loc] f32, [ws * n_loc, M] int32)."""
+    blocks = words_all.view(ws, -1)
+    scores = blocks[:, :n_loc].contiguous().view(torch.float32).reshape(ws * n_loc)
+    codes = blocks[:, n_loc:].contiguous().view(torch.int16)[:, :n_loc * M].reshape(ws * n_loc, M)
+    return scores, codes.to(torch.int32)
+
+
+def gather_candidates(scores_local, codes_local):
+    """THE collective of the path: ONE all_gather of every rank's CLVP scores f32 [n] and codes [n, M] (as int16: mel
+    codes are < 8194), packed into one int32 buffer per rank (scores bit-cast, two codes per word) -> global ([N] f32, [N, M] int32)
+    on every rank, ordered by global candidate index."""
+    if _single():
+        return scores_local, codes_local
+    ws = dist.get_world_size()
+    n_loc, M = codes_local.shape
+    words_local = pack_candidates(scores_local, codes_local)
     dev = scores_local.device
     if _host_staged() and dev.type != "cpu":
-        scores_local, words_local = scores_local.cpu(), words_local.cpu()
-    s_all = torch.empty(ws * scores_local.shape[0], dtype=scores_local.dtype, device=scores_local.device)
-    w_all = torch.empty(ws * words_local.shape[0], dtype=torch.int32, device=words_local.device)
-    dist.all_gather_into_tensor(s_all, scores_local)
-    dist.all_gather_into_tensor(w_all, words_local)
-    c_all = w_all.view(ws, -1).view(torch.int16)[:, :n_loc * M].reshape(ws * n_loc, M)
-    return s_all.to(dev), c_all.to(dev).to(torch.int32)
+        words_local = words_local.cpu()
+    words_all = torch.empty(ws * words_local.shape[0], dtype=torch.int32, device=words_local.device)
+    dist.all_gather_into_tensor(words_all, words_local)
+    COLLECTIVE_CALLS["all_gather"] = COLLECTIVE_CALLS.get("all_gather", 0) + 1
+    s_all, c_all = unpack_candidates(words_all, ws, n_loc, M)
+    return s_all.to(dev), c_all.to(dev)
+
+
+COLLECTIVE_CALLS = {}  # data-path collectives issued by this process so far (tests assert ONE all_gather per utterance)
+
+
+def ranks_seen():
+    """(number of distinct ranks that answered an all_gather of rank ids over the active backend, backend name): what bench.py reports as
+    `rccl_ranks_seen` - N means all N processes really talked to each other through RCCL (backend "nccl") rather than N replicas running alone."""
+    if not dist.is_initialized():
+        return 1, None
+    ws, backend = dist.get_world_size(), dist.get_backend()
+    dev = "cpu" if _host_staged() or not torch.cuda.is_available() else "cuda"
+    mine = torch.tensor([dist.get_rank()], dtype=torch.int32, device=dev)
+    out = torch.full((ws,), -1, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(out, mine)
+    return len(set(int(v) for v in out.tolist() if int(v) >= 0)), backend
 
 
 def collect_on_rank0(wavs, k):

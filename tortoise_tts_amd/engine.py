@@ -1,4 +1,4 @@
-"""ctypes binding of include/tortoise_mi355x.h.
+"""ctypes binding of include/tortoise_mi355x.h (the drop-in boundary) and include/tortoise_mi355x_test.h (operator-level test entries).
 
 The library is the product: there is no PyTorch/CPU fallback.  If the shared object is missing
 or the device is not gfx950, loading fails loudly.
@@ -11,9 +11,10 @@ LIB_PATH = os.environ.get("TORTOISE_MI355X_LIB") or os.path.join(HERE, "lib", "l
 
 TT_BF16, TT_F16, TT_F32 = 0, 1, 2  # TT_F32: the slow fp32-operand VERIFICATION mode of the AR / CLVP / diffusion / vocoder stages (tests)
 DTYPE_NAMES = {TT_BF16: "bf16", TT_F16: "fp16", TT_F32: "fp32"}
-TT_AR_OPT_FUSED_STEP, TT_AR_OPT_LOOKAHEAD = 2, 4
+TT_AR_OPT_LOOKAHEAD = 4
 TT_DIFF_OPT_OVERLAP_PREPASS = 1
 TT_DIFF_OPT_FUSED_GN = 2
+TTX_FLASH32, TTX_GEMM_P8, TTX_VOC_MFMA, TTX_GEMM_SKINNY = 0, 1, 2, 3  # ttx_kernel_variant families (include/tortoise_mi355x_test.h)
 
 
 def dtype_code(name):
@@ -35,8 +36,7 @@ class EngineError(RuntimeError):
 
 class GptLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_proj", "b_proj", "ln2_g", "ln2_b",
-                                  "w_fc", "b_fc", "w_proj2", "b_proj2",
-                                  "w_qkv_ln", "c_qkv_ln", "b_qkv_ln", "w_fc_ln", "c_fc_ln", "b_fc_ln")]
+                                  "w_fc", "b_fc", "w_proj2", "b_proj2")]
 
 
 class ArConfig(C.Structure):
@@ -197,17 +197,18 @@ _PROTOS = {
     "tt_prof_classes": (_i, []),
     "tt_prof_class_name": (C.c_char_p, [_i]),
     "tt_prof_read": (_i, [_i, C.POINTER(C.c_double)]),
+}
+# include/tortoise_mi355x_test.h: operator-level TEST entries + the A/B switch (not part of the boundary a maintainer binds)
+_TEST_PROTOS = {
+    "ttx_kernel_variant": (_i, [_i, _i]),
     "tt_op_gemm": (_i, [_i, vp, _i, vp, _i, _i, _i, _i, _i, _i, _i, vp, _i, vp, vp, vp, vp]),
     "tt_op_layernorm": (_i, [_i, vp, _i, _i, vp, vp, _f, _i, vp, vp, vp]),
     "tt_op_groupnorm": (_i, [_i, vp, _i, _i, _i, vp, vp, vp, _i, vp, vp, vp, vp]),
     "tt_op_groupnorm_workspace": (_sz, [_i, _i]),
     "tt_op_gn_gemm": (_i, [_i, vp, _i, _i, vp, vp, _i, vp, vp, _i, vp, vp, vp]),
     "tt_op_gn_gemm_workspace": (_sz, [_i, _i]),
-    "tt_op_resid_ln": (_i, [_i, vp, _i, vp, vp, vp, _i, _i, _i, vp, vp, vp, _i, vp, vp, vp, vp]),
-    "tt_flash_variant": (_i, [_i]),
-    "tt_gemm_variant": (_i, [_i]),
-    "tt_voc_variant": (_i, [_i]),
     "tt_op_flash_attention": (_i, [_i, vp, vp, vp, vp, _i, _i, _i, _i, _i, vp, vp]),
+    "tt_op_decode_attention": (_i, [_i, vp, vp, vp, _i, vp, vp, _i, _i, vp, _i, _i, _i, vp]),
     "tt_op_sample": (_i, [vp, _i, _i, _i, vp, C.POINTER(Sampling), _i, vp, _i, vp, _i, vp]),
     "tt_op_conv1d": (_i, [vp, vp, vp, vp, _i, _i, _i, _i, _i, _i, _f, _i, _f, vp]),
     "tt_op_convt1d": (_i, [vp, vp, vp, vp, _i, _i, _i, _f, vp]),
@@ -230,7 +231,7 @@ def load_library():
     # both have to bind to the ONE HIP runtime that torch ships (libamdhip64.so.7, resolved by SONAME).
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in _PROTOS.items():
+    for name, (res, args) in list(_PROTOS.items()) + list(_TEST_PROTOS.items()):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
@@ -249,9 +250,9 @@ def init():
     if not _initialised:
         check(lib.tt_init())
         # process-wide kernel A/B switches (diagnostics; the defaults are the measured winners)
-        for env, fn in (("TT_GEMM_VARIANT", "tt_gemm_variant"), ("TT_FLASH_VARIANT", "tt_flash_variant"), ("TT_VOC_VARIANT", "tt_voc_variant")):
+        for env, which in (("TT_GEMM_VARIANT", TTX_GEMM_P8), ("TT_FLASH_VARIANT", TTX_FLASH32), ("TT_VOC_VARIANT", TTX_VOC_MFMA), ("TT_GEMM_SKINNY", TTX_GEMM_SKINNY)):
             if os.environ.get(env, "") != "":
-                getattr(lib, fn)(int(os.environ[env]))
+                lib.ttx_kernel_variant(which, int(os.environ[env]))
         _initialised = True
     return lib
 

@@ -55,25 +55,10 @@ def _p(t):
 
 
 # ----------------------------------------------------------------------------------------- AR
-def fold_layernorm(h, w, b, gamma, beta):
-    """LayerNorm folded into the Linear that consumes it (the five-launch decode step, csrc/gemm.h ln_stats):
-        LN(x) W^T + b = rstd * (x Wg^T - mean * colsum) + b',   Wg = W * gamma (rounded to the operand type ONCE, from the fp32 product),
-        colsum[n] = sum_k Wg[n][k] of the ROUNDED weight (what the MFMA multiplies the raw rows with), b' = b + W beta.
-    w: [out][in] fp32 (the reference's layout after the Conv1D transpose).  Returns (Wg operand, colsum f32, b' f32)."""
-    w = w.detach().to(device=h.device, dtype=torch.float64)
-    gamma = gamma.detach().to(device=h.device, dtype=torch.float64)
-    beta = beta.detach().to(device=h.device, dtype=torch.float64)
-    wg = h.op((w * gamma[None, :]).float())
-    colsum = h.f32(wg.double().sum(dim=1))
-    bias = h.f32(b.detach().to(device=h.device, dtype=torch.float64) + w @ beta)
-    return wg, colsum, bias
-
-
 def pack_ar(sd, cfg: ARConfig, device, dtype):
     h = Holder(device, dtype)
     wop = h.op
     layers = (E.GptLayer * cfg.layers)()
-    fold = dtype != E.TT_F32 and cfg.model_dim % 64 == 0 and cfg.model_dim <= 1024
     for i in range(cfg.layers):
         p = f"gpt.h.{i}"
         L = layers[i]
@@ -89,11 +74,6 @@ def pack_ar(sd, cfg: ARConfig, device, dtype):
         L.b_fc = _p(h.f32(sd[f"{p}.mlp.c_fc.bias"]))
         L.w_proj2 = _p(wop(sd[f"{p}.mlp.c_proj.weight"].t()))
         L.b_proj2 = _p(h.f32(sd[f"{p}.mlp.c_proj.bias"]))
-        if fold:
-            wg, cs, bb = fold_layernorm(h, sd[f"{p}.attn.c_attn.weight"].t(), sd[f"{p}.attn.c_attn.bias"], sd[f"{p}.ln_1.weight"], sd[f"{p}.ln_1.bias"])
-            L.w_qkv_ln, L.c_qkv_ln, L.b_qkv_ln = _p(wg), _p(cs), _p(bb)
-            wg, cs, bb = fold_layernorm(h, sd[f"{p}.mlp.c_fc.weight"].t(), sd[f"{p}.mlp.c_fc.bias"], sd[f"{p}.ln_2.weight"], sd[f"{p}.ln_2.bias"])
-            L.w_fc_ln, L.c_fc_ln, L.b_fc_ln = _p(wg), _p(cs), _p(bb)
     w = E.ArWeights()
     w.layers_host = layers
     w.lnf_g = _p(h.f32(sd["gpt.ln_f.weight"]))

@@ -71,16 +71,16 @@ class ArStage:
         self.h = E.vp()
         E.check(self.lib.tt_ar_create(C.byref(c), C.byref(self.w.weights), C.byref(self.h)))
         # A/B switches of the measurement scripts (scripts/ab_stage.py); the product default is what tt_ar_create sets
-        for env, opt in (("TT_AR_FUSED_STEP", E.TT_AR_OPT_FUSED_STEP), ("TT_AR_LOOKAHEAD", E.TT_AR_OPT_LOOKAHEAD)):
+        for env, opt in (("TT_AR_LOOKAHEAD", E.TT_AR_OPT_LOOKAHEAD),):
             if os.environ.get(env):
                 self.set_option(opt, int(os.environ[env]))
 
     def set_option(self, option, value):
-        """tt_ar_set_option: five- or seven-launch decode step (two roundings of the same network) / host lookahead (no effect on the codes)."""
+        """tt_ar_set_option: host lookahead of the paced decode loop (no effect on the codes)."""
         E.check(self.lib.tt_ar_set_option(self.h, int(option), int(value)))
 
     def stat(self, which):
-        """tt_ar_stat: 0 decode-step graph captures, 1 queue drains of the launch loop, 2 launches per decode step, 3 five-launch form in use."""
+        """tt_ar_stat: 0 decode-step graph captures, 1 queue drains of the launch loop, 2 launches per decode step."""
         return self.lib.tt_ar_stat(self.h, int(which))
 
     def guard(self, reset=True):
