@@ -69,7 +69,7 @@ static int prof_class(int tile, int epi, bool conv, bool stats = false) {
 static void plan_core(const GemmArgs& a, int epi, GemmPlan& p, int force_tile = -1, int force_bm = 0, int force_bn = 0) {
   int tile = force_tile >= 0 ? force_tile : pick_tile(a, epi);
   const int bm = force_bm ? force_bm : tile == TILE_32x16 ? 32 : (tile == TILE_64x64 || tile == TILE_64x16) ? 64 : tile == TILE_256x256 ? 256 : 128;
-  const int bn = force_bn ? force_bn : (tile == TILE_32x16 || tile == TILE_64x16) ? 16 : tile == TILE_256x256 ? 256 : tile == TILE_128x128 ? 128 : 64;
+  const int bn = force_bn ? force_bn : (tile == TILE_32x16 || tile == TILE_64x16) ? kSkinnyBN : tile == TILE_256x256 ? 256 : tile == TILE_128x128 ? 128 : 64;
   GemmCore& c = p.core;
   memset(&c, 0, sizeof(c));
   c.A = a.A; c.W = a.W; c.lda = a.lda; c.ldw = a.ldw; c.M = a.M; c.N = a.N;

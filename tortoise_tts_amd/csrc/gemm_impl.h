@@ -974,7 +974,20 @@ static inline bool p8_ok(const GemmCore& c, const dim3& grid) {
 // L2 -> LDS path; 16-column tiles spread the same weight stream over 192 - 256 CUs at 96 KB each.  Same MFMA, same k order per output
 // element, same split-K ranges: a row's bits do not depend on which tile computed it (asserted by the batch-independence tests).
 enum Tile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x256 = 3, TILE_32x16 = 4, TILE_64x16 = 5, TILE_COUNT = 6 };
-constexpr int kSkinnyStages = 8;
+// build knobs of the A/B runs (build.py --variant): ring depth, tile width, waves (measured: profiles/r06_ab_small_batch_decode.txt)
+#ifndef TT_SKINNY_ST
+#define TT_SKINNY_ST 8     // 32 x 16: 4 / 8 / 12 stages = 1.117 / 1.078 / 1.118 ms per step at 32 candidates
+#endif
+#ifndef TT_SKINNY_ST64
+#define TT_SKINNY_ST64 4   // 64 x 16: 4 / 8 / 12 stages = 1.237 / 1.282 / 1.355 ms per step at 64 candidates (the split-K projections have 4 k-tiles per range:
+#endif                     // a deeper ring only re-requests the last tile)
+#ifndef TT_SKINNY_BN
+#define TT_SKINNY_BN 16
+#endif
+#ifndef TT_SKINNY_NW
+#define TT_SKINNY_NW 2
+#endif
+constexpr int kSkinnyStages = TT_SKINNY_ST, kSkinnyStages64 = TT_SKINNY_ST64, kSkinnyBN = TT_SKINNY_BN, kSkinnyNW = TT_SKINNY_NW, kSkinnyWM = 2;
 // EPI_STD kernel variants: the generic one tests everything at run time, the others compile the unused features out
 enum StdVariant { V_GEN = 0, V_NONE = 1, V_SLAB = 2, V_GELU_T = 3, V_ST_F32 = 4, V_ST_RES = 5, V_ST_A2 = 6, V_BIAS_T = 7, V_SERIAL = 8, V_COUNT = 9 };
 constexpr int kNoKernel = -100;  // visit_*: this combination is not instantiated
@@ -1065,7 +1078,7 @@ static int visit_std_tile(int variant, bool conv, bool al, V&& v) {
 template <typename T, int BM, int BN, typename V>
 static int visit_skinny(int variant, bool conv, bool al, V&& v) {
   if (conv || !al) return kNoKernel;
-  constexpr int NW = 2, WM = 2, ST = kSkinnyStages;
+  constexpr int NW = kSkinnyNW, WM = kSkinnyWM, ST = BM == 32 ? kSkinnyStages : kSkinnyStages64;
   switch (variant) {
     case V_GEN: return v(KernelRef<T, BM, BN, NW, WM, ST, EpiStd<T, -1, 0, -1>, false, true, 0>{});
     case V_NONE: return v(KernelRef<T, BM, BN, NW, WM, ST, EpiStd<T, ACT_NONE, 0, -1>, false, true, 0>{});
@@ -1078,8 +1091,8 @@ static int visit_skinny(int variant, bool conv, bool al, V&& v) {
 template <typename T, typename V>
 static int visit_std(int tile, int variant, bool conv, bool al, V&& v) {
   switch (tile) {
-    case TILE_32x16: return visit_skinny<T, 32, 16>(variant, conv, al, v);
-    case TILE_64x16: return visit_skinny<T, 64, 16>(variant, conv, al, v);
+    case TILE_32x16: return visit_skinny<T, 32, kSkinnyBN>(variant, conv, al, v);
+    case TILE_64x16: return visit_skinny<T, 64, kSkinnyBN>(variant, conv, al, v);
     case TILE_256x256: return visit_std_tile<T, 256, 256, 16, 4, 2>(variant, conv, al, v);   // 4 x 4 waves of 64 x 64, two 64 KB stages
     case TILE_128x128: return visit_std_tile<T, 128, 128, 8, 2, 2>(variant, conv, al, v);
     case TILE_128x64: return visit_std_tile<T, 128, 64, 8, 4, 4>(variant, conv, al, v);   // 4 x 2 waves of 32 x 32: 1 LDS fragment read per MFMA (2 x 4 of 64 x 16: 1.25)
@@ -1090,8 +1103,8 @@ template <typename T, typename Epi, typename V>
 static int visit_qkv(int tile, V&& v) {
   if (tile == TILE_32x16 || tile == TILE_64x16) {  // decode-step QKV scatter only
     if constexpr (Epi::kId == 2) {
-      if (tile == TILE_32x16) return v(KernelRef<T, 32, 16, 2, 2, kSkinnyStages, Epi, false, true, 0>{});
-      return v(KernelRef<T, 64, 16, 2, 2, kSkinnyStages, Epi, false, true, 0>{});
+      if (tile == TILE_32x16) return v(KernelRef<T, 32, kSkinnyBN, kSkinnyNW, kSkinnyWM, kSkinnyStages, Epi, false, true, 0>{});
+      return v(KernelRef<T, 64, kSkinnyBN, kSkinnyNW, kSkinnyWM, kSkinnyStages64, Epi, false, true, 0>{});
     } else {
       return kNoKernel;
     }
