@@ -188,6 +188,10 @@ void tt_clvp_destroy(tt_clvp* h);
 /* text int32 [T] (one prompt, evaluated once instead of B times — api.py:463 repeats it),
  * codes int32 [B][n] -> scores f32 [B]. */
 int tt_clvp_score(tt_clvp* h, const int* text, int T, const int* codes, int B, int n, float* scores, void* stream);
+/* G <= 16 utterances in ONE speech-tower pass (long-form reading, tortoise/read.py:66-71 ranks its chunks one call after the other):
+ * texts int32 = the G token sequences back to back, T_host[g] their lengths (HOST array); codes int32 [G * N][n], candidates
+ * [g * N, (g + 1) * N) belong to utterance g; scores f32 [G * N].  Every score equals tt_clvp_score's on that utterance alone, bit for bit. */
+int tt_clvp_score_groups(tt_clvp* h, const int* texts, const int* T_host, int G, const int* codes, int N, int n, float* scores, void* stream);
 int tt_clvp_guard(tt_clvp* h, int reset);  /* operand-overflow guard of this stage, see tt_ar_guard */
 
 /* ============================================================================================

@@ -54,7 +54,8 @@ int tt_op_sample(const float* logits, int ldl, int B, int V, unsigned* seen, con
 int tt_op_conv1d(const float* x, const float* w, const float* bias, float* y, int Cin, int Cout, int T, int k, int dilation,
                  int reflect, float in_slope, int out_act, float out_slope, void* stream);
 int tt_op_convt1d(const float* x, const float* w, const float* bias, float* y, int C, int Tin, int stride, float in_slope, void* stream);
-int tt_op_lvc(const float* x_in, const float* kernels, int ldk, int koff, const float* bias, int ldb, int boff, float* x, int L,
+/* location-variable convolution + gate (vocoder.py:182-216, 178-179); kernels [L][ldk] in the operand type `dtype` (TT_F32: float) */
+int tt_op_lvc(int dtype, const float* x_in, const void* kernels, int ldk, int koff, const float* bias, int ldb, int boff, float* x, int L,
               int hop, void* stream);
 
 #ifdef __cplusplus

@@ -181,6 +181,23 @@ def main():
                 chk(lib.tt_kb_kv_pattern(mode, 256, 16, tmax, 30, 10, C.byref(us)))
                 mb = 256 * 16 * 32768 / 1e6
                 print(f"kvpat tmax {tmax:3d} {tag:60s}: {us.value:7.2f} us per launch of {mb:.0f} MB = {mb / us.value:5.2f} TB/s", flush=True)
+    if "attn_line" in which:  # round 6: T(t) of the product decode attention against a pure-load kernel of its geometry, two bursts (K, then V) and one
+        lib.tt_kb_kv_pattern2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(D)]
+        for B in (256, 32):
+            for t in (16, 32, 64, 96, 128):
+                nl = t // 8
+                by = (B * t) * 16 * 64 * 2 * 2
+                row = [f"attn_line B={B:3d} own keys={t:3d} ({by / 1e6:6.1f} MB)"]
+                us, _ = attn(0, B, 16, 59, t, 208, 30, chain=30)
+                row.append(f"product kernel {us:6.2f} us")
+                for ob, tag in ((0, "loads only, K burst then V burst"), (1, "loads only, ONE burst")):
+                    u2 = D(0)
+                    if ob and nl > 12:
+                        row.append(f"{tag}: (register budget)")
+                        continue
+                    chk(lib.tt_kb_kv_pattern2(nl, ob, B, 16, 208, 30, 10, C.byref(u2)))
+                    row.append(f"{tag} {u2.value:6.2f} us")
+                print(" | ".join(row), flush=True)
     if "bw3" in which:   # working-set series: what does a set resident in the Infinity Cache (256 MiB) stream at, against one that only HBM holds?
         for mib in (16, 64, 128, 192, 512, 2048, 8192):
             for nb in (512, 1024):

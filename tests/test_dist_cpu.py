@@ -160,6 +160,8 @@ def _longform_worker(rank, world, port, out_dir, ubatch=1, nsamp=2, tag=""):
         if ubatch > 1 and mine > 1:
             assert not calls and tts.ar.group_batches >= 1  # the chunks went through shared decode batches, not one call per chunk
             assert sum(tts.diffusion.batched) + (mine - sum(tts.diffusion.batched)) == mine
+            # round 6: the CLVP ranking of a wave is ONE grouped call (one speech-tower pass), not one call per chunk
+            assert sum(tts.clvp.grouped) == mine and len(tts.clvp.grouped) == -(-mine // ubatch), tts.clvp.grouped
         else:
             assert calls and all(c == 5 for c in calls)  # the same seed for every chunk (read.py:54, 70-71)
             assert len(calls) == mine

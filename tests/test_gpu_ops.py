@@ -301,13 +301,18 @@ def test_univnet_kernels(lib):
         kb = dev(torch.randn(L, 256, generator=g) * 0.1)
         j = 2
         xr = xres.clone()
-        E.check(lib.tt_op_lvc(E.ptr(xin), E.ptr(kern), 4 * 6144, j * 6144, E.ptr(kb), 256, j * 64, E.ptr(xr), L, hop, None))
-        torch.cuda.synchronize()
-        kk = kern[:, j * 6144:(j + 1) * 6144].reshape(L, 32, 64, 3).permute(1, 2, 3, 0)[None].cpu()  # [1, i, o, k, L]
-        bb = kb[:, j * 64:(j + 1) * 64].t()[None].cpu()
-        o = O.location_variable_convolution(xin[None].cpu(), kk, bb, hop)
-        ref = xres.cpu() + (torch.sigmoid(o[:, :32]) * torch.tanh(o[:, 32:]))[0]
-        report(f"lvc hop={hop}", xr, ref, 1e-5)
+        # round 6: the predicted kernels arrive in the operand type the KernelPredictor GEMM wrote them in (f32 in the verification mode);
+        # the arithmetic is f32 on the widened values either way, so every form must match the oracle on the SAME (rounded) kernels
+        for kdt, tdt_k, kname in ((E.TT_F32, torch.float32, "f32"), (E.TT_F16, torch.float16, "f16"), (E.TT_BF16, torch.bfloat16, "bf16")):
+            kern_t = kern.to(tdt_k).contiguous()
+            xr = xres.clone()
+            E.check(lib.tt_op_lvc(kdt, E.ptr(xin), E.ptr(kern_t), 4 * 6144, j * 6144, E.ptr(kb), 256, j * 64, E.ptr(xr), L, hop, None))
+            torch.cuda.synchronize()
+            kk = kern_t.float()[:, j * 6144:(j + 1) * 6144].reshape(L, 32, 64, 3).permute(1, 2, 3, 0)[None].cpu()  # [1, i, o, k, L]
+            bb = kb[:, j * 64:(j + 1) * 64].t()[None].cpu()
+            o = O.location_variable_convolution(xin[None].cpu(), kk, bb, hop)
+            ref = xres.cpu() + (torch.sigmoid(o[:, :32]) * torch.tanh(o[:, 32:]))[0]
+            report(f"lvc hop={hop} kernels {kname}", xr, ref, 1e-5)
 
 
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)

@@ -167,3 +167,31 @@ def test_skinny_decode_tiles_are_bit_identical_to_the_64x64_tile(lib, name, dt, 
         else:
             got, ref = outs[0][0], ref + bias
         report(f"skinny GEMM {name} M={M} N={N} K={K} splitk={sk} {form}", got, ref, 2e-5 if form != "t" else {"bf16": 4e-3, "f16": 6e-4}[name])
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@torch.no_grad()
+def test_grouped_clvp_scores_equal_scoring_every_utterance_alone(sds, name, dt, tdt, tol):
+    """tt_clvp_score_groups (long-form reading: the utterances of a tts_many wave ranked in ONE speech-tower pass; tortoise/read.py:66-71 +
+    api.py:460-477 score chunk after chunk): 3 utterances with texts of different lengths x 8 candidates of 40 codes on the 768 / 12 / 20
+    towers - every score is bit-identical to tt_clvp_score on that utterance alone, and both track the oracle."""
+    from tortoise_tts_amd.config import CLVPConfig
+    cfg = CLVPConfig()
+    g = torch.Generator().manual_seed(12)
+    texts = [torch.randint(1, 255, (1, T), generator=g) for T in (23, 61, 40)]
+    N, n = 8, 40
+    codes = torch.randint(0, 8192, (3 * N, n), generator=g)
+    st = stages.ClvpStage(sds["clvp"], cfg, dtype=dt, max_rows=3 * N * n)
+    grouped = st.score_groups(texts, codes).cpu()
+    alone = torch.cat([st.score(t, codes[i * N:(i + 1) * N]).cpu() for i, t in enumerate(texts)])
+    small = stages.ClvpStage(sds["clvp"], cfg, dtype=dt, max_rows=N * n)  # capacity of ONE utterance: the grouped call falls back to per-utterance passes
+    assert torch.equal(small.score_groups(texts, codes).cpu(), alone)
+    small.close()
+    st.close()
+    assert torch.equal(grouped, alone), "a candidate's CLVP score depends on which utterances share its speech-tower pass"
+    from tests.gpu_util import quantize_sd
+    sdq = quantize_sd(sds["clvp"], tdt)
+    want = torch.cat([O.clvp_score(sdq, cfg, t.long().repeat(N, 1), codes[i * N:(i + 1) * N]) for i, t in enumerate(texts)])
+    err = float((grouped - want).abs().max()) / float(want.abs().max())
+    print(f"[parity] grouped CLVP scores (3 utterances x {N} candidates) {name} vs oracle: max_abs/scale={err:.3e} (tol {tol:.1e})")
+    assert err < tol

@@ -240,7 +240,9 @@ class TextToSpeech:
                                      max_text=c["max_text_tokens"], max_new_tokens=c["max_mel_tokens"], max_latent_candidates=4,
                                      kv_cache=self.kv_cache, max_groups=self.utterance_batch)
         elif name == "clvp":
-            self.clvp = stages.ClvpStage(self._sd("clvp"), self.clvp_cfg, self.device, dt, max_rows=max(c["cap"], 8) * c["max_mel_tokens"])
+            # (tts_many ranks the utterances of a wave in ONE speech-tower pass: capacity for utterance_batch x cap candidates)
+            self.clvp = stages.ClvpStage(self._sd("clvp"), self.clvp_cfg, self.device, dt,
+                                         max_rows=max(c["cap"], 8) * c["max_mel_tokens"] * self.utterance_batch)
         elif name == "diffusion":
             self.diffusion = stages.DiffusionStage(self._sd("diffusion"), self.diff_cfg, self.device, dt, max_seq=c["max_S"],
                                                    max_codes=c["max_mel_tokens"] + 8, max_steps=512, max_batch=self.utterance_batch)
@@ -502,8 +504,9 @@ class TextToSpeech:
         Returns [tts(text, ...) for text in texts] (k = 1: one clip f32 [1, 1, n] per text), computed with the autoregressive stage
         batched over `utterance_batch` utterances at a time: their candidates share one decode batch (own prefix, own Philox key per
         utterance), so every weight matrix streams once per step for all of them and the sampled codes of an utterance are
-        bit-identical to rendering it alone.  CLVP ranking, the latent re-pass, diffusion and UnivNet then run per utterance exactly
-        as in tts().  Single-rank instances only (long-form reading spreads whole chunks over the ranks, longform.py)."""
+        bit-identical to rendering it alone.  With utterance_batch > 1 the CLVP ranking of a wave is ONE speech-tower pass over all its
+        candidates (every score the bits of scoring the utterance alone) and the denoiser runs in shared, padded passes; the latent re-pass
+        and UnivNet (2 ms per utterance) run per utterance as in tts().  Single-rank instances only (long-form reading spreads whole chunks over the ranks, longform.py)."""
         if self.world != 1:
             raise ValueError("tts_many batches utterances on one GPU: build TextToSpeech(candidate_sharding=False)")
         settings = dict(kwargs)
@@ -582,10 +585,8 @@ class TextToSpeech:
         sched = Schedule(int(settings.get("diffusion_iterations", 100)), self.diff_cfg.trained_steps, settings.get("cond_free", True),
                          settings.get("cond_free_k", 2))
 
-        def prepare(t, smp):
-            """CLVP winner + latent re-pass of one utterance (api.py:447-524) and its diffusion inputs with the noise tts() would draw."""
-            fixed = fix_autoregressive_output(smp.to(dev).long(), stop)
-            scores = self.clvp.score(t, fixed)
+        def prepare(t, fixed, scores):
+            """Winner + latent re-pass of one utterance (api.py:477-524) and its diffusion inputs with the noise tts() would draw."""
             best = tdist.topk_lowest_index(scores, 1)
             best_results = fixed.to(torch.int32)[best].long()
             self.last_best_codes = best_results
@@ -629,7 +630,10 @@ class TextToSpeech:
             sync_current()
             t_host["ar_s"] += _time.perf_counter() - t0
             t0 = _time.perf_counter()
-            prepared = [prepare(toks[j], smp) for j, smp in zip(idx, samples)]
+            # CLVP ranking of the whole wave in ONE speech-tower pass (api.py:460-477 per utterance; read.py:66-71 one call per chunk)
+            fixed = [fix_autoregressive_output(smp.to(dev).long(), stop) for smp in samples]
+            scores_all = self.clvp.score_groups([toks[j] for j in idx], torch.cat(fixed, dim=0))
+            prepared = [prepare(toks[j], fx, scores_all[g * N:(g + 1) * N]) for g, (j, fx) in enumerate(zip(idx, fixed))]
             sync_current()
             t_host["rank_s"] += _time.perf_counter() - t0
             t0 = _time.perf_counter()

@@ -171,11 +171,11 @@ int tt_op_convt1d(const float* x, const float* w, const float* bias, float* y, i
   return convt1d_launch(a, (hipStream_t)stream);
 }
 
-int tt_op_lvc(const float* x_in, const float* kernels, int ldk, int koff, const float* bias, int ldb, int boff, float* x, int L, int hop,
+int tt_op_lvc(int dtype, const float* x_in, const void* kernels, int ldk, int koff, const float* bias, int ldb, int boff, float* x, int L, int hop,
               void* stream) {
   LvcArgs a;
   memset(&a, 0, sizeof(a));
-  a.x_in = x_in; a.kernels = kernels; a.ldk = ldk; a.koff = koff; a.bias = bias; a.ldb = ldb; a.boff = boff; a.x = x; a.L = L; a.hop = hop;
+  a.x_in = x_in; a.kernels = kernels; a.dtype = dtype; a.ldk = ldk; a.koff = koff; a.bias = bias; a.ldb = ldb; a.boff = boff; a.x = x; a.L = L; a.hop = hop;
   a.in_slope = -1.f;
   return lvc_launch(a, (hipStream_t)stream);
 }

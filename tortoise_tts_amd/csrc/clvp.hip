@@ -103,7 +103,7 @@ int tt_clvp_create(const tt_clvp_config* cfg, const tt_clvp_tower* text, const t
   if (!rc) rc = e->arena.alloc_t(&e->enc, rows * D);
   if (!rc) rc = e->arena.alloc_t(&e->pooled, rows * D / 8 + D);
   if (!rc) rc = e->arena.alloc(&e->pooled_t, (rows * D / 8 + D) * es);
-  if (!rc) rc = e->arena.alloc_t(&e->text_latent, cfg->latent_dim);
+  if (!rc) rc = e->arena.alloc_t(&e->text_latent, 16 * (size_t)cfg->latent_dim);  // one row per utterance of a tt_clvp_score_groups call
   if (!rc) rc = e->arena.alloc_t(&e->speech_latent, (rows / 8 + 8) * cfg->latent_dim);
   if (!rc) rc = e->arena.alloc_t(&e->guard, 4);
   if (!rc && hipHostMalloc((void**)&e->guard_host, 4 * sizeof(int)) != hipSuccess) { set_error("tt_clvp_create: hipHostMalloc failed"); rc = -2; }
@@ -134,6 +134,28 @@ int tt_clvp_score(tt_clvp* e, const int* text, int T, const int* codes, int B, i
   TT_TRY(clvp_tower_run(e, e->text, text, 1, T, e->text_latent, s));
   TT_TRY(clvp_tower_run(e, e->speech, codes, B, n, e->speech_latent, s));
   TT_TRY(clvp_score_launch(e->text_latent, 1, e->speech_latent, e->temperature, scores, B, e->cfg.latent_dim, s));
+  TT_CHECK_HIP(hipMemcpyAsync(e->guard_host, e->guard, sizeof(int), hipMemcpyDeviceToHost, s));
+  return e->sb.leave(us);
+}
+
+// Several utterances of one voice in ONE speech-tower pass (long-form reading: tortoise/read.py:66-71 scores its chunks one after the other,
+// api.py:460-477 each time): utterance g has its own text (its tower pass is a few dozen rows) and candidates [g * N, (g + 1) * N) of `codes`.
+// A candidate's score is the same bits as from tt_clvp_score on its utterance alone (row-local towers, batch-independent GEMM k order).
+int tt_clvp_score_groups(tt_clvp* e, const int* texts, const int* T_host, int G, const int* codes, int N, int n, float* scores, void* stream) {
+  TT_REQUIRE(e && texts && T_host && codes && scores, "tt_clvp_score_groups: null argument");
+  TT_REQUIRE(G >= 1 && G <= 16 && N >= 1 && n >= 8 && (size_t)G * N * n <= (size_t)e->cfg.max_rows, "tt_clvp_score_groups: %d utterances x %d candidates x %d codes exceed capacity %d rows (<= 16 utterances, n >= 8)", G, N, n, e->cfg.max_rows);
+  hipStream_t us = (hipStream_t)stream, s = e->sb.own;
+  TT_TRY(e->sb.enter(us));
+  const int LD = e->cfg.latent_dim;
+  size_t off = 0;
+  for (int g = 0; g < G; ++g) {
+    TT_REQUIRE(T_host[g] >= 1 && T_host[g] <= e->cfg.max_rows, "tt_clvp_score_groups: text %d has %d tokens", g, T_host[g]);
+    TT_TRY(clvp_tower_run(e, e->text, texts + off, 1, T_host[g], e->text_latent + (size_t)g * LD, s));
+    off += T_host[g];
+  }
+  TT_TRY(clvp_tower_run(e, e->speech, codes, G * N, n, e->speech_latent, s));
+  for (int g = 0; g < G; ++g)
+    TT_TRY(clvp_score_launch(e->text_latent + (size_t)g * LD, 1, e->speech_latent + (size_t)g * N * LD, e->temperature, scores + (size_t)g * N, N, LD, s));
   TT_CHECK_HIP(hipMemcpyAsync(e->guard_host, e->guard, sizeof(int), hipMemcpyDeviceToHost, s));
   return e->sb.leave(us);
 }

@@ -725,6 +725,68 @@ extern "C" int tt_kb_kv_pattern(int mode, int B, int heads, int tmax, int chain,
   return rc;
 }
 
+// Round 6: the same probe with NL loads (= 8 NL keys) per burst, product layout, and ONE burst instead of two (K and V requests all issued before the first
+// use): the T(t) line of a pure-load kernel of the decode attention's geometry - what is left of decode_attn_lds_kernel's intercept once the loads are free.
+template <int NL, bool ONE_BURST>
+__global__ __launch_bounds__(256, 4) void kv_pattern2_kernel(const char* kbuf, const char* vbuf, size_t region, int tmax, float* sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t w = (size_t)blockIdx.y * gridDim.x * 4 + (size_t)blockIdx.x * 4 + wave;
+  const size_t kblk = (size_t)8 * tmax * 16, vblk = (size_t)tmax * 128;
+  const char* kb = kbuf + region + w * kblk;
+  const char* vb = vbuf + region + w * vblk;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 k[NL], v[NL];
+  // K: NL loads = NL / 8 slots of 64 keys x 8 chunks (chunk-major runs of 1 KB per 64 keys); V: NL loads of 8 rows (1 KB contiguous each)
+#pragma unroll
+  for (int u = 0; u < NL; ++u) k[u] = *(const f32x4*)(kb + (size_t)(u & 7) * tmax * 16 + (size_t)(u >> 3) * 1024 + lane * 16);
+  if (ONE_BURST) {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) v[u] = *(const f32x4*)(vb + (size_t)u * 1024 + lane * 16);
+  }
+#pragma unroll
+  for (int u = 0; u < NL; ++u) acc += k[u];
+  if (!ONE_BURST) {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) v[u] = *(const f32x4*)(vb + (size_t)u * 1024 + lane * 16);
+  }
+#pragma unroll
+  for (int u = 0; u < NL; ++u) acc += v[u];
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = acc[0];
+}
+
+extern "C" int tt_kb_kv_pattern2(int nl, int one_burst, int B, int heads, int tmax, int chain, int reps, double* us_out) {
+  Arena ar;
+  GraphTimer gt;
+  TT_TRY(gt.init());
+  const size_t nw = (size_t)B * heads;
+  const size_t kblk = (size_t)8 * tmax * 16, vblk = (size_t)tmax * 128;
+  const size_t region = nw * (kblk + vblk) + 65536;
+  void* kbuf = nullptr; void* vbuf = nullptr; float* sink = nullptr;
+  int rc = dev_bf16(ar, &kbuf, region * chain / 2 + 4096, 5u);
+  if (!rc) rc = dev_bf16(ar, &vbuf, region * chain / 2 + 4096, 6u);
+  if (!rc) rc = ar.alloc_t(&sink, 64);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
+  if (!rc) rc = gt.run([&](hipStream_t s) -> int {
+    for (int i = 0; i < chain; ++i) {
+      const dim3 grid(heads, B / 4);
+      const size_t off = (size_t)i * region;
+#define KVP2(NLV)                                                                                                                        \
+      do {                                                                                                                                \
+        if (one_burst) kv_pattern2_kernel<NLV, true><<<grid, 256, 0, s>>>((const char*)kbuf, (const char*)vbuf, off, tmax, sink);        \
+        else kv_pattern2_kernel<NLV, false><<<grid, 256, 0, s>>>((const char*)kbuf, (const char*)vbuf, off, tmax, sink);                 \
+      } while (0)
+      if (nl == 2) KVP2(2); else if (nl == 4) KVP2(4); else if (nl == 8) KVP2(8); else if (nl == 12) KVP2(12); else KVP2(16);
+#undef KVP2
+    }
+    TT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }, reps, us_out);
+  if (!rc) *us_out /= chain;
+  gt.destroy();
+  ar.release();
+  return rc;
+}
+
 extern "C" int tt_kb_flash(int B, int H, int n, int causal, int relpos, int chain, int reps, double* us_out) {
   Arena ar;
   GraphTimer gt;

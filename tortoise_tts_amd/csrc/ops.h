@@ -230,8 +230,9 @@ struct ConvT1dArgs {
 int convt1d_launch(const ConvT1dArgs& a, hipStream_t stream);
 struct LvcArgs {
   const float* x_in;    // [32][T] conv output (LeakyReLU applied here)
-  const float* kernels; // [L][ldk] row l holds layer j's [32][64][3] block at column koff
-  int ldk, koff;
+  const void* kernels;  // [L][ldk] row l holds layer j's [32][64][3] block at column koff, in the operand type `dtype` (round 6: the
+  int ldk, koff;        // KernelPredictor GEMM writes its result once, in 16 bits; f32 in the fp32 verification mode / the operator tests)
+  int dtype;            // DT_BF16 / DT_F16 / DT_F32
   const float* bias;    // [L][ldb], layer j's [64] block at column boff
   int ldb, boff;
   float* x;             // [32][T] residual stream: x += sigmoid(o[:32]) * tanh(o[32:])

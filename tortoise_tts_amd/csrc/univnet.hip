@@ -163,9 +163,38 @@ int convt1d_launch(const ConvT1dArgs& a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------- location-variable convolution + gate
+// One frame's predicted kernel [6144] in the operand type -> f32 in LDS; returns true when a non-finite tap was staged.
+template <typename T>
+__device__ __forceinline__ bool lvc_stage_kernel(const void* kernels, size_t elem_off, float* wk) {
+  bool bad = false;
+  if constexpr (sizeof(T) == 4) {
+    const float* kg = (const float*)kernels + elem_off;
+    for (int i = threadIdx.x * 4; i < 32 * 64 * 3; i += 1024) {
+      const float4 kv = *(const float4*)(kg + i);
+      bad = bad || !(fabsf(kv.x) < INFINITY) || !(fabsf(kv.y) < INFINITY) || !(fabsf(kv.z) < INFINITY) || !(fabsf(kv.w) < INFINITY);
+      *(float4*)(wk + i) = kv;
+    }
+  } else {
+    typedef typename Vec<T>::x8 x8;
+    const T* kg = (const T*)kernels + elem_off;
+    for (int i = threadIdx.x * 8; i < 32 * 64 * 3; i += 2048) {
+      const x8 kv = *(const x8*)(kg + i);
+      float f[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        f[c] = (float)kv[c];
+        bad = bad || !(fabsf(f[c]) < INFINITY);
+      }
+      *(float4*)(wk + i) = make_float4(f[0], f[1], f[2], f[3]);
+      *(float4*)(wk + i + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    }
+  }
+  return bad;
+}
+
 // vocoder.py:182-216 (dilation 1) fused with the sigmoid*tanh gate and the residual add (vocoder.py:178-179).
 // One block per mel frame l: its [32][64][3] kernel and the (hop+2)-sample input window sit in LDS.
-template <int HOP>
+template <typename KT, int HOP>
 __global__ __launch_bounds__(256) void lvc_kernel(LvcArgs a) {
   constexpr int OG = 256 / HOP;     // output groups across threads
   constexpr int HALF = 32 / OG;     // gate pairs per thread
@@ -173,13 +202,7 @@ __global__ __launch_bounds__(256) void lvc_kernel(LvcArgs a) {
   __shared__ float xs[32][HOP + 2];
   const int l = blockIdx.x;
   const int T = a.L * HOP;
-  const float* kg = a.kernels + (size_t)l * a.ldk + a.koff;
-  bool bad = false;
-  for (int i = threadIdx.x * 4; i < 32 * 64 * 3; i += 1024) {
-    const float4 kv = *(const float4*)(kg + i);
-    bad = bad || !(fabsf(kv.x) < INFINITY) || !(fabsf(kv.y) < INFINITY) || !(fabsf(kv.z) < INFINITY) || !(fabsf(kv.w) < INFINITY);
-    *(float4*)(wk + i) = kv;
-  }
+  const bool bad = lvc_stage_kernel<KT>(a.kernels, (size_t)l * a.ldk + a.koff, wk);
   // an overflowed fp16 KernelPredictor operand shows up HERE as inf / NaN taps; behind the sigmoid * tanh gate it would be a finite sample
   if (a.guard && __any(bad) && (threadIdx.x & 63) == 0) atomicAdd(a.guard, 1);
   for (int i = threadIdx.x; i < 32 * (HOP + 2); i += 256) {
@@ -221,7 +244,7 @@ __global__ __launch_bounds__(256) void lvc_kernel(LvcArgs a) {
 // kidx = 3 ci + tap; K_l is the frame's predicted kernel as the KernelPredictor GEMM left it ([ci][co][tap]: co is the MFMA row, read at a
 // stride of 3 floats - conflict-free).  A wave owns sample blocks of 32 and BOTH output halves of them (sigmoid half rows 0 .. 31, tanh
 // half rows 32 .. 63 land in the same lane / register of two accumulators), so the gate needs no exchange.
-template <int HOP>
+template <typename KT, int HOP>
 __global__ __launch_bounds__(256) void lvc_mfma_kernel(LvcArgs a) {
   constexpr int NSB = HOP / 32;                    // sample blocks per frame
   constexpr int SBW = NSB >= 4 ? NSB / 4 : 1;      // sample blocks per wave (waves beyond NSB idle after the staging)
@@ -229,13 +252,7 @@ __global__ __launch_bounds__(256) void lvc_mfma_kernel(LvcArgs a) {
   __shared__ float xs[32][HOP + 2];
   const int l = blockIdx.x;
   const int T = a.L * HOP;
-  const float* kg = a.kernels + (size_t)l * a.ldk + a.koff;
-  bool bad = false;
-  for (int i = threadIdx.x * 4; i < 32 * 64 * 3; i += 1024) {
-    const float4 kv = *(const float4*)(kg + i);
-    bad = bad || !(fabsf(kv.x) < INFINITY) || !(fabsf(kv.y) < INFINITY) || !(fabsf(kv.z) < INFINITY) || !(fabsf(kv.w) < INFINITY);
-    *(float4*)(wk + i) = kv;
-  }
+  const bool bad = lvc_stage_kernel<KT>(a.kernels, (size_t)l * a.ldk + a.koff, wk);
   // an overflowed fp16 KernelPredictor operand shows up HERE as inf / NaN taps; behind the sigmoid * tanh gate it would be a finite sample
   if (a.guard && __any(bad) && (threadIdx.x & 63) == 0) atomicAdd(a.guard, 1);
   for (int i = threadIdx.x; i < 32 * (HOP + 2); i += 256) {
@@ -283,22 +300,26 @@ __global__ __launch_bounds__(256) void lvc_mfma_kernel(LvcArgs a) {
 }
 
 int lvc_launch(const LvcArgs& a, hipStream_t stream) {
-  if (g_voc_mfma && a.in_slope < 0.f && (a.hop == 64 || a.hop == 256) && a.ldk % 4 == 0 && a.koff % 4 == 0) {
-    ProfScope ps(PROF_LVC, stream, 2.0 * 96 * 64 * (double)a.L * a.hop, 4.0 * (6144.0 + 64) * a.L + 4.0 * 96 * (double)a.L * a.hop);
-    if (a.hop == 64) lvc_mfma_kernel<64><<<a.L, 256, 0, stream>>>(a);
-    else lvc_mfma_kernel<256><<<a.L, 256, 0, stream>>>(a);
-    TT_CHECK_HIP(hipGetLastError());
-    return 0;
-  }
-  TT_REQUIRE(a.ldk % 4 == 0 && a.koff % 4 == 0, "lvc: kernel rows must be 16-byte aligned");
-  // algorithmic bytes: the predicted kernels (L x 6144 f32) are read once, x_in read + x updated
-  ProfScope ps(PROF_LVC, stream, 2.0 * 96 * 64 * (double)a.L * a.hop, 4.0 * (6144.0 + 64) * a.L + 4.0 * 96 * (double)a.L * a.hop);
-  switch (a.hop) {
-    case 8: lvc_kernel<8><<<a.L, 256, 0, stream>>>(a); break;
-    case 64: lvc_kernel<64><<<a.L, 256, 0, stream>>>(a); break;
-    case 256: lvc_kernel<256><<<a.L, 256, 0, stream>>>(a); break;
-    default: set_error("lvc: hop=%d unsupported (8, 64, 256)", a.hop); return -1;
-  }
+  const int eb = a.dtype == DT_F32 ? 4 : 2;
+  const int al = 16 / eb;  // elements per 16-byte staging load
+  TT_REQUIRE(a.dtype == DT_BF16 || a.dtype == DT_F16 || a.dtype == DT_F32, "lvc: unknown kernel dtype %d", a.dtype);
+  TT_REQUIRE(a.ldk % al == 0 && a.koff % al == 0 && ((size_t)a.kernels & 15) == 0, "lvc: kernel rows must be 16-byte aligned");
+  // algorithmic bytes: the predicted kernels (L x 6144, operand type) are read once, x_in read + x updated
+  ProfScope ps(PROF_LVC, stream, 2.0 * 96 * 64 * (double)a.L * a.hop, (double)eb * 6144.0 * a.L + 4.0 * 64 * a.L + 4.0 * 96 * (double)a.L * a.hop);
+  const bool mfma = g_voc_mfma && a.in_slope < 0.f && (a.hop == 64 || a.hop == 256);
+#define TT_LVC(T)                                                                  \
+  do {                                                                             \
+    if (mfma && a.hop == 64) lvc_mfma_kernel<T, 64><<<a.L, 256, 0, stream>>>(a);   \
+    else if (mfma) lvc_mfma_kernel<T, 256><<<a.L, 256, 0, stream>>>(a);            \
+    else if (a.hop == 8) lvc_kernel<T, 8><<<a.L, 256, 0, stream>>>(a);             \
+    else if (a.hop == 64) lvc_kernel<T, 64><<<a.L, 256, 0, stream>>>(a);           \
+    else if (a.hop == 256) lvc_kernel<T, 256><<<a.L, 256, 0, stream>>>(a);         \
+    else { set_error("lvc: hop=%d unsupported (8, 64, 256)", a.hop); return -1; }  \
+  } while (0)
+  if (a.dtype == DT_F32) TT_LVC(float);
+  else if (a.dtype == DT_BF16) TT_LVC(bf16);
+  else TT_LVC(f16);
+#undef TT_LVC
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -1,7 +1,8 @@
 // Stage 3: UnivNetGenerator.inference (reference: tortoise/models/vocoder.py:267-312).
 // Mel-rate KernelPredictor convolutions run on MFMA (conv-GEMM); everything at the audio rate is
-// fp32 VALU over channels-first rows (univnet.hip).  The predicted location-variable kernels are
-// kept in fp32: [L][24576] per LVC block (86 MB at 9.3 s of audio), written once and read once.
+// f32 matrix-core / VALU work over channels-first rows (univnet.hip).  The predicted location-variable kernels are
+// written ONCE, in the operand type, by the KernelPredictor GEMM's epilogue ([L][24576] per LVC block: 43 MB at 9.3 s of
+// audio, f32 until round 5) and read once by the four LVC layers of the block, which widen them on the way into LDS.
 #include "runtime.h"
 #include "../../include/tortoise_mi355x.h"
 
@@ -19,7 +20,7 @@ struct tt_voc {
   float* kp_h = nullptr;     // [L][64] f32 KernelPredictor hidden state
   void* kp_ht = nullptr;     // [L][64] T
   void* kp_t1 = nullptr;     // [L][64] T
-  float* kernels = nullptr;  // [L][24576]
+  void* kernels = nullptr;   // [L][24576] T
   float* kbias = nullptr;    // [L][256]
   float* xa = nullptr;       // [32][T] ping
   float* xb = nullptr;       // [32][T] pong
@@ -58,7 +59,11 @@ int tt_voc_create(const tt_voc_config* cfg, const tt_voc_weights* w, tt_voc** ou
   if (!rc) rc = e->arena.alloc_t(&e->kp_h, (L + 8) * 64);
   if (!rc) rc = e->arena.alloc(&e->kp_ht, (L + 8) * 64 * es);
   if (!rc) rc = e->arena.alloc(&e->kp_t1, (L + 8) * 64 * es);
-  if (!rc) rc = e->arena.alloc_t(&e->kernels, L * 24576);
+#if defined(TT_VOC_KERNELS_F32)  // A/B knob (build.py --variant): the round-5 form, predicted kernels materialised in f32
+  if (!rc) rc = e->arena.alloc(&e->kernels, L * 24576 * 4 + 64);
+#else
+  if (!rc) rc = e->arena.alloc(&e->kernels, L * 24576 * es + 64);
+#endif
   if (!rc) rc = e->arena.alloc_t(&e->kbias, L * 256);
   if (!rc) rc = e->arena.alloc_t(&e->xa, 32 * T);
   if (!rc) rc = e->arena.alloc_t(&e->xb, 32 * T);
@@ -143,7 +148,12 @@ int tt_voc_run(tt_voc* e, const float* mel, int S, const float* z, float* audio,
       TT_TRY(gemm_launch(dt, EPI_STD, g, s));
     }
     g = gemm_args(e->kp_ht, 64, b.w_kp_kernel, 192, L, 24576, 192);
-    g.taps = 3; g.seq_len = L; g.bias = b.b_kp_kernel; g.out_f32 = e->kernels; g.ldo32 = 24576;
+    g.taps = 3; g.seq_len = L; g.bias = b.b_kp_kernel;
+#if defined(TT_VOC_KERNELS_F32)
+    g.out_f32 = (float*)e->kernels; g.ldo32 = 24576;
+#else
+    g.out_t = e->kernels; g.ldot = 24576;
+#endif
     TT_TRY(gemm_launch(dt, EPI_STD, g, s));
     g = gemm_args(e->kp_ht, 64, b.w_kp_bias, 192, L, 256, 192);
     g.taps = 3; g.seq_len = L; g.bias = b.b_kp_bias; g.out_f32 = e->kbias; g.ldo32 = 256;
@@ -156,7 +166,10 @@ int tt_voc_run(tt_voc* e, const float* mel, int S, const float* z, float* audio,
       TT_TRY(conv1d_direct_launch(ca, s));
       LvcArgs la;
       memset(&la, 0, sizeof(la));
-      la.x_in = e->o; la.kernels = e->kernels; la.ldk = 24576; la.koff = j * 6144; la.bias = e->kbias; la.ldb = 256; la.boff = j * 64;
+      la.x_in = e->o; la.kernels = e->kernels; la.dtype = dt; la.ldk = 24576; la.koff = j * 6144; la.bias = e->kbias; la.ldb = 256; la.boff = j * 64;
+#if defined(TT_VOC_KERNELS_F32)
+      la.dtype = DT_F32;
+#endif
       la.x = x; la.L = L; la.hop = hop; la.in_slope = -1.f; la.guard = e->guard;
       TT_TRY(lvc_launch(la, s));
     }

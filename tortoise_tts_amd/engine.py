@@ -167,6 +167,7 @@ _PROTOS = {
     "tt_clvp_create": (_i, [C.POINTER(ClvpConfig), C.POINTER(ClvpTower), C.POINTER(ClvpTower), vp, C.POINTER(vp)]),
     "tt_clvp_destroy": (None, [vp]),
     "tt_clvp_score": (_i, [vp, vp, _i, vp, _i, _i, vp, vp]),
+    "tt_clvp_score_groups": (_i, [vp, vp, C.POINTER(_i), _i, vp, _i, _i, vp, vp]),
     "tt_diff_create": (_i, [C.POINTER(DiffConfig), C.POINTER(DiffWeights), C.POINTER(vp)]),
     "tt_diff_destroy": (None, [vp]),
     "tt_diff_condition": (_i, [vp, vp, _i, vp, vp, _i, vp]),
@@ -212,7 +213,7 @@ _TEST_PROTOS = {
     "tt_op_sample": (_i, [vp, _i, _i, _i, vp, C.POINTER(Sampling), _i, vp, _i, vp, _i, vp]),
     "tt_op_conv1d": (_i, [vp, vp, vp, vp, _i, _i, _i, _i, _i, _i, _f, _i, _f, vp]),
     "tt_op_convt1d": (_i, [vp, vp, vp, vp, _i, _i, _i, _f, vp]),
-    "tt_op_lvc": (_i, [vp, vp, _i, _i, vp, _i, _i, vp, _i, _i, vp]),
+    "tt_op_lvc": (_i, [_i, vp, vp, _i, _i, vp, _i, _i, vp, _i, _i, vp]),
 }
 
 _lib = None

@@ -247,6 +247,28 @@ class ClvpStage:
             outs.append(out)
         return torch.cat(outs)
 
+    def score_groups(self, texts, codes):
+        """Several utterances of one voice (long-form reading): texts = list of G int tensors [1, T_g], codes int [G * N, n] with the N
+        candidates of utterance g in rows [g * N, (g + 1) * N) -> f32 [G * N].  ONE speech-tower pass for as many utterances as the
+        handle's capacity holds (at most 16 per pass); every score equals score() on that utterance alone, bit for bit."""
+        G = len(texts)
+        GN, n = codes.shape
+        assert G >= 1 and GN % G == 0
+        N = GN // G
+        per = max(1, min(16, self.max_rows // max(1, N * n)))
+        if N * n > self.max_rows:  # one utterance's candidates do not fit one pass: fall back to the chunked single-utterance form
+            return torch.cat([self.score(texts[g], codes[g * N:(g + 1) * N]) for g in range(G)])
+        outs = []
+        for g0 in range(0, G, per):
+            sel = texts[g0:g0 + per]
+            flat = torch.cat([_i32(t.reshape(-1), self.device) for t in sel])
+            lens = (C.c_int * len(sel))(*[int(t.numel()) for t in sel])
+            c = _i32(codes[g0 * N:(g0 + len(sel)) * N], self.device)
+            out = torch.empty(c.shape[0], device=self.device, dtype=torch.float32)
+            E.check(self.lib.tt_clvp_score_groups(self.h, E.ptr(flat), lens, len(sel), E.ptr(c), N, n, E.ptr(out), E.stream_ptr()))
+            outs.append(out)
+        return torch.cat(outs)
+
 
 def nearest_interp_index(m, s):
     """Source row of F.interpolate(mode='nearest') for each of s outputs given m inputs
