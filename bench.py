@@ -265,7 +265,10 @@ def stage_rooflines(stages_s, N, M, iters, cond_free, text_tokens):
         ach = v_bytes / stages_s["vocoder_s"] / 1e9
         out["univnet"] = {"bound": "hbm", "algorithmic_bytes": v_bytes, "algorithmic_flops": v_flops, "seconds": stages_s["vocoder_s"],
                           "achieved": ach, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS,
-                          "achieved_tflops_fp32_valu": v_flops / stages_s["vocoder_s"] / 1e12}
+                          "achieved_tflops_fp32_valu": v_flops / stages_s["vocoder_s"] / 1e12,
+                          # the audio-rate layers run on v_mfma_f32_32x32x2_f32 (exact f32 at the f32 VECTOR rate, 157.3 TFLOP/s): what actually bounds
+                          # this stage (removing the conv-output round trip made it slower), next to the HBM line SURVEY 8(d) assigns it
+                          "frac_f32_matrix": v_flops / stages_s["vocoder_s"] / 157.3e12}
     return out
 
 
