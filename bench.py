@@ -272,11 +272,11 @@ def stage_rooflines(stages_s, N, M, iters, cond_free, text_tokens):
     return out
 
 
-PMC_SUMMARY = os.path.join("profiles", "r05_pmc_bench.json")
+PMC_SUMMARY = os.path.join("profiles", "r06_pmc_bench.json")
 
 
 def pmc_traffic(kernel_class):
-    """HBM-side bytes per launch of one kernel class from the committed PMC summary (profiles/r02_pmc_bench.json, written by
+    """HBM-side bytes per launch of one kernel class from the committed PMC summary (profiles/r06_pmc_bench.json, written by
     scripts/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes over this same workload, aggregated
     per kernel class under the names the engine's profiler uses).  Counters cannot be read from inside a timed run, so the
     bench line carries the figure of the last committed PMC pass, corrected as MI355X_MICROARCH.md prescribes for gfx950:

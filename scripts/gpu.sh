@@ -56,7 +56,9 @@ PY
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o prof -- python $OLDPWD/bench.py ${PROF_ARGS:---steps 1 --warmup 1 --no-cpu-baseline --no-roofline} > $OLDPWD/$OUT/prof.log 2>&1); echo "prof rc=$?"
       find $OUT/prof -type f -size +8M -delete; find $OUT/prof -name "*kernel_stats.csv" | head -3; tail -2 $OUT/prof.log ;;
     pmc)
-      timeout 700 bash scripts/pmc_bench.sh > $OUT/pmc_bench.log 2>&1; tail -4 $OUT/pmc_bench.log ;;
+      timeout 700 bash scripts/pmc_bench.sh > $OUT/pmc_bench.log 2>&1; tail -4 $OUT/pmc_bench.log
+      # the bench line of THIS call reads the traffic of THIS build (the committed copy is made from gpurun_out/ afterwards)
+      [ -f $OUT/pmc_bench.json ] && cp $OUT/pmc_bench.json profiles/${ROUND_TAG:-r06}_pmc_bench.json ;;
     pmc_sq)
       PMC_SETS="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_ANY" PMC_JSON=pmc_sq.json \
         timeout 450 bash scripts/pmc_bench.sh > $OUT/pmc_sq.log 2>&1; tail -3 $OUT/pmc_sq.log ;;
