@@ -1,4 +1,4 @@
-"""In-situ A/B of the 256 x 256 GEMM tile kernels (tt_gemm_variant: 1 = 8 waves / eight phases, csrc/gemm_p8.h; 0 = 16 waves / two stages) through
+"""In-situ A/B of the 256 x 256 GEMM tile kernels (ttx_kernel_variant(TTX_GEMM_P8): 1 = 8 waves / eight phases, csrc/gemm_p8.h; 0 = 16 waves / two stages) through
 tt_op_gemm at the large-M product shapes: chains of launches between two events, variants alternating in one process."""
 import math
 import sys

@@ -31,12 +31,12 @@ def main():
     ap.add_argument("--ar-variants", default="",
                     help="';'-separated host-lookahead settings of tt_ar_set_option to time one after the other on ONE handle")
     ap.add_argument("--flash-variants", default="",
-                    help="';'-separated tt_flash_variant settings (1 = 32-query-wave attention kernel, 0 = 16-query waves) to time the diffusion "
+                    help="';'-separated ttx_kernel_variant(TTX_FLASH32) settings (1 = 32-query-wave attention kernel, 0 = 16-query waves) to time the diffusion "
                          "stage with, one fresh stage object each, e.g. '1;0;1;0'")
     ap.add_argument("--gn-variants", default="",
                     help="';'-separated TT_DIFF_OPT_FUSED_GN values (0 = stand-alone applies, 1 = ResBlock in_layers fused, 2 = + the attention norm on "
                          "the QKV GEMM's A path) timed one after the other on ONE diffusion stage object, e.g. '1;2;1;2'")
-    ap.add_argument("--voc-variants", default="", help="';'-separated tt_voc_variant settings (1 = f32-MFMA audio-rate kernels, 0 = VALU) for the 'voc' stage")
+    ap.add_argument("--voc-variants", default="", help="';'-separated ttx_kernel_variant(TTX_VOC_MFMA) settings (1 = f32-MFMA audio-rate kernels, 0 = VALU) for the 'voc' stage")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     args = ap.parse_args()
     from bench import bench_prompt

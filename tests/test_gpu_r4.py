@@ -1,7 +1,7 @@
 """-m gpu, round 4: what changed in the engines' control structure, each asserted as an EQUALITY (these are scheduling changes, the
 arithmetic of a row must not move):
   * (the row-range option of round 4 lost its A/B and left the product in round 5: profiles/r04_ab_ar_subbatches.txt keeps the record;
-    the repeated bit-identity checks it introduced now guard the five-launch decode step, tests/test_gpu_r5.py);
+    the repeated bit-identity checks it introduced now guard the decode step itself, tests/test_gpu_r5.py);
   * the launch loop paced by progress words in pinned memory (no queue drain inside the loop): same codes, same early exit;
   * seeds, row_offset and the caller's code buffer are DATA of the kept decode-step graph (one capture for all of them);
   * the sampler-step graph of the diffusion stage stays on the handle (one capture for several calls with fresh tensors);

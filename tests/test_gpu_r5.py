@@ -213,7 +213,7 @@ def test_vocoder_overflow_guard_sees_what_the_waveform_hides():
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES[:2])
 def test_eight_phase_256_tile_is_bit_identical_to_the_16_wave_tile(name, dt, tdt, tol):
     """csrc/gemm_p8.h (8 waves, eight-phase schedule, counted LDS-DMA waits) against gemm_glds_kernel<256, 256, 16 waves> on the same
-    launches (tt_gemm_variant): the accumulation order per output element is the same, so every output form must agree bit for bit -
+    launches (ttx_kernel_variant(TTX_GEMM_P8)): the accumulation order per output element is the same, so every output form must agree bit for bit -
     ragged M, N not a multiple of the tile, 4 and 16 k-tiles; run several times (a misplaced wait shows as rare wrong tiles)."""
     lib = E.init()
     g = torch.Generator().manual_seed(23)
@@ -252,7 +252,7 @@ def test_eight_phase_256_tile_is_bit_identical_to_the_16_wave_tile(name, dt, tdt
 def test_engines_agree_bit_for_bit_with_either_256_tile(sds):
     """The two 256 x 256 GEMM kernels behind their users: CLVP scores of 64 candidates (QKV-heads and bias -> T epilogues at
     12 800 rows; the GEGLU feed-forward stays on the 16-wave tile) and a full-width denoiser sample of 12 iterations whose conditioning-integrator pre-pass runs its 1 x 1 GEMMs and
-    QKV projections on that tile (statistics, skip and head-layout epilogues) - identical bits with tt_gemm_variant 0 and 1."""
+    QKV projections on that tile (statistics, skip and head-layout epilogues) - identical bits with ttx_kernel_variant(TTX_GEMM_P8, 0 / 1)."""
     from tortoise_tts_amd.config import DiffusionConfig
     from tortoise_tts_amd.schedule import Schedule
     lib = E.init()
