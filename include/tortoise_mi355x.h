@@ -59,7 +59,9 @@ typedef struct tt_ar_config {
   int vocab;             /* number_mel_codes (8194) */
   int start_mel_token, stop_mel_token;
   int mel_pos_len;       /* rows of mel_pos_embedding */
-  int max_batch;         /* candidates decoded together */
+  int max_batch;         /* candidates decoded together.  A handle of <= 4 (16-bit operands, one group) is a streaming-size handle: its decode
+                          * step runs GEMV-shaped kernels (csrc/gemv.hip) - deterministic and the same for every call on the handle, but another
+                          * summation order than larger handles; create handles of >= 5 where codes must not depend on the capacity */
   int max_prefix;        /* max P+1 (conditioning + text + start token) */
   int max_new_tokens;    /* per-sequence KV slots */
   int max_full_rows;     /* rows of the largest teacher-forced pass (k * (1 + T+2 + M+2)) */

@@ -19,11 +19,15 @@ extern "C" {
  *   TTX_VOC_MFMA  1 (default) = UnivNet's dilated 32 -> 32 convolutions and location-variable convolutions (hop 64 / 256) on
  *                 v_mfma_f32_32x32x2_f32 (exact f32), 0 = the thread-per-sample VALU kernels
  *   TTX_GEMM_SKINNY 1 (default) = 32 x 16 / 64 x 16 tiles for the weight-streaming GEMMs of decode batches of <= 64 rows, 0 = 64 x 64 tiles
- *                 (bit-identical results) */
+ *                 (bit-identical results)
+ *   TTX_AR_GEMV   a level: autoregressive handles created with max_batch <= 4 (the streaming engine) run the decode step's GEMMs
+ *                 2 (default) = GEMV-shaped with the layer norms inside the QKV / c_fc launches (csrc/gemv.hip: five launches per layer),
+ *                 1 = GEMV-shaped behind row-norm launches of their own (seven), 0 = on the MFMA tiles.  Read at tt_ar_create. */
 #define TTX_FLASH32 0
 #define TTX_GEMM_P8 1
 #define TTX_VOC_MFMA 2
 #define TTX_GEMM_SKINNY 3
+#define TTX_AR_GEMV 4
 int ttx_kernel_variant(int which, int v);
 
 /* ============================================================================================
@@ -49,6 +53,11 @@ int tt_op_flash_attention(int dtype, const void* q, const void* k, const void* v
  * variant 0 = chosen from the shape, 1 = per-wave prefix kernel, 2 / 3 = shared-prefix kernel with 16 / 4 sequences per workgroup */
 int tt_op_decode_attention(int dtype, const void* q, const void* kp, const void* vp, int P1, const void* kc, const void* vc, int tmax,
                            int tgen, void* out, int B, int heads, int variant, void* stream);
+/* GEMV-shaped decode GEMM (csrc/gemv.hip): A T [M][K], W T [N][K], M <= 4, K in {1024, 2048, 4096}, N % 4 == 0;
+ * epi 0: out_f32 [M][N] = A W^T + bias; 1: out_f32 += A W^T + bias (residual rows, in place); 2: out_t T [M][N] = gelu_tanh(A W^T + bias) */
+int tt_op_gemv(int dtype, const void* A, const void* W, int M, int N, int K, const float* bias, int epi, float* out_f32, void* out_t, void* stream);
+/* out_t[M][N] = gelu_tanh(LayerNorm(x[M][1024] f32; g, b, eps) W^T + bias): the same kernel with the layer norm inside */
+int tt_op_gemv_ln(int dtype, const float* x, const float* g, const float* b, float eps, const void* W, int M, int N, const float* bias, void* out_t, void* stream);
 int tt_op_sample(const float* logits, int ldl, int B, int V, unsigned* seen, const tt_sampling* s, int step, int* unfinished,
                  int stop_token, int* codes, int ldcodes, void* stream);
 int tt_op_conv1d(const float* x, const float* w, const float* bias, float* y, int Cin, int Cout, int T, int k, int dilation,

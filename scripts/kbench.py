@@ -181,6 +181,17 @@ def main():
                 chk(lib.tt_kb_kv_pattern(mode, 256, 16, tmax, 30, 10, C.byref(us)))
                 mb = 256 * 16 * 32768 / 1e6
                 print(f"kvpat tmax {tmax:3d} {tag:60s}: {us.value:7.2f} us per launch of {mb:.0f} MB = {mb / us.value:5.2f} TB/s", flush=True)
+    if "gemv" in which:  # round 6: a GEMV-shaped kernel against the product's skinny MFMA tile at the decode shapes, M = 1 .. 8 rows, cold weights, rotating A
+        lib.tt_kb_gemv_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(D)]
+        for name, N, K in (("qkv", 3072, 1024), ("proj", 1024, 1024), ("fc", 4096, 1024), ("proj2", 1024, 4096), ("lm_head", 8196, 1024)):
+            nw = max(8, int(700e6 // (N * K * 2)))
+            for M in (1, 4, 8):
+                if K == 4096 and M > 4:
+                    continue
+                up = gemm_prod(M, N, K, splitk=1, nw=nw, na=4)
+                u = D(0)
+                chk(lib.tt_kb_gemv_probe(M, N, K, nw, 4, 32, 10, C.byref(u)))
+                print(f"gemv {name:8s} M={M} N={N} K={K}: product (32 x 16 MFMA tile, no split-K) {up:6.2f} us | GEMV probe {u.value:6.2f} us", flush=True)
     if "attn_line" in which:  # round 6: T(t) of the product decode attention against a pure-load kernel of its geometry, two bursts (K, then V) and one
         lib.tt_kb_kv_pattern2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(D)]
         for B in (256, 32):

@@ -27,6 +27,8 @@ def klass(k):
             bm, bn, epi, conv = m.groups()
             return "gemm_glds<%s,%s,%s%s>" % (bm, bn, epi, (",conv" if conv == "true" else ",1x1") if epi == "EpiStd" else "")
         return "gemm_glds<?>"
+    if "gemv_kernel" in k:
+        return "gemv_kernel"
     for pat, name in (("flash32_kernel", "flash_kernel"), ("conv1d_mfma", "conv1d_direct_kernel"), ("lvc_mfma", "lvc_kernel"), ("flash_lds_kernel", "flash_kernel"), ("flash_kernel", "flash_kernel"), ("decode_attn_lds_kernel", "decode_attn_kernel"), ("decode_attn_kernel", "decode_attn_kernel"),
                       ("gn_apply", "gn_apply_kernel(+gn_stats)"), ("gn_stats", "gn_apply_kernel(+gn_stats)"), ("rownorm", "rownorm_kernel"),
                       ("sample_kernel", "sample_kernel"), ("lvc_kernel", "lvc_kernel"), ("conv1d_direct", "conv1d_direct_kernel"), ("convt1d", "convt1d_kernel")):

@@ -195,3 +195,92 @@ def test_grouped_clvp_scores_equal_scoring_every_utterance_alone(sds, name, dt, 
     err = float((grouped - want).abs().max()) / float(want.abs().max())
     print(f"[parity] grouped CLVP scores (3 utterances x {N} candidates) {name} vs oracle: max_abs/scale={err:.3e} (tol {tol:.1e})")
     assert err < tol
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+def test_gemv_decode_gemm_operator(lib, name, dt, tdt, tol, M):
+    """csrc/gemv.hip (round 6): the decode step's GEMMs for handles of <= 4 sequences (the streaming engine decodes ONE; reference work:
+    tortoise/models/autoregressive.py:150-163 per token, api_fast.py:389-420) - W rows streamed once per workgroup, the rows in registers,
+    v_dot2 products, one cross-lane sum per output.  Every epilogue against torch fp32 from the same rounded operands: f32 + bias at the
+    padded vocabulary (lm_head), in-place residual update (the projections, K = 1024 and 4096), bias + tanh-GELU + T (c_fc)."""
+    g = torch.Generator().manual_seed(40 + M)
+    for (N, K, epi) in ((8196, 1024, 0), (1024, 1024, 1), (1024, 4096, 1), (4096, 1024, 2)):
+        A = torch.randn(M, K, generator=g).to(tdt).cuda()
+        Wt = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        x0 = torch.randn(M, N, generator=g).cuda()
+        o32 = x0.clone()
+        ot = torch.zeros(M, N, device="cuda", dtype=tdt)
+        E.check(lib.tt_op_gemv(dt, E.ptr(A), E.ptr(Wt), M, N, K, E.ptr(bias), epi, E.ptr(o32), E.ptr(ot), None))
+        torch.cuda.synchronize()
+        ref = A.float() @ Wt.float().t() + bias
+        if epi == 0:
+            report(f"gemv {name} M={M} N={N} K={K} f32 + bias", o32, ref, 2e-5)
+        elif epi == 1:
+            report(f"gemv {name} M={M} N={N} K={K} residual update", o32, x0 + ref, 2e-5)
+        else:
+            report(f"gemv {name} M={M} N={N} K={K} bias + gelu -> T", ot.float(), torch.nn.functional.gelu(ref, approximate="tanh"), {"bf16": 4e-3, "f16": 6e-4}[name])
+    # the same kernel with the LayerNorm in front of c_fc inside it (f32 residual rows in; the normalised row is rounded to T as the row-norm kernel's output is)
+    x = (torch.randn(M, 1024, generator=g) * 3 + 0.5).cuda()
+    gam = (1 + 0.2 * torch.randn(1024, generator=g)).cuda()
+    bet = (0.1 * torch.randn(1024, generator=g)).cuda()
+    Wt = (torch.randn(4096, 1024, generator=g) / 32).to(tdt).cuda()
+    bias = torch.randn(4096, generator=g).cuda()
+    ot = torch.zeros(M, 4096, device="cuda", dtype=tdt)
+    E.check(lib.tt_op_gemv_ln(dt, E.ptr(x), E.ptr(gam), E.ptr(bet), 1e-5, E.ptr(Wt), M, 4096, E.ptr(bias), E.ptr(ot), None))
+    torch.cuda.synchronize()
+    h = torch.nn.functional.layer_norm(x, (1024,), gam, bet, 1e-5).to(tdt).float()
+    report(f"gemv {name} M={M} LayerNorm inside, bias + gelu -> T", ot.float(), torch.nn.functional.gelu(h @ Wt.float().t() + bias, approximate="tanh"), {"bf16": 4e-3, "f16": 6e-4}[name])
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@torch.no_grad()
+def test_streaming_handle_decodes_on_the_gemv_path_within_the_parity_bars(sds, lib, name, dt, tdt, tol):
+    """A handle created for <= 4 sequences (api_fast's engine: max_batch = 1) runs the decode step GEMV-shaped.  Teacher-forced on rows of
+    tests/golden/full_ar_long.npz for 130 steps (two 64-key slots of the attention kernel): logits against the reference's own
+    GPT2InferenceModel at the usual 16-bit bars, against the MFMA path (ttx_kernel_variant(TTX_AR_GEMV, 0): another summation order, so operand
+    noise apart), and generation on the handle is deterministic and chunked == one-shot (the handle never changes kernels between calls).
+    Levels of TTX_AR_GEMV: 2 (default) = the layer norms computed inside the QKV / c_fc GEMVs, 1 = behind row-norm launches, 0 = MFMA tiles."""
+    g = np.load(os.path.join(GOLD, "full_ar_long.npz"))
+    cfg = ARConfig()
+    text, auto, _ = GF.prompt()
+    toks = GF.arl_tokens()
+    keep = torch.ones(cfg.number_mel_codes, dtype=torch.bool)
+    keep[cfg.stop_mel_token] = False
+    got = {}
+    LEVEL = {2: "GEMV + inner norms", 1: "GEMV", 0: "MFMA"}
+    for gemv in (2, 1, 0):
+        prev = lib.ttx_kernel_variant(E.TTX_AR_GEMV, gemv)
+        try:
+            st = stages.ArStage(sds["autoregressive"], cfg, dtype=dt, max_batch=4, max_text=80, max_new_tokens=140, max_latent_candidates=1)
+        finally:
+            lib.ttx_kernel_variant(E.TTX_AR_GEMV, prev)
+        for B in (1, 3):
+            st.prefill(auto, text)
+            st.begin(B)
+            for s in range(130):
+                st.decode_step(toks[s, :B])
+                if s + 1 in (1, 64, 65, 128):
+                    lgts = st.logits(B).cpu()
+                    got[(gemv, B, s + 1)] = lgts
+                    want = torch.from_numpy(g["logits_%d" % (s + 1)])[:B]
+                    report(f"streaming-size handle ({LEVEL[gemv]} decode GEMMs) {name} B={B} logits after {s + 1} tokens vs reference golden",
+                           lgts[:, keep], want[:, keep], tol * 1.6)
+        if gemv:
+            st.prefill(auto, text)
+            a, n = st.generate(1, 48, seed=5)
+            a = a.clone()
+            st.prefill(auto, text)
+            b, _ = st.generate(1, 48, seed=5)
+            assert torch.equal(a, b), "generation on the GEMV path is not deterministic"
+            st.prefill(auto, text)
+            last = None
+            for c, _fin in st.generate_stream(1, 48, 16, first_chunk=16, seed=5):
+                last = c.clone()
+            assert last.shape[1] == a.shape[1] and torch.equal(last, a), "chunked decoding differs from one-shot on the GEMV path"
+        st.close()
+    for B in (1, 3):
+        for n_ in (1, 64, 65, 128):
+            report(f"GEMV vs MFMA decode GEMMs {name} B={B} after {n_} tokens", got[(1, B, n_)][:, keep], got[(0, B, n_)][:, keep], tol)
+            report(f"GEMV with inner norms vs GEMV behind norm launches {name} B={B} after {n_} tokens", got[(2, B, n_)][:, keep], got[(1, B, n_)][:, keep], tol)

@@ -236,7 +236,9 @@ class TextToSpeech:
         if old is not None:
             old.close()
         if name == "ar":
-            self.ar = stages.ArStage(self._sd("autoregressive"), self.ar_cfg, self.device, dt, max_batch=c["cap"] * self.utterance_batch,
+            # (capacity of at least 8 sequences: handles of <= 4 are streaming-size handles whose decode GEMMs run GEMV-shaped - other bits than
+            #  the MFMA path - and a candidate's codes must not depend on how few candidates a rank happens to get: csrc/gemv.hip)
+            self.ar = stages.ArStage(self._sd("autoregressive"), self.ar_cfg, self.device, dt, max_batch=max(c["cap"], 8) * self.utterance_batch,
                                      max_text=c["max_text_tokens"], max_new_tokens=c["max_mel_tokens"], max_latent_candidates=4,
                                      kv_cache=self.kv_cache, max_groups=self.utterance_batch)
         elif name == "clvp":

@@ -4,7 +4,7 @@
 #include "../../include/tortoise_mi355x_test.h"
 
 using namespace tt;
-namespace tt { extern bool g_flash32; extern bool g_voc_mfma; extern bool g_gemm_p8; extern bool g_gemm_skinny; }  // attention.hip, univnet.hip, gemm.hip
+namespace tt { extern bool g_flash32; extern bool g_voc_mfma; extern bool g_gemm_p8; extern bool g_gemm_skinny; extern int g_ar_gemv; }  // attention.hip, univnet.hip, gemm.hip
 
 extern "C" {
 
@@ -89,6 +89,12 @@ int tt_op_gn_gemm(int dtype, const float* x, int B, int S, const float* gamma, c
 // Process-wide A/B switches of kernel families (include/tortoise_mi355x_test.h; like tt_graph_replay: set them before an engine captures
 // its graphs - a kept graph replays the kernels it was captured with).  Returns the previous value.
 int ttx_kernel_variant(int which, int v) {
+  if (which == TTX_AR_GEMV) {  // a level, not a switch: 0 MFMA tiles | 1 GEMV launches behind the row-norm launches | 2 the layer norms inside the GEMVs
+    TT_REQUIRE(v >= 0 && v <= 2, "ttx_kernel_variant(TTX_AR_GEMV): level %d", v);
+    const int prev = tt::g_ar_gemv;
+    tt::g_ar_gemv = v;
+    return prev;
+  }
   bool* sw = which == TTX_FLASH32 ? &tt::g_flash32 : which == TTX_GEMM_P8 ? &tt::g_gemm_p8 : which == TTX_VOC_MFMA ? &tt::g_voc_mfma : which == TTX_GEMM_SKINNY ? &tt::g_gemm_skinny : nullptr;
   TT_REQUIRE(sw != nullptr, "ttx_kernel_variant: unknown kernel family %d", which);
   const int prev = *sw ? 1 : 0;
@@ -103,6 +109,22 @@ int tt_op_flash_attention(int dtype, const void* q, const void* k, const void* v
   f.q = q; f.k = k; f.vt = vt; f.out = out; f.ldo = heads * 64; f.BH = B * heads; f.heads = heads; f.n = n; f.n_pad = n_pad;
   f.causal = causal; f.relpos = relpos;
   return flash_attention_launch(dtype, f, (hipStream_t)stream);
+}
+
+// GEMV-shaped decode GEMM (gemv.hip; handles of <= 4 sequences): epi 0 = out_f32 = A W^T + bias, 1 = x (out_f32) += A W^T + bias, 2 = out_t = gelu_tanh(A W^T + bias)
+int tt_op_gemv(int dtype, const void* A, const void* W, int M, int N, int K, const float* bias, int epi, float* out_f32, void* out_t, void* stream) {
+  TT_REQUIRE(epi >= 0 && epi <= 2, "tt_op_gemv: epi %d (the QKV scatter is tested through the engine)", epi);
+  GemvArgs v;
+  memset(&v, 0, sizeof(v));
+  v.A = A; v.lda = K; v.W = W; v.ldw = K; v.M = M; v.N = N; v.K = K; v.bias = bias; v.epi = epi; v.out_f32 = out_f32; v.ldo32 = N; v.out_t = out_t; v.ldot = N;
+  return gemv_launch(dtype, v, (hipStream_t)stream);
+}
+// out_t[M][N] = gelu_tanh(LayerNorm(x[M][1024]; g, b, eps) W^T + bias): the GEMV with the layer norm inside (the decode step's c_fc at <= 4 sequences)
+int tt_op_gemv_ln(int dtype, const float* x, const float* g, const float* b, float eps, const void* W, int M, int N, const float* bias, void* out_t, void* stream) {
+  GemvArgs v;
+  memset(&v, 0, sizeof(v));
+  v.ln_x = x; v.ldx = 1024; v.ln_g = g; v.ln_b = b; v.ln_eps = eps; v.W = W; v.ldw = 1024; v.M = M; v.N = N; v.K = 1024; v.bias = bias; v.epi = GEMV_GELU_T; v.out_t = out_t; v.ldot = N;
+  return gemv_launch(dtype, v, (hipStream_t)stream);
 }
 
 // The decode step's attention (HF GPT2Attention with a KV cache: one query per (sequence, head) over [shared prefix | own keys]) on

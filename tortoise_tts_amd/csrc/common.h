@@ -206,6 +206,7 @@ enum ProfId {  // one class per kernel instantiation that actually runs (names: 
   PROF_GEMM_64x64_STATS,  // the denoiser's 1x1 GEMMs with the GroupNorm-statistics epilogue (M = 1740): kept apart from the decode GEMMs of the same tile
   PROF_GEMM_GNA,          // GEMM with the GroupNorm apply on its A path (gemm_gna.h)
   PROF_GEMM_32x16_STD, PROF_GEMM_32x16_QKVDEC, PROF_GEMM_64x16_STD, PROF_GEMM_64x16_QKVDEC,  // skinny decode tiles (small batches)
+  PROF_GEMV,              // GEMV-shaped decode GEMMs of handles with max_batch <= 4 (gemv.hip)
   PROF_COUNT
 };
 extern bool g_prof_on;

@@ -33,7 +33,7 @@ static const char* g_prof_names[PROF_COUNT] = {
     "flash_kernel", "decode_attn_kernel", "rownorm_kernel", "gn_apply_kernel(+gn_stats)", "sample_kernel", "glue",
     "conv1d_direct_kernel", "convt1d_kernel", "lvc_kernel", "gemm_glds<64,64,EpiStd,1x1,stats>",
     "gemm_gna<32,256,EpiStd,stats>",
-    "gemm_glds<32,16,EpiStd,1x1>", "gemm_glds<32,16,EpiQkvDecode>", "gemm_glds<64,16,EpiStd,1x1>", "gemm_glds<64,16,EpiQkvDecode>"};
+    "gemm_glds<32,16,EpiStd,1x1>", "gemm_glds<32,16,EpiQkvDecode>", "gemm_glds<64,16,EpiStd,1x1>", "gemm_glds<64,16,EpiQkvDecode>", "gemv_kernel"};
 const char* prof_name(int id) { return id >= 0 && id < PROF_COUNT ? g_prof_names[id] : "?"; }
 
 void prof_record(int id, hipStream_t s, bool begin, double flops, double bytes) {

@@ -87,9 +87,14 @@ struct tt_ar {
   int* progress_host = nullptr;
   int* progress_dev = nullptr;
   int lookahead = 6;
+  // Handles that decode at most 4 sequences (the streaming engine of api_fast.py: max_batch = 1): the decode step's GEMMs run GEMV-shaped
+  // (gemv.hip) - a property of the HANDLE, not of a call's batch, so a handle's kernels never change between calls
+  int gemv = 0;  // 0 | 1 GEMV launches | 2 GEMV launches that also do the layer norm in front of them (five launches per layer)
   int captures = 0;   // decode-step captures so far (tt_ar_stat: tests assert the kept graph is reused)
   int drains = 0;     // host-side queue drains the launch loop fell back to (0 when the progress words arrive)
 };
+
+namespace tt { int g_ar_gemv = 2; }  // ttx_kernel_variant(TTX_AR_GEMV), read at tt_ar_create: handles of <= 4 sequences run 0 = the MFMA decode GEMMs | 1 = GEMV launches | 2 = GEMVs with the layer norms inside
 
 static void ar_drop_step_graph(tt_ar* e) {
   if (e->step_exec) (void)hipGraphExecDestroy(e->step_exec);
@@ -205,6 +210,15 @@ static int ar_head_norm(tt_ar* e, float* x, void* h_out, int M, const float* add
   return rownorm_launch(e->cfg.dtype, a, s);
 }
 static int ar_head_gemm(tt_ar* e, int M, hipStream_t s, int logits_row0 = 0) {
+  if (e->gemv && M <= 4) {
+    GemvArgs v;
+    memset(&v, 0, sizeof(v));
+    v.A = e->h; v.lda = e->D; v.W = e->w_head_p; v.ldw = e->D; v.M = M; v.N = e->Vp; v.K = e->D; v.bias = e->b_head_p; v.epi = GEMV_F32;
+    v.out_f32 = e->logits + (size_t)logits_row0 * e->Vp; v.ldo32 = e->Vp;
+    TT_TRY(gemv_launch(e->cfg.dtype, v, s));
+    e->logits_rows = logits_row0 + M;
+    return 0;
+  }
   GemmArgs g = ar_gemm(e, e->h, e->D, e->w_head_p, e->D, M, e->Vp, e->D);
   g.bias = e->b_head_p; g.out_f32 = e->logits + (size_t)logits_row0 * e->Vp; g.ldo32 = e->Vp;
   TT_TRY(gemm_launch(e->cfg.dtype, EPI_STD, g, s));
@@ -225,7 +239,38 @@ static int decode_layers_enqueue(tt_ar* e, hipStream_t s) {
   int pend_slabs = 0;
   for (int l = 0; l < e->cfg.layers; ++l) {
     const tt_gpt_layer& w = e->L[l];
-    TT_TRY(ar_rownorm_rows(e, x, e->h, nb, w.ln1_g, w.ln1_b, pend_bias, slabs, pend_slabs, nb, s));
+    if (e->gemv < 2) TT_TRY(ar_rownorm_rows(e, x, e->h, nb, w.ln1_g, w.ln1_b, pend_bias, slabs, pend_slabs, nb, s));
+    if (e->gemv) {  // <= 4 sequences: GEMV-shaped launches, no split-K - the projections update x in place, the norms fold nothing
+      GemvArgs v;
+      memset(&v, 0, sizeof(v));
+      v.A = e->h; v.lda = D; v.W = w.w_qkv; v.ldw = D; v.M = nb; v.N = 3 * D; v.K = D; v.bias = w.b_qkv; v.epi = GEMV_QKV;
+      v.step = e->state + 1; v.qbuf = e->q; v.kc = offset_t(e->kc, (size_t)l * e->gen_layer_elems, e->es); v.vc = offset_t(e->vc, (size_t)l * e->gen_layer_elems, e->es);
+      v.heads = H; v.tmax = e->tmax; v.dmodel = D; v.q_scale = 0.125f;
+      if (e->gemv == 2) { v.ln_x = x; v.ldx = D; v.ln_g = w.ln1_g; v.ln_b = w.ln1_b; v.ln_eps = 1e-5f; v.guard = e->guard; }
+      TT_TRY(gemv_launch(dt, v, s));
+      DecodeAttnArgs a;
+      memset(&a, 0, sizeof(a));
+      a.q = e->q;
+      a.kp = offset_t(e->kp, (size_t)l * e->prefix_layer_elems, e->es);
+      a.vp = offset_t(e->vp, (size_t)l * e->prefix_layer_elems, e->es);
+      a.P1 = e->P1; a.kc = v.kc; a.vc = v.vc; a.tmax = e->tmax; a.step = e->state + 1;
+      a.out = e->attn; a.B = nb; a.heads = H; a.host_tgen = e->host_slot + 1;
+      TT_TRY(decode_attention_launch(dt, a, s));
+      memset(&v, 0, sizeof(v));
+      v.A = e->attn; v.lda = D; v.W = w.w_proj; v.ldw = D; v.M = nb; v.N = D; v.K = D; v.bias = w.b_proj; v.epi = GEMV_RES; v.out_f32 = x; v.ldo32 = D;
+      TT_TRY(gemv_launch(dt, v, s));
+      if (e->gemv < 2) TT_TRY(ar_rownorm_rows(e, x, e->h, nb, w.ln2_g, w.ln2_b, nullptr, slabs, 0, nb, s));
+      memset(&v, 0, sizeof(v));
+      if (e->gemv == 2) { v.ln_x = x; v.ldx = D; v.ln_g = w.ln2_g; v.ln_b = w.ln2_b; v.ln_eps = 1e-5f; v.guard = e->guard; }
+      v.A = e->h; v.lda = D; v.W = w.w_fc; v.ldw = D; v.M = nb; v.N = 4 * D; v.K = D; v.bias = w.b_fc; v.epi = GEMV_GELU_T; v.out_t = e->ff; v.ldot = 4 * D;
+      TT_TRY(gemv_launch(dt, v, s));
+      memset(&v, 0, sizeof(v));
+      v.A = e->ff; v.lda = 4 * D; v.W = w.w_proj2; v.ldw = 4 * D; v.M = nb; v.N = D; v.K = 4 * D; v.bias = w.b_proj2; v.epi = GEMV_RES; v.out_f32 = x; v.ldo32 = D;
+      TT_TRY(gemv_launch(dt, v, s));
+      pend_bias = nullptr;
+      pend_slabs = 0;
+      continue;
+    }
     GemmArgs g = ar_gemm(e, e->h, D, w.w_qkv, D, nb, 3 * D, D);
     g.bias = w.b_qkv;
     g.dmodel = D; g.heads = H; g.q_scale = 0.125f;
@@ -384,6 +429,8 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
     e->guard_host[0] = 0;
     e->progress_host[0] = 0; e->progress_host[1] = -1; e->progress_host[2] = e->progress_host[3] = 0;
   }
+  // GEMV-shaped decode step: <= 4 sequences per handle, 16-bit operands, the trunk's K in {1024, 2048, 4096} (gemv.hip)
+  e->gemv = (cfg->max_batch <= 4 && cfg->dtype != DT_F32 && cfg->max_groups <= 1 && D == 1024) ? tt::g_ar_gemv : 0;
   if (rc) {
     tt_ar_destroy(e);
     return rc;

@@ -382,6 +382,83 @@ int tt_kb_gemm_prod(int M, int N, int K, int taps, int seq_len, int splitk, int 
 }  // extern "C"
 
 
+__device__ __forceinline__ float kb_dot8_fwd(Vec<bf16>::x8 a, Vec<bf16>::x8 b, float acc) {
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), acc, false);
+  return acc;
+}
+// --------------------------------------------------------------------------------------------------------------------
+// Round 6: GEMV-shaped decode GEMM for M <= 8 rows (the streaming path decodes ONE sequence; DESIGN 5.13: the regime where the row tile of an MFMA
+// kernel is mostly padding).  A workgroup of 4 waves owns 16 output columns; a wave owns 4 of them and streams their W rows once (K / 512 sixteen-byte
+// loads per lane per row, ALL requested before the first use), the M activation rows sit in registers, products on v_dot2, one cross-lane sum per
+// (row, column).  No LDS, no barrier, W bytes only (32 KB per workgroup at K = 1024 against 96 KB for the 32 x 16 MFMA tile).  out f32 [M][N] + bias.
+template <int MR, int KC>  // MR rows of A, KC = K / 512 chunks per lane
+__global__ __launch_bounds__(256) void gemv_probe_kernel(const bf16* A, const bf16* W, const float* bias, float* out, int M, int N, int K) {
+  typedef Vec<bf16>::x8 x8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 16 + wave * 4;
+  x8 w[4][KC];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bf16* wr = W + (size_t)min(n0 + c, N - 1) * K + lane * 8;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) w[c][k] = *(const x8*)(wr + k * 512);
+  }
+  x8 a[MR][KC];
+#pragma unroll
+  for (int r = 0; r < MR; ++r)
+#pragma unroll
+    for (int k = 0; k < KC; ++k) a[r][k] = *(const x8*)(A + (size_t)min(r, M - 1) * K + lane * 8 + k * 512);
+#pragma unroll
+  for (int r = 0; r < MR; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < KC; ++k) acc = kb_dot8_fwd(a[r][k], w[c][k], acc);
+      acc = wave_sum(acc);
+      if (lane == 0 && r < M && n0 + c < N) out[(size_t)r * N + n0 + c] = acc + bias[n0 + c];
+    }
+}
+
+extern "C" int tt_kb_gemv_probe(int M, int N, int K, int nw, int na, int chain, int reps, double* us_out) {
+  Arena ar;
+  GraphTimer gt;
+  TT_TRY(gt.init());
+  TT_REQUIRE((K == 1024 || K == 4096) && M >= 1 && M <= 8, "gemv probe: K 1024 / 4096, M <= 8");
+  float* out = nullptr; float* bias = nullptr;
+  std::vector<void*> W(nw), Av(na);
+  int rc = 0;
+  for (int i = 0; i < na && !rc; ++i) rc = dev_bf16(ar, &Av[i], (size_t)(M + 8) * K, 1u + i);
+  if (!rc) rc = ar.alloc_t(&out, (size_t)M * N + 64);
+  if (!rc) rc = dev_f32(ar, &bias, N + 64, 5u);
+  for (int i = 0; i < nw && !rc; ++i) rc = dev_bf16(ar, &W[i], (size_t)(N + 64) * K, 77u + i);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -2;
+  if (!rc) rc = gt.run([&](hipStream_t s) -> int {
+    for (int i = 0; i < chain; ++i) {
+      const bf16* a_ = (const bf16*)Av[i % na];
+      const bf16* w_ = (const bf16*)W[i % nw];
+      const dim3 grid((N + 15) / 16);
+      if (K == 1024) {
+        if (M <= 1) gemv_probe_kernel<1, 2><<<grid, 256, 0, s>>>(a_, w_, bias, out, M, N, K);
+        else if (M <= 4) gemv_probe_kernel<4, 2><<<grid, 256, 0, s>>>(a_, w_, bias, out, M, N, K);
+        else gemv_probe_kernel<8, 2><<<grid, 256, 0, s>>>(a_, w_, bias, out, M, N, K);
+      } else {
+        if (M <= 1) gemv_probe_kernel<1, 8><<<grid, 256, 0, s>>>(a_, w_, bias, out, M, N, K);
+        else gemv_probe_kernel<4, 8><<<grid, 256, 0, s>>>(a_, w_, bias, out, M, N, K);
+      }
+    }
+    TT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }, reps, us_out);
+  if (!rc) *us_out /= chain;
+  gt.destroy();
+  ar.release();
+  return rc;
+}
+
 // --------------------------------------------------------------------------------------------------------------------
 // Decode attention experiment: same score phase as the product kernel; PV phase with 16-byte V loads (8 lanes per key
 // row of 128 B, 8 keys per wave instruction = 1 KiB like the K loads) instead of 8-byte loads (512 B per instruction).

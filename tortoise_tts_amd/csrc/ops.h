@@ -112,6 +112,38 @@ struct DecodeAttnArgs {
 int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stream);
 int decode_attn_f32_launch(const DecodeAttnArgs& a, hipStream_t stream);  // fp32 verification mode (attention_f32.hip)
 
+// ------------------------------------------------------------------------------ GEMV-shaped decode GEMMs (gemv.hip): M <= 4 rows
+enum GemvEpi { GEMV_F32 = 0, GEMV_RES = 1, GEMV_GELU_T = 2, GEMV_QKV = 3 };
+struct GemvArgs {
+  const void* A;      // [M][lda] T activation rows
+  int lda;
+  const void* W;      // [N][ldw] T
+  int ldw;
+  int M, N, K;        // M <= 4; K in {1024, 2048, 4096}; N % 4 == 0
+  const float* bias;  // [N] or null
+  int epi;            // GemvEpi
+  float* out_f32;     // GEMV_F32: [M][ldo32] = A W^T + bias; GEMV_RES: the residual rows, updated in place (x += A W^T + bias)
+  int ldo32;
+  void* out_t;        // GEMV_GELU_T: [M][ldot] T = gelu_tanh(A W^T + bias)
+  int ldot;
+  // GEMV_QKV (the decode step's QKV projection: q pre-scaled into qbuf, K / V appended at slot *step; layouts as DecodeAttnArgs)
+  const int* step;
+  void* qbuf;
+  void* kc;
+  void* vc;
+  int heads, tmax, dmodel;
+  float q_scale;
+  // fused LayerNorm (GEMV_QKV / GEMV_GELU_T, K == 1024): when ln_x is set the activation rows are LayerNorm(ln_x[M][ldx] f32; ln_g, ln_b, ln_eps) and A is unused
+  const float* ln_x;
+  int ldx;
+  const float* ln_g;
+  const float* ln_b;
+  float ln_eps;
+  int* guard;  // counts rows whose variance is not finite (norm.hip's overflow guard), or null
+};
+bool gemv_supported(int dtype, const GemvArgs& a);
+int gemv_launch(int dtype, const GemvArgs& a, hipStream_t stream);
+
 // ------------------------------------------------------------------------------ AR sampling
 struct SampleArgs {
   const float* logits;  // [B][ldl]; ldl == 0 broadcasts one row per utterance group (the shared-prefix prefill logits), ldg apart

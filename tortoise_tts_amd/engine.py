@@ -14,7 +14,7 @@ DTYPE_NAMES = {TT_BF16: "bf16", TT_F16: "fp16", TT_F32: "fp32"}
 TT_AR_OPT_LOOKAHEAD = 4
 TT_DIFF_OPT_OVERLAP_PREPASS = 1
 TT_DIFF_OPT_FUSED_GN = 2
-TTX_FLASH32, TTX_GEMM_P8, TTX_VOC_MFMA, TTX_GEMM_SKINNY = 0, 1, 2, 3  # ttx_kernel_variant families (include/tortoise_mi355x_test.h)
+TTX_FLASH32, TTX_GEMM_P8, TTX_VOC_MFMA, TTX_GEMM_SKINNY, TTX_AR_GEMV = 0, 1, 2, 3, 4  # ttx_kernel_variant families (include/tortoise_mi355x_test.h)
 
 
 def dtype_code(name):
@@ -210,6 +210,8 @@ _TEST_PROTOS = {
     "tt_op_gn_gemm_workspace": (_sz, [_i, _i]),
     "tt_op_flash_attention": (_i, [_i, vp, vp, vp, vp, _i, _i, _i, _i, _i, vp, vp]),
     "tt_op_decode_attention": (_i, [_i, vp, vp, vp, _i, vp, vp, _i, _i, vp, _i, _i, _i, vp]),
+    "tt_op_gemv": (_i, [_i, vp, vp, _i, _i, _i, vp, _i, vp, vp, vp]),
+    "tt_op_gemv_ln": (_i, [_i, vp, vp, vp, _f, vp, _i, _i, vp, vp, vp]),
     "tt_op_sample": (_i, [vp, _i, _i, _i, vp, C.POINTER(Sampling), _i, vp, _i, vp, _i, vp]),
     "tt_op_conv1d": (_i, [vp, vp, vp, vp, _i, _i, _i, _i, _i, _i, _f, _i, _f, vp]),
     "tt_op_convt1d": (_i, [vp, vp, vp, vp, _i, _i, _i, _f, vp]),
@@ -251,7 +253,7 @@ def init():
     if not _initialised:
         check(lib.tt_init())
         # process-wide kernel A/B switches (diagnostics; the defaults are the measured winners)
-        for env, which in (("TT_GEMM_VARIANT", TTX_GEMM_P8), ("TT_FLASH_VARIANT", TTX_FLASH32), ("TT_VOC_VARIANT", TTX_VOC_MFMA), ("TT_GEMM_SKINNY", TTX_GEMM_SKINNY)):
+        for env, which in (("TT_GEMM_VARIANT", TTX_GEMM_P8), ("TT_FLASH_VARIANT", TTX_FLASH32), ("TT_VOC_VARIANT", TTX_VOC_MFMA), ("TT_GEMM_SKINNY", TTX_GEMM_SKINNY), ("TT_AR_GEMV", TTX_AR_GEMV)):
             if os.environ.get(env, "") != "":
                 lib.ttx_kernel_variant(which, int(os.environ[env]))
         _initialised = True
