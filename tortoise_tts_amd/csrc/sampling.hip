@@ -15,6 +15,14 @@ namespace tt {
 
 constexpr int SURV_CAP = 512;
 
+// -DTT_SAMPLE_STAMPS (a variant build, scripts/sample_phases.py): thread 0 of block 0 files the 100 MHz wall clock at the phase boundaries
+#ifdef TT_SAMPLE_STAMPS
+__device__ unsigned long long g_sample_stamps[16];
+#define TT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sample_stamps[i] = wall_clock64(); } while (0)
+#else
+#define TT_STAMP(i)
+#endif
+
 __device__ __forceinline__ unsigned f2key(float f) {
   const unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -80,11 +88,14 @@ __device__ __forceinline__ void sample_embed(const SampleArgs& a, int b, int ste
   }
 }
 
+// PER: vocabulary entries per thread (V <= 256 PER): 33 covers the model's 8194 mel codes, 40 anything up to 10240 - every unrolled loop below is PER long
+template <int PER>
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __shared__ float cnt_s[2][3][4];
+  __shared__ unsigned tmax_s[256];
+  __shared__ unsigned long long pair_s[SURV_CAP];
   __shared__ unsigned wtot[4];
   __shared__ int nsurv, ncand;
-  __shared__ unsigned kth_s;
   __shared__ float sv[SURV_CAP];
   __shared__ int si[SURV_CAP];
   __shared__ float sorted_v[SURV_CAP];
@@ -95,6 +106,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __shared__ int red_i[4];
 
   const int b = blockIdx.x, tid = threadIdx.x;
+  TT_STAMP(0);
   const int V = a.V;
   const int step = a.state[0];
   const int grp = a.ngroups > 1 ? b / a.group_size : 0;  // utterance of this row (block-uniform)
@@ -104,7 +116,6 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   const int row_offset = a.row_offset_dev ? *a.row_offset_dev : a.row_offset;  // (block-uniform scalar load)
   const float* lg = a.logits + (a.ldl ? (size_t)b * a.ldl : (size_t)grp * (a.ldg ? a.ldg : V));
   unsigned* seen = a.seen + (size_t)b * ((V + 31) / 32);
-  constexpr int PER = 40;  // supports V <= 10240
   float val[PER];
   bool bad = false;  // NaN / +inf logits: an operand overflowed somewhere upstream (-inf is legitimate: a suppressed token)
   {
@@ -127,21 +138,28 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       bad = bad || (live && (s != s || s == INFINITY));
       if (a.rep_penalty != 1.0f && ((sw[j] >> (t & 31)) & 1u)) s = s < 0.f ? s * a.rep_penalty : s / a.rep_penalty;
       if (a.temperature != 1.0f) s = s / a.temperature;
+      if (__float_as_uint(s) == 0x80000000u) s = 0.f;  // -0.0 ties with +0.0 in the reference's float comparisons: one zero, so that key order == float order
       val[j] = live ? s : -INFINITY;
     }
   }
   if (a.guard && __ballot(bad) != 0ull && (tid & 63) == 0) atomicAdd(a.guard, 1);
+  TT_STAMP(1);
 
   // ---- top-k (ties kept) + order.  k (<= 256) is tiny against the vocabulary, so the work runs on a small candidate set:
   //   1. a lower bound L of the k-th largest key: the k-th largest of the 256 per-thread maxima, to 16 bits (k keys are >= it) -
-  //      "greatest t with count(max >= t) >= k", two bits per round by counting: one compare per thread, DPP wave sums, 8 rounds;
-  //   2. every (score, token) with key >= L is a candidate (typically 60 - 120 of 8194);
-  //   3. among the candidates, by counting over the LDS: the k-th largest key = the top-k threshold (scores below it drop out, ties at
-  //      it stay: TopKLogitsWarper), then each survivor's rank in (score descending, token ascending) order.
-  // A plateau of equal scores that overflows the candidate buffer, or k beyond the populated threads, takes the generic path: the
-  // same counting search over all register-resident keys, 16 rounds.  (Round 3's radix select put ~8 000 LDS atomicAdds on three or
+  //      "greatest t with count(max >= t) >= k".  The maxima go through the LDS once; then every wave finds L on its own with ballot
+  //      counts (4 maxima per lane, one bit per round, the count in scalar registers): one barrier instead of round 4's eight;
+  //   2. every (score, token) with key >= L is a candidate (typically 60 - 120 of 8194): wave-aggregated compaction - ballot prefix
+  //      inside the wave, ONE LDS atomic per wave for its base slot (the slot order is irrelevant: everything below is a total order);
+  //   3. among the candidates: the k-th largest score = the top-k threshold (scores below it drop out, ties at it stay:
+  //      TopKLogitsWarper) and every candidate's place in (score descending, token ascending) order, from ONE all-pairs count that
+  //      all four waves share; a lane sees the other candidates through v_readlane of a register - round 4 read them one dependent
+  //      LDS round trip at a time in two passes on one wave: 2.4 + 6.6 us of the kernel's 25 (scripts/sample_phases.py).
+  // A plateau of equal scores that overflows the candidate buffer, or k beyond the populated threads, takes the generic path: a
+  // counting search over all register-resident keys, 16 rounds.  (Round 3's radix select put ~8 000 LDS atomicAdds on three or
   // four bins in its first pass: logits share their sign / exponent byte.)
   const int k = a.top_k < V ? a.top_k : V;
+  const int lane = tid & 63;
   unsigned key[PER];
   unsigned tmax = 0u;
 #pragma unroll
@@ -149,72 +167,95 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     key[j] = tid + 256 * j < V ? f2key(val[j]) : 0u;  // (real keys are > 0: f2key(-inf) = 0x007FFFFF)
     tmax = max(tmax, key[j]);
   }
+  tmax_s[tid] = tmax;
+  pair_s[tid] = 0ull;
+  pair_s[tid + 256] = 0ull;
   if (tid == 0) {
     nsurv = 0;
     ncand = 0;
   }
+  __syncthreads();
   const float kf = (float)k;
   int round = 0;
   unsigned lower = 0u;
+  {
+    const unsigned m0 = tmax_s[lane], m1 = tmax_s[lane + 64], m2 = tmax_s[lane + 128], m3 = tmax_s[lane + 192];
 #pragma unroll 1
-  for (int bit = 30; bit >= 16; bit -= 2, ++round) {
-    const unsigned c1 = lower | (1u << bit), c2 = lower | (2u << bit), c3 = lower | (3u << bit);
-    const float n1 = wave_sum(tmax >= c1 ? 1.f : 0.f), n2 = wave_sum(tmax >= c2 ? 1.f : 0.f), n3 = wave_sum(tmax >= c3 ? 1.f : 0.f);
-    float* cs = &cnt_s[round & 1][0][0];
-    if ((tid & 63) == 0) {
-      cs[0 * 4 + (tid >> 6)] = n1;
-      cs[1 * 4 + (tid >> 6)] = n2;
-      cs[2 * 4 + (tid >> 6)] = n3;
+    for (int bit = 31; bit >= 16; --bit) {
+      const unsigned c = lower | (1u << bit);
+      const int cnt = __popcll(__ballot(m0 >= c)) + __popcll(__ballot(m1 >= c)) + __popcll(__ballot(m2 >= c)) + __popcll(__ballot(m3 >= c));
+      lower = cnt >= k ? c : lower;  // (wave-uniform)
     }
-    __syncthreads();  // (one barrier per round: the next round writes the other buffer)
-    const float t1 = cs[0] + cs[1] + cs[2] + cs[3], t2 = cs[4] + cs[5] + cs[6] + cs[7], t3 = cs[8] + cs[9] + cs[10] + cs[11];
-    lower = t3 >= kf ? c3 : t2 >= kf ? c2 : t1 >= kf ? c1 : lower;
   }
+  TT_STAMP(2);
   if (lower > 0u) {
+    int wcnt = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) wcnt += __popcll(__ballot(key[j] >= lower));
+    int off = 0;
+    if (lane == 0) off = atomicAdd(&ncand, wcnt);
+    off = __builtin_amdgcn_readfirstlane(off);
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-      if (key[j] >= lower) {
-        const int slot = atomicAdd(&ncand, 1);
-        if (slot < SURV_CAP) {
+      const bool c = key[j] >= lower;
+      const unsigned long long m = __ballot(c);
+      if (m != 0ull) {  // (wave-uniform)
+        const int slot = off + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (c && slot < SURV_CAP) {
           sv[slot] = val[j];
           si[slot] = tid + 256 * j;
         }
+        off += __popcll(m);
       }
     }
   }
   __syncthreads();
   const bool fast = lower > 0u && ncand <= SURV_CAP;  // (block-uniform)
+  TT_STAMP(3);
+#ifdef TT_SAMPLE_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_sample_stamps[15] = (unsigned long long)ncand;
+#endif
   if (fast) {
-    const int nc = ncand;
-    // the k-th largest candidate key and the number of candidates >= it
-    for (int i = tid; i < nc; i += 256) {
-      const unsigned ki = f2key(sv[i]);
-      int g = 0, ge = 0;
-#pragma unroll 8
-      for (int j = 0; j < nc; ++j) {
-        const unsigned kj = f2key(sv[j]);
-        g += kj > ki ? 1 : 0;
-        ge += kj >= ki ? 1 : 0;
+    const int nc = __builtin_amdgcn_readfirstlane(ncand);
+    // ONE all-pairs pass over the candidates: for candidate i, g = #{w_j > v_i}, eq = #{w_j == v_i}, lt = #{w_j == v_i, token_j < token_i}.
+    // The k-th largest score is the candidate with g < k <= g + eq (ties kept: g + eq survivors), and i's place in (score descending,
+    // token ascending) order is g + lt - the survivors are the first g + eq places, so no second pass separates them.  (Scores are
+    // never -0.0 here, so the float order IS the key order.)  A lane owns candidate (64 m + lane) and reads the others 64 at a time
+    // out of a register with v_readlane; the four waves split every 64 into 16s and add their partial counts into one packed LDS word
+    // per candidate (16-bit fields: counts <= 512).
+    const int wv = tid >> 6;
+#pragma unroll 1
+    for (int ibase = 0; ibase < nc; ibase += 64) {
+      const int own = ibase + lane;
+      const bool has = own < nc;
+      const float v = has ? sv[own] : __builtin_nanf("");
+      const int id = has ? si[own] : 0;
+      int g = 0, eq = 0, lt = 0;
+#pragma unroll 1
+      for (int base = 0; base < nc; base += 64) {
+        const bool in = base + lane < nc;
+        const int wb = __builtin_bit_cast(int, in ? sv[base + lane] : __builtin_nanf(""));  // (NaN: counted by nobody)
+        const int wid = in ? si[base + lane] : 0;
+        const int jhi = min(wv * 16 + 16, nc - base);
+        for (int j = wv * 16; j < jhi; ++j) {
+          const float wj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(wb, j));
+          const int idj = __builtin_amdgcn_readlane(wid, j);
+          g += wj > v ? 1 : 0;
+          eq += wj == v ? 1 : 0;
+          lt += (wj == v && idj < id) ? 1 : 0;
+        }
       }
-      if (g < k && k <= ge) {  // (every thread that qualifies writes the same pair)
-        kth_s = ki;
-        nsurv = ge;
-      }
+      if (has) atomicAdd(&pair_s[own], (unsigned long long)g | ((unsigned long long)eq << 16) | ((unsigned long long)lt << 32));
     }
     __syncthreads();
-    const unsigned kth = kth_s;
-    for (int i = tid; i < nc; i += 256) {
-      const float v = sv[i];
-      if (f2key(v) < kth) continue;
-      const int id = si[i];
-      int rank = 0;
-#pragma unroll 8
-      for (int j = 0; j < nc; ++j) {
-        const float w = sv[j];
-        rank += (f2key(w) >= kth && ((w > v) || (w == v && si[j] < id))) ? 1 : 0;
-      }
-      sorted_v[rank] = v;
-      sorted_i[rank] = id;
+    TT_STAMP(4);
+#pragma unroll 1
+    for (int own = tid; own < nc; own += 256) {
+      const unsigned long long pc = pair_s[own];
+      const int g = (int)(pc & 0xFFFFu), eq = (int)((pc >> 16) & 0xFFFFu), lt = (int)((pc >> 32) & 0xFFFFu);
+      sorted_v[g + lt] = sv[own];
+      sorted_i[g + lt] = si[own];
+      if (g < k && k <= g + eq) nsurv = g + eq;  // (every thread that qualifies writes the same count)
     }
     __syncthreads();
   } else {
@@ -317,101 +358,180 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     __syncthreads();
   }
   const int n = nsurv < SURV_CAP ? nsurv : SURV_CAP;
-  // ---- top-p on the survivors (everything else already has probability 0).  The exponentials are evaluated by all
-  // threads; the three sums stay sequential in index order (one thread, n <= a few dozen adds) so the kept set is decided
-  // with exactly the arithmetic the oracle's cumulative sum uses.
-  for (int i = tid; i < n; i += 256) sv[i] = __expf(sorted_v[i] - sorted_v[0]);  // sv is free after the rank sort
-  __syncthreads();
-  if (tid < 64) {  // (wave 0; every lane gets the same sum)
-    const float total = seq_sum_lds(sv, n, tid);
-    if (tid == 0) kept_total = total;  // (parked here for the parallel divisions below; overwritten with the kept sum afterwards)
-  }
-  __syncthreads();
-  {  // the probabilities sv[r] / total, by all threads (the same IEEE division one thread did serially in round 3); si is free
-    const float total = kept_total;
-    float* pr = (float*)si;
-    for (int i = tid; i < n; i += 256) pr[i] = sv[i] / total;
-  }
-  __syncthreads();
-  if (tid < 64) {  // wave 0, every lane redundantly: the same sequential arithmetic as one thread walking the arrays
-    const float* pr = (const float*)si;
-    int keep = n;
-    if (a.top_p < 1.0f) {
-      float tail = 0.f;
-      keep = 1;
-      const float thr = 1.0f - a.top_p;
-      // ascending cumulative probability of element r == sum of probabilities of elements r..n-1
-      bool done = false;
-      for (int hi = n - 1; hi >= 1 && !done; hi -= 64) {  // elements hi, hi - 1, ... in chunks of 64 (lane j holds element hi - j)
-        const int r_l = hi - tid;
-        const float v = r_l >= 1 ? pr[r_l] : 0.f;
-        const int cnt = min(64, hi);
-        for (int j = 0; j < cnt; ++j) {
-          tail += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
-          if (tail > thr) {
-            keep = hi - j + 1;
-            done = true;
-            break;
+  TT_STAMP(5);
+  // ---- top-p on the survivors (everything else already has probability 0) and the draw.  The three sums stay sequential in index
+  // order so that the kept set is decided with exactly the arithmetic the oracle's cumulative sum uses.
+  if (n <= 64) {
+    // The usual case (k = 50; more than 64 survivors takes a tie plateau): the whole tail in wave 0 with the survivors in registers -
+    // no LDS round trip, no barrier; every sum is the same left-to-right chain of additions as below, handed round with v_readlane
+    // (lanes beyond the survivors hold +0.0, which changes no partial sum), fully unrolled: no loop or branch per element.
+    if (tid < 64) {
+      const bool in = tid < n;
+      const float sl = in ? sorted_v[tid] : -INFINITY;
+      const int id = in ? sorted_i[tid] : 0x7fffffff;
+      const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl), 0));
+      const float e = in ? __expf(sl - m) : 0.f;
+      const int eb = __builtin_bit_cast(int, e);
+      float total = 0.f;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) total += __builtin_bit_cast(float, __builtin_amdgcn_readlane(eb, j));
+      TT_STAMP(6);
+      TT_STAMP(7);
+      int keep = n;
+      if (a.top_p < 1.0f) {
+        // ascending cumulative probability of element r == sum of the probabilities of elements n-1 .. r; the partial sums never decrease,
+        // so "the first r (from the top) whose sum exceeds 1 - top_p" is 1 + the number of r in [1, n) whose sum does
+        const int pb = __builtin_bit_cast(int, e / total);
+        const float thr = 1.0f - a.top_p;
+        float tail = 0.f;
+        int over = 0;
+#pragma unroll
+        for (int r = 63; r >= 1; --r) {
+          tail += __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, r));
+          over += tail > thr ? 1 : 0;
+        }
+        keep = over + 1;
+      }
+      const int kb = __builtin_bit_cast(int, tid < keep ? e : 0.f);
+      float kt = 0.f;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) kt += __builtin_bit_cast(float, __builtin_amdgcn_readlane(kb, j));
+      TT_STAMP(8);
+      // multinomial == argmax(p / q)
+      float best = -1.f;
+      int best_i = 0x7fffffff;
+      if (tid < keep) {
+        const float p = e / kt;
+        float q;
+        if (a.exp_noise) {
+          q = a.exp_noise[((size_t)step * a.B + b) * V + id];
+        } else {
+          unsigned r[4];
+          const unsigned long long key = philox_key;
+          const int cand = a.ngroups > 1 ? b - grp * a.group_size : b;  // index within the utterance: the draw does not depend on the batching
+          philox4x32_10((unsigned)id, (unsigned)step, (unsigned)(row_offset + cand), 0u, (unsigned)key, (unsigned)(key >> 32), r);
+          const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+          q = -__logf(u);
+        }
+        const float sc = p / q;
+        if (sc > best || (sc == best && id < best_i)) {
+          best = sc;
+          best_i = id;
+        }
+      }
+      TT_STAMP(9);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(best_i, o, 64);
+        if (ov > best || (ov == best && oi < best_i)) {
+          best = ov;
+          best_i = oi;
+        }
+      }
+      if (tid == 0) red_i[0] = sample_commit(a, b, step, best_i, seen);
+    }
+  } else {
+    // (a tie plateau: the exponentials by all threads through the LDS, the sums by wave 0)
+    for (int i = tid; i < n; i += 256) sv[i] = __expf(sorted_v[i] - sorted_v[0]);  // sv is free after the rank sort
+    __syncthreads();
+    if (tid < 64) {  // (wave 0; every lane gets the same sum)
+      const float total = seq_sum_lds(sv, n, tid);
+      if (tid == 0) kept_total = total;  // (parked here for the parallel divisions below; overwritten with the kept sum afterwards)
+    }
+    __syncthreads();
+    TT_STAMP(6);
+    {  // the probabilities sv[r] / total, by all threads (the same IEEE division one thread did serially in round 3); si is free
+      const float total = kept_total;
+      float* pr = (float*)si;
+      for (int i = tid; i < n; i += 256) pr[i] = sv[i] / total;
+    }
+    __syncthreads();
+    TT_STAMP(7);
+    if (tid < 64) {  // wave 0, every lane redundantly: the same sequential arithmetic as one thread walking the arrays
+      const float* pr = (const float*)si;
+      int keep = n;
+      if (a.top_p < 1.0f) {
+        float tail = 0.f;
+        keep = 1;
+        const float thr = 1.0f - a.top_p;
+        // ascending cumulative probability of element r == sum of probabilities of elements r..n-1
+        bool done = false;
+        for (int hi = n - 1; hi >= 1 && !done; hi -= 64) {  // elements hi, hi - 1, ... in chunks of 64 (lane j holds element hi - j)
+          const int r_l = hi - tid;
+          const float v = r_l >= 1 ? pr[r_l] : 0.f;
+          const int cnt = min(64, hi);
+          for (int j = 0; j < cnt; ++j) {
+            tail += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+            if (tail > thr) {
+              keep = hi - j + 1;
+              done = true;
+              break;
+            }
           }
         }
       }
-    }
-    const float kt = seq_sum_lds(sv, keep, tid);
-    if (tid == 0) {
-      kept = keep;
-      kept_total = kt;
-    }
-  }
-  __syncthreads();
-  // ---- multinomial == argmax(p / q)
-  const int keep = kept;
-  const float m = sorted_v[0];
-  float best = -1.f;
-  int best_i = 0x7fffffff;
-  for (int i = tid; i < keep; i += 256) {
-    const int id = sorted_i[i];
-    const float p = __expf(sorted_v[i] - m) / kept_total;
-    float q;
-    if (a.exp_noise) {
-      q = a.exp_noise[((size_t)step * a.B + b) * V + id];
-    } else {
-      unsigned r[4];
-      const unsigned long long key = philox_key;
-      const int cand = a.ngroups > 1 ? b - grp * a.group_size : b;  // index within the utterance: the draw does not depend on the batching
-      philox4x32_10((unsigned)id, (unsigned)step, (unsigned)(row_offset + cand), 0u, (unsigned)key, (unsigned)(key >> 32), r);
-      const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
-      q = -__logf(u);
-    }
-    const float sc = p / q;
-    if (sc > best || (sc == best && id < best_i)) {
-      best = sc;
-      best_i = id;
-    }
-  }
-  // block argmax (value desc, index asc)
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(best_i, o, 64);
-    if (ov > best || (ov == best && oi < best_i)) {
-      best = ov;
-      best_i = oi;
-    }
-  }
-  if ((tid & 63) == 0) {
-    red_v[tid >> 6] = best;
-    red_i[tid >> 6] = best_i;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < 4; ++w)
-      if (red_v[w] > best || (red_v[w] == best && red_i[w] < best_i)) {
-        best = red_v[w];
-        best_i = red_i[w];
+      const float kt = seq_sum_lds(sv, keep, tid);
+      if (tid == 0) {
+        kept = keep;
+        kept_total = kt;
       }
-    red_i[0] = sample_commit(a, b, step, best_i, seen);
+    }
+    __syncthreads();
+    TT_STAMP(8);
+    // ---- multinomial == argmax(p / q)
+    const int keep = kept;
+    const float m = sorted_v[0];
+    float best = -1.f;
+    int best_i = 0x7fffffff;
+    for (int i = tid; i < keep; i += 256) {
+      const int id = sorted_i[i];
+      const float p = __expf(sorted_v[i] - m) / kept_total;
+      float q;
+      if (a.exp_noise) {
+        q = a.exp_noise[((size_t)step * a.B + b) * V + id];
+      } else {
+        unsigned r[4];
+        const unsigned long long key = philox_key;
+        const int cand = a.ngroups > 1 ? b - grp * a.group_size : b;  // index within the utterance: the draw does not depend on the batching
+        philox4x32_10((unsigned)id, (unsigned)step, (unsigned)(row_offset + cand), 0u, (unsigned)key, (unsigned)(key >> 32), r);
+        const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+        q = -__logf(u);
+      }
+      const float sc = p / q;
+      if (sc > best || (sc == best && id < best_i)) {
+        best = sc;
+        best_i = id;
+      }
+    }
+    TT_STAMP(9);
+    // block argmax (value desc, index asc)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(best_i, o, 64);
+      if (ov > best || (ov == best && oi < best_i)) {
+        best = ov;
+        best_i = oi;
+      }
+    }
+    if ((tid & 63) == 0) {
+      red_v[tid >> 6] = best;
+      red_i[tid >> 6] = best_i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (red_v[w] > best || (red_v[w] == best && red_i[w] < best_i)) {
+          best = red_v[w];
+          best_i = red_i[w];
+        }
+      red_i[0] = sample_commit(a, b, step, best_i, seen);
+    }
   }
+  TT_STAMP(10);
   sample_embed(a, b, step, red_i, tid, 256);
+  TT_STAMP(11);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -562,7 +682,8 @@ int sample_launch(const SampleArgs& a, hipStream_t stream) {
   TT_REQUIRE(a.temperature > 0.f && a.top_p > 0.f && a.rep_penalty > 0.f, "sample: bad sampling parameters");
   ProfScope ps(PROF_SAMPLE, stream, 0.0, (double)a.B * a.V * 4.0, true);
   if (a.top_k >= 1 && a.top_k <= 256) {
-    launch_timed(ps, sample_kernel, dim3(a.B), dim3(256), 0, stream, a);
+    if (a.V <= 33 * 256) launch_timed(ps, sample_kernel<33>, dim3(a.B), dim3(256), 0, stream, a);
+    else launch_timed(ps, sample_kernel<40>, dim3(a.B), dim3(256), 0, stream, a);
   } else {  // top_k == 0 (HF: no top-k warper), > 256, or beyond the vocabulary: the full-sort kernel
     constexpr size_t smem = (size_t)WIDE_N * 6 + (size_t)WIDE_V * 4;
     static bool attr_done = false;
@@ -575,6 +696,14 @@ int sample_launch(const SampleArgs& a, hipStream_t stream) {
   TT_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+#ifdef TT_SAMPLE_STAMPS
+}  // namespace tt
+extern "C" int ttx_sample_stamps(unsigned long long* out16) {
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(tt::g_sample_stamps), sizeof(tt::g_sample_stamps));
+}
+namespace tt {
+#endif
 
 // Last kernel of a step.  state[0] = tokens sampled so far, state[1] = slot / index of the newest token (the one the next decode
 // step feeds), state[2] = index of the first token after which every row had stopped (-1: none yet).  With `progress` (pinned
