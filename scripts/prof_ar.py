@@ -17,12 +17,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--candidates", type=int, default=256)
 ap.add_argument("--tokens", type=int, default=40)
 ap.add_argument("--fused", type=int, default=0)
+ap.add_argument("--capacity", type=int, default=0, help="KV slots per sequence (default: tokens + 8)")
 args = ap.parse_args()
 B, NT = args.candidates, args.tokens
 lib = E.init()
 cfg = ARConfig()
 sd = W.suppress_stop_token(W.synthetic_state_dict(W.ar_manifest(cfg), 1234), cfg)
-ar = stages.ArStage(sd, cfg, max_batch=B, max_new_tokens=max(64, NT + 8), max_latent_candidates=1)
+ar = stages.ArStage(sd, cfg, max_batch=B, max_new_tokens=args.capacity or max(64, NT + 8), max_latent_candidates=1)
 text, (auto, _) = bench_prompt()
 tt = F.pad(text.int()[None], (0, 1)).cuda()
 ar.prefill(auto.cuda(), tt)

@@ -1017,10 +1017,22 @@ __global__ __launch_bounds__(256, 4) void decode_attn_kernel(DecodeAttnArgs a, i
 // conflict-free ds_read_b128), and only the per-sequence cache is streamed from HBM.  The first own-key slots are requested
 // before the workgroup waits for the staged prefix (counted vmcnt: the direct-to-LDS loads are older in the queue), so the
 // HBM stream starts at once.  Arithmetic and summation order per (sequence, head) are exactly those of decode_attn_kernel.
+// -DTT_ATTN_STAMPS (a variant build, scripts/attn_phases.py): wave 0 of every workgroup keeps the 100 MHz wall clock of its phase
+// boundaries in scalar registers (no vector-memory operation: the counted vmcnt waits are untouched) and files them at the end
+#ifdef TT_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[4096][10];
+#define TT_ASTAMP(i) do { st[i] = wall_clock64(); } while (0)
+#else
+#define TT_ASTAMP(i)
+#endif
 template <typename T, int NSEQ>
 __global__ __launch_bounds__(NSEQ * 64, 4) void decode_attn_lds_kernel(DecodeAttnArgs a, int ctx_cap, int kl_bytes, int vl_bytes) {
   typedef typename Vec<T>::x8 x8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_dec[];
+#ifdef TT_ATTN_STAMPS
+  unsigned long long st[10];
+#endif
+  TT_ASTAMP(0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tgen = *a.step + 1;       // generated keys 0..*step (read first: a scalar load, nothing in front of it to drain)
@@ -1085,10 +1097,12 @@ __global__ __launch_bounds__(NSEQ * 64, 4) void decode_attn_lds_kernel(DecodeAtt
   x8 k0[8], k1[8];
   load_own(k0, 0);
   load_own(k1, 1);
+  TT_ASTAMP(1);
   // the staged prefix must have landed (this wave's direct-to-LDS loads are older than the 16 register loads above)
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(qlo), "+s"(qhi)::"memory");  // q has landed (every later use depends on this statement)
+  TT_ASTAMP(2);
   x8 qk[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
@@ -1109,6 +1123,7 @@ __global__ __launch_bounds__(NSEQ * 64, 4) void decode_attn_lds_kernel(DecodeAtt
       mx = fmaxf(mx, sv);
     }
   }
+  TT_ASTAMP(3);
   // own scores, two slots per iteration
 #pragma unroll 1
   for (int sl0 = 0; sl0 < nso; sl0 += 2) {
@@ -1133,6 +1148,7 @@ __global__ __launch_bounds__(NSEQ * 64, 4) void decode_attn_lds_kernel(DecodeAtt
     }
   }
 
+  TT_ASTAMP(4);
   const int kk8 = lane >> 3, cg = lane & 7;
   const int nvp = (P1 + DEC_VKEYS - 1) / DEC_VKEYS, nvo = (tgen + DEC_VKEYS - 1) / DEC_VKEYS;
   auto load_v = [&](x8 (&t)[DEC_VROWS], int it) {  // own rows of iteration `it` (past the end: the last rows again, weighted 0)
@@ -1154,6 +1170,7 @@ __global__ __launch_bounds__(NSEQ * 64, 4) void decode_attn_lds_kernel(DecodeAtt
   }
   sum = wave_sum(sum);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // sc[] is private to this wave: LDS operations of a wave execute in order
+  TT_ASTAMP(5);
   float o[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) o[c] = 0.f;
@@ -1170,6 +1187,7 @@ __global__ __launch_bounds__(NSEQ * 64, 4) void decode_attn_lds_kernel(DecodeAtt
       for (int c = 0; c < 8; ++c) o[c] += pj * (float)t[c];
     }
   }
+  TT_ASTAMP(6);
   auto consume = [&](const x8 (&t)[DEC_VROWS], int it) {
     const int k0r = it * DEC_VKEYS + kk8, lim = it < nvo ? tgen : 0;
     const float* scs = sc + P1;
@@ -1192,6 +1210,7 @@ __global__ __launch_bounds__(NSEQ * 64, 4) void decode_attn_lds_kernel(DecodeAtt
     consume(tb, it + 1);
     __builtin_amdgcn_sched_barrier(0);
   }
+  TT_ASTAMP(7);
 #pragma unroll
   for (int c = 0; c < 8; ++c) {  // sum the 8 key sub-rows (lanes with equal channel group)
     o[c] = add_xor8(o[c]);
@@ -1205,7 +1224,26 @@ __global__ __launch_bounds__(NSEQ * 64, 4) void decode_attn_lds_kernel(DecodeAtt
     for (int c = 0; c < 8; ++c) r[c] = (T)(o[c] * inv);
     *(x8*)((T*)a.out + (size_t)b * a.heads * 64 + h * 64 + cg * 8) = r;
   }
+#ifdef TT_ATTN_STAMPS
+  TT_ASTAMP(8);
+  if (threadIdx.x == 0) {
+    const int wg = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    if (wg < 4096) {
+      for (int i = 0; i < 9; ++i) g_attn_stamps[wg][i] = st[i];
+      unsigned xcc = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_attn_stamps[wg][9] = xcc;
+    }
+  }
+#endif
 }
+#ifdef TT_ATTN_STAMPS
+}  // namespace tt
+extern "C" int ttx_attn_stamps(unsigned long long* out, int nwg) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tt::g_attn_stamps), (size_t)nwg * 10 * sizeof(unsigned long long));
+}
+namespace tt {
+#endif
 
 int decode_attention_launch(int dtype, const DecodeAttnArgs& a, hipStream_t stream) {
   if (dtype == DT_F32) return decode_attn_f32_launch(a, stream);  // verification mode (attention_f32.hip)

@@ -379,7 +379,14 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
   e->D = cfg->model_dim; e->H = cfg->heads; e->V = cfg->vocab;
   e->es = dtype_bytes(cfg->dtype);
   const size_t es = e->es;
+  // KV slots per sequence, rounded up to 8: the K cache is chunk-major with a chunk stride of 16 tmax bytes, and strides within ~100 bytes of a
+  // multiple of 4 KB (tmax = 254, 506, 508, 510, 516 ...) cost the decode attention up to 30 % (scripts/attn_stride.py, profiles/r06_attn_phase_stamps.txt);
+  // a multiple of 8 slots is a multiple of 128 bytes and cannot fall inside that band
+#ifdef TT_KV_NO_ROUND  // (A/B builds)
   e->tmax = cfg->max_new_tokens;
+#else
+  e->tmax = round_up(cfg->max_new_tokens, 8);
+#endif
   const int D = e->D, H = e->H;
   int rc = e->sb.init();
   e->max_rows = std::max(std::max(cfg->max_prefix, cfg->max_full_rows), cfg->max_batch);
