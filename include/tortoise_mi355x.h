@@ -63,7 +63,8 @@ typedef struct tt_ar_config {
                           * step runs GEMV-shaped kernels (csrc/gemv.hip) - deterministic and the same for every call on the handle, but another
                           * summation order than larger handles; create handles of >= 5 where codes must not depend on the capacity */
   int max_prefix;        /* max P+1 (conditioning + text + start token) */
-  int max_new_tokens;    /* per-sequence KV slots */
+  int max_new_tokens;    /* per-sequence KV slots (the handle allocates the next multiple of 8: cache strides next to a multiple of 4 KB
+                          * slow the decode attention down by up to 30 %) */
   int max_full_rows;     /* rows of the largest teacher-forced pass (k * (1 + T+2 + M+2)) */
   int mel_pos_offset;    /* mel position row of generated token i (i >= 0; the start token uses row 0) = i + mel_pos_offset:
                           * 2 = TextToSpeech(kv_cache=True): rows 0,2,3,... (autoregressive.py:145-149, attention_mask.shape[1] - mel_len)
