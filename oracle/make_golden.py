@@ -35,6 +35,11 @@ COND_SEED, COND_CLIPS, COND_T_AR, COND_T_DIFF = 16, 2, 37, 44
 # HF generate() cases pinning the sampling loop: (kv_cache, logit boost of the stop token); B rows x up to N tokens
 SAMPLE_SEED, SAMPLE_B, SAMPLE_N = 5, 6, 24
 SAMPLE_CASES = [(True, None), (True, 3.0), (True, 5.0), (False, None), (False, 3.0), (False, 5.0)]
+# typical sampling (tts(typical_sampling=True, typical_mass=...), api.py:361-364): (kv_cache, stop-token boost, typical_mass) for the
+# whole generate() loop, and warper-level vectors at the model's vocabulary: (seed, logit scale, typical_mass)
+TYPICAL_CASES = [(True, None, 0.9), (True, 3.0, 0.5), (False, None, 0.2)]
+TYPICAL_VOCAB, TYPICAL_ROWS = 8194, 4
+TYPICAL_WARP_CASES = [(0, 1.0, 0.9), (1, 3.0, 0.9), (2, 6.0, 0.5), (3, 2.0, 0.2), (4, 0.25, 0.99)]
 
 
 def ar_inputs(cfg):
@@ -111,14 +116,17 @@ def build_ref_ar(ref, cfg, sd, kv_cache=True):
 
 
 @torch.no_grad()
-def hf_generate_codes(ref, cfg, sd, kv_cache):
+def hf_generate_codes(ref, cfg, sd, kv_cache, typical_mass=None):
     """Codes of a real HF `generate(do_sample=True, ...)` run of the reference model through its own
-    UnifiedVoice.inference_speech (autoregressive.py:535-563) with the api.py:416-424 arguments, on CPU."""
+    UnifiedVoice.inference_speech (autoregressive.py:535-563) with the api.py:416-424 arguments, on CPU.
+    typical_mass: additionally `typical_sampling=True, typical_mass=...` (tts()'s hf_generate_kwargs, api.py:361-364), which
+    inference_speech turns into its logits_processor list [TypicalLogitsWarper] (autoregressive.py:558)."""
     m = ref_shims.enable_generate(build_ref_ar(ref, cfg, sd, kv_cache))
     cond, text = ar_inputs(cfg)
     torch.manual_seed(SAMPLE_SEED)
+    extra = {} if typical_mass is None else {"typical_sampling": True, "typical_mass": typical_mass}
     return m.inference_speech(cond, text, do_sample=True, top_p=0.8, temperature=0.8, num_return_sequences=SAMPLE_B,
-                              length_penalty=1, repetition_penalty=2.0, max_generate_length=SAMPLE_N)
+                              length_penalty=1, repetition_penalty=2.0, max_generate_length=SAMPLE_N, **extra)
 
 
 @torch.no_grad()
@@ -129,6 +137,33 @@ def golden_sampling(ref):
         codes = hf_generate_codes(ref, cfg, sampling_state_dict(cfg, boost), kv)
         out[f"codes_kv{int(kv)}_eos{boost}"] = codes.numpy()
     np.savez_compressed(os.path.join(OUT, "sampling.npz"), **out)
+
+
+def typical_warp_scores(seed, scale):
+    """Scores [TYPICAL_ROWS, TYPICAL_VOCAB] as the typical warper sees them (after the repetition penalty): seeded normal logits,
+    the stop token suppressed in every row (the benchmark's EOS suppression), a band of -inf in row 2, two exactly equal logits in row 3."""
+    g = torch.Generator().manual_seed(100 + seed)
+    x = torch.randn(TYPICAL_ROWS, TYPICAL_VOCAB, generator=g) * scale
+    x[:, TYPICAL_VOCAB - 1] = -float("inf")
+    x[2, 100:4000] = -float("inf")
+    x[3, 17] = x[3, 4242]
+    return x
+
+
+@torch.no_grad()
+def golden_typical(ref):
+    """The reference's OWN TypicalLogitsWarper (tortoise/utils/typical_sampling.py) on fixed score rows, and real HF generate() runs of
+    the reference model through inference_speech(typical_sampling=True, typical_mass=...) (autoregressive.py:535-563)."""
+    from tortoise.utils.typical_sampling import TypicalLogitsWarper
+    cfg = ARConfig(**AR_CFG)
+    out = {}
+    for seed, scale, mass in TYPICAL_WARP_CASES:
+        kept = TypicalLogitsWarper(mass=mass)(None, typical_warp_scores(seed, scale)) > -float("inf")
+        out[f"kept_s{seed}"] = np.packbits(kept.numpy(), axis=1)
+    for kv, boost, mass in TYPICAL_CASES:
+        codes = hf_generate_codes(ref, cfg, sampling_state_dict(cfg, boost), kv, typical_mass=mass)
+        out[f"codes_kv{int(kv)}_eos{boost}_mass{mass}"] = codes.numpy()
+    np.savez_compressed(os.path.join(OUT, "typical.npz"), **out)
 
 
 @torch.no_grad()
@@ -357,6 +392,7 @@ def main():
     ref = ref_shims.import_reference()
     golden_ar(ref)
     golden_sampling(ref)
+    golden_typical(ref)
     golden_clvp(ref)
     golden_diffusion(ref)
     golden_vocoder(ref)

@@ -9,7 +9,8 @@ Shimmed imports (all import-only; none of the stubbed symbols is ever called on 
   * torchaudio(+.transforms,.functional)   <- tortoise/models/arch_util.py:8 (TorchMelSpectrogram only)
   * rotary_embedding_torch                 <- tortoise/models/transformer.py (unused: use_xformers=True, api.py:232)
   * transformers.utils.model_parallel_utils <- tortoise/models/autoregressive.py:8 (dead parallelize())
-  * tortoise.utils.typical_sampling         <- autoregressive.py:10 (typical_sampling=False default)
+  * transformers.LogitsWarper (base-class NAME only; 5.x merged it into LogitsProcessor) so that the reference's REAL
+    tortoise/utils/typical_sampling.py imports (autoregressive.py:10): TypicalLogitsWarper itself is the reference's code
 """
 import os
 import sys
@@ -54,13 +55,13 @@ def install():
     _stub("transformers.utils.model_parallel_utils",
           get_device_map=lambda *a, **k: None, assert_device_map=lambda *a, **k: None)
 
-    class _TypicalStub:
-        def __init__(self, *a, **k):
-            raise RuntimeError("typical sampling is out of scope (default off)")
-
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
-    _stub("tortoise.utils.typical_sampling", TypicalLogitsWarper=_TypicalStub)
+    if not hasattr(transformers, "LogitsWarper"):  # 4.31 had LogitsWarper next to LogitsProcessor (same __call__ protocol)
+        transformers.LogitsWarper = transformers.LogitsProcessor
+    # imported NOW, while the alias is visible: the first `from transformers import <model class>` makes the package swap the module
+    # object registered in sys.modules, and a later `from transformers import LogitsWarper` would not find the alias any more
+    import tortoise.utils.typical_sampling  # noqa: F401
     _installed = True
 
 

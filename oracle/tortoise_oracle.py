@@ -155,12 +155,32 @@ def top_p_(scores, top_p, min_tokens_to_keep=1):
     return scores.masked_fill(remove, -float("inf"))
 
 
-def warp_logits(logits, input_ids, repetition_penalty=2.0, temperature=0.8, top_k=50, top_p=0.8):
-    """Processor order in 4.31 `generate(do_sample=True)`: repetition penalty (processor), then
-    warpers temperature -> top-k (GenerationConfig default 50, never overridden by api.py) -> top-p."""
+def typical_(scores, mass=0.9):
+    """TypicalLogitsWarper (tortoise/utils/typical_sampling.py:11-33; `typical_sampling=True` of tts(), api.py:361-364,
+    autoregressive.py:558): tokens ordered by |surprisal - entropy| ascending; the shortest such prefix whose probability reaches
+    `mass` stays (the token that crosses the mass included, ties at its distance included), everything farther from the entropy is removed."""
+    logp = torch.log_softmax(scores, dim=-1)
+    p = logp.exp()
+    entropy = -(logp * p).nansum(-1, keepdim=True)  # 0 * -inf of a suppressed token is skipped
+    dist = ((-logp) - entropy).abs()
+    dist_sorted, order = torch.sort(dist, descending=False)
+    cum = scores.gather(-1, order).softmax(dim=-1).cumsum(dim=-1)
+    last = (cum < mass).sum(dim=1).clamp_(min=0)
+    remove_sorted = dist_sorted > dist_sorted.gather(1, last.view(-1, 1))
+    remove = remove_sorted.scatter(1, order, remove_sorted)
+    return scores.masked_fill(remove, -float("inf"))
+
+
+def warp_logits(logits, input_ids, repetition_penalty=2.0, temperature=0.8, top_k=50, top_p=0.8, typical_mass=None):
+    """Processor order in 4.31 `generate(do_sample=True)`: repetition penalty (processor), the caller's logits_processor list
+    (inference_speech passes [TypicalLogitsWarper(typical_mass)] when typical_sampling=True, autoregressive.py:558: generate()
+    appends it to the default processors), then warpers temperature -> top-k (GenerationConfig default 50, never overridden by
+    api.py) -> top-p."""
     s = logits.float()
     if repetition_penalty is not None and repetition_penalty != 1.0:
         s = repetition_penalty_(s, input_ids, repetition_penalty)
+    if typical_mass is not None:
+        s = typical_(s, typical_mass)
     if temperature is not None and temperature != 1.0:
         s = s / temperature
     if top_k is not None and top_k != 0:
@@ -178,7 +198,7 @@ def multinomial_from_exponential(probs, q):
 
 def ar_sample_loop(sd, cfg: ARConfig, cond_latent, text_tokens, batch, max_new, exp_noise,
                    repetition_penalty=2.0, temperature=0.8, top_k=50, top_p=0.8, kv_cache=True,
-                   return_logits=False):
+                   return_logits=False, typical_mass=None):
     """UnifiedVoice.inference_speech + GenerationMixin.sample (autoregressive.py:535-563;
     stream_generator.py:916-1000).  exp_noise: [max_new, batch, V] Exp(1) draws.
     Returns int64 codes [batch, n] (n <= max_new; shorter only if every row hit stop), like
@@ -194,7 +214,7 @@ def ar_sample_loop(sd, cfg: ARConfig, cond_latent, text_tokens, batch, max_new, 
     for step in range(max_new):
         if return_logits:
             all_logits.append(logits.clone())
-        scores = warp_logits(logits, input_ids, repetition_penalty, temperature, top_k, top_p)
+        scores = warp_logits(logits, input_ids, repetition_penalty, temperature, top_k, top_p, typical_mass)
         probs = torch.softmax(scores, dim=-1)
         nxt = multinomial_from_exponential(probs, exp_noise[step])
         nxt = nxt * unfinished + cfg.stop_mel_token * (1 - unfinished)

@@ -45,6 +45,34 @@ def test_ar_logits_and_latents():
     close(lat, g["latents"], 2e-4)
 
 
+@pytest.mark.parametrize("seed,scale,mass", G.TYPICAL_WARP_CASES)
+def test_typical_warper_equals_reference_golden(seed, scale, mass):
+    """oracle.typical_ == the reference's own TypicalLogitsWarper (tortoise/utils/typical_sampling.py:11-33) on the committed rows
+    (tests/golden/typical.npz, oracle/make_golden.py:golden_typical): the kept set, token for token - rows with the stop token
+    suppressed, a band of -inf, an exact tie."""
+    x = G.typical_warp_scores(seed, scale)
+    want = np.unpackbits(gold("typical.npz")[f"kept_s{seed}"], axis=1)[:, :G.TYPICAL_VOCAB].astype(bool)
+    got = (O.typical_(x, mass) > -float("inf")).numpy()
+    assert np.array_equal(got, want)
+    assert 1 <= got.sum(1).min() and got.sum(1).max() < G.TYPICAL_VOCAB - 1  # the warper really removes something, and never everything
+
+
+@pytest.mark.parametrize("kv_cache,eos_boost,mass", G.TYPICAL_CASES)
+@torch.no_grad()
+def test_sampling_loop_with_typical_sampling_equals_hf_generate_golden(kv_cache, eos_boost, mass):
+    """oracle.ar_sample_loop(typical_mass=...) == the committed codes of HF generate() run through the reference's
+    inference_speech(typical_sampling=True, typical_mass=...) (autoregressive.py:558: the warper rides in generate()'s logits_processor
+    list, i.e. after the repetition penalty and before temperature / top-k / top-p), bit for bit."""
+    cfg = ARConfig(**G.AR_CFG)
+    want = gold("typical.npz")[f"codes_kv{int(kv_cache)}_eos{eos_boost}_mass{mass}"]
+    sd = G.sampling_state_dict(cfg, eos_boost)
+    cond, text = G.ar_inputs(cfg)
+    got = O.ar_sample_loop(sd, cfg, cond, text, G.SAMPLE_B, G.SAMPLE_N, G.sampling_noise(cfg), kv_cache=kv_cache, typical_mass=mass)
+    assert got.shape == want.shape and np.array_equal(got.numpy(), want)
+    plain = gold("sampling.npz")[f"codes_kv{int(kv_cache)}_eos{eos_boost}"]
+    assert plain.shape != want.shape or not np.array_equal(plain, want)  # and the option is not a no-op on these cases
+
+
 @pytest.mark.parametrize("kv_cache,eos_boost", G.SAMPLE_CASES)
 @torch.no_grad()
 def test_sampling_loop_equals_hf_generate_golden(kv_cache, eos_boost):

@@ -96,6 +96,30 @@ def test_sampling_loop_equals_hf_generate(ref, kv_cache, eos_boost):
         assert want.shape[1] < G.SAMPLE_N  # every row finished: generate() returned early
 
 
+@torch.no_grad()
+def test_typical_sampling_equals_reference_warper_and_hf_generate(ref):
+    """tts(typical_sampling=True, typical_mass=...) (api.py:361-364): (1) oracle.typical_ against the reference's OWN
+    TypicalLogitsWarper (tortoise/utils/typical_sampling.py) live, on fresh rows and masses; (2) oracle.ar_sample_loop(typical_mass)
+    against a real generate() run through the reference's inference_speech(typical_sampling=True) - same generator state =>
+    identical codes."""
+    from tortoise.utils.typical_sampling import TypicalLogitsWarper
+    from oracle import make_golden as G
+    for seed in range(3):
+        g = torch.Generator().manual_seed(900 + seed)
+        x = torch.randn(5, 8194, generator=g) * (0.5 + 2 * seed)
+        x[:, 8193] = -float("inf")
+        x[1, 50:5000] = -float("inf")
+        for mass in (0.9, 0.6, 0.3):
+            assert torch.equal(O.typical_(x, mass), TypicalLogitsWarper(mass=mass)(None, x))
+    cfg = small_ar()
+    kv_cache, eos_boost, mass = G.TYPICAL_CASES[1]
+    sd = G.sampling_state_dict(cfg, eos_boost)
+    want = G.hf_generate_codes(ref, cfg, sd, kv_cache, typical_mass=mass)
+    cond, text = G.ar_inputs(cfg)
+    got = O.ar_sample_loop(sd, cfg, cond, text, G.SAMPLE_B, G.SAMPLE_N, G.sampling_noise(cfg), kv_cache=kv_cache, typical_mass=mass)
+    assert got.shape == want.shape and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("kv_cache,eos_boost", [(True, None), (True, 3.0), (True, 5.0), (False, None), (False, 3.0), (False, 5.0)])
 @torch.no_grad()
 def test_sampling_loop_and_streamed_latents_equal_reference_sample_stream(ref, kv_cache, eos_boost):
