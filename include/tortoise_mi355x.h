@@ -111,6 +111,9 @@ typedef struct tt_sampling {
   int row_offset;            /* global index of candidate 0 of this rank */
   const float* exp_noise;    /* optional f32 [max_new][B][vocab] Exp(1) draws: multinomial == argmax(p/q) */
   const unsigned long long* group_seeds;  /* optional HOST array [n_groups]: Philox key per group (NULL: `seed` for every group) */
+  float typical_mass;        /* tts(typical_sampling=True, typical_mass=.9) (api.py:361-364): 0 < typical_mass < 1 runs the reference's
+                              * TypicalLogitsWarper (tortoise/utils/typical_sampling.py:11-33) where generate() runs it - after the
+                              * repetition penalty, before temperature / top-k / top-p (autoregressive.py:558); 0 = off (the default) */
 } tt_sampling;
 
 /* Replaces `self.inference_model.generate(... do_sample=True ...)` (autoregressive.py:560-563;

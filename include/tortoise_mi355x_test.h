@@ -60,6 +60,11 @@ int tt_op_gemv(int dtype, const void* A, const void* W, int M, int N, int K, con
 int tt_op_gemv_ln(int dtype, const float* x, const float* g, const float* b, float eps, const void* W, int M, int N, const float* bias, void* out_t, void* stream);
 int tt_op_sample(const float* logits, int ldl, int B, int V, unsigned* seen, const tt_sampling* s, int step, int* unfinished,
                  int stop_token, int* codes, int ldcodes, void* stream);
+/* The typical-sampling mask alone (csrc/sampling.hip typical_mask_kernel; reference tortoise/utils/typical_sampling.py:11-33): out f32 [B][ldl]
+ * = logits with every token outside the typical set of mass `mass` at -inf; the set is formed on the repetition-penalised scores (seen:
+ * [B][(V+31)/32] bit mask of the ids generated so far), kept tokens carry their raw logit. */
+int tt_op_typical_mask(const float* logits, int ldl, int B, int V, const unsigned* seen, float repetition_penalty, float mass, float* out,
+                       void* stream);
 int tt_op_conv1d(const float* x, const float* w, const float* bias, float* y, int Cin, int Cout, int T, int k, int dilation,
                  int reflect, float in_slope, int out_act, float out_slope, void* stream);
 int tt_op_convt1d(const float* x, const float* w, const float* bias, float* y, int C, int Tin, int stride, float in_slope, void* stream);

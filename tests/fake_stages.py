@@ -55,7 +55,7 @@ class FakeArStage:
         self.group_batches = getattr(self, "group_batches", 0) + (1 if group == 0 else 0)
 
     def generate(self, B, max_new, temperature=0.8, top_p=0.8, repetition_penalty=2.0, top_k=50, seed=0, row_offset=0, exp_noise=None,
-                 group_seeds=None):
+                 group_seeds=None, typical_mass=0.0):
         assert B <= self.max_batch
         self.generated = True
         if self.dtype == 1 and getattr(FakeArStage, "trip", 0):  # an overflowed fp16 decode: rows cut short with the stop token
@@ -68,7 +68,7 @@ class FakeArStage:
             for g, (cond, text) in enumerate(groups):
                 self.cond, self.text = cond, text
                 outs.append(self.generate(Bg, max_new, temperature, top_p, repetition_penalty, top_k, group_seeds[g] if group_seeds else seed,
-                                          row_offset, None)[0])
+                                          row_offset, None, typical_mass=typical_mass)[0])
             n = max(o.shape[1] for o in outs)
             outs = [torch.nn.functional.pad(o, (0, n - o.shape[1]), value=self.cfg.stop_mel_token) for o in outs]
             return torch.cat(outs, dim=0), n
@@ -80,7 +80,7 @@ class FakeArStage:
                 rows.append(torch.empty(max_new, V).exponential_(1, generator=g))
             exp_noise = torch.stack(rows, dim=1)
         codes = O.ar_sample_loop(self.sd, self.cfg, self.cond, self.text, B, max_new, exp_noise.cpu(), repetition_penalty, temperature,
-                                 top_k, top_p, kv_cache=self.kv_cache)
+                                 top_k, top_p, kv_cache=self.kv_cache, typical_mass=typical_mass or None)
         self.gen_codes = codes
         return codes, codes.shape[1]
 

@@ -43,7 +43,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_mirrors_match(lib):
     for i, st in enumerate(E.BOUNDARY_STRUCTS):
         assert C.sizeof(st) == lib.tt_struct_size(i), st.__name__
-    assert lib.tt_abi_version() == 5
+    assert lib.tt_abi_version() == 6
 
 
 def test_fails_loudly_without_gpu(lib):

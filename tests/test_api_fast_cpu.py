@@ -102,8 +102,16 @@ def test_tts_and_stream_flow_on_oracle_backed_stages(monkeypatch):
         tts.tts(text, cvvp_amount=0.5)
     with pytest.raises(NotImplementedError, match="num_beams"):
         list(tts.tts_stream(text, num_beams=4))
-    with pytest.raises(NotImplementedError, match="typical"):
-        tts.tts(text, typical_sampling=True)
+    # typical sampling (api.py:361-364 -> autoregressive.py:558) is honoured: other codes than plain sampling on the same seed, the
+    # mass only counts with the switch on (as upstream), an impossible mass is refused
+    tts.tts(text, max_mel_tokens=40, use_deterministic_seed=4)
+    plain = tts.last_codes.clone()
+    tts.tts(text, max_mel_tokens=40, use_deterministic_seed=4, typical_mass=0.2)
+    assert torch.equal(tts.last_codes, plain)
+    tts.tts(text, max_mel_tokens=40, use_deterministic_seed=4, typical_sampling=True, typical_mass=0.2)
+    assert tts.last_codes.shape != plain.shape or not torch.equal(tts.last_codes, plain)
+    with pytest.raises(ValueError, match="typical_mass"):
+        tts.tts(text, typical_sampling=True, typical_mass=1.0)
 
 
 def reference_decode_points(n_pairs, stream_chunk_size):

@@ -104,6 +104,19 @@ def test_tts_many_equals_one_utterance_after_the_other(monkeypatch):
     assert all(torch.equal(a, b) for a, b in zip(odd, want))
     with pytest.raises(NotImplementedError):
         t.tts_many(texts, conditioning_latents=lat, k=2, **kw)
+    # typical sampling (tts(typical_sampling=True, typical_mass=...), api.py:361-364) rides through both entry points: the grouped decode
+    # equals the per-utterance calls, and it is not a no-op
+    typ = dict(kw, typical_sampling=True, typical_mass=0.3)
+    one_typ = [t.tts(x, conditioning_latents=lat, use_deterministic_seed=5, verbose=False, **typ) for x in texts[:2]]
+    codes_typ = t.last_best_codes.clone()
+    many_typ = t.tts_many(texts[:2], conditioning_latents=lat, use_deterministic_seed=5, **typ)
+    assert all(torch.equal(a, b) for a, b in zip(many_typ, one_typ))
+    t.tts(texts[1], conditioning_latents=lat, use_deterministic_seed=5, verbose=False, **kw)
+    assert not torch.equal(t.last_best_codes, codes_typ)
+    with pytest.raises(NotImplementedError, match="num_beams"):
+        t.tts(texts[0], conditioning_latents=lat, num_beams=2, **kw)
+    with pytest.raises(ValueError, match="typical_mass"):
+        t.tts(texts[0], conditioning_latents=lat, typical_sampling=True, typical_mass=0.0, **kw)
 
 
 @torch.no_grad()

@@ -55,6 +55,24 @@ class _StageTimer:
         torch.cuda.synchronize()
 
 
+def sampler_kwargs(hf_generate_kwargs):
+    """The **hf_generate_kwargs of tts() the on-device sampler honours -> (top_k, typical_mass); anything else raises instead of
+    being dropped.  `top_k`: HF GenerationConfig default 50, which the reference inherits (api.py never overrides it).
+    `typical_sampling` / `typical_mass` (api.py:361-364): inference_speech turns them into generate()'s logits_processor list
+    [TypicalLogitsWarper(mass=typical_mass)] (autoregressive.py:536, 558); typical_mass is ignored unless typical_sampling is set,
+    as upstream.  Returns typical_mass = 0.0 for "off"."""
+    kw = dict(hf_generate_kwargs)
+    top_k = int(kw.pop("top_k", 50))
+    typical = bool(kw.pop("typical_sampling", False))
+    mass = float(kw.pop("typical_mass", .9))
+    if kw:
+        raise NotImplementedError(f"unsupported generate kwargs {sorted(kw)}: the on-device sampler implements temperature / top_k / top_p / "
+                                  f"repetition_penalty / typical_sampling + typical_mass (length_penalty is a no-op when sampling)")
+    if typical and not 0.0 < mass < 1.0:
+        raise ValueError(f"typical_mass={mass} must lie in (0, 1) (the reference's warper indexes past the vocabulary at >= 1)")
+    return top_k, (mass if typical else 0.0)
+
+
 def fix_autoregressive_output(codes, stop_token, calm_token=CALM_TOKEN):
     """Vectorised api.py:87-114 for a batch int tensor [B, n] (any device); rows without a stop token are
     returned unchanged exactly like the reference (which only prints a warning)."""
@@ -366,10 +384,7 @@ class TextToSpeech:
             diffusion_iterations=100, cond_free=True, cond_free_k=2, diffusion_temperature=1.0,
             **hf_generate_kwargs):
         noise = hf_generate_kwargs.pop("noise_override", None) or {}
-        top_k = int(hf_generate_kwargs.pop("top_k", 50))  # HF GenerationConfig default the reference inherits
-        if hf_generate_kwargs:
-            raise NotImplementedError(f"unsupported generate kwargs {sorted(hf_generate_kwargs)}: the on-device sampler implements "
-                                      f"temperature / top_k / top_p / repetition_penalty (length_penalty is a no-op when sampling)")
+        top_k, typical_mass = sampler_kwargs(hf_generate_kwargs)
         if cvvp_amount != 0:
             raise NotImplementedError("CVVP was removed upstream (CHANGELOG) and is not part of the accelerated path")
         dev = self.device
@@ -415,7 +430,7 @@ class TextToSpeech:
             self.ar.prefill(auto_conditioning, text_tokens)
             en = exp_noise[:, c0 - lo:c0 - lo + B] if exp_noise is not None else None
             codes, n = self.ar.generate(B, max_mel_tokens, temperature=temperature, top_p=top_p, repetition_penalty=repetition_penalty,
-                                        top_k=top_k, seed=seed, row_offset=c0, exp_noise=en)
+                                        top_k=top_k, seed=seed, row_offset=c0, exp_noise=en, typical_mass=typical_mass)
             batches.append(F.pad(codes, (0, max_mel_tokens - codes.shape[1]), value=stop))  # api.py:425-426
         samples = torch.cat(batches, dim=0)
         ev.mark(1)
@@ -485,7 +500,9 @@ class TextToSpeech:
                             num_autoregressive_samples=num_autoregressive_samples, temperature=temperature, length_penalty=length_penalty,
                             repetition_penalty=repetition_penalty, top_p=top_p, max_mel_tokens=max_mel_tokens, cvvp_amount=cvvp_amount,
                             diffusion_iterations=diffusion_iterations, cond_free=cond_free, cond_free_k=cond_free_k,
-                            diffusion_temperature=diffusion_temperature, top_k=top_k, **({"noise_override": noise} if noise else {}))
+                            diffusion_temperature=diffusion_temperature, top_k=top_k,
+                            **({"typical_sampling": True, "typical_mass": typical_mass} if typical_mass else {}),
+                            **({"noise_override": noise} if noise else {}))
         self.timings = {"ar_s": ev.seconds(0, 1), "clvp_s": ev.seconds(1, 2), "latents_s": ev.seconds(2, 3),
                         "diffusion_s": ev.seconds(3, 4), "vocoder_s": ev.seconds(4, 5), "total_s": ev.seconds(0, 5)}
         # Rendered winners go to rank 0 only (the reference returns the audio to ONE caller); other ranks get None entries.
@@ -522,11 +539,11 @@ class TextToSpeech:
         hf = {k_: settings[k_] for k_ in list(settings) if k_ not in (
             "num_autoregressive_samples", "temperature", "length_penalty", "repetition_penalty", "top_p", "max_mel_tokens", "cvvp_amount",
             "diffusion_iterations", "cond_free", "cond_free_k", "diffusion_temperature")}
-        top_k = int(hf.get("top_k", 50))
-        if set(hf) - {"top_k"} or settings.get("cvvp_amount", 0) != 0 or N > self.autoregressive_batch_size or N % 4 != 0:
+        if set(hf) - {"top_k", "typical_sampling", "typical_mass"} or settings.get("cvvp_amount", 0) != 0 or N > self.autoregressive_batch_size or N % 4 != 0:
             # anything tts() refuses or the grouped decode cannot hold: let tts() handle (or refuse) it, one utterance at a time
             return [self.tts(t, voice_samples=voice_samples, conditioning_latents=conditioning_latents, k=1, verbose=verbose,
                              use_deterministic_seed=use_deterministic_seed, **settings) for t in texts]
+        top_k, typical_mass = sampler_kwargs(hf)
         seed = self.deterministic_state(seed=use_deterministic_seed)
         dev = self.device
         toks = []
@@ -555,7 +572,7 @@ class TextToSpeech:
                 self.ar.prefill_group(g, len(idx), auto_conditioning, toks[j])
             codes, _ = self.ar.generate(N * len(idx), max_mel_tokens, temperature=settings.get("temperature", .8), top_p=settings.get("top_p", .8),
                                         repetition_penalty=settings.get("repetition_penalty", 2.0), top_k=top_k, seed=seed, row_offset=0,
-                                        group_seeds=[seed] * len(idx))
+                                        group_seeds=[seed] * len(idx), typical_mass=typical_mass)
             codes = F.pad(codes, (0, max_mel_tokens - codes.shape[1]), value=stop)
             return [codes[g * N:(g + 1) * N] for g in range(len(idx))]
 

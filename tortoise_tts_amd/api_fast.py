@@ -29,7 +29,7 @@ import torch.nn.functional as F
 from . import engine as E
 from . import stages
 from . import weights as W
-from .api import MODELS_DIR, _load_state_dict, _load_file
+from .api import MODELS_DIR, _load_state_dict, _load_file, sampler_kwargs
 from .config import ARConfig, HifiganConfig
 
 
@@ -142,25 +142,22 @@ class TextToSpeech:
     def _check_kwargs(k, cvvp_amount, hf_generate_kwargs):
         """Same refusals as tortoise_tts_amd.api.TextToSpeech.tts: a sampling option the on-device sampler cannot honour raises
         instead of being dropped.  `k` is accepted and unused exactly as in the reference, whose fast path always decodes one
-        autoregressive sample into one clip (api_fast.py:421-519).  Returns top_k."""
+        autoregressive sample into one clip (api_fast.py:421-519).  Returns (top_k, typical_mass) (api.sampler_kwargs)."""
         if cvvp_amount:
             raise NotImplementedError("cvvp_amount != 0: CVVP was removed upstream")
-        unknown = sorted(set(hf_generate_kwargs) - {"top_k"})
-        if unknown:
-            raise NotImplementedError(f"hf_generate_kwargs {unknown} are not supported by the on-device sampler (only top_k)")
-        return int(hf_generate_kwargs.get("top_k", 50))
+        return sampler_kwargs(hf_generate_kwargs)
 
     # ------------------------------------------------------------------ non-streaming (api_fast.py:421-519)
     @torch.no_grad()
     def tts(self, text, voice_samples=None, k=1, verbose=True, use_deterministic_seed=None, conditioning_latents=None,
             num_autoregressive_samples=512, temperature=.8, length_penalty=1, repetition_penalty=2.0, top_p=.8, max_mel_tokens=500,
             cvvp_amount=.0, **hf_generate_kwargs):
-        top_k = self._check_kwargs(k, cvvp_amount, hf_generate_kwargs)
+        top_k, typical_mass = self._check_kwargs(k, cvvp_amount, hf_generate_kwargs)
         seed = self.deterministic_state(seed=use_deterministic_seed)
         text_tokens, cond = self._prepare(text, voice_samples, conditioning_latents, max_mel_tokens)
         self.ar.prefill(cond, text_tokens)
         codes, _ = self.ar.generate(1, max_mel_tokens, temperature=temperature, top_p=top_p, repetition_penalty=float(repetition_penalty),
-                                    top_k=top_k, seed=seed, row_offset=0)
+                                    top_k=top_k, seed=seed, row_offset=0, typical_mass=typical_mass)
         self.last_codes = codes
         latents = self.ar.latents(cond, text_tokens, codes)          # api_fast.py:510-514 (return_latent=True)
         wav = self.hifi_decoder.inference(latents, cond)             # api_fast.py:517
@@ -214,7 +211,7 @@ class TextToSpeech:
                    num_autoregressive_samples=512, temperature=.8, length_penalty=1, repetition_penalty=2.0, top_p=.8, max_mel_tokens=500,
                    cvvp_amount=.0, diffusion_iterations=100, cond_free=True, cond_free_k=2, diffusion_temperature=1.0,
                    **hf_generate_kwargs):
-        top_k = self._check_kwargs(k, cvvp_amount, hf_generate_kwargs)
+        top_k, typical_mass = self._check_kwargs(k, cvvp_amount, hf_generate_kwargs)
         seed = self.deterministic_state(seed=use_deterministic_seed)
         text_tokens, cond = self._prepare(text, voice_samples, conditioning_latents, max_mel_tokens)
         self.ar.prefill(cond, text_tokens)
@@ -224,7 +221,8 @@ class TextToSpeech:
         emitted = 0          # (token, latent) pairs already decoded into an emitted chunk
         threshold = first    # pairs the reference buffers before the next decode (api_fast.py:412)
         for codes, done in self.ar.generate_stream(1, max_mel_tokens, chunk, first_chunk=first, temperature=temperature, top_p=top_p,
-                                                   repetition_penalty=float(repetition_penalty), top_k=top_k, seed=seed):
+                                                   repetition_penalty=float(repetition_penalty), top_k=top_k, seed=seed,
+                                                   typical_mass=typical_mass):
             if done and codes.shape[1] > 0 and int(codes[0, -1]) == self.stop_mel_token:
                 codes = codes[:, :-1]  # the reference's generator stops BEFORE yielding the stop token's pair
             if codes.shape[1] == 0:

@@ -9,7 +9,7 @@ namespace tt { extern bool g_flash32; extern bool g_voc_mfma; extern bool g_gemm
 extern "C" {
 
 const char* tt_last_error(void) { return tt::last_error(); }
-int tt_abi_version(void) { return 5; }  // ABI changes
+int tt_abi_version(void) { return 6; }  // ABI changes
 
 int tt_init(void) {
   int dev = 0;
@@ -169,12 +169,31 @@ int tt_op_sample(const float* logits, int ldl, int B, int V, unsigned* seen, con
   a.exp_noise = sp->exp_noise; a.seed = sp->seed; a.row_offset = sp->row_offset;
   a.state = scratch; a.unfinished = unfinished; a.stop_token = stop_token; a.codes = codes; a.ldcodes = ldcodes;
   a.next_tok = scratch + 2; a.unfinished_count = scratch + 2 + B;
+  float* typ = nullptr;
+  if (sp->typical_mass != 0.f) {
+    if (hipMalloc((void**)&typ, (size_t)B * (ldl ? ldl : V) * sizeof(float)) != hipSuccess) {
+      (void)hipFree(scratch);
+      set_error("tt_op_sample: hipMalloc failed");
+      return -2;
+    }
+    a.typical_mass = sp->typical_mass; a.typical_out = typ;
+  }
   int rc = sample_launch(a, s);
   hipError_t e = hipStreamSynchronize(s);
   (void)hipFree(scratch);
+  if (typ) (void)hipFree(typ);
   TT_TRY(rc);
   TT_CHECK_HIP(e);
   return 0;
+}
+
+int tt_op_typical_mask(const float* logits, int ldl, int B, int V, const unsigned* seen, float repetition_penalty, float mass, float* out,
+                       void* stream) {
+  SampleArgs a;
+  memset(&a, 0, sizeof(a));
+  a.logits = logits; a.ldl = ldl; a.B = B; a.V = V; a.seen = const_cast<unsigned*>(seen);
+  a.rep_penalty = repetition_penalty; a.typical_mass = mass; a.typical_out = out;
+  return typical_mask_launch(a, (hipStream_t)stream);
 }
 
 int tt_op_conv1d(const float* x, const float* w, const float* bias, float* y, int Cin, int Cout, int T, int k, int dilation, int reflect,

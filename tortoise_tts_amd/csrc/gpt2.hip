@@ -50,6 +50,7 @@ struct tt_ar {
   void* vt = nullptr;      // full pass V^T [BH][64][n_pad]
   float* slabs = nullptr;  // split-K partials [MAX_SPLIT][max_batch][D]
   float* logits = nullptr; // [max_batch][V]
+  float* typ_logits = nullptr;  // [max_batch][Vp]: the rows the sampler reads under typical sampling (tt_sampling.typical_mass)
   int* state = nullptr; unsigned* seen = nullptr; int* unfinished = nullptr; int* unfinished_count = nullptr;
   int* next_tok = nullptr;
   int* guard = nullptr;    // [4] device counters: [0] rows with a non-finite value seen by the row norms / the sampler (tt_ar_guard)
@@ -409,6 +410,7 @@ int tt_ar_create(const tt_ar_config* cfg, const tt_ar_weights* w, tt_ar** out) {
   if (!rc) rc = e->arena.alloc_t(&e->slabs, (size_t)MAX_SPLIT * cfg->max_batch * D);
   e->Vp = round_up(e->V, 4);
   if (!rc) rc = e->arena.alloc_t(&e->logits, (size_t)cfg->max_batch * e->Vp);
+  if (!rc) rc = e->arena.alloc_t(&e->typ_logits, (size_t)cfg->max_batch * e->Vp);
   if (!rc) rc = e->arena.alloc(&e->w_head_p, (size_t)e->Vp * D * es);   // (arena memory is zeroed: the padding rows / bias entries are 0)
   if (!rc) rc = e->arena.alloc_t(&e->b_head_p, e->Vp);
   if (!rc && hipMemcpy(e->w_head_p, w->w_mel_head, (size_t)e->V * D * es, hipMemcpyDeviceToDevice) != hipSuccess) { set_error("tt_ar_create: copying the head weight failed"); rc = -2; }
@@ -539,6 +541,8 @@ int tt_ar_decode_step(tt_ar* e, const int* tokens, void* stream) {
 // replaying the step graph again).  Tokens [e->gen_done, target) are produced; codes is the caller's [B][ldcodes] buffer.
 static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes, const tt_sampling* sp, int* codes, int* n_steps_host,
                            int* finished_host, hipStream_t s) {
+  TT_REQUIRE(sp->typical_mass == 0.f || (sp->typical_mass > 0.f && sp->typical_mass < 1.f), "tt_ar_generate: typical_mass %g outside (0, 1) (0 = off)",
+             (double)sp->typical_mass);
   SampleArgs sa;
   memset(&sa, 0, sizeof(sa));
   sa.B = B; sa.V = e->V; sa.seen = e->seen;
@@ -549,6 +553,7 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
   sa.embed_x = e->x; sa.tok_emb = e->w.mel_emb; sa.pos_emb = e->w.mel_pos; sa.D = e->D; sa.pos_offset = e->cfg.mel_pos_offset;
   sa.pos_len = e->cfg.mel_pos_len;
   sa.guard = e->guard;
+  sa.typical_mass = sp->typical_mass; sa.typical_out = e->typ_logits;
   // the Philox keys and the row offset go through device memory (sa.seed / sa.group_seeds / sa.row_offset stay zero): neither the
   // seed nor the candidate range of a call is part of the step graph
   sa.seed = 0;

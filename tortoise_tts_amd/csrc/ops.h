@@ -177,8 +177,15 @@ struct SampleArgs {
   const unsigned long long* keys_dev;
   const int* row_offset_dev;  // != null: row_offset is read from device memory as well (same reason)
   int* guard;                 // optional device counter: += 1 per wave that read a NaN / +inf logit
+  // typical sampling (tts(typical_sampling=True, typical_mass): tortoise/utils/typical_sampling.py, autoregressive.py:558): with
+  // 0 < typical_mass < 1 a first launch writes the rows with every token outside the typical set at -inf to typical_out (laid out
+  // like `logits`: same ldl / ldg), and the sampler reads those rows instead; 0 = off
+  float typical_mass;
+  float* typical_out;
 };
 int sample_launch(const SampleArgs& a, hipStream_t stream);
+// the typical-sampling mask alone: rows of a.logits -> a.typical_out (sample_launch runs it ahead of the sampler when a.typical_mass != 0)
+int typical_mask_launch(const SampleArgs& a, hipStream_t stream);
 // state[0] += 1, state[1] = newest token's index; with `progress` (host-mapped int[2]) also publishes {tokens so far, first step
 // after which unfinished_count was 0} for the host's launch loop (state[2] mirrors the latter on the device)
 int ar_state_advance_launch(int* state, const int* unfinished_count, int* progress, hipStream_t stream);

@@ -676,10 +676,122 @@ __global__ __launch_bounds__(1024) void sample_wide_kernel(SampleArgs a) {
   sample_embed(a, b, step, red_i, tid, 1024);
 }
 
-int sample_launch(const SampleArgs& a, hipStream_t stream) {
+// ---------------------------------------------------------------------------------------------------------------------------
+// Typical sampling: the reference's TypicalLogitsWarper (tortoise/utils/typical_sampling.py:11-33), which inference_speech puts into
+// generate()'s logits_processor list when tts() is called with typical_sampling=True (api.py:361-364, autoregressive.py:558) - it runs
+// AFTER the repetition penalty and BEFORE temperature / top-k / top-p.  Per row, on the penalised scores s:
+//   logp = log_softmax(s), p = exp(logp), H = -nansum(logp p), d = |(-logp) - H|;
+//   tokens in ascending order of d, c_j = cumsum(softmax(s in that order)); last = #{j : c_j < mass}; everything with d > d_(last) is removed.
+// c is nondecreasing, so d_(last) = tau = the smallest distance whose closed set {d <= tau} carries a probability >= mass - no sort is
+// needed: tau is found bit by bit over the (non-negative) float keys of d, 31 counting rounds, each one block-wide sum.  The sums run
+// in double (the reference's CPU cumsum accumulates float probabilities in double and compares the float-rounded value with mass),
+// partials combined in a fixed order: the kept set does not depend on the launch geometry.  One 1024-thread workgroup per logits row.
+// The kernel only MASKS: kept tokens keep their RAW logit (the sampler applies the penalty itself; a removed token stays -inf under it).
+constexpr int TYP_PER = WIDE_V / 1024;
+
+__device__ __forceinline__ double typ_block_sum(double v, double* slots /* [16] of this round */, int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((tid & 63) == 0) slots[tid >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) t += slots[w];
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void typical_mask_kernel(SampleArgs a) {
+  __shared__ double red_d[4][16];
+  __shared__ float red_f[16];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int V = a.V;
+  // row r of the logits: a candidate (ldl != 0) or, while every candidate of a group still shares the prefill logits, the group's row;
+  // the ids seen so far are then the same for all its candidates (the fake prefix ids): the first one's mask is read
+  const size_t row_off = a.ldl ? (size_t)r * a.ldl : (size_t)r * (a.ldg ? a.ldg : V);
+  const int seen_row = a.ldl ? r : (a.ngroups > 1 ? r * a.group_size : 0);
+  const float* lg = a.logits + row_off;
+  float* out = a.typical_out + row_off;
+  const unsigned* seen = a.seen + (size_t)seen_row * ((V + 31) / 32);
+  float raw[TYP_PER], s[TYP_PER];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < TYP_PER; ++j) {
+    const int t = tid + 1024 * j;
+    const int tc = min(t, V - 1);
+    raw[j] = lg[tc];
+    float x = raw[j];
+    if (a.rep_penalty != 1.0f && ((seen[tc >> 5] >> (tc & 31)) & 1u)) x = x < 0.f ? x * a.rep_penalty : x / a.rep_penalty;
+    s[j] = t < V ? x : -INFINITY;
+    m = fmaxf(m, s[j]);
+  }
+  m = wave_max(m);
+  if ((tid & 63) == 0) red_f[tid >> 6] = m;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 16; ++w) m = fmaxf(m, red_f[w]);
+  // softmax / log_softmax pieces as ATen forms them: e = exp(s - max), total = sum e, logp = (s - max) - log(total)
+  float e[TYP_PER];
+  double part = 0.0;
+#pragma unroll
+  for (int j = 0; j < TYP_PER; ++j) {
+    e[j] = expf(s[j] - m);  // exp(-inf) = 0: suppressed tokens and the padding beyond V
+    part += (double)e[j];
+  }
+  const float total = (float)typ_block_sum(part, red_d[0], tid);
+  const float log_total = logf(total);
+  float logp[TYP_PER];
+  part = 0.0;
+#pragma unroll
+  for (int j = 0; j < TYP_PER; ++j) {
+    logp[j] = (s[j] - m) - log_total;
+    const float prod = logp[j] * expf(logp[j]);
+    if (prod == prod) part += (double)prod;  // nansum: -inf * 0 of a suppressed token does not count
+  }
+  const float ent = -(float)typ_block_sum(part, red_d[1], tid);
+  unsigned key[TYP_PER];
+  float pc[TYP_PER];
+#pragma unroll
+  for (int j = 0; j < TYP_PER; ++j) {
+    key[j] = tid + 1024 * j < V ? (__float_as_uint(fabsf((-logp[j]) - ent)) & 0x7FFFFFFFu) : 0x7FFFFFFFu;
+    pc[j] = e[j] / total;
+  }
+  // tau = the greatest c with (float)sum{pc : key < c} < mass  ==  the smallest c whose closed set reaches the mass
+  unsigned tau = 0u;
+#pragma unroll 1
+  for (int bit = 30; bit >= 0; --bit) {
+    const unsigned c = tau | (1u << bit);
+    part = 0.0;
+#pragma unroll
+    for (int j = 0; j < TYP_PER; ++j) part += key[j] < c ? (double)pc[j] : 0.0;
+    const float below = (float)typ_block_sum(part, red_d[2 + (bit & 1)], tid);  // two slot sets: one barrier per round
+    tau = below < a.typical_mass ? c : tau;  // (block-uniform: every thread adds the same 16 partials in the same order)
+  }
+#pragma unroll
+  for (int j = 0; j < TYP_PER; ++j) {
+    const int t = tid + 1024 * j;
+    if (t < V) out[t] = key[j] <= tau ? raw[j] : -INFINITY;
+  }
+}
+
+int typical_mask_launch(const SampleArgs& a, hipStream_t stream) {
+  TT_REQUIRE(a.B > 0 && a.V > 0 && a.V <= WIDE_V, "typical mask: V=%d unsupported (<= %d)", a.V, WIDE_V);
+  TT_REQUIRE(a.typical_mass > 0.f && a.typical_mass < 1.f, "sample: typical_mass %g outside (0, 1)", (double)a.typical_mass);
+  TT_REQUIRE(a.typical_out != nullptr && a.rep_penalty > 0.f, "sample: typical sampling needs a row buffer and a positive repetition penalty");
+  const int rows = a.ldl ? a.B : (a.ngroups > 1 ? a.ngroups : 1);
+  hipLaunchKernelGGL(typical_mask_kernel, dim3(rows), dim3(1024), 0, stream, a);
+  TT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int sample_launch(const SampleArgs& a_in, hipStream_t stream) {
+  SampleArgs a = a_in;
   TT_REQUIRE(a.B > 0 && a.V > 0 && a.V <= WIDE_V, "sample: V=%d unsupported (<= %d)", a.V, WIDE_V);
   TT_REQUIRE(a.ngroups <= 1 || (a.ngroups <= 16 && a.group_size > 0 && a.B == a.ngroups * a.group_size), "sample: %d groups of %d rows do not make %d rows", a.ngroups, a.group_size, a.B);
   TT_REQUIRE(a.temperature > 0.f && a.top_p > 0.f && a.rep_penalty > 0.f, "sample: bad sampling parameters");
+  if (a.typical_mass != 0.f) {
+    TT_TRY(typical_mask_launch(a, stream));
+    a.logits = a.typical_out;
+  }
   ProfScope ps(PROF_SAMPLE, stream, 0.0, (double)a.B * a.V * 4.0, true);
   if (a.top_k >= 1 && a.top_k <= 256) {
     if (a.V <= 33 * 256) launch_timed(ps, sample_kernel<33>, dim3(a.B), dim3(256), 0, stream, a);

@@ -52,7 +52,8 @@ class ArWeights(C.Structure):
 
 class Sampling(C.Structure):
     _fields_ = [("temperature", C.c_float), ("top_p", C.c_float), ("repetition_penalty", C.c_float), ("top_k", C.c_int),
-                ("seed", C.c_ulonglong), ("row_offset", C.c_int), ("exp_noise", vp), ("group_seeds", C.POINTER(C.c_ulonglong))]
+                ("seed", C.c_ulonglong), ("row_offset", C.c_int), ("exp_noise", vp), ("group_seeds", C.POINTER(C.c_ulonglong)),
+                ("typical_mass", C.c_float)]
 
 
 class ClvpLayer(C.Structure):
@@ -213,6 +214,7 @@ _TEST_PROTOS = {
     "tt_op_gemv": (_i, [_i, vp, vp, _i, _i, _i, vp, _i, vp, vp, vp]),
     "tt_op_gemv_ln": (_i, [_i, vp, vp, vp, _f, vp, _i, _i, vp, vp, vp]),
     "tt_op_sample": (_i, [vp, _i, _i, _i, vp, C.POINTER(Sampling), _i, vp, _i, vp, _i, vp]),
+    "tt_op_typical_mask": (_i, [vp, _i, _i, _i, vp, _f, _f, vp, vp]),
     "tt_op_conv1d": (_i, [vp, vp, vp, vp, _i, _i, _i, _i, _i, _i, _f, _i, _f, vp]),
     "tt_op_convt1d": (_i, [vp, vp, vp, vp, _i, _i, _i, _f, vp]),
     "tt_op_lvc": (_i, [_i, vp, vp, _i, _i, vp, _i, _i, vp, _i, _i, vp]),

@@ -137,11 +137,13 @@ class ArStage:
         return torch.empty(B, max_new, device=self.device, dtype=torch.int32)
 
     def generate(self, B, max_new, temperature=0.8, top_p=0.8, repetition_penalty=2.0, top_k=50, seed=0, row_offset=0,
-                 exp_noise=None, group_seeds=None):
+                 exp_noise=None, group_seeds=None, typical_mass=0.0):
         """Returns (codes int64 [B, n_steps], n_steps).  exp_noise: optional f32 [max_new, B, V] Exp(1) draws.
-        group_seeds: after prefill_group calls, one Philox key per utterance (default: `seed` for all of them)."""
+        group_seeds: after prefill_group calls, one Philox key per utterance (default: `seed` for all of them).
+        typical_mass: 0 < mass < 1 = tts(typical_sampling=True, typical_mass=mass) (autoregressive.py:558); 0 = off."""
         s = E.Sampling()
         s.temperature, s.top_p, s.repetition_penalty, s.top_k = temperature, top_p, repetition_penalty, top_k
+        s.typical_mass = float(typical_mass)
         s.seed, s.row_offset = seed, row_offset
         if group_seeds is not None:
             gs = (C.c_ulonglong * len(group_seeds))(*[int(v) for v in group_seeds])
@@ -156,12 +158,13 @@ class ArStage:
         return codes[:, :n.value].long(), n.value
 
     def generate_stream(self, B, max_new, chunk, first_chunk=None, temperature=0.8, top_p=0.8, repetition_penalty=2.0, top_k=50, seed=0,
-                        row_offset=0):
+                        row_offset=0, typical_mass=0.0):
         """Generator over the sampling loop in pieces (api_fast.py:389-420 pulls get_generator() token by token and decodes every
         `stream_chunk_size` tokens): yields (codes int64 [B, n_so_far], finished) after each chunk."""
         s = E.Sampling()
         s.temperature, s.top_p, s.repetition_penalty, s.top_k = temperature, top_p, repetition_penalty, top_k
         s.seed, s.row_offset = seed, row_offset
+        s.typical_mass = float(typical_mass)
         s.exp_noise = None
         codes = self._codes_buffer(B, max_new)
         n, fin = C.c_int(0), C.c_int(0)
