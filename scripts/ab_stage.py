@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--iterations", type=int, default=200)
     ap.add_argument("--ar-variants", default="",
                     help="';'-separated host-lookahead settings of tt_ar_set_option to time one after the other on ONE handle")
+    ap.add_argument("--typical-variants", default="",
+                    help="';'-separated typical_mass settings (0 = off) of the AR stage's sampler, timed one after the other on ONE handle, e.g. '0;0.9;0;0.9'")
     ap.add_argument("--flash-variants", default="",
                     help="';'-separated ttx_kernel_variant(TTX_FLASH32) settings (1 = 32-query-wave attention kernel, 0 = 16-query waves) to time the diffusion "
                          "stage with, one fresh stage object each, e.g. '1;0;1;0'")
@@ -55,9 +57,16 @@ def main():
             ar = stages.ArStage(sd, cfg, dtype=dt, max_batch=args.candidates, max_new_tokens=max(args.mel_tokens, 32), max_latent_candidates=1)
             tt = F.pad(text.int()[None], (0, 1)).to(dev)
             variants = [tuple(int(v) for v in item.split(",")) for item in args.ar_variants.split(";") if item.strip()] or [None]
+            masses = [float(v) for v in args.typical_variants.split(";") if v.strip()]
+            if masses:
+                variants = [("typical", m) for m in masses]
             for var in variants:
                 tag = args.tag
-                if var is not None:
+                mass = 0.0
+                if var is not None and var[0] == "typical":
+                    mass = var[1]
+                    tag = "typical=%g" % mass
+                elif var is not None:
                     ar.set_option(E.TT_AR_OPT_LOOKAHEAD, var[0])
                     tag = "look=%d" % var[0]
                 times = []
@@ -66,7 +75,7 @@ def main():
                     ar.prefill(auto.to(dev), tt)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    codes, n = ar.generate(args.candidates, args.mel_tokens, seed=77)
+                    codes, n = ar.generate(args.candidates, args.mel_tokens, seed=77, typical_mass=mass)
                     torch.cuda.synchronize()
                     if r:
                         times.append((time.perf_counter() - t0) / n)

@@ -93,6 +93,7 @@ struct tt_ar {
   int gemv = 0;  // 0 | 1 GEMV launches | 2 GEMV launches that also do the layer norm in front of them (five launches per layer)
   int captures = 0;   // decode-step captures so far (tt_ar_stat: tests assert the kept graph is reused)
   int drains = 0;     // host-side queue drains the launch loop fell back to (0 when the progress words arrive)
+  bool typical = false;  // the last generation ran the typical-sampling mask ahead of the sampler (one more launch per step)
 };
 
 namespace tt { int g_ar_gemv = 2; }  // ttx_kernel_variant(TTX_AR_GEMV), read at tt_ar_create: handles of <= 4 sequences run 0 = the MFMA decode GEMMs | 1 = GEMV launches | 2 = GEMVs with the layer norms inside
@@ -554,6 +555,7 @@ static int ar_generate_run(tt_ar* e, int B, bool fresh, int target, int ldcodes,
   sa.pos_len = e->cfg.mel_pos_len;
   sa.guard = e->guard;
   sa.typical_mass = sp->typical_mass; sa.typical_out = e->typ_logits;
+  e->typical = sp->typical_mass != 0.f;
   // the Philox keys and the row offset go through device memory (sa.seed / sa.group_seeds / sa.row_offset stay zero): neither the
   // seed nor the candidate range of a call is part of the step graph
   sa.seed = 0;
@@ -774,7 +776,7 @@ int tt_ar_guard(tt_ar* e, int reset) {
 // 2 = kernel launches of one decode step (layers + head + sampler + step counter).
 int tt_ar_stat(tt_ar* e, int which) {
   if (!e) { set_error("tt_ar_stat: null handle"); return -1; }
-  const int per_step = 7 * e->cfg.layers + 4;
+  const int per_step = 7 * e->cfg.layers + 4 + (e->typical ? 1 : 0);
   return which == 0 ? e->captures : which == 1 ? e->drains : which == 2 ? per_step : -1;
 }
 
