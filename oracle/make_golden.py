@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from oracle import ref_shims
 from tortoise_tts_amd import weights as W
-from tortoise_tts_amd.config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
+from tortoise_tts_amd.config import ARConfig, CLVPConfig, CVVPConfig, DiffusionConfig, VocoderConfig
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
@@ -28,6 +28,10 @@ AR_TOKENS = [[5, 77, 8000], [1, 2, 3], [4000, 4001, 9]]
 LAT_SEED, LAT_K, LAT_N, LAT_T = 12, 2, 24, 7
 CLVP_CFG = dict(dim=128, dim_latent=128, depth=2, heads=2)
 CLVP_SEED, CLVP_B, CLVP_T, CLVP_N = 13, 3, 13, 40
+# CVVP (tts(cvvp_amount > 0), api.py:450-472): a reduced instance and the instance api.py:254 builds (512 wide, 8 heads, depth 8)
+CVVP_CFG = dict(model_dim=128, heads=2, depth=2)
+CVVP_SEED, CVVP_CLIPS, CVVP_T, CVVP_B, CVVP_N = 31, 2, 61, 5, 37
+CVVP_FULL_CLIPS, CVVP_FULL_T, CVVP_FULL_B, CVVP_FULL_N = 2, 130, 6, 100
 DIFF_CFG = dict(model_channels=128, num_layers=2, in_latent_channels=128, num_heads=2)
 DIFF_SEED, DIFF_M, DIFF_STEPS, DIFF_TS = 14, 12, 5, 2999
 VOC_SEED, VOC_S = 15, 6
@@ -62,6 +66,15 @@ def clvp_inputs():
     text = torch.randint(0, 256, (1, CLVP_T), generator=g)
     codes = torch.randint(0, 8192, (CLVP_B, CLVP_N), generator=g)
     return text, codes
+
+
+def cvvp_inputs(full=False):
+    """auto_conds f32 [1, n_clips, 80, T] (the voice clips' mel spectrograms, api.py:262-276) and candidate codes int64 [B, n]."""
+    clips, T, B, n = (CVVP_FULL_CLIPS, CVVP_FULL_T, CVVP_FULL_B, CVVP_FULL_N) if full else (CVVP_CLIPS, CVVP_T, CVVP_B, CVVP_N)
+    g = torch.Generator().manual_seed(17 if full else 7)
+    mels = torch.randn(1, clips, 80, T, generator=g) * 2 - 5
+    codes = torch.randint(0, 8192, (B, n), generator=g)
+    return mels, codes
 
 
 def diff_inputs(cfg):
@@ -211,6 +224,25 @@ def golden_clvp(ref):
     text, codes = clvp_inputs()
     scores = m(text.repeat(CLVP_B, 1), codes, return_loss=False)
     np.savez_compressed(os.path.join(OUT, "clvp.npz"), scores=scores.numpy())
+
+
+@torch.no_grad()
+def golden_cvvp(ref):
+    """The reference's CVVP class (tortoise/models/cvvp.py) as api.py:464-468 drives it: per conditioning clip, the clip repeated for
+    every candidate; mean over the clips.  Reduced instance and the api.py:254 instance."""
+    from tortoise.models.cvvp import CVVP
+    out = {}
+    for tag, cfg, full in (("small", CVVPConfig(**CVVP_CFG), False), ("full", CVVPConfig(), True)):
+        sd = W.synthetic_state_dict(W.cvvp_manifest(cfg), seed=CVVP_SEED)
+        m = CVVP(model_dim=cfg.model_dim, transformer_heads=cfg.heads, dropout=0, mel_codes=cfg.mel_codes, conditioning_enc_depth=cfg.depth,
+                 cond_mask_percentage=0, speech_enc_depth=cfg.depth, speech_mask_percentage=0, latent_multiplier=cfg.latent_multiplier).eval()
+        m.load_state_dict(sd, strict=True)
+        mels, codes = cvvp_inputs(full)
+        acc = 0
+        for cl in range(mels.shape[1]):
+            acc = acc + m(mels[:, cl].repeat(codes.shape[0], 1, 1), codes, return_loss=False)
+        out[f"scores_{tag}"] = (acc / mels.shape[1]).numpy()
+    np.savez_compressed(os.path.join(OUT, "cvvp.npz"), **out)
 
 
 @torch.no_grad()
@@ -394,6 +426,7 @@ def main():
     golden_sampling(ref)
     golden_typical(ref)
     golden_clvp(ref)
+    golden_cvvp(ref)
     golden_diffusion(ref)
     golden_vocoder(ref)
     golden_conditioning(ref)

@@ -30,7 +30,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from tortoise_tts_amd.config import (ARConfig, DiffusionConfig, CLVPConfig, VocoderConfig, CALM_TOKEN,
+from tortoise_tts_amd.config import (ARConfig, DiffusionConfig, CLVPConfig, CVVPConfig, VocoderConfig, CALM_TOKEN,
                                      TACOTRON_MEL_MAX, TACOTRON_MEL_MIN)
 
 
@@ -328,10 +328,12 @@ def _rotate_half(x):
     return torch.cat((-x2, x1), dim=-1)
 
 
-def clvp_encoder(sd, cfg: CLVPConfig, tower, x):
+def clvp_encoder(sd, cfg: CLVPConfig, tower, x, wrap=".wrap"):
     """x-transformers Encoder as CLVP builds it (clvp.py:54-83; xtransformers.py:731-1013):
     pre-RMSNorm, bias-free q/k/v, rotary on the first 32 dims of q, k AND v (625-629), softmax(q k^T / 8),
-    to_out; GEGLU feed-forward with erf-GELU (429-437), final LayerNorm (1234).  Eval masks are all-ones."""
+    to_out; GEGLU feed-forward with erf-GELU (429-437), final LayerNorm (1234).  Eval masks are all-ones.
+    wrap: CLVP's CheckpointedXTransformerEncoder wraps every sublayer (state_dict keys `...layers.N.1.wrap.to_q`); CVVP's plain
+    ContinuousTransformerWrapper does not (`...layers.N.1.to_q`)."""
     base = f"{tower}.transformer"
     B, n, D = x.shape
     H = cfg.heads
@@ -351,17 +353,17 @@ def clvp_encoder(sd, cfg: CLVPConfig, tower, x):
         p = f"{base}.attn_layers.layers.{li}"
         h = _rmsnorm(x, sd[f"{p}.0.0.g"])
         if li % 2 == 0:
-            q = (h @ sd[f"{p}.1.wrap.to_q.weight"].t()).view(B, n, H, hd).transpose(1, 2)
-            k = (h @ sd[f"{p}.1.wrap.to_k.weight"].t()).view(B, n, H, hd).transpose(1, 2)
-            v = (h @ sd[f"{p}.1.wrap.to_v.weight"].t()).view(B, n, H, hd).transpose(1, 2)
+            q = (h @ sd[f"{p}.1{wrap}.to_q.weight"].t()).view(B, n, H, hd).transpose(1, 2)
+            k = (h @ sd[f"{p}.1{wrap}.to_k.weight"].t()).view(B, n, H, hd).transpose(1, 2)
+            v = (h @ sd[f"{p}.1{wrap}.to_v.weight"].t()).view(B, n, H, hd).transpose(1, 2)
             q, k, v = rot(q), rot(k), rot(v)
             att = torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1)
             o = (att @ v).transpose(1, 2).reshape(B, n, D)
-            o = o @ sd[f"{p}.1.wrap.to_out.weight"].t() + sd[f"{p}.1.wrap.to_out.bias"]
+            o = o @ sd[f"{p}.1{wrap}.to_out.weight"].t() + sd[f"{p}.1{wrap}.to_out.bias"]
         else:
-            u = h @ sd[f"{p}.1.wrap.net.0.proj.weight"].t() + sd[f"{p}.1.wrap.net.0.proj.bias"]
+            u = h @ sd[f"{p}.1{wrap}.net.0.proj.weight"].t() + sd[f"{p}.1{wrap}.net.0.proj.bias"]
             a, gate = u.chunk(2, dim=-1)
-            o = (a * F.gelu(gate)) @ sd[f"{p}.1.wrap.net.3.weight"].t() + sd[f"{p}.1.wrap.net.3.bias"]
+            o = (a * F.gelu(gate)) @ sd[f"{p}.1{wrap}.net.3.weight"].t() + sd[f"{p}.1{wrap}.net.3.bias"]
         x = x + o
     return F.layer_norm(x, (D,), sd[f"{base}.norm.weight"], sd[f"{base}.norm.bias"], 1e-5)
 
@@ -376,6 +378,49 @@ def clvp_score(sd, cfg: CLVPConfig, text_tokens, codes):
     tl = F.normalize(tl, p=2, dim=-1)
     sl = F.normalize(sl, p=2, dim=-1)
     return (tl * sl).sum(-1) * sd["temperature"].exp()
+
+
+# =============================================================================== CVVP
+def cvvp_collapse(sd, cfg, tower, x):
+    """CollapsingTransformer.forward in eval mode (cvvp.py:19-51): ContinuousTransformerWrapper(use_pos_emb=False) over the same
+    x-transformers Encoder CLVP uses (ff_mult = 1) incl. its final LayerNorm (xtransformers.py:1187-1247), then pre_combiner =
+    conv1x1 -> AttentionBlock (no relative positions) -> conv1x1 on [B, C, n], then the mean over time (the eval mask is all ones).
+    x f32 [B, n, D] -> [B, out]."""
+    h = clvp_encoder(sd, cfg, tower, x, wrap="").permute(0, 2, 1)
+    h = F.conv1d(h, sd[f"{tower}.pre_combiner.0.weight"], sd[f"{tower}.pre_combiner.0.bias"])
+    h = attention_block(sd, f"{tower}.pre_combiner.1", h, cfg.heads)
+    h = F.conv1d(h, sd[f"{tower}.pre_combiner.2.weight"], sd[f"{tower}.pre_combiner.2.bias"])
+    return h.mean(dim=-1)
+
+
+def cvvp_forward(sd, cfg, mel_cond, codes):
+    """CVVP.forward(mel_cond, mel_input, return_loss=False) in eval mode (cvvp.py:107-131) with mel_codes set (speech_emb is an
+    embedding, cvvp.py:89-93).  mel_cond f32 [B, 80, T], codes int64 [B, n] -> f32 [B]."""
+    c = F.conv1d(mel_cond.float(), sd["cond_emb.0.weight"], sd["cond_emb.0.bias"], stride=2, padding=2)
+    c = F.conv1d(c, sd["cond_emb.1.weight"], sd["cond_emb.1.bias"], stride=2, padding=1).permute(0, 2, 1)
+    cl = cvvp_collapse(sd, cfg, "conditioning_transformer", c) @ sd["to_conditioning_latent.weight"].t()
+    sl = cvvp_collapse(sd, cfg, "speech_transformer", sd["speech_emb.emb.weight"][codes.long()]) @ sd["to_speech_latent.weight"].t()
+    cl, sl = F.normalize(cl, p=2, dim=-1), F.normalize(sl, p=2, dim=-1)
+    return (cl * sl).sum(-1) * sd["temperature"].exp()
+
+
+def cvvp_score(sd, cfg, auto_conds, codes):
+    """The CVVP term of the candidate ranking (api.py:464-468): the mean over the voice's conditioning clips of
+    cvvp(clip repeated for every candidate, codes).  auto_conds f32 [1, n_clips, 80, T], codes int64 [B, n] -> f32 [B]."""
+    B = codes.shape[0]
+    acc = 0
+    for cl in range(auto_conds.shape[1]):
+        acc = acc + cvvp_forward(sd, cfg, auto_conds[:, cl].repeat(B, 1, 1), codes)
+    return acc / auto_conds.shape[1]
+
+
+def blend_candidate_scores(clvp_out, cvvp_out, cvvp_amount):
+    """api.py:462-472: what the top-k runs on.  cvvp_amount == 1: CVVP alone; cvvp_out None (no conditioning clips, or amount 0): CLVP alone."""
+    if cvvp_out is None or cvvp_amount == 0:
+        return clvp_out
+    if cvvp_amount == 1:
+        return cvvp_out
+    return cvvp_out * cvvp_amount + clvp_out * (1 - cvvp_amount)
 
 
 # =============================================================================== diffusion network

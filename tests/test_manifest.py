@@ -6,7 +6,7 @@ import torch
 
 from oracle import ref_shims
 from tortoise_tts_amd import weights as W
-from tortoise_tts_amd.config import ARConfig, CLVPConfig, DiffusionConfig, HifiganConfig, VocoderConfig
+from tortoise_tts_amd.config import ARConfig, CLVPConfig, CVVPConfig, DiffusionConfig, HifiganConfig, VocoderConfig
 
 pytestmark = pytest.mark.skipif(not ref_shims.reference_available(), reason="reference tree not present")
 
@@ -40,6 +40,11 @@ def test_manifests_match_the_reference_modules():
                                 text_enc_depth=c.depth, text_seq_len=350, text_heads=c.heads, num_speech_tokens=c.num_speech_tokens,
                                 speech_enc_depth=c.depth, speech_heads=c.heads, speech_seq_len=430, use_xformers=True),
                W.clvp_manifest(c))
+    from tortoise.models.cvvp import CVVP
+    v = CVVPConfig()
+    _meta_load(lambda: CVVP(model_dim=v.model_dim, transformer_heads=v.heads, dropout=0, mel_codes=v.mel_codes, conditioning_enc_depth=v.depth,
+                            cond_mask_percentage=0, speech_enc_depth=v.depth, speech_mask_percentage=0, latent_multiplier=v.latent_multiplier),
+               W.cvvp_manifest(v))  # api.py:254-255
     _meta_load(lambda: ref.UnivNetGenerator(), W.vocoder_manifest(VocoderConfig()))
     from tortoise.models.hifigan_decoder import HifiganGenerator
     from tortoise.models.random_latent_generator import RandomLatentConverter

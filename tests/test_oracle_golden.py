@@ -10,7 +10,7 @@ import torch
 from oracle import make_golden as G
 from oracle import tortoise_oracle as O
 from tortoise_tts_amd import weights as W
-from tortoise_tts_amd.config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
+from tortoise_tts_amd.config import ARConfig, CLVPConfig, CVVPConfig, DiffusionConfig, VocoderConfig
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -92,6 +92,17 @@ def test_clvp_scores():
     sd = W.synthetic_state_dict(W.clvp_manifest(cfg), seed=G.CLVP_SEED)
     text, codes = G.clvp_inputs()
     close(O.clvp_score(sd, cfg, text.repeat(G.CLVP_B, 1), codes), gold("clvp.npz")["scores"], 1e-4)
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+@torch.no_grad()
+def test_cvvp_scores(tag):
+    """oracle.cvvp_score == the committed scores of the reference's CVVP class driven as api.py:464-468 drives it (tests/golden/cvvp.npz):
+    a reduced instance and the 512-wide / 8-head / depth-8 instance api.py:254 builds."""
+    cfg = CVVPConfig(**G.CVVP_CFG) if tag == "small" else CVVPConfig()
+    sd = W.synthetic_state_dict(W.cvvp_manifest(cfg), seed=G.CVVP_SEED)
+    mels, codes = G.cvvp_inputs(tag == "full")
+    close(O.cvvp_score(sd, cfg, mels, codes), gold("cvvp.npz")[f"scores_{tag}"], 1e-5)
 
 
 @torch.no_grad()

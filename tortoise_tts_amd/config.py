@@ -66,6 +66,23 @@ class CLVPConfig:
 
 
 @dataclass
+class CVVPConfig:
+    """CVVP as api.py builds it on demand (reference: tortoise/models/cvvp.py:63-98, api.py:252-257): two CollapsingTransformers
+    (x-transformers Encoder with ff_mult = 1 -> 1 x 1 conv -> AttentionBlock -> 1 x 1 conv -> mean over time) and a latent projection each."""
+    model_dim: int = 512
+    heads: int = 8
+    depth: int = 8           # conditioning_enc_depth == speech_enc_depth == 8
+    mel_channels: int = 80
+    mel_codes: int = 8192
+    latent_multiplier: int = 1
+    rotary_dim: int = 32     # max(dim_head // 2, 32), xtransformers.py:781
+
+    @property
+    def latent_dim(self):
+        return self.latent_multiplier * self.model_dim
+
+
+@dataclass
 class VocoderConfig:
     """UnivNetGenerator (reference: tortoise/models/vocoder.py:225-265)."""
     noise_dim: int = 64

@@ -15,7 +15,7 @@ from collections import OrderedDict
 import math
 import torch
 
-from .config import ARConfig, DiffusionConfig, CLVPConfig, VocoderConfig
+from .config import ARConfig, DiffusionConfig, CLVPConfig, CVVPConfig, VocoderConfig
 
 
 # ----------------------------------------------------------------------------- manifests
@@ -159,6 +159,45 @@ def clvp_manifest(cfg: CLVPConfig = CLVPConfig()):
         d[f"{base}.attn_layers.rotary_pos_emb.inv_freq"] = (cfg.rotary_dim // 2,)
         d[f"{base}.norm.weight"] = (D,)
         d[f"{base}.norm.bias"] = (D,)
+    return d
+
+
+def cvvp_manifest(cfg: CVVPConfig = CVVPConfig()):
+    """CVVP.state_dict() with mel_codes set (cvvp.py:63-98; CollapsingTransformer 19-51; xtransformers.py:731-904, 1187-1213)."""
+    D, L = cfg.model_dim, cfg.latent_dim
+    d = OrderedDict()
+    d["temperature"] = ()
+    d["cond_emb.0.weight"] = (D // 2, cfg.mel_channels, 5)
+    d["cond_emb.0.bias"] = (D // 2,)
+    d["cond_emb.1.weight"] = (D, D // 2, 3)
+    d["cond_emb.1.bias"] = (D,)
+    for tower, out in (("conditioning_transformer", D), ("speech_transformer", L)):
+        base = f"{tower}.transformer"
+        d[f"{base}.attn_layers.rotary_pos_emb.inv_freq"] = (cfg.rotary_dim // 2,)
+        for li in range(2 * cfg.depth):
+            p = f"{base}.attn_layers.layers.{li}"
+            d[f"{p}.0.0.g"] = (D,)
+            if li % 2 == 0:
+                for nm in ("to_q", "to_k", "to_v"):
+                    d[f"{p}.1.{nm}.weight"] = (D, D)
+                d[f"{p}.1.to_out.weight"] = (D, D)
+                d[f"{p}.1.to_out.bias"] = (D,)
+            else:  # GEGLU feed-forward, ff_mult = 1
+                d[f"{p}.1.net.0.proj.weight"] = (2 * D, D)
+                d[f"{p}.1.net.0.proj.bias"] = (2 * D,)
+                d[f"{p}.1.net.3.weight"] = (D, D)
+                d[f"{p}.1.net.3.bias"] = (D,)
+        d[f"{base}.norm.weight"] = (D,)
+        d[f"{base}.norm.bias"] = (D,)
+        d[f"{tower}.pre_combiner.0.weight"] = (out, D, 1)
+        d[f"{tower}.pre_combiner.0.bias"] = (out,)
+        d.update(_attention_block(f"{tower}.pre_combiner.1", out, cfg.heads, rel_pos=False))
+        d[f"{tower}.pre_combiner.2.weight"] = (out, out, 1)
+        d[f"{tower}.pre_combiner.2.bias"] = (out,)
+        if tower == "conditioning_transformer":
+            d["to_conditioning_latent.weight"] = (L, L)
+            d["speech_emb.emb.weight"] = (cfg.mel_codes, D)
+    d["to_speech_latent.weight"] = (L, L)
     return d
 
 
