@@ -424,6 +424,44 @@ int tt_hifi_output_frames(int n_latents);
  * -> wav f32 [*n_samples] in [-1, 1] (tanh), *n_samples = tt_hifi_output_frames(T) * prod(up_factor) */
 int tt_hifi_run(tt_hifi* h, const float* latents, int T, const float* g, float* wav, int* n_samples, void* stream);
 
+/* ============================================================================================
+ * CVVP scoring - the optional second ranking model of tts(cvvp_amount > 0)
+ * (reference: tortoise/models/cvvp.py:63-131, built at api.py:252-257, called per conditioning clip at api.py:464-472:
+ *  clip_results = cvvp * cvvp_amount + clvp * (1 - cvvp_amount); the CHANGELOG calls the model "removed", the call sites remain)
+ * ============================================================================================ */
+typedef struct tt_cvvp_tower {              /* cvvp.CollapsingTransformer (cvvp.py:19-51) */
+  const tt_clvp_layer* layers_host;         /* HOST array [depth]: the x-transformers Encoder, same sublayer layout as CLVP's (ff_mult = 1: inner = dim) */
+  const float* inv_freq;                    /* [rot_dim / 2] */
+  const float* norm_g; const float* norm_b; /* ContinuousTransformerWrapper.norm (LayerNorm, xtransformers.py:1213) */
+  const void* w_pre0; const float* b_pre0;  /* pre_combiner.0 (1x1 conv) T [dim][dim] */
+  tt_attn_block attn;                       /* pre_combiner.1 AttentionBlock(dim, heads), relpos = NULL */
+  const void* w_pre2; const float* b_pre2;  /* pre_combiner.2 (1x1 conv) T [dim][dim] */
+  const void* w_latent;                     /* to_conditioning_latent / to_speech_latent T [dim][dim], no bias */
+} tt_cvvp_tower;
+typedef struct tt_cvvp_config {
+  int dtype;
+  int dim, heads, depth, rot_dim;           /* 512, 8, 8, 32 (latent_multiplier 1: latent width == dim) */
+  int mel_channels, mel_pad;                /* 80, padded to a multiple of 64 for the first convolution's operand */
+  int max_rows;                             /* candidates x codes of one call */
+  int max_cond_frames;                      /* mel frames of one conditioning clip (api.py:73-84 pads / cuts clips to 132300 samples = 517 frames) */
+} tt_cvvp_config;
+typedef struct tt_cvvp_weights {
+  tt_cvvp_tower cond, speech;               /* conditioning_transformer / speech_transformer */
+  const void* w_cond0; const float* b_cond0;   /* cond_emb.0 Conv1d(mel, dim/2, k 5, stride 2, padding 2) as T [dim/2][5][mel_pad] */
+  const void* w_cond1; const float* b_cond1;   /* cond_emb.1 Conv1d(dim/2, dim, k 3, stride 2, padding 1) as T [dim][3][dim/2] */
+  const float* speech_emb;                  /* f32 [mel_codes][dim]  speech_emb.emb.weight */
+  const float* temperature;                 /* f32 [1] */
+} tt_cvvp_weights;
+typedef struct tt_cvvp tt_cvvp;
+int tt_cvvp_create(const tt_cvvp_config* cfg, const tt_cvvp_weights* w, tt_cvvp** out);
+void tt_cvvp_destroy(tt_cvvp* h);
+/* Replaces the loop `for cl in range(auto_conds.shape[1]): cvvp_accumulator += self.cvvp(auto_conds[:, cl].repeat(B, 1, 1), batch,
+ * return_loss=False)` and the division by the clip count (api.py:464-468).  mels f32 [n_clips][mel_channels][T] (the voice's conditioning
+ * clips, api.py:262-276; every clip T frames), codes int32 [B][n] (fix_autoregressive_output'ed candidates, values < mel_codes)
+ * -> scores f32 [B].  A clip's conditioning latent is computed ONCE (the reference repeats the clip B times). */
+int tt_cvvp_score(tt_cvvp* h, const float* mels, int n_clips, int T, const int* codes, int B, int n, float* scores, void* stream);
+int tt_cvvp_guard(tt_cvvp* h, int reset);  /* operand-overflow guard of this stage, see tt_ar_guard */
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtortoise_mi355x.so")
 KBENCH_LIB = os.path.join(LIBDIR, "libtortoise_kbench.so")  # experiments only (scripts/kbench.py); never loaded by the product
 SOURCES = ["common.hip", "gemm.hip", "gemm_bf16.hip", "gemm_f16.hip", "gemm_f32.hip", "gemv.hip", "norm.hip", "attention.hip", "attention_f32.hip", "sampling.hip", "misc.hip", "univnet.hip",
-           "gpt2.hip", "clvp.hip", "diffusion.hip", "cond.hip", "hifigan.hip", "vocoder.hip", "capi.hip"]
+           "gpt2.hip", "clvp.hip", "cvvp.hip", "diffusion.hip", "cond.hip", "hifigan.hip", "vocoder.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-ffp-contract=on",
          "-Werror=extra-tokens", "-Werror=return-type"]  # (a knob inserted as `#endif <rest of the line>` silently drops the rest: round 6 lost a GPU call to one)
 

@@ -247,6 +247,9 @@ extern "C" size_t tt_struct_size(int which) {
     case 17: return sizeof(tt_hifi_resblock);
     case 18: return sizeof(tt_hifi_config);
     case 19: return sizeof(tt_hifi_weights);
+    case 20: return sizeof(tt_cvvp_tower);
+    case 21: return sizeof(tt_cvvp_config);
+    case 22: return sizeof(tt_cvvp_weights);
   }
   return 0;
 }

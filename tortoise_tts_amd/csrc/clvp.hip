@@ -3,8 +3,7 @@
 // dims of q, k and v, softmax(q k^T / 8), GEGLU feed-forward, final LayerNorm, mean pool, latent
 // projection, cosine similarity * exp(temperature).  The text tower runs once per utterance (the
 // reference repeats the prompt B times, api.py:463); the speech tower runs over B x n code rows.
-#include "runtime.h"
-#include "../../include/tortoise_mi355x.h"
+#include "xenc.h"
 
 using namespace tt;
 
@@ -30,38 +29,10 @@ struct tt_clvp {
 
 static int clvp_tower_run(tt_clvp* e, const ClvpTower& t, const int* tokens, int B, int n, float* latent_out, hipStream_t s) {
   const int D = e->cfg.dim, H = e->cfg.heads, inner = e->cfg.ff_inner, dt = e->cfg.dtype;
-  const int M = B * n, n_pad = round_up(n, 32);
+  const int M = B * n;
   TT_TRY(gather_rows_launch(t.w.emb, tokens, e->x, M, D, s));
-  for (int l = 0; l < e->cfg.depth; ++l) {
-    const tt_clvp_layer& w = t.L[l];
-    RowNormArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x = e->x; a.ldx = D; a.M = M; a.D = D; a.mode = NORM_RMS; a.g1 = w.attn_norm_g; a.eps1 = 1e-8f;
-    a.out_t = e->h; a.ldot = D;
-    a.guard = e->guard;
-    TT_TRY(rownorm_launch(dt, a, s));
-    GemmArgs g = gemm_args(e->h, D, w.w_qkv, D, M, 3 * D, D);
-    g.seq_len = n; g.dmodel = D; g.heads = H; g.q = e->q; g.k = e->k; g.vt = e->vt; g.seq_pad = n_pad; g.q_scale = 0.125f;
-    TT_TRY(gemm_launch(dt, EPI_QKV_HEADS, g, s));
-    TT_TRY(rotary_launch(dt, e->q, e->k, e->vt, t.w.inv_freq, B * H, n, n_pad, e->cfg.rot_dim, s));
-    FlashArgs f;
-    memset(&f, 0, sizeof(f));
-    f.q = e->q; f.k = e->k; f.vt = e->vt; f.out = e->attn; f.ldo = D; f.BH = B * H; f.heads = H; f.n = n; f.n_pad = n_pad;
-    TT_TRY(flash_attention_launch(dt, f, s));
-    g = gemm_args(e->attn, D, w.w_out, D, M, D, D);
-    g.bias = w.b_out; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
-    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
-    a.g1 = w.ff_norm_g;
-    TT_TRY(rownorm_launch(dt, a, s));
-    // GEGLU (xtransformers.py:429-437): value * gelu(gate) formed in the projection's epilogue (value / gate rows interleaved at pack
-    // time) - the [M][2 inner] projection (315 MB at 256 candidates x 200 codes) is never written or re-read
-    g = gemm_args(e->h, D, w.w_ff1, D, M, 2 * inner, D);
-    g.bias = w.b_ff1; g.out_t = e->gg; g.ldot = inner;
-    TT_TRY(gemm_launch(dt, EPI_GEGLU, g, s));
-    g = gemm_args(e->gg, inner, w.w_ff2, inner, M, D, inner);
-    g.bias = w.b_ff2; g.res = e->x; g.ldres = D; g.out_f32 = e->x; g.ldo32 = D;
-    TT_TRY(gemm_launch(dt, EPI_STD, g, s));
-  }
+  XencBufs xb{e->x, e->h, e->gg, e->attn, e->q, e->k, e->vt, e->guard};
+  TT_TRY(xenc_layers_run(dt, xb, t.L.data(), e->cfg.depth, t.w.inv_freq, D, H, inner, e->cfg.rot_dim, B, n, s));
   RowNormArgs a;
   memset(&a, 0, sizeof(a));
   a.x = e->x; a.ldx = D; a.M = M; a.D = D; a.mode = NORM_LAYER; a.g1 = t.w.norm_g; a.b1 = t.w.norm_b; a.eps1 = 1e-5f;

@@ -119,6 +119,20 @@ class CondWeights(C.Structure):
                 ("diff_w_c0", vp), ("diff_b_c0", vp), ("diff_w_c1", vp), ("diff_b_c1", vp), ("diff_attn_host", C.POINTER(AttnBlock))]
 
 
+class CvvpTower(C.Structure):
+    _fields_ = [("layers_host", C.POINTER(ClvpLayer)), ("inv_freq", vp), ("norm_g", vp), ("norm_b", vp), ("w_pre0", vp), ("b_pre0", vp),
+                ("attn", AttnBlock), ("w_pre2", vp), ("b_pre2", vp), ("w_latent", vp)]
+
+
+class CvvpConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("dtype", "dim", "heads", "depth", "rot_dim", "mel_channels", "mel_pad", "max_rows", "max_cond_frames")]
+
+
+class CvvpWeights(C.Structure):
+    _fields_ = [("cond", CvvpTower), ("speech", CvvpTower), ("w_cond0", vp), ("b_cond0", vp), ("w_cond1", vp), ("b_cond1", vp),
+                ("speech_emb", vp), ("temperature", vp)]
+
+
 HIFI_MAX_STAGES = 6
 
 
@@ -139,7 +153,8 @@ class HifiWeights(C.Structure):
 
 # order == tt_struct_size(which)
 BOUNDARY_STRUCTS = [GptLayer, ArConfig, ArWeights, Sampling, ClvpLayer, ClvpTower, ClvpConfig, AttnBlock, ResBlock, DiffConfig,
-                    DiffWeights, DiffStep, VocBlock, VocConfig, VocWeights, CondConfig, CondWeights, HifiResBlock, HifiConfig, HifiWeights]
+                    DiffWeights, DiffStep, VocBlock, VocConfig, VocWeights, CondConfig, CondWeights, HifiResBlock, HifiConfig, HifiWeights,
+                    CvvpTower, CvvpConfig, CvvpWeights]
 
 _i, _f, _sz = C.c_int, C.c_float, C.c_size_t
 _PROTOS = {
@@ -194,6 +209,10 @@ _PROTOS = {
     "tt_voc_destroy": (None, [vp]),
     "tt_voc_run": (_i, [vp, vp, _i, vp, vp, vp]),
     "tt_voc_guard": (_i, [vp, _i]),
+    "tt_cvvp_create": (_i, [C.POINTER(CvvpConfig), C.POINTER(CvvpWeights), C.POINTER(vp)]),
+    "tt_cvvp_destroy": (None, [vp]),
+    "tt_cvvp_score": (_i, [vp, vp, _i, _i, vp, _i, _i, vp, vp]),
+    "tt_cvvp_guard": (_i, [vp, _i]),
     "tt_prof_enable": (_i, [_i]),
     "tt_graph_replay": (_i, [_i]),
     "tt_prof_classes": (_i, []),

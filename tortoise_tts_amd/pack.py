@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import engine as E
-from .config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
+from .config import ARConfig, CLVPConfig, CVVPConfig, DiffusionConfig, VocoderConfig
 
 
 def torch_dtype(dtype):
@@ -103,24 +103,31 @@ def geglu_interleave(inner):
     return torch.stack([v, v + inner], dim=1).reshape(-1)
 
 
-def _pack_clvp_tower(h, sd, cfg: CLVPConfig, tower, emb_key, latent_key):
-    base = f"{tower}.transformer"
-    layers = (E.ClvpLayer * cfg.depth)()
-    for li in range(cfg.depth):
+def _pack_xenc_layers(h, sd, base, depth, wrap=".wrap"):
+    """The x-transformers Encoder sublayers of `base`.attn_layers as tt_clvp_layer[depth] (q / k / v stacked, GEGLU rows interleaved).
+    wrap: CLVP's CheckpointedXTransformerEncoder wraps every sublayer (keys `...layers.N.1.wrap.to_q`), CVVP's plain wrapper does not."""
+    layers = (E.ClvpLayer * depth)()
+    for li in range(depth):
         pa = f"{base}.attn_layers.layers.{2 * li}"
         pf = f"{base}.attn_layers.layers.{2 * li + 1}"
         L = layers[li]
         L.attn_norm_g = _p(h.f32(sd[f"{pa}.0.0.g"]))
-        L.w_qkv = _p(h.op(torch.cat([sd[f"{pa}.1.wrap.to_q.weight"], sd[f"{pa}.1.wrap.to_k.weight"],
-                                     sd[f"{pa}.1.wrap.to_v.weight"]], dim=0)))
-        L.w_out = _p(h.op(sd[f"{pa}.1.wrap.to_out.weight"]))
-        L.b_out = _p(h.f32(sd[f"{pa}.1.wrap.to_out.bias"]))
+        L.w_qkv = _p(h.op(torch.cat([sd[f"{pa}.1{wrap}.to_q.weight"], sd[f"{pa}.1{wrap}.to_k.weight"],
+                                     sd[f"{pa}.1{wrap}.to_v.weight"]], dim=0)))
+        L.w_out = _p(h.op(sd[f"{pa}.1{wrap}.to_out.weight"]))
+        L.b_out = _p(h.f32(sd[f"{pa}.1{wrap}.to_out.bias"]))
         L.ff_norm_g = _p(h.f32(sd[f"{pf}.0.0.g"]))
-        gl = geglu_interleave(sd[f"{pf}.1.wrap.net.0.proj.weight"].shape[0] // 2)
-        L.w_ff1 = _p(h.op(sd[f"{pf}.1.wrap.net.0.proj.weight"][gl]))
-        L.b_ff1 = _p(h.f32(sd[f"{pf}.1.wrap.net.0.proj.bias"][gl]))
-        L.w_ff2 = _p(h.op(sd[f"{pf}.1.wrap.net.3.weight"]))
-        L.b_ff2 = _p(h.f32(sd[f"{pf}.1.wrap.net.3.bias"]))
+        gl = geglu_interleave(sd[f"{pf}.1{wrap}.net.0.proj.weight"].shape[0] // 2)
+        L.w_ff1 = _p(h.op(sd[f"{pf}.1{wrap}.net.0.proj.weight"][gl]))
+        L.b_ff1 = _p(h.f32(sd[f"{pf}.1{wrap}.net.0.proj.bias"][gl]))
+        L.w_ff2 = _p(h.op(sd[f"{pf}.1{wrap}.net.3.weight"]))
+        L.b_ff2 = _p(h.f32(sd[f"{pf}.1{wrap}.net.3.bias"]))
+    return layers
+
+
+def _pack_clvp_tower(h, sd, cfg: CLVPConfig, tower, emb_key, latent_key):
+    base = f"{tower}.transformer"
+    layers = _pack_xenc_layers(h, sd, base, cfg.depth)
     t = E.ClvpTower()
     t.layers_host = layers
     t.emb = _p(h.f32(sd[emb_key]))
@@ -137,6 +144,38 @@ def pack_clvp(sd, cfg: CLVPConfig, device, dtype):
     h.text = _pack_clvp_tower(h, sd, cfg, "text_transformer", "text_emb.weight", "to_text_latent.weight")
     h.speech = _pack_clvp_tower(h, sd, cfg, "speech_transformer", "speech_emb.weight", "to_speech_latent.weight")
     h.temperature = h.f32(sd["temperature"].reshape(1))
+    return h
+
+
+def pack_cvvp(sd, cfg: CVVPConfig, device, dtype, mel_pad=128):
+    """CVVP.state_dict() (cvvp.py:63-98, the api.py:254 instance) for tt_cvvp_create."""
+    assert cfg.latent_multiplier == 1, "the reference builds CVVP with latent_multiplier=1 (api.py:254-255)"
+    h = Holder(device, dtype)
+    D = cfg.model_dim
+    w = E.CvvpWeights()
+    for tower, dst in (("conditioning_transformer", w.cond), ("speech_transformer", w.speech)):
+        base = f"{tower}.transformer"
+        layers = _pack_xenc_layers(h, sd, base, cfg.depth, wrap="")
+        h.keep.append(layers)
+        dst.layers_host = layers
+        dst.inv_freq = _p(h.f32(sd[f"{base}.attn_layers.rotary_pos_emb.inv_freq"]))
+        dst.norm_g = _p(h.f32(sd[f"{base}.norm.weight"]))
+        dst.norm_b = _p(h.f32(sd[f"{base}.norm.bias"]))
+        dst.w_pre0 = _p(h.op(sd[f"{tower}.pre_combiner.0.weight"]))
+        dst.b_pre0 = _p(h.f32(sd[f"{tower}.pre_combiner.0.bias"]))
+        dst.attn = _pack_attn(h, sd, f"{tower}.pre_combiner.1", D, cfg.heads)
+        dst.w_pre2 = _p(h.op(sd[f"{tower}.pre_combiner.2.weight"]))
+        dst.b_pre2 = _p(h.f32(sd[f"{tower}.pre_combiner.2.bias"]))
+    w.cond.w_latent = _p(h.op(sd["to_conditioning_latent.weight"]))
+    w.speech.w_latent = _p(h.op(sd["to_speech_latent.weight"]))
+    w.w_cond0 = _p(h.conv(sd["cond_emb.0.weight"], mel_pad))
+    w.b_cond0 = _p(h.f32(sd["cond_emb.0.bias"]))
+    w.w_cond1 = _p(h.conv(sd["cond_emb.1.weight"]))
+    w.b_cond1 = _p(h.f32(sd["cond_emb.1.bias"]))
+    w.speech_emb = _p(h.f32(sd["speech_emb.emb.weight"]))
+    w.temperature = _p(h.f32(sd["temperature"].reshape(1)))
+    h.weights = w
+    h.mel_pad = mel_pad
     return h
 
 

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from . import engine as E
 from . import pack
-from .config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig
+from .config import ARConfig, CLVPConfig, CVVPConfig, DiffusionConfig, VocoderConfig
 from .schedule import Schedule
 
 
@@ -279,6 +279,53 @@ def nearest_interp_index(m, s):
     scale = np.float32(m) / np.float32(s)
     idx = np.floor(np.arange(s, dtype=np.float32) * scale).astype(np.int64)
     return np.minimum(idx, m - 1).astype(np.int32)
+
+
+class CvvpStage:
+    """The CVVP term of the candidate ranking, tts(cvvp_amount > 0) (cvvp.py:107-131 as api.py:464-468 drives it)."""
+
+    def __init__(self, sd, cfg: CVVPConfig = CVVPConfig(), device="cuda", dtype=E.TT_F16, max_rows=256 * 500, max_cond_frames=520):
+        self.lib = E.init()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.w = pack.pack_cvvp(sd, cfg, self.device, dtype)
+        c = E.CvvpConfig()
+        c.dtype, c.dim, c.heads, c.depth, c.rot_dim = dtype, cfg.model_dim, cfg.heads, cfg.depth, cfg.rotary_dim
+        c.mel_channels, c.mel_pad, c.max_rows, c.max_cond_frames = cfg.mel_channels, self.w.mel_pad, max_rows, max_cond_frames
+        self.max_rows, self.max_cond_frames = max_rows, max_cond_frames
+        self.h = E.vp()
+        E.check(self.lib.tt_cvvp_create(C.byref(c), C.byref(self.w.weights), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib.tt_cvvp_destroy(self.h)
+            self.h = E.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def guard(self, reset=True):
+        return E.guard_count(self.lib.tt_cvvp_guard(self.h, int(reset)))
+
+    def score(self, auto_conds, codes):
+        """auto_conds f32 [1, n_clips, 80, T] (the voice's conditioning clips, api.py:262-276), codes int [B, n] -> f32 [B]: the mean over
+        the clips of cvvp(clip, codes) (api.py:464-468)."""
+        mels = auto_conds.to(self.device).float().reshape(-1, auto_conds.shape[-2], auto_conds.shape[-1]).contiguous()
+        n_clips, _, T = mels.shape
+        if T > self.max_cond_frames:
+            raise ValueError(f"conditioning clips of {T} mel frames exceed this CVVP handle's capacity ({self.max_cond_frames})")
+        B, n = codes.shape
+        outs = []
+        per = max(1, self.max_rows // n)
+        for i in range(0, B, per):
+            c = _i32(codes[i:i + per], self.device)
+            out = torch.empty(c.shape[0], device=self.device, dtype=torch.float32)
+            E.check(self.lib.tt_cvvp_score(self.h, E.ptr(mels), n_clips, T, E.ptr(c), c.shape[0], n, E.ptr(out), E.stream_ptr()))
+            outs.append(out)
+        return torch.cat(outs)
 
 
 class DiffusionStage:
