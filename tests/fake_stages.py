@@ -132,6 +132,18 @@ class FakeClvpStage:
         return torch.cat([self.score(t.reshape(1, -1), codes[g * N:(g + 1) * N]) for g, t in enumerate(texts)])
 
 
+class FakeCvvpStage:
+    def __init__(self, sd, cfg, device="cpu", dtype=0, max_rows=0, max_cond_frames=520):
+        self.sd, self.cfg, self.dtype, self.calls = sd, cfg, dtype, 0
+
+    def score(self, auto_conds, codes):
+        self.calls += 1
+        return O.cvvp_score(self.sd, self.cfg, auto_conds.float().cpu(), codes.long().cpu())
+
+    def close(self):
+        pass
+
+
 class FakeDiffusionStage:
     def __init__(self, sd, cfg, device="cpu", dtype=0, max_seq=0, max_codes=0, max_steps=0, max_batch=1):
         self.sd, self.cfg, self.max_batch, self.dtype = sd, cfg, max_batch, dtype
@@ -210,6 +222,7 @@ def install(monkeypatch):
     from tortoise_tts_amd import api
     monkeypatch.setattr(api.stages, "ArStage", FakeArStage)
     monkeypatch.setattr(api.stages, "ClvpStage", FakeClvpStage)
+    monkeypatch.setattr(api.stages, "CvvpStage", FakeCvvpStage)
     monkeypatch.setattr(api.stages, "DiffusionStage", FakeDiffusionStage)
     monkeypatch.setattr(api.stages, "VocoderStage", FakeVocoderStage)
     monkeypatch.setattr(api.stages, "RandomLatentStage", FakeRandomLatentStage)

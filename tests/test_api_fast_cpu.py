@@ -98,8 +98,10 @@ def test_tts_and_stream_flow_on_oracle_backed_stages(monkeypatch):
     assert tts2.ar.latent_calls == [False, False]
     with pytest.raises(ValueError, match="Too much text"):
         tts.tts(list(range(1, 255)) * 2)
-    with pytest.raises(NotImplementedError):
-        tts.tts(text, cvvp_amount=0.5)
+    tts.tts(text, max_mel_tokens=40, use_deterministic_seed=4)
+    base = tts.last_codes.clone()
+    tts.tts(text, max_mel_tokens=40, use_deterministic_seed=4, cvvp_amount=0.5)  # accepted and unused, as upstream (api_fast.py:426: one sample, no ranking)
+    assert torch.equal(tts.last_codes, base)
     with pytest.raises(NotImplementedError, match="num_beams"):
         list(tts.tts_stream(text, num_beams=4))
     # typical sampling (api.py:361-364 -> autoregressive.py:558) is honoured: other codes than plain sampling on the same seed, the

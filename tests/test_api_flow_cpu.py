@@ -134,8 +134,8 @@ def test_random_voice_and_error_behaviour(tts):
         tts.tts(list(range(1, 255)) * 2, conditioning_latents=(a, d))
     with pytest.raises(NotImplementedError, match="bracket"):
         tts.tts("[I am so sad,] hello", conditioning_latents=(a, d))
-    with pytest.raises(NotImplementedError):
-        tts.tts("hello", conditioning_latents=(a, d), cvvp_amount=0.5)
+    with pytest.raises(ValueError, match="cvvp_amount"):
+        tts.tts("hello", conditioning_latents=(a, d), cvvp_amount=1.5)
     with pytest.raises(ValueError, match="max_mel_tokens"):
         tts.tts("hello", conditioning_latents=(a, d), max_mel_tokens=500)
 
@@ -157,6 +157,52 @@ def test_voice_samples_path(tts):
     wav = tts.tts("hello there", voice_samples=clips, num_autoregressive_samples=4, diffusion_iterations=4, max_mel_tokens=24,
                   use_deterministic_seed=2)
     assert torch.is_tensor(wav) and wav.shape[:2] == (1, 1) and torch.isfinite(wav).all()
+
+
+@torch.no_grad()
+def test_cvvp_amount_blends_the_candidate_ranking(tts):
+    """tts(cvvp_amount > 0) (api.py:450-472): the CVVP model is built on first use, scores the candidates against the voice's conditioning
+    clips (mean over the clips) and is blended with CLVP as cvvp * amount + clvp * (1 - amount); amount == 1 ranks by CVVP alone; without
+    clips (latents-only voice) the ranking stays CLVP's, as upstream."""
+    from oracle import tortoise_oracle as O
+    from tortoise_tts_amd import weights as W
+    from tortoise_tts_amd.config import CVVPConfig
+    ccfg = CVVPConfig(**G.CVVP_CFG)
+    tts.cvvp_cfg = ccfg
+    tts._state_dicts["cvvp"] = W.synthetic_state_dict(W.cvvp_manifest(ccfg), seed=G.CVVP_SEED)
+    g = torch.Generator().manual_seed(8)
+    pairs = [(torch.randn(1, 80, 64, generator=g) * 2 - 5, torch.randn(1, 100, 70, generator=g) * 2 - 5) for _ in range(2)]
+    kw = dict(voice_samples=pairs, num_autoregressive_samples=8, diffusion_iterations=3, max_mel_tokens=24, use_deterministic_seed=3, k=2)
+    assert tts.cvvp is None
+    tts.tts("hello there", **kw)
+    assert tts.cvvp is None  # "only loaded if used" (api.py:234)
+    clvp_best = tts.last_best_codes.clone()
+    tts.tts("hello there", cvvp_amount=1.0, **kw)
+    assert tts.cvvp is not None and tts.cvvp.calls == 1
+    cvvp_best = tts.last_best_codes.clone()
+    # recompute both rankings from the candidates (same seed -> same candidates; the winners are rows of the same candidate set)
+    auto_conds = torch.stack([p[0] for p in pairs], dim=1)
+    cand = tts.ar.gen_codes
+    from tortoise_tts_amd.api import fix_autoregressive_output
+    import torch.nn.functional as F
+    fixed = fix_autoregressive_output(F.pad(cand, (0, 24 - cand.shape[1]), value=tts.stop_mel_token), tts.stop_mel_token)
+    want = fixed[torch.topk(O.cvvp_score(tts._state_dicts["cvvp"], ccfg, auto_conds, fixed), 2).indices]
+    assert torch.equal(cvvp_best, want) and not torch.equal(cvvp_best, clvp_best)
+    tts.tts("hello there", cvvp_amount=0.5, **kw)
+    text = torch.as_tensor(tts.tokenizer.encode("hello there")).reshape(1, -1)
+    clvp = O.clvp_score(tts._state_dicts["clvp"], tts._cfgs["clvp"], F.pad(text, (0, 1)).repeat(8, 1), fixed)
+    blend = O.blend_candidate_scores(clvp, O.cvvp_score(tts._state_dicts["cvvp"], ccfg, auto_conds, fixed), 0.5)
+    assert torch.equal(tts.last_best_codes, fixed[torch.topk(blend, 2).indices])
+    # latents only: nothing for CVVP to compare with -> CLVP's ranking (api.py:464, 473); amount 1 has nothing to rank by at all
+    lat = voice_latents(tts._cfgs)
+    kw2 = dict(kw, voice_samples=None, conditioning_latents=lat)
+    tts.tts("hello there", **kw2)
+    only_clvp = tts.last_best_codes.clone()
+    n_calls = tts.cvvp.calls
+    tts.tts("hello there", cvvp_amount=0.5, **kw2)
+    assert torch.equal(tts.last_best_codes, only_clvp) and tts.cvvp.calls == n_calls
+    with pytest.raises(ValueError, match="voice_samples"):
+        tts.tts("hello there", cvvp_amount=1.0, **kw2)
 
 
 def test_constructor_flags(monkeypatch):

@@ -72,3 +72,47 @@ def test_cvvp_ranks_a_full_candidate_batch_like_the_oracle():
           f"score spread {float(want.std()):.3f}")
     assert err < 2e-3 and rho > 0.999 and len(top_g & top_w) >= 7
     st.close()
+
+
+@torch.no_grad()
+def test_tts_with_cvvp_amount_on_the_device():
+    """The whole tts() call at the reference's hyper-parameters with a voice given as clips (mel pairs) and cvvp_amount in {0, 0.5, 1}: the CVVP
+    stage is built on first use (api.py:234, 450-453), the ranking tts() used equals the blend api.py:462-472 prescribes - recomputed here
+    from the stages' own scores of the same candidates - and cvvp_amount = 1 never runs CLVP."""
+    import bench
+    from oracle import tortoise_oracle as O
+    from tortoise_tts_amd.api import TextToSpeech, fix_autoregressive_output
+    import torch.nn.functional as F
+    sds = bench.synthetic_weights()
+    sds["cvvp"] = W.synthetic_state_dict(W.cvvp_manifest(CVVPConfig()), seed=G.CVVP_SEED)
+    text, _ = bench.synthetic_prompt()
+    tts = TextToSpeech(state_dicts=sds, max_candidates=16, max_mel_tokens=48)
+    g = torch.Generator().manual_seed(12)
+    pairs = [(torch.randn(1, 80, 517, generator=g) * 2 - 5, torch.randn(1, 100, 564, generator=g) * 2 - 5) for _ in range(2)]
+    kw = dict(voice_samples=pairs, num_autoregressive_samples=16, diffusion_iterations=4, max_mel_tokens=48, use_deterministic_seed=5, k=3, verbose=False)
+    wav0 = tts.tts(text, **kw)
+    assert tts.cvvp is None and len(wav0) == 3
+    best0 = tts.last_best_codes.clone()
+    calls = {"clvp": 0}
+    orig = tts.clvp.score
+    tts.clvp.score = lambda *a, **k_: (calls.__setitem__("clvp", calls["clvp"] + 1), orig(*a, **k_))[1]
+    wav1 = tts.tts(text, cvvp_amount=1.0, **kw)
+    assert tts.cvvp is not None and calls["clvp"] == 0 and all(torch.isfinite(w).all() for w in wav1)
+    best1 = tts.last_best_codes.clone()
+    tts.tts(text, cvvp_amount=0.5, **kw)
+    assert calls["clvp"] == 1
+    best_half = tts.last_best_codes.clone()
+    # the same candidates again (same seed), scored by the two stages directly
+    auto, _, auto_conds, _ = tts.get_conditioning_latents(pairs, return_mels=True)
+    tt = F.pad(text.int()[None].to(tts.device), (0, 1))
+    tts.ar.prefill(auto.to(tts.device).float(), tt)
+    codes, _ = tts.ar.generate(16, 48, seed=5, row_offset=0)
+    fixed = fix_autoregressive_output(F.pad(codes, (0, 48 - codes.shape[1]), value=tts.stop_mel_token), tts.stop_mel_token)
+    clvp, cvvp = orig(tt, fixed), tts.cvvp.score(auto_conds, fixed)
+    assert float(cvvp.std()) > 1e-3
+    for amount, best in ((0.0, best0), (1.0, best1), (0.5, best_half)):
+        scores = O.blend_candidate_scores(clvp, cvvp, amount)
+        assert torch.equal(best.cpu(), fixed[torch.topk(scores, 3).indices].cpu()), f"ranking at cvvp_amount={amount}"
+    print(f"[parity] tts(cvvp_amount): winners at 0 / 0.5 / 1 = {torch.topk(clvp, 3).indices.tolist()} / "
+          f"{torch.topk(O.blend_candidate_scores(clvp, cvvp, 0.5), 3).indices.tolist()} / {torch.topk(cvvp, 3).indices.tolist()}; "
+          f"CVVP score spread {float(cvvp.std()):.3f}, CLVP {float(clvp.std()):.3f}; stage seconds {({k: round(v, 4) for k, v in tts.timings.items()})}")

@@ -16,8 +16,9 @@ Constructor flags of the reference and what they mean here:
   * half       True selects fp16 MFMA operands (the reference's fp16 autocast), False the engine default (bf16) unless
                the engine-only `dtype=` says otherwise;
   * enable_redaction  bracketed text needs the wav2vec2 aligner (out of scope): such text raises, other text is unaffected.
-Out of scope (raise, never silently fall back): CVVP (cvvp_amount != 0, removed upstream), wav2vec redaction of
-bracketed text, DeepSpeed flag.
+cvvp_amount > 0 (api.py:450-472; the CHANGELOG calls CVVP "removed", the call sites and cvvp.pth remain): the CVVP model is built on
+first use like upstream (load_cvvp -> stages.CvvpStage, csrc/cvvp.hip) and blended into the CLVP ranking when voice_samples are given.
+Out of scope (raise, never silently fall back): wav2vec redaction of bracketed text, DeepSpeed flag.
 """
 import os
 import random
@@ -30,12 +31,12 @@ from . import dist as tdist
 from . import engine as E
 from . import stages
 from . import weights as W
-from .config import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig, PRESETS, BASE_SETTINGS, CALM_TOKEN
+from .config import ARConfig, CLVPConfig, CVVPConfig, DiffusionConfig, VocoderConfig, PRESETS, BASE_SETTINGS, CALM_TOKEN
 from .schedule import Schedule
 
 MODELS_DIR = os.environ.get("TORTOISE_MODELS_DIR", os.path.join(os.path.expanduser("~"), ".cache", "tortoise", "models"))
 MODEL_FILES = {"autoregressive": "autoregressive.pth", "clvp": "clvp2.pth", "diffusion": "diffusion_decoder.pth",
-               "vocoder": "vocoder.pth", "rlg_auto": "rlg_auto.pth", "rlg_diffuser": "rlg_diffuser.pth"}
+               "vocoder": "vocoder.pth", "rlg_auto": "rlg_auto.pth", "rlg_diffuser": "rlg_diffuser.pth", "cvvp": "cvvp.pth"}
 
 
 class _StageTimer:
@@ -196,6 +197,7 @@ class TextToSpeech:
         self.clvp_cfg = cfgs.get("clvp", CLVPConfig())
         self.diff_cfg = cfgs.get("diffusion", DiffusionConfig())
         self.voc_cfg = cfgs.get("vocoder", VocoderConfig())
+        self.cvvp_cfg = cfgs.get("cvvp", CVVPConfig())
         sds = state_dicts or {}
 
         def sd(name):
@@ -231,6 +233,7 @@ class TextToSpeech:
         for name in STAGE_NAMES:
             self._build_stage(name)
         self.rlg = None         # random-voice latent MLPs, built lazily like the reference (api.py:301-309)
+        self.cvvp = None        # "CVVP model is only loaded if used" (api.py:234): built by the first tts(cvvp_amount > 0)
         self.conditioning = None  # conditioning encoders (voice_samples path), built lazily
         self.mel_front_end = None
         # attributes the reference exposes and callers touch (api.py:408, 523)
@@ -263,6 +266,10 @@ class TextToSpeech:
             # (tts_many ranks the utterances of a wave in ONE speech-tower pass: capacity for utterance_batch x cap candidates)
             self.clvp = stages.ClvpStage(self._sd("clvp"), self.clvp_cfg, self.device, dt,
                                          max_rows=max(c["cap"], 8) * c["max_mel_tokens"] * self.utterance_batch)
+            if getattr(self, "cvvp", None) is not None:  # CVVP runs under the same autocast as CLVP in the reference (api.py:447-449): same operand type
+                self.cvvp.close()
+                self.cvvp = None
+                self.load_cvvp()
         elif name == "diffusion":
             self.diffusion = stages.DiffusionStage(self._sd("diffusion"), self.diff_cfg, self.device, dt, max_seq=c["max_S"],
                                                    max_codes=c["max_mel_tokens"] + 8, max_steps=512, max_batch=self.utterance_batch)
@@ -274,6 +281,14 @@ class TextToSpeech:
         else:
             raise ValueError(name)
 
+    def load_cvvp(self):
+        """api.py:252-256: the CVVP model (cvvp.pth) as a device stage, with the CLVP stage's operand type."""
+        if self.cvvp is None:
+            c = self._caps
+            self.cvvp = stages.CvvpStage(self._sd("cvvp"), self.cvvp_cfg, self.device, self.dtypes["clvp"],
+                                         max_rows=max(c["cap"], 8) * c["max_mel_tokens"])
+        return self.cvvp
+
     def _tripped_stages(self, wav_ok=True):
         """Stages whose operand-overflow guard counted non-finite values during the utterance that just finished (the caller has
         synchronised); agreed over the ranks so that every rank takes the same decision.  Resets the counters."""
@@ -281,6 +296,8 @@ class TextToSpeech:
         for name in ("ar", "clvp", "diffusion"):
             g = getattr(getattr(self, name), "guard", None)
             flags.append(bool(g()) if g is not None else False)
+            if name == "clvp" and self.cvvp is not None and getattr(self.cvvp, "guard", None) is not None:
+                flags[-1] = bool(self.cvvp.guard()) or flags[-1]  # (always read: reading resets the counter)
         vg = getattr(self.vocoder, "guard", None)  # non-finite predicted LVC kernels: the gate and the final tanh would hide them from wav_ok
         voc_tripped = bool(vg()) if vg is not None else False  # (always read: reading resets the counter)
         flags.append((not wav_ok) or voc_tripped)
@@ -385,8 +402,8 @@ class TextToSpeech:
             **hf_generate_kwargs):
         noise = hf_generate_kwargs.pop("noise_override", None) or {}
         top_k, typical_mass = sampler_kwargs(hf_generate_kwargs)
-        if cvvp_amount != 0:
-            raise NotImplementedError("CVVP was removed upstream (CHANGELOG) and is not part of the accelerated path")
+        if not 0 <= cvvp_amount <= 1:
+            raise ValueError(f"cvvp_amount={cvvp_amount} must lie in [0, 1] (api.py:366-367)")
         dev = self.device
         if self.enable_redaction and isinstance(text, str) and "[" in text and "]" in text:
             raise NotImplementedError("text with [bracketed] passages needs the wav2vec2 aligner to redact them from the audio "
@@ -403,12 +420,18 @@ class TextToSpeech:
         text_tokens = F.pad(text_tokens.to(dev), (0, 1))  # api.py:391
         if text_tokens.shape[-1] >= 400:  # api.py:392
             raise ValueError("Too much text provided. Break the text up into separate segments and re-try inference.")
+        auto_conds = None  # the voice clips' mels: what CVVP compares the candidates with (api.py:393-395)
         if voice_samples is not None:
-            auto_conditioning, diffusion_conditioning = self.get_conditioning_latents(voice_samples)
+            auto_conditioning, diffusion_conditioning, auto_conds, _ = self.get_conditioning_latents(voice_samples, return_mels=True)
         elif conditioning_latents is not None:
             auto_conditioning, diffusion_conditioning = conditioning_latents
         else:
             auto_conditioning, diffusion_conditioning = self.get_random_conditioning_latents()
+        if cvvp_amount > 0:
+            if cvvp_amount == 1 and auto_conds is None:
+                raise ValueError("cvvp_amount=1 ranks the candidates by CVVP alone, which compares them with the voice's conditioning clips: "
+                                 "pass voice_samples (with latents only the reference has nothing to rank by, api.py:462-472)")
+            self.load_cvvp()  # api.py:450-453 (loaded even when there are no clips to use it on)
         auto_conditioning = auto_conditioning.to(dev).float()
         diffusion_conditioning = diffusion_conditioning.to(dev).float()
         if max_mel_tokens > self.max_mel_tokens_cap:
@@ -437,7 +460,11 @@ class TextToSpeech:
 
         # ---- CLVP ranking (api.py:447-477) + the one collective of the path
         fixed = fix_autoregressive_output(samples, stop)
-        scores = self.clvp.score(text_tokens, fixed)
+        # api.py:462-472: CLVP unless cvvp_amount == 1; CVVP (mean over the voice's conditioning clips) when there are clips and cvvp_amount > 0
+        scores = self.clvp.score(text_tokens, fixed) if cvvp_amount != 1 else None
+        if auto_conds is not None and cvvp_amount > 0:
+            cvvp = self.cvvp.score(auto_conds, fixed)
+            scores = cvvp if cvvp_amount == 1 else cvvp * cvvp_amount + scores * (1 - cvvp_amount)
         scores_all, codes_all = tdist.gather_candidates(scores, fixed.to(torch.int32)) if self.world > 1 else (scores, fixed.to(torch.int32))
         best = tdist.topk_lowest_index(scores_all, k)
         best_results = codes_all[best].long()

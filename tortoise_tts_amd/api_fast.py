@@ -141,10 +141,9 @@ class TextToSpeech:
     @staticmethod
     def _check_kwargs(k, cvvp_amount, hf_generate_kwargs):
         """Same refusals as tortoise_tts_amd.api.TextToSpeech.tts: a sampling option the on-device sampler cannot honour raises
-        instead of being dropped.  `k` is accepted and unused exactly as in the reference, whose fast path always decodes one
-        autoregressive sample into one clip (api_fast.py:421-519).  Returns (top_k, typical_mass) (api.sampler_kwargs)."""
-        if cvvp_amount:
-            raise NotImplementedError("cvvp_amount != 0: CVVP was removed upstream")
+        instead of being dropped.  `k` and `cvvp_amount` are accepted and unused exactly as in the reference, whose fast path always
+        decodes ONE autoregressive sample into one clip - there is no candidate ranking CLVP or CVVP could take part in
+        (api_fast.py:316, 426, 421-519).  Returns (top_k, typical_mass) (api.sampler_kwargs)."""
         return sampler_kwargs(hf_generate_kwargs)
 
     # ------------------------------------------------------------------ non-streaming (api_fast.py:421-519)
