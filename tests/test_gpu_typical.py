@@ -137,6 +137,25 @@ def test_mask_behind_the_repetition_penalty_and_sampler_behind_the_mask(lib):
     assert torch.isfinite(scores[torch.arange(B), got_tok])[clean].all()
 
 
+def test_mask_over_a_thousand_rows(lib):
+    """How often the kept set differs from the reference's arithmetic at all: 1024 rows from near-uniform (scale 0.2: ~7 000 tokens kept)
+    to peaked (scale 8: a handful), mass 0.9, repetition penalty 2.0 over 60 seen ids per row.  Every difference must be a boundary swap
+    (compare_sets asserts it); the rate is printed and bounded."""
+    g = torch.Generator().manual_seed(77)
+    B, V = 1024, 8194
+    logits = torch.randn(B, V, generator=g) * torch.logspace(-0.7, 0.9, B)[:, None]
+    logits[:, 8193] = -float("inf")
+    ids = torch.randint(0, V - 1, (B, 60), generator=g)
+    seen = seen_mask(ids, V)
+    pen = O.repetition_penalty_(logits.clone(), ids, 2.0)
+    want = O.typical_(pen, 0.9) > -float("inf")
+    got = device_mask(lib, logits, seen, 2.0, 0.9)
+    rows = compare_sets("1024 rows, penalty 2.0, mass 0.9", got, want, pen, 0.9)
+    moved = int((got != want).sum())
+    print(f"[parity] typical mask over 1024 rows: {len(rows)} rows differ ({moved} of {int(want.sum())} kept tokens), each by its boundary token")
+    assert len(rows) <= 20
+
+
 def oracle_replay(st, cfg, cond, text, codes, noise, mass):
     """The oracle's warpers + draw applied to the ENGINE's own logits, step by step (teacher-forced with the engine's codes): the
     fraction of (row, step) pairs where that reproduces the engine's token.  Free-running codes cannot be compared with an fp32 CPU
